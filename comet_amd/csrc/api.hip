@@ -1,0 +1,295 @@
+// api.hip — the extern "C" surface declared in include/comet_gpu.h.
+#include "index.hpp"
+
+using namespace comet;
+
+namespace {
+
+void check_metric(int m) { if (m < COMET_L2 || m > COMET_COSINE) COMET_FAIL(COMET_ERR_UNKNOWN_METRIC, "unknown distance kind"); }  // distance.go:9
+struct CallGuard {   // serialise calls on a context, bind the device, reset the per-call scratch arena
+    Ctx* c; std::unique_lock<std::recursive_mutex> lk;
+    explicit CallGuard(Ctx* c_) : c(c_), lk(c_->mu) { c->bind(); c->scratch_reset(); }
+};
+}  // namespace
+
+extern "C" {
+
+const char* comet_last_error(void) { return last_error().c_str(); }
+const char* comet_version(void) { return "comet-mi355x 0.1 (gfx950, HIP)"; }
+
+int comet_device_count(int* out_count) {
+    return guarded([&] {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess) { n = 0; (void)hipGetLastError(); }
+        *out_count = n;
+        return COMET_OK;
+    });
+}
+
+int comet_ctx_create(int device_id, comet_ctx** out) {
+    return guarded([&] {
+        *out = nullptr;
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); COMET_FAIL(COMET_ERR_NO_DEVICE, "no HIP device visible: the comet GPU backend requires an MI355X (gfx950)"); }
+        if (device_id < 0 || device_id >= n) COMET_FAIL(COMET_ERR_INVALID_ARG, "device %d out of range [0,%d)", device_id, n);
+        auto* c = new comet_ctx();
+        c->device = device_id;
+        HIP_CHECK(hipSetDevice(device_id));
+        HIP_CHECK(hipGetDeviceProperties(&c->prop, device_id));
+        if (std::strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+            std::string arch = c->prop.gcnArchName; delete c;
+            COMET_FAIL(COMET_ERR_NO_DEVICE, "device %d is %s; this library contains gfx950 (MI355X) code only", device_id, arch.c_str());
+        }
+        HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        *out = c;
+        return COMET_OK;
+    });
+}
+int comet_ctx_destroy(comet_ctx* c) {
+    return guarded([&] {
+        if (!c) return COMET_OK;
+        c->bind();
+        (void)hipStreamSynchronize(c->stream);
+        c->collect_profile();
+        c->scratch_reset();
+        if (c->scratch) (void)hipFree(c->scratch);
+        if (c->pinned) (void)hipHostFree(c->pinned);
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return COMET_OK;
+    });
+}
+int comet_ctx_sync(comet_ctx* c) { return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->sync(); return COMET_OK; }); }
+void* comet_ctx_stream(comet_ctx* c) { return (void*)c->stream; }
+int comet_dev_alloc(comet_ctx* c, size_t bytes, void** out) { return guarded([&] { c->bind(); HIP_CHECK(hipMalloc(out, bytes ? bytes : 4)); return COMET_OK; }); }
+int comet_dev_free(comet_ctx* c, void* p) { return guarded([&] { c->bind(); if (p) HIP_CHECK(hipFree(p)); return COMET_OK; }); }
+int comet_memcpy_h2d(comet_ctx* c, void* d, const void* s, size_t bytes) {
+    return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->h2d(d, s, bytes); HIP_CHECK(hipStreamSynchronize(c->stream)); return COMET_OK; });
+}
+int comet_memcpy_d2h(comet_ctx* c, void* d, const void* s, size_t bytes) {
+    return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->d2h(d, s, bytes); HIP_CHECK(hipStreamSynchronize(c->stream)); return COMET_OK; });
+}
+int comet_synth_fill_dev(comet_ctx* c, uint64_t seed, uint64_t offset, uint64_t n, float* out_dev) {
+    return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); launch_synth_fill(c, seed, offset, n, out_dev); return COMET_OK; });
+}
+
+int comet_profile_enable(comet_ctx* c, int on) { return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->sync(); c->profile = on != 0; return COMET_OK; }); }
+int comet_profile_reset(comet_ctx* c) { return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->sync(); c->prof.clear(); return COMET_OK; }); }
+int comet_profile_get(comet_ctx* c, const char* prefix, double* total_ms, int64_t* launches) {
+    return guarded([&] {
+        std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->sync();
+        double ms = 0; int64_t n = 0; size_t pl = std::strlen(prefix);
+        for (auto& kv : c->prof) if (kv.first.compare(0, pl, prefix) == 0) { ms += kv.second.ms; n += kv.second.n; }
+        if (total_ms) *total_ms = ms;
+        if (launches) *launches = n;
+        return COMET_OK;
+    });
+}
+int comet_profile_dump(comet_ctx* c, char* buf, size_t cap) {
+    return guarded([&] {
+        std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->sync();
+        std::string s;
+        for (auto& kv : c->prof) { char line[256]; snprintf(line, sizeof(line), "%s %.6f %lld\n", kv.first.c_str(), kv.second.ms, (long long)kv.second.n); s += line; }
+        if (cap) { size_t m = std::min(cap - 1, s.size()); std::memcpy(buf, s.data(), m); buf[m] = 0; }
+        return COMET_OK;
+    });
+}
+
+// ---- Distance singletons ------------------------------------------------------------------------
+int comet_distance_batch(comet_ctx* c, int metric, const float* queries, int nq, const float* target, int d, float* out) {
+    return guarded([&] {
+        check_metric(metric);
+        if (nq <= 0) return (int)COMET_OK;
+        if (d < 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "negative dimension");
+        CallGuard g(c);
+        float* dq = c->salloc<float>((size_t)nq * std::max(d, 1));
+        float* dt = c->salloc<float>(std::max(d, 1));
+        float* dout = c->salloc<float>(nq);
+        c->h2d(dq, queries, (size_t)nq * d * sizeof(float));
+        c->h2d(dt, target, (size_t)d * sizeof(float));
+        launch_dist_pairs(c, metric, dq, dt, nq, d, d, 0, dout);
+        c->d2h(out, dout, nq * sizeof(float));
+        c->sync();
+        return (int)COMET_OK;
+    });
+}
+int comet_distance(comet_ctx* c, int metric, const float* a, const float* b, int d, float* out) {
+    return comet_distance_batch(c, metric, a, 1, b, d, out);
+}
+int comet_preprocess(comet_ctx* c, int metric, const float* x, int d, float* out) {
+    return guarded([&] {
+        check_metric(metric);
+        if (d <= 0) return (int)COMET_OK;
+        CallGuard g(c);
+        float* dx = c->salloc<float>(d);
+        float* dp = c->salloc<float>(padded_dim(d));
+        int32_t* zf = c->salloc<int32_t>(1);
+        c->h2d(dx, x, d * sizeof(float));
+        launch_ingest_rows(c, metric, dx, 1, d, dp, padded_dim(d), zf);
+        int32_t hz = 0;
+        std::vector<float> tmp(d);
+        c->d2h(&hz, zf, sizeof(int32_t));
+        c->d2h(tmp.data(), dp, d * sizeof(float));
+        c->sync();
+        if (hz) COMET_FAIL(COMET_ERR_ZERO_VECTOR, "zero vector not allowed for this metric");   // distance.go:12
+        std::memcpy(out, tmp.data(), d * sizeof(float));
+        return (int)COMET_OK;
+    });
+}
+
+// ---- index lifecycle ----------------------------------------------------------------------------
+static void check_dim(int dim) { if (dim <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "dimension must be positive"); }  // flat_index.go:129
+
+int comet_flat_create(comet_ctx* c, int dim, int metric, comet_index** out) {
+    return guarded([&] { *out = nullptr; check_dim(dim); check_metric(metric); c->bind(); *out = make_flat(c, dim, metric); return (int)COMET_OK; });
+}
+int comet_ivf_create(comet_ctx* c, int dim, int metric, int nlist, comet_index** out) {
+    return guarded([&] {
+        *out = nullptr; check_dim(dim);
+        if (nlist <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "nlist must be positive");   // ivf_index.go:147
+        check_metric(metric); c->bind(); *out = make_ivf(c, dim, metric, nlist); return (int)COMET_OK;
+    });
+}
+static void check_pq(int dim, int M, int nbits) {
+    if (M <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "parameter M must be positive");                              // pq_index.go:141
+    if (dim % M != 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "dimension %d must be divisible by M %d", dim, M);       // pq_index.go:146
+    if (nbits <= 0 || nbits > 16) COMET_FAIL(COMET_ERR_INVALID_ARG, "parameter Nbits must be in [1,16]");       // pq_index.go:151
+}
+int comet_pq_create(comet_ctx* c, int dim, int metric, int M, int nbits, comet_index** out) {
+    return guarded([&] { *out = nullptr; check_dim(dim); check_pq(dim, M, nbits); check_metric(metric); c->bind(); *out = make_pq(c, dim, metric, M, nbits); return (int)COMET_OK; });
+}
+int comet_ivfpq_create(comet_ctx* c, int dim, int metric, int nlist, int M, int nbits, comet_index** out) {
+    return guarded([&] {
+        *out = nullptr; check_dim(dim);
+        if (nlist <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "nlist must be positive");   // ivfpq_index.go:120
+        check_pq(dim, M, nbits); check_metric(metric); c->bind(); *out = make_ivfpq(c, dim, metric, nlist, M, nbits); return (int)COMET_OK;
+    });
+}
+int comet_index_destroy(comet_index* idx) {
+    return guarded([&] { if (!idx) return (int)COMET_OK; Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); (void)hipStreamSynchronize(c->stream); delete idx; return (int)COMET_OK; });
+}
+int comet_index_kind(const comet_index* idx) { return idx->kind; }
+int comet_index_dim(const comet_index* idx) { return idx->dim; }
+int comet_index_metric(const comet_index* idx) { return idx->metric; }
+int comet_index_trained(const comet_index* idx) { return idx->trained ? 1 : 0; }
+int64_t comet_index_size(const comet_index* idx) { return idx->size(); }
+int comet_index_default_nprobes(const comet_index* idx) { return idx->default_nprobes(); }
+
+int comet_index_train_dev(comet_index* idx, const float* vecs_dev, int64_t n) {
+    return guarded([&] { CallGuard g(idx->c); idx->train_dev(vecs_dev, n); idx->c->sync(); return (int)COMET_OK; });
+}
+int comet_index_train(comet_index* idx, const float* vecs, int64_t n) {
+    return guarded([&] {
+        if (idx->kind == COMET_KIND_FLAT) return (int)COMET_OK;   // FlatIndex.Train is a no-op
+        if (n < 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "negative count");
+        Ctx* c = idx->c; CallGuard g(c);
+        DevBuf tmp; tmp.reserve(std::max<size_t>(4, (size_t)n * idx->dim * sizeof(float)), c->stream, 0);
+        c->h2d(tmp.p, vecs, (size_t)n * idx->dim * sizeof(float));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        idx->train_dev(tmp.as<float>(), n);
+        c->sync();
+        return (int)COMET_OK;
+    });
+}
+
+static int add_common(comet_index* idx, const uint32_t* ids_dev, const uint32_t* ids_host, const float* vecs_dev, int64_t n,
+                      int64_t* out_added, float* normalized_dev) {
+    int64_t zero_at = -1;
+    int64_t added = idx->add_dev(ids_dev, ids_host, vecs_dev, n, &zero_at, normalized_dev);
+    if (out_added) *out_added = added;
+    if (zero_at >= 0) COMET_FAIL(COMET_ERR_ZERO_VECTOR, "zero vector not allowed for this metric");
+    return COMET_OK;
+}
+int comet_index_add(comet_index* idx, const uint32_t* ids, const float* vecs, int64_t n, int64_t* out_added, float* normalized_out) {
+    return guarded([&] {
+        if (out_added) *out_added = 0;
+        if (n <= 0) return (int)COMET_OK;
+        Ctx* c = idx->c; CallGuard g(c);
+        DevBuf tmp, nrm;
+        const size_t bytes = (size_t)n * idx->dim * sizeof(float);
+        tmp.reserve(bytes, c->stream, 0);
+        c->h2d(tmp.p, vecs, bytes);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (normalized_out) nrm.reserve(bytes, c->stream, 0);
+        int64_t added = 0;
+        int rc = COMET_OK;
+        try { rc = add_common(idx, nullptr, ids, tmp.as<float>(), n, &added, normalized_out ? nrm.as<float>() : nullptr); }
+        catch (const StatusError& s) { rc = s.code; }
+        if (out_added) *out_added = added;
+        if (normalized_out && added > 0) { c->d2h(normalized_out, nrm.p, (size_t)added * idx->dim * sizeof(float)); }
+        c->sync();
+        return rc;
+    });
+}
+int comet_index_add_dev(comet_index* idx, const uint32_t* ids_dev, const float* vecs_dev, int64_t n, int64_t* out_added) {
+    return guarded([&] {
+        if (out_added) *out_added = 0;
+        if (n <= 0) return (int)COMET_OK;
+        Ctx* c = idx->c; CallGuard g(c);
+        std::vector<uint32_t> ids_h(n);
+        c->d2h(ids_h.data(), ids_dev, n * 4);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        int rc = add_common(idx, ids_dev, ids_h.data(), vecs_dev, n, out_added, nullptr);
+        c->sync();
+        return rc;
+    });
+}
+int comet_index_remove(comet_index* idx, uint32_t id) {
+    return guarded([&] {
+        std::lock_guard<std::recursive_mutex> lk(idx->c->mu);
+        if (!idx->contains_id(id)) COMET_FAIL(COMET_ERR_NOT_FOUND, "vector with ID %u not found", id);              // flat_index.go:233
+        if (idx->deleted.count(id)) COMET_FAIL(COMET_ERR_ALREADY_DELETED, "vector with ID %u already deleted", id);  // flat_index.go:236
+        idx->deleted.insert(id); idx->deleted_dirty = true;
+        return (int)COMET_OK;
+    });
+}
+int comet_index_flush(comet_index* idx) { return guarded([&] { CallGuard g(idx->c); idx->flush(); idx->c->sync(); return (int)COMET_OK; }); }
+
+// ---- search ---------------------------------------------------------------------------------------
+static void check_search_args(const comet_index* idx, int B, const comet_search_params* p, int k_cap) {
+    if (!p) COMET_FAIL(COMET_ERR_INVALID_ARG, "null search params");
+    if (B < 0 || k_cap <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "bad batch size / k_cap");
+    (void)idx;
+}
+int comet_index_search_dev(comet_index* idx, const float* queries_dev, int32_t B, const comet_search_params* p,
+                           uint32_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev, int32_t k_cap) {
+    return guarded([&] {
+        check_search_args(idx, B, p, k_cap);
+        if (B == 0) return (int)COMET_OK;
+        CallGuard g(idx->c);
+        idx->search_dev(queries_dev, B, *p, out_ids_dev, out_scores_dev, out_counts_dev, k_cap);
+        return (int)COMET_OK;
+    });
+}
+int comet_index_search(comet_index* idx, const float* queries, int32_t B, const comet_search_params* p, uint32_t* out_ids,
+                       float* out_scores, int32_t* out_counts, int32_t k_cap) {
+    return guarded([&] {
+        check_search_args(idx, B, p, k_cap);
+        if (B == 0) return (int)COMET_OK;
+        Ctx* c = idx->c; CallGuard g(c);
+        float* dq = c->salloc<float>((size_t)B * idx->dim);
+        uint32_t* dids = c->salloc<uint32_t>((size_t)B * k_cap);
+        float* dsc = c->salloc<float>((size_t)B * k_cap);
+        int32_t* dcn = c->salloc<int32_t>(B);
+        c->h2d(dq, queries, (size_t)B * idx->dim * sizeof(float));
+        idx->search_dev(dq, B, *p, dids, dsc, dcn, k_cap);
+        c->d2h(out_ids, dids, (size_t)B * k_cap * 4);
+        c->d2h(out_scores, dsc, (size_t)B * k_cap * 4);
+        c->d2h(out_counts, dcn, (size_t)B * 4);
+        c->sync();
+        for (int i = 0; i < B; i++) if (out_counts[i] == -(int)COMET_ERR_ZERO_VECTOR)
+            COMET_FAIL(COMET_ERR_ZERO_VECTOR, "zero vector not allowed for this metric");   // Preprocess(query) error, flat_index_search.go:236-239
+        return (int)COMET_OK;
+    });
+}
+
+// ---- introspection -----------------------------------------------------------------------------
+int comet_index_get_centroids(const comet_index* idx, float* out) { return guarded([&] { CallGuard g(idx->c); idx->get_centroids(out); return (int)COMET_OK; }); }
+int comet_index_get_codebooks(const comet_index* idx, float* out) { return guarded([&] { CallGuard g(idx->c); idx->get_codebooks(out); return (int)COMET_OK; }); }
+int comet_index_list_size(const comet_index* idx, int32_t list, int64_t* out) { return guarded([&] { *out = idx->list_size(list); return (int)COMET_OK; }); }
+int comet_index_list_read(const comet_index* idx, int32_t list, uint32_t* out_ids, uint8_t* out_codes, float* out_vecs) {
+    return guarded([&] { CallGuard g(idx->c); idx->list_read(list, out_ids, out_codes, out_vecs); return (int)COMET_OK; });
+}
+
+}  // extern "C"

@@ -1,0 +1,159 @@
+// common.hpp — context, error plumbing, device buffers and kernel-launch timing for libcomet_hip.
+// gfx950 only; no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/comet_gpu.h"
+
+namespace comet {
+
+// thread-local error text (comet_last_error)
+inline std::string& last_error() { static thread_local std::string e; return e; }
+inline int set_error(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+struct HipError { hipError_t e; const char* what; const char* file; int line; };
+#define HIP_CHECK(expr)                                                                      \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) throw ::comet::HipError{_e, #expr, __FILE__, __LINE__};        \
+    } while (0)
+
+struct StatusError { int code; };  // thrown after set_error()
+#define COMET_FAIL(code, ...) throw ::comet::StatusError{::comet::set_error((code), __VA_ARGS__)}
+
+// Wrap a C-ABI body: translate exceptions into status codes.
+template <class F> inline int guarded(F&& f) {
+    try { return f(); }
+    catch (const StatusError& s) { return s.code; }
+    catch (const HipError& h) {
+        return set_error(COMET_ERR_HIP, "HIP error %d (%s) in %s at %s:%d", (int)h.e, hipGetErrorString(h.e), h.what, h.file, h.line);
+    }
+    catch (const std::bad_alloc&) { return set_error(COMET_ERR_HIP, "host allocation failed"); }
+    catch (const std::exception& e) { return set_error(COMET_ERR_INVALID_ARG, "%s", e.what()); }
+}
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
+
+struct Ctx;
+
+// Growable device allocation owned by an index (doubling growth, preserves contents).
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void reserve(size_t bytes, hipStream_t s, size_t keep_bytes) {
+        if (bytes <= cap) return;
+        size_t ncap = cap ? cap : 4096;
+        while (ncap < bytes) ncap = ncap + ncap / 2 + 4096;
+        void* np = nullptr;
+        HIP_CHECK(hipMalloc(&np, ncap));
+        if (p && keep_bytes) { HIP_CHECK(hipMemcpyAsync(np, p, keep_bytes, hipMemcpyDeviceToDevice, s)); HIP_CHECK(hipStreamSynchronize(s)); }
+        if (p) HIP_CHECK(hipFree(p));
+        p = np; cap = ncap;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct ProfEntry { double ms = 0; int64_t n = 0; };
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop{};
+    std::recursive_mutex mu;  // serialises calls that share the scratch arena / stream
+    // scratch arena: bump allocator over one device allocation, reset at the start of every call.
+    void* scratch = nullptr; size_t scratch_cap = 0, scratch_off = 0;
+    std::vector<void*> retired;  // old arenas kept alive until the call that outgrew them finishes
+    // pinned host staging for small readbacks
+    void* pinned = nullptr; size_t pinned_cap = 0;
+    // profiling
+    bool profile = false;
+    struct Pending { std::string name; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::map<std::string, ProfEntry> prof;
+
+    void bind() { HIP_CHECK(hipSetDevice(device)); }
+    void scratch_reset() {
+        scratch_off = 0;
+        for (void* r : retired) (void)hipFree(r);
+        retired.clear();
+    }
+    // 256-byte aligned scratch; contents undefined. Pointers stay valid until the next scratch_reset().
+    void* scratch_alloc(size_t bytes) {
+        size_t off = (scratch_off + 255) & ~(size_t)255;
+        if (off + bytes > scratch_cap) {
+            // outgrown: allocate a bigger arena; keep the old one alive (earlier pointers of this call remain valid)
+            size_t ncap = scratch_cap ? scratch_cap * 2 : ((size_t)64 << 20);
+            while (ncap < bytes + 256) ncap *= 2;
+            if (scratch) retired.push_back(scratch);
+            HIP_CHECK(hipMalloc(&scratch, ncap));
+            scratch_cap = ncap; off = 0;
+        }
+        scratch_off = off + bytes;
+        return (char*)scratch + off;
+    }
+    template <class T> T* salloc(size_t n) { return (T*)scratch_alloc(n * sizeof(T)); }
+    void* pinned_buf(size_t bytes) {
+        if (bytes > pinned_cap) {
+            if (pinned) (void)hipHostFree(pinned);
+            size_t ncap = pinned_cap ? pinned_cap : 4096; while (ncap < bytes) ncap *= 2;
+            HIP_CHECK(hipHostMalloc(&pinned, ncap, hipHostMallocDefault)); pinned_cap = ncap;
+        }
+        return pinned;
+    }
+    void sync() { HIP_CHECK(hipStreamSynchronize(stream)); collect_profile(); }
+    void h2d(void* dst, const void* src, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream)); }
+    void d2h(void* dst, const void* src, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream)); }
+    void d2d(void* dst, const void* src, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream)); }
+    void zero(void* dst, size_t bytes) { if (bytes) HIP_CHECK(hipMemsetAsync(dst, 0, bytes, stream)); }
+
+    void prof_begin(const char* name) {
+        if (!profile) return;
+        Pending p; p.name = name;
+        HIP_CHECK(hipEventCreate(&p.a)); HIP_CHECK(hipEventCreate(&p.b));
+        HIP_CHECK(hipEventRecord(p.a, stream));
+        pending.push_back(p);
+    }
+    void prof_end() {
+        if (!profile) return;
+        (void)hipEventRecord(pending.back().b, stream);
+    }
+    void collect_profile() {
+        for (auto& p : pending) {
+            float ms = 0;
+            if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+                auto& e = prof[p.name]; e.ms += ms; e.n += 1;
+            }
+            (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+        }
+        pending.clear();
+    }
+};
+
+// RAII: time one kernel launch under a name when profiling is on.
+struct ProfScope {
+    Ctx* c;
+    ProfScope(Ctx* c_, const char* name) : c(c_) { c->prof_begin(name); }
+    ~ProfScope() { c->prof_end(); }
+};
+
+#define LAUNCH_CHECK() HIP_CHECK(hipGetLastError())
+
+}  // namespace comet

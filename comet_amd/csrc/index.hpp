@@ -1,0 +1,78 @@
+// index.hpp — host-side index objects behind the C ABI. They mirror the reference's containers
+// (FlatIndex flat_index.go:82-100, IVFIndex ivf_index.go:98-118, PQIndex pq_index.go:99-120,
+// IVFPQIndex ivfpq_index.go:40-100) but keep the data resident in HBM in layouts chosen for the
+// kernels (padded row-major fp32 matrices, list-major inverted lists, interleaved PQ code blocks).
+#pragma once
+#include <algorithm>
+#include <memory>
+#include <unordered_map>
+#include <unordered_set>
+
+#include "kernels.hpp"
+
+struct comet_ctx : comet::Ctx {};
+
+struct comet_index {
+    comet::Ctx* c = nullptr;
+    int kind = 0, dim = 0, ld = 0, metric = 0;
+    bool trained = false;
+    // soft deletes (deletedNodes roaring bitmap in the reference, flat_index.go:88)
+    std::unordered_set<uint32_t> deleted;
+    comet::DevBuf deleted_dev; int n_deleted_dev = 0; bool deleted_dirty = false;
+
+    virtual ~comet_index() {}
+    virtual int64_t size() const = 0;
+    virtual int default_nprobes() const { return 0; }
+    virtual void train_dev(const float* /*vecs_dev*/, int64_t /*n*/) {}   // VectorIndex.Train; no-op for Flat (flat_index.go:150)
+    // add n rows already on device (dense n x dim); returns rows added; sets *zero_at = index of first
+    // zero-norm vector (or -1). normalized_dev (nullable): receives the preprocessed rows (dense).
+    virtual int64_t add_dev(const uint32_t* ids_dev, const uint32_t* ids_host, const float* vecs_dev, int64_t n,
+                            int64_t* zero_at, float* normalized_dev) = 0;
+    virtual bool contains_id(uint32_t id) const = 0;
+    virtual void flush() = 0;
+    virtual void search_dev(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids,
+                            float* out_scores, int32_t* out_counts, int k_cap) = 0;
+    virtual int64_t list_size(int /*list*/) const { return size(); }
+    virtual void list_read(int /*list*/, uint32_t* /*ids*/, uint8_t* /*codes*/, float* /*vecs*/) const {}
+    virtual void get_centroids(float*) const { COMET_FAIL(COMET_ERR_UNSUPPORTED, "index has no centroids"); }
+    virtual void get_codebooks(float*) const { COMET_FAIL(COMET_ERR_UNSUPPORTED, "index has no codebooks"); }
+
+    // sorted device copy of the soft-delete set (rebuilt lazily)
+    const uint32_t* deleted_sorted_dev() {
+        if (deleted_dirty) {
+            std::vector<uint32_t> v(deleted.begin(), deleted.end());
+            std::sort(v.begin(), v.end());
+            deleted_dev.reserve(std::max<size_t>(4, v.size() * 4), c->stream, 0);
+            c->h2d(deleted_dev.p, v.data(), v.size() * 4);
+            HIP_CHECK(hipStreamSynchronize(c->stream));   // v is a temporary
+            n_deleted_dev = (int)v.size(); deleted_dirty = false;
+        }
+        return deleted_dev.as<uint32_t>();
+    }
+    // sorted filter ids in scratch (nullptr / 0 when no filter)
+    const uint32_t* filter_sorted_scratch(const comet_search_params& p, int* n_out) {
+        *n_out = 0;
+        if (!p.filter_ids || p.n_filter <= 0) return nullptr;
+        std::vector<uint32_t> v(p.filter_ids, p.filter_ids + p.n_filter);
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        uint32_t* d = c->salloc<uint32_t>(v.size());
+        c->h2d(d, v.data(), v.size() * 4);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        *n_out = (int)v.size();
+        return d;
+    }
+};
+
+namespace comet {
+comet_index* make_flat(Ctx* c, int dim, int metric);
+comet_index* make_ivf(Ctx* c, int dim, int metric, int nlist);
+comet_index* make_pq(Ctx* c, int dim, int metric, int M, int nbits);
+comet_index* make_ivfpq(Ctx* c, int dim, int metric, int nlist, int M, int nbits);
+
+// preprocess B queries (dense B x dim) into padded B x ld; zflag[q] = 1 for zero-norm cosine queries
+void prepare_queries(Ctx* c, int metric, const float* queries_dev, int B, int dim, int ld, float** Qp, int32_t** zflag);
+// out_ids[q][i] = ids[pos[q][i]] ; counts[q] = -COMET_ERR_ZERO_VECTOR where zflag[q]
+void launch_finalize(Ctx* c, const uint32_t* ids_table, const uint32_t* pos, int B, int k_cap, const int32_t* zflag,
+                     uint32_t* out_ids, int32_t* counts);
+}  // namespace comet

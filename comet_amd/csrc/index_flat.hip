@@ -1,0 +1,161 @@
+// index_flat.hip — FlatIndex on the GPU (reference: flat_index.go, flat_index_search.go) plus the
+// helpers every index kind shares (query preprocessing, position -> id finalisation).
+#include "index.hpp"
+
+namespace comet {
+
+// ------------------------------------------------------------------------------------------------
+// shared helpers
+// ------------------------------------------------------------------------------------------------
+void prepare_queries(Ctx* c, int metric, const float* queries_dev, int B, int dim, int ld, float** Qp, int32_t** zflag) {
+    *Qp = c->salloc<float>((size_t)B * ld);
+    *zflag = c->salloc<int32_t>(B);
+    // Distance.Preprocess(query): normalised copy for cosine, unchanged for L2 (flat_index_search.go:236)
+    launch_ingest_rows(c, metric, queries_dev, B, dim, *Qp, ld, *zflag);
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(const unsigned* __restrict__ ids_table, const unsigned* __restrict__ pos,
+                                                       int B, int k_cap, const int* __restrict__ zflag,
+                                                       unsigned* __restrict__ out_ids, int* __restrict__ counts) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)B * k_cap;
+    if (i < total) {
+        unsigned p = pos[i];
+        out_ids[i] = (p == 0xFFFFFFFFu) ? 0u : (ids_table ? ids_table[p] : p);
+    }
+    if (i < B && zflag && zflag[i]) counts[i] = -(int)COMET_ERR_ZERO_VECTOR;
+}
+void launch_finalize(Ctx* c, const uint32_t* ids_table, const uint32_t* pos, int B, int k_cap, const int32_t* zflag,
+                     uint32_t* out_ids, int32_t* counts) {
+    long total = std::max<long>((long)B * k_cap, B);
+    finalize_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, c->stream>>>(ids_table, pos, B, k_cap, zflag, out_ids, counts);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// FlatIndex
+// ------------------------------------------------------------------------------------------------
+struct FlatIndex : comet_index {
+    DevBuf X;        // n x ld fp32, preprocessed rows (idx.vectors, flat_index.go:82)
+    DevBuf ids_dev;  // n uint32
+    std::vector<uint32_t> ids;  // host mirror of the ids (Remove / lookup)
+    std::unordered_map<uint32_t, int> id_count;
+    int64_t n = 0;
+
+    int64_t size() const override { return n; }
+    bool contains_id(uint32_t id) const override { return id_count.count(id) != 0; }
+
+    // FlatIndex.Add flat_index.go:170-186, batched.
+    int64_t add_dev(const uint32_t* ids_d, const uint32_t* ids_h, const float* vecs_dev, int64_t m, int64_t* zero_at,
+                    float* normalized_dev) override {
+        *zero_at = -1;
+        if (m <= 0) return 0;
+        X.reserve((size_t)(n + m) * ld * sizeof(float), c->stream, (size_t)n * ld * sizeof(float));
+        ids_dev.reserve((size_t)(n + m) * 4, c->stream, (size_t)n * 4);
+        float* dst = X.as<float>() + (size_t)n * ld;
+        int32_t* zf = c->salloc<int32_t>(m);
+        launch_ingest_rows(c, metric, vecs_dev, m, dim, dst, ld, zf);
+        int64_t added = m;
+        if (metric == COMET_COSINE) {   // ErrZeroVector stops the batch at the first offending vector
+            std::vector<int32_t> h(m);
+            c->d2h(h.data(), zf, m * sizeof(int32_t));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            for (int64_t i = 0; i < m; i++) if (h[i]) { *zero_at = i; added = i; break; }
+        }
+        if (added > 0) {
+            if (ids_d) c->d2d(ids_dev.as<uint32_t>() + n, ids_d, added * 4);
+            else c->h2d(ids_dev.as<uint32_t>() + n, ids_h, added * 4);
+            if (normalized_dev) launch_unpad_rows(c, dst, added, ld, normalized_dev, dim);
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            ids.insert(ids.end(), ids_h, ids_h + added);
+            for (int64_t i = 0; i < added; i++) id_count[ids_h[i]]++;
+            n += added;
+        }
+        return added;
+    }
+
+    // FlatIndex.Flush flat_index.go:268-296: compact away soft-deleted rows.
+    void flush() override {
+        if (deleted.empty()) return;
+        std::vector<int64_t> keep;
+        for (int64_t i = 0; i < n; i++) if (!deleted.count(ids[i])) keep.push_back(i);
+        DevBuf nx, nid;
+        size_t nk = keep.size();
+        nx.reserve(std::max<size_t>(1, nk) * ld * sizeof(float), c->stream, 0);
+        nid.reserve(std::max<size_t>(1, nk) * 4, c->stream, 0);
+        std::vector<uint32_t> nids(nk);
+        // copy surviving runs (device-to-device, contiguous runs coalesced)
+        size_t i = 0;
+        while (i < nk) {
+            size_t j = i;
+            while (j + 1 < nk && keep[j + 1] == keep[j] + 1) j++;
+            size_t run = j - i + 1;
+            c->d2d(nx.as<float>() + i * ld, X.as<float>() + (size_t)keep[i] * ld, run * ld * sizeof(float));
+            for (size_t t = 0; t < run; t++) nids[i + t] = ids[keep[i] + t];
+            i = j + 1;
+        }
+        c->h2d(nid.p, nids.data(), nk * 4);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        std::swap(X.p, nx.p); std::swap(X.cap, nx.cap);
+        std::swap(ids_dev.p, nid.p); std::swap(ids_dev.cap, nid.cap);
+        ids.swap(nids); n = (int64_t)nk;
+        id_count.clear(); for (auto id : ids) id_count[id]++;
+        deleted.clear(); deleted_dirty = true;
+    }
+
+    // flatIndexSearch.searchSingleQuery flat_index_search.go:221-294 for B queries at once.
+    void search_dev(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
+                    int32_t* out_counts, int k_cap) override {
+        float* Qp; int32_t* zflag;
+        prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag);
+        if (n == 0) {   // empty index: zero results (sanitizeK(k, 0) == 0)
+            uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
+            launch_select_topk(c, nullptr, 0, B, 0, nullptr, 0.0f, p.k, pos, out_scores, out_counts, k_cap);
+            launch_finalize(c, nullptr, pos, B, k_cap, zflag, out_ids, out_counts);
+            return;
+        }
+        // eligibility: soft deletes (flat_index_search.go:256) and WithDocumentIDs filter (:261)
+        const uint8_t* elig = nullptr;
+        int nf = 0;
+        const uint32_t* flt = filter_sorted_scratch(p, &nf);
+        const uint32_t* del = deleted.empty() ? nullptr : deleted_sorted_dev();
+        const int nd = deleted.empty() ? 0 : n_deleted_dev;
+        if (nd > 0 || nf > 0) {
+            uint8_t* e = c->salloc<uint8_t>(n);
+            launch_build_elig(c, ids_dev.as<uint32_t>(), n, del, nd, flt, nf, e);
+            elig = e;
+        }
+        const int64_t ldD = round_up(n, 16);
+        // bound the distance-matrix scratch: process the batch in slices of queries
+        const size_t budget = (size_t)2 << 30;
+        int qb = (int)std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(budget / ((size_t)ldD * sizeof(float)))));
+        if (qb >= 16) qb = qb / 16 * 16;
+        float* D = c->salloc<float>((size_t)qb * ldD);
+        uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
+        for (int b0 = 0; b0 < B; b0 += qb) {
+            const int bn = std::min(qb, B - b0);
+            launch_dist_exact(c, metric, X.as<float>(), n, ld, Qp + (size_t)b0 * ld, bn, D, ldD, elig);
+            launch_select_topk(c, D, ldD, bn, n, nullptr, p.threshold, p.k, pos + (size_t)b0 * k_cap,
+                               out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);
+        }
+        launch_finalize(c, ids_dev.as<uint32_t>(), pos, B, k_cap, zflag, out_ids, out_counts);
+    }
+
+    void list_read(int, uint32_t* oids, uint8_t*, float* ovecs) const override {
+        if (oids) std::copy(ids.begin(), ids.end(), oids);
+        if (ovecs && n > 0) {
+            float* tmp = c->salloc<float>((size_t)n * dim);
+            launch_unpad_rows(c, X.as<float>(), n, ld, tmp, dim);
+            c->d2h(ovecs, tmp, (size_t)n * dim * sizeof(float));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
+    }
+};
+
+comet_index* make_flat(Ctx* c, int dim, int metric) {
+    auto* f = new FlatIndex();
+    f->c = c; f->kind = COMET_KIND_FLAT; f->dim = dim; f->ld = padded_dim(dim); f->metric = metric; f->trained = true;
+    return f;
+}
+
+}  // namespace comet

@@ -1,0 +1,299 @@
+// kernels_dist.hip — exact-arithmetic distance kernels for gfx950 (CDNA4, wave64).
+//
+// "Exact" = the value each kernel writes is bit-identical to the reference's scalar Go loop
+// (distance.go:114-121 L2, :158-165 L2², :201-216 cosine): float32 accumulation strictly in
+// dimension order, product rounded before the add (the file is compiled with -ffp-contract=off, so
+// no v_fma/v_fmac/v_mad is emitted for these chains), sqrt correctly rounded.
+//
+// Hardware mapping (MI355X): the sum over the dimension for ONE (query,row) pair is a serial chain,
+// so parallelism comes from pairs: one lane owns one corpus row and QT query accumulators. Corpus
+// tiles (256 rows x 32 floats) are fetched with coalesced 16-byte loads (8 lanes cover one row's
+// 128-byte line), transposed through LDS (row stride 36 floats: conflict-free ds_write_b128 /
+// ds_read_b128 per the 64-bank rule), next tile prefetched into registers while the current one is
+// consumed. Query values are wave-uniform and come in through scalar loads (SGPR operands of the
+// VALU ops). Workgroups that share a row tile (different query groups) are mapped to the same XCD so
+// the tile is fetched from HBM once and re-served from that XCD's L2.
+#include "kernels.hpp"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace comet {
+
+// ------------------------------------------------------------------------------------------------
+// per-element steps — written as separate statements so each product / difference is rounded to
+// float32 before the add, exactly like the Go source.
+// ------------------------------------------------------------------------------------------------
+template <int METRIC> __device__ __forceinline__ float acc_step(float acc, float q, float x) {
+    if constexpr (METRIC == COMET_COSINE) {
+        float p = q * x;          // dot += a[i] * b[i]  (distance.go:204-206)
+        return acc + p;
+    } else {
+        float diff = q - x;       // diff := a[i] - b[i] (distance.go:116-119)
+        float sq = diff * diff;
+        return acc + sq;
+    }
+}
+template <int METRIC> __device__ __forceinline__ float acc_finish(float acc) {
+    if constexpr (METRIC == COMET_COSINE) {
+        if (acc > 1.0f) acc = 1.0f; else if (acc < -1.0f) acc = -1.0f;   // distance.go:209-213
+        return 1.0f - acc;
+    } else if constexpr (METRIC == COMET_L2) {
+        return __fsqrt_rn(acc);   // float32(math.Sqrt(float64(sum))) == correctly-rounded sqrtf (53 >= 2*24+2)
+    } else {
+        return acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ingest: dense rows -> padded, preprocessed rows. One lane per row, sequential over the dimension.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ingest_rows_kernel(int metric, const float* __restrict__ src, long n, int d,
+                                                          float* __restrict__ dst, int ld, int* __restrict__ zero_flag) {
+    long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float* s = src + r * (long)d;
+    float* o = dst + r * (long)ld;
+    float scale = 1.0f;
+    int zf = 0;
+    if (metric == COMET_COSINE) {
+        float sum = 0.0f;
+        for (int i = 0; i < d; i++) { float p = s[i] * s[i]; sum = sum + p; }   // distance.go:247-250
+        float norm = __fsqrt_rn(sum);
+        if (norm == 0.0f) zf = 1;
+        else scale = 1.0f / norm;                                              // distance.go:258 (float32 divide)
+    }
+    if (metric == COMET_COSINE && !zf) { for (int i = 0; i < d; i++) o[i] = s[i] * scale; }
+    else { for (int i = 0; i < d; i++) o[i] = s[i]; }
+    for (int i = d; i < ld; i++) o[i] = 0.0f;
+    if (zero_flag) zero_flag[r] = zf;
+}
+void launch_ingest_rows(Ctx* c, int metric, const float* src, int64_t n, int d, float* dst, int ld, int32_t* zero_flag) {
+    if (n <= 0) return;
+    ProfScope ps(c, "ingest_rows");
+    ingest_rows_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, c->stream>>>(metric, src, n, d, dst, ld, zero_flag);
+    LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void unpad_rows_kernel(const float* __restrict__ src, long n, int ld, float* __restrict__ dst, int d) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = n * (long)d;
+    if (i >= total) return;
+    long r = i / d; int col = (int)(i - r * d);
+    dst[i] = src[r * (long)ld + col];
+}
+void launch_unpad_rows(Ctx* c, const float* src, int64_t n, int ld, float* dst, int d) {
+    if (n <= 0) return;
+    unpad_rows_kernel<<<dim3((unsigned)ceil_div(n * d, 256)), dim3(256), 0, c->stream>>>(src, n, ld, dst, d);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact distance matrix
+// ------------------------------------------------------------------------------------------------
+constexpr int DC = 32;          // floats per row per staged chunk (one 128-byte line)
+constexpr int TILE_ROWS = 256;  // rows per workgroup == threads per workgroup
+constexpr int XS_LD = DC + 4;   // LDS row stride in floats: 144 B keeps 16-B alignment, conflict-free
+
+template <int METRIC, int QT>
+__global__ __launch_bounds__(256) void dist_exact_kernel(const float* __restrict__ X, long n, int ld,
+                                                         const float* __restrict__ Qt, int B, float* __restrict__ D,
+                                                         long ldD, int n_qg, long n_tiles,
+                                                         const unsigned char* __restrict__ elig) {
+    __shared__ __attribute__((aligned(16))) float xs[TILE_ROWS * XS_LD];
+    // XCD-aware decomposition: block b runs on XCD b%8; give each XCD whole row tiles (all query groups).
+    const long L = blockIdx.x;
+    const int xcd = (int)(L & 7);
+    const long slot = L >> 3;
+    const long tile = (slot / n_qg) * 8 + xcd;
+    const int qg = (int)(slot % n_qg);
+    if (tile >= n_tiles) return;
+
+    const int t = threadIdx.x;
+    const long row0 = tile * TILE_ROWS;
+    const int q0 = qg * QT;
+
+    float acc[QT];
+#pragma unroll
+    for (int q = 0; q < QT; q++) acc[q] = 0.0f;
+
+    // loader: thread t fetches float4 #(j*256+t) of the 256x32 tile -> row j*32 + t/8, column 4*(t%8)
+    const int lrow = t >> 3, lc4 = (t & 7) * 4;
+    f32x4 pre[8];
+    const float* xrow[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        long r = row0 + j * 32 + lrow;
+        if (r > n - 1) r = n - 1;              // tail rows re-read the last row; their results are not stored
+        xrow[j] = X + r * (long)ld + lc4;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) pre[j] = *reinterpret_cast<const f32x4*>(xrow[j]);
+
+    const int nchunks = ld / DC;
+    for (int c = 0; c < nchunks; c++) {
+        __syncthreads();  // everyone finished reading the previous chunk
+#pragma unroll
+        for (int j = 0; j < 8; j++) *reinterpret_cast<f32x4*>(&xs[(j * 32 + lrow) * XS_LD + lc4]) = pre[j];
+        __syncthreads();
+        {   // prefetch the next chunk into registers while this one is consumed (the last iteration
+            // harmlessly re-reads its own chunk: keeps the loads unconditional and `pre` in VGPRs)
+            const int cn = (c + 1 < nchunks) ? c + 1 : c;
+#pragma unroll
+            for (int j = 0; j < 8; j++) pre[j] = *reinterpret_cast<const f32x4*>(xrow[j] + cn * DC);
+        }
+        // query values: Qt is the per-query-group transposed copy [qg][col][QT], so the QT values that
+        // multiply element `col` are contiguous -> one scalar load per element, operands stay in SGPRs.
+        const float* __restrict__ qt = Qt + ((long)qg * ld + (long)c * DC) * QT;
+#pragma unroll 1
+        for (int i4 = 0; i4 < DC / 4; i4++) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[t * XS_LD + i4 * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float xe = x[e];
+                const float* __restrict__ qrow = qt + (i4 * 4 + e) * QT;
+#pragma unroll
+                for (int q = 0; q < QT; q++) acc[q] = acc_step<METRIC>(acc[q], qrow[q], xe);
+            }
+        }
+    }
+    const long row = row0 + t;
+    if (row < n) {
+        const bool ok = elig ? (elig[row] != 0) : true;
+#pragma unroll
+        for (int q = 0; q < QT; q++) {
+            if (q0 + q < B) {
+                float v = ok ? acc_finish<METRIC>(acc[q]) : __uint_as_float(EXCLUDED_BITS);
+                D[(long)(q0 + q) * ldD + row] = v;
+            }
+        }
+    }
+}
+
+// Qt[(qg*ld + col)*QT + qq] = Q[min(qg*QT+qq, B-1)][col]
+__global__ __launch_bounds__(256) void transpose_queries_kernel(const float* __restrict__ Q, int B, int ld, int QT, int n_qg, float* __restrict__ Qt) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)n_qg * ld * QT;
+    if (i >= total) return;
+    int qq = (int)(i % QT); long r = i / QT; int col = (int)(r % ld); int qg = (int)(r / ld);
+    int q = qg * QT + qq; if (q > B - 1) q = B - 1;
+    Qt[i] = Q[(long)q * ld + col];
+}
+
+template <int METRIC, int QT>
+static void launch_dist_exact_t(Ctx* c, const float* X, int64_t n, int ld, const float* Q, int B, float* D, int64_t ldD,
+                                const uint8_t* elig) {
+    const int n_qg = (int)ceil_div(B, QT);
+    const long n_tiles = ceil_div(n, TILE_ROWS);
+    const long tiles8 = round_up(n_tiles, 8);
+    const long grid = tiles8 * n_qg;
+    float* Qt = c->salloc<float>((size_t)n_qg * ld * QT);
+    {
+        long total = (long)n_qg * ld * QT;
+        transpose_queries_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, c->stream>>>(Q, B, ld, QT, n_qg, Qt);
+        LAUNCH_CHECK();
+    }
+    dist_exact_kernel<METRIC, QT><<<dim3((unsigned)grid), dim3(256), 0, c->stream>>>(X, n, ld, Qt, B, D, ldD, n_qg, n_tiles, elig);
+    LAUNCH_CHECK();
+}
+template <int METRIC>
+static void launch_dist_exact_m(Ctx* c, const float* X, int64_t n, int ld, const float* Q, int B, float* D, int64_t ldD,
+                                const uint8_t* elig) {
+    if (B <= 1) launch_dist_exact_t<METRIC, 1>(c, X, n, ld, Q, B, D, ldD, elig);
+    else if (B <= 2) launch_dist_exact_t<METRIC, 2>(c, X, n, ld, Q, B, D, ldD, elig);
+    else if (B <= 4) launch_dist_exact_t<METRIC, 4>(c, X, n, ld, Q, B, D, ldD, elig);
+    else if (B <= 8) launch_dist_exact_t<METRIC, 8>(c, X, n, ld, Q, B, D, ldD, elig);
+    else launch_dist_exact_t<METRIC, 16>(c, X, n, ld, Q, B, D, ldD, elig);
+}
+void launch_dist_exact(Ctx* c, int metric, const float* X, int64_t n, int ld, const float* Q, int B, float* D, int64_t ldD,
+                       const uint8_t* elig) {
+    if (n <= 0 || B <= 0) return;
+    ProfScope ps(c, "dist_exact");
+    switch (metric) {
+        case COMET_L2: launch_dist_exact_m<COMET_L2>(c, X, n, ld, Q, B, D, ldD, elig); break;
+        case COMET_L2SQ: launch_dist_exact_m<COMET_L2SQ>(c, X, n, ld, Q, B, D, ldD, elig); break;
+        default: launch_dist_exact_m<COMET_COSINE>(c, X, n, ld, Q, B, D, ldD, elig); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a handful of pairs, one thread each (comet.Distance singletons; not a throughput path)
+// ------------------------------------------------------------------------------------------------
+__global__ void dist_pairs_kernel(int metric, const float* __restrict__ A, const float* __restrict__ Bv, int npairs, int d,
+                                  int a_stride, int b_stride, float* __restrict__ out) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    const float* a = A + (long)p * a_stride;
+    const float* b = Bv + (long)p * b_stride;
+    float acc = 0.0f;
+    if (metric == COMET_COSINE) { for (int i = 0; i < d; i++) acc = acc_step<COMET_COSINE>(acc, a[i], b[i]); out[p] = acc_finish<COMET_COSINE>(acc); }
+    else {
+        for (int i = 0; i < d; i++) acc = acc_step<COMET_L2SQ>(acc, a[i], b[i]);
+        out[p] = metric == COMET_L2 ? acc_finish<COMET_L2>(acc) : acc;
+    }
+}
+void launch_dist_pairs(Ctx* c, int metric, const float* A, const float* Bv, int npairs, int d, int a_stride, int b_stride, float* out) {
+    if (npairs <= 0) return;
+    dist_pairs_kernel<<<dim3((unsigned)ceil_div(npairs, 64)), dim3(64), 0, c->stream>>>(metric, A, Bv, npairs, d, a_stride, b_stride, out);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// SplitMix64 synthetic data; element i uses counter offset+i
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void synth_fill_kernel(unsigned long long seed, unsigned long long offset, unsigned long long n, float* __restrict__ out) {
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned long long z = seed + (offset + i + 1ull) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+        out[i] = 2.0f * u - 1.0f;
+    }
+}
+void launch_synth_fill(Ctx* c, uint64_t seed, uint64_t offset, uint64_t n, float* out) {
+    if (!n) return;
+    unsigned grid = (unsigned)std::min<uint64_t>(ceil_div((int64_t)n, 256), 256 * 32);
+    synth_fill_kernel<<<dim3(grid), dim3(256), 0, c->stream>>>(seed, offset, n, out);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// eligibility bytes and id gather
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sorted_contains(const unsigned* __restrict__ a, int n, unsigned v) {
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo < n && a[lo] == v;
+}
+__global__ __launch_bounds__(256) void build_elig_kernel(const unsigned* __restrict__ ids, long n, const unsigned* __restrict__ del, int nd,
+                                                         const unsigned* __restrict__ flt, int nf, unsigned char* __restrict__ elig) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned id = ids[i];
+    bool ok = true;
+    if (nd > 0 && sorted_contains(del, nd, id)) ok = false;          // deletedNodes.Contains(id) flat_index_search.go:256
+    if (ok && nf > 0 && !sorted_contains(flt, nf, id)) ok = false;   // docFilter.ShouldSkip(id)   flat_index_search.go:261
+    elig[i] = ok ? 1 : 0;
+}
+void launch_build_elig(Ctx* c, const uint32_t* ids, int64_t n, const uint32_t* deleted_sorted, int n_deleted,
+                       const uint32_t* filter_sorted, int n_filter, uint8_t* elig) {
+    if (n <= 0) return;
+    ProfScope ps(c, "build_elig");
+    build_elig_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, c->stream>>>(ids, n, deleted_sorted, n_deleted, filter_sorted, n_filter, elig);
+    LAUNCH_CHECK();
+}
+__global__ __launch_bounds__(256) void gather_u32_kernel(const unsigned* __restrict__ table, const unsigned* __restrict__ idx, long n, unsigned* __restrict__ out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned p = idx[i];
+    out[i] = p == 0xFFFFFFFFu ? 0u : table[p];
+}
+void launch_gather_u32(Ctx* c, const uint32_t* table, const uint32_t* idx, int64_t n, uint32_t* out) {
+    if (n <= 0) return;
+    gather_u32_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, c->stream>>>(table, idx, n, out);
+    LAUNCH_CHECK();
+}
+
+}  // namespace comet

@@ -1,0 +1,321 @@
+// kernels_select.hip — exact, deterministic top-K selection on gfx950.
+//
+// Replaces the reference's "sort everything, take k" (flat_index_search.go:277-291 and the identical
+// tails of the IVF / PQ / IVFPQ / HNSW searches). The reference sorts with an unstable sort keyed on
+// distance only, so the order among equal distances is undefined there; here it is canonical:
+// (score ascending, scan position ascending) — what a stable sort of the reference's candidate list
+// would give, and what the oracle implements.
+//
+// Algorithm (per query, all queries of a batch in the same launches):
+//   three radix-histogram passes over the candidate row (12 + 12 + 8 bits of the order-preserving
+//   uint32 image of the float score) find the K-th smallest key key* and r = how many candidates
+//   equal to key* belong to the answer; a count pass + an ordered gather pass then emit every
+//   candidate with key < key* plus the first r (by position) with key == key*; one workgroup per
+//   query finally sorts the K composites (key<<32 | position) in LDS (bitonic) and writes the row.
+// All passes are streaming reads of the distance matrix with 16-byte loads, histogram in LDS.
+#include "kernels.hpp"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace comet {
+
+constexpr int SEL_THREADS = 256;
+constexpr int SEL_EPT = 16;                         // elements per thread per chunk (4 x float4)
+constexpr int SEL_CHUNK = SEL_THREADS * SEL_EPT;    // 4096 candidates per workgroup
+constexpr int SEL_BINS = 4096;
+constexpr int SORT_MAX = 4096;                      // max K sorted in LDS
+
+int select_max_k() { return SORT_MAX; }
+
+struct SelState {
+    unsigned prefix;     // bits of key* decided so far
+    unsigned mask;       // which bits are decided
+    int remaining;       // rank of key* among candidates matching the prefix (1-based count still to take)
+    int kq;              // number of results for this query = min(K, #eligible)
+    int total;           // #eligible candidates
+    int less_cursor;     // atomic cursor for "key < key*" outputs
+    int pad0, pad1;
+};
+
+// order-preserving map float -> uint32 (ascending floats => ascending keys; -0 < +0)
+__device__ __forceinline__ unsigned f2key(unsigned u) { return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ unsigned key2f(unsigned k) { return (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; }
+
+// candidate participates iff not the EXCLUDED sentinel and not beyond the threshold
+__device__ __forceinline__ bool cand_ok(unsigned bits, float thr) {
+    if (bits == EXCLUDED_BITS) return false;
+    if (thr > 0.0f && __uint_as_float(bits) > thr) return false;   // `s.threshold > 0 && dist > s.threshold`
+    return true;
+}
+
+// load SEL_EPT consecutive candidates of one thread: positions base + t*16 .. +15 (clipped to cnt)
+__device__ __forceinline__ void load16(const float* __restrict__ row, long base, long cnt, unsigned (&v)[SEL_EPT], bool (&in)[SEL_EPT]) {
+    const long p0 = base + (long)threadIdx.x * SEL_EPT;
+    if (p0 + SEL_EPT <= cnt && ((reinterpret_cast<uintptr_t>(row + p0) & 15) == 0)) {
+#pragma unroll
+        for (int j = 0; j < SEL_EPT / 4; j++) {
+            f32x4 x = *reinterpret_cast<const f32x4*>(row + p0 + j * 4);
+            v[j * 4 + 0] = __float_as_uint(x[0]); v[j * 4 + 1] = __float_as_uint(x[1]);
+            v[j * 4 + 2] = __float_as_uint(x[2]); v[j * 4 + 3] = __float_as_uint(x[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < SEL_EPT; j++) in[j] = true;
+    } else {
+#pragma unroll
+        for (int j = 0; j < SEL_EPT; j++) {
+            in[j] = (p0 + j) < cnt;
+            v[j] = in[j] ? __float_as_uint(row[p0 + j]) : EXCLUDED_BITS;
+        }
+    }
+}
+
+// ---- pass: histogram of `bits` bits at `shift` among candidates matching the decided prefix --------
+__global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const float* __restrict__ D, long ldD, long C,
+                                                               const int* __restrict__ cnts, float thr,
+                                                               const SelState* __restrict__ st, int shift, int bits,
+                                                               unsigned* __restrict__ hist /*[B][SEL_BINS]*/) {
+    __shared__ unsigned lh[SEL_BINS];
+    const int q = blockIdx.y;
+    const long cnt = cnts ? (long)cnts[q] : C;
+    const long base = (long)blockIdx.x * SEL_CHUNK;
+    if (base >= cnt) return;
+    const int nb = 1 << bits;
+    for (int i = threadIdx.x; i < nb; i += SEL_THREADS) lh[i] = 0;
+    __syncthreads();
+    const unsigned prefix = st[q].prefix, mask = st[q].mask;
+    unsigned v[SEL_EPT]; bool in[SEL_EPT];
+    load16(D + (long)q * ldD, base, cnt, v, in);
+#pragma unroll
+    for (int j = 0; j < SEL_EPT; j++) {
+        if (in[j] && cand_ok(v[j], thr)) {
+            unsigned k = f2key(v[j]);
+            if ((k & mask) == prefix) atomicAdd(&lh[(k >> shift) & (nb - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    unsigned* gh = hist + (long)q * SEL_BINS;
+    for (int i = threadIdx.x; i < nb; i += SEL_THREADS) { unsigned c = lh[i]; if (c) atomicAdd(&gh[i], c); }
+}
+
+// ---- scan: one workgroup per query; pick the bin holding the `remaining`-th candidate ---------------
+__global__ __launch_bounds__(SEL_THREADS) void sel_scan_kernel(unsigned* __restrict__ hist, SelState* __restrict__ st,
+                                                               int shift, int bits, int K, int first) {
+    __shared__ unsigned part[SEL_THREADS];
+    __shared__ int s_bin; __shared__ unsigned s_before; __shared__ int s_remaining;
+    const int q = blockIdx.x;
+    const int nb = 1 << bits;
+    unsigned* gh = hist + (long)q * SEL_BINS;
+    const int per = (nb + SEL_THREADS - 1) / SEL_THREADS;   // bins per thread (contiguous)
+    const int b0 = threadIdx.x * per;
+    unsigned mine = 0;
+    for (int i = 0; i < per; i++) if (b0 + i < nb) mine += gh[b0 + i];
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    // serial exclusive scan by one thread (256 partials) — negligible
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int i = 0; i < SEL_THREADS; i++) { unsigned x = part[i]; part[i] = run; run += x; }
+        SelState s = st[q];
+        if (first) {
+            s.total = (int)run;
+            s.kq = (K <= 0 || (unsigned)K > run) ? (int)run : K;   // sanitizeK limiter.go:12-17
+            s.remaining = s.kq; s.prefix = 0; s.mask = 0; s.less_cursor = 0;
+        }
+        st[q] = s;
+        s_bin = -1; s_before = 0; s_remaining = s.remaining;
+    }
+    __syncthreads();
+    const int remaining = s_remaining;
+    if (remaining > 0) {
+        unsigned run = part[threadIdx.x];
+        for (int i = 0; i < per; i++) {
+            if (b0 + i < nb) {
+                unsigned c = gh[b0 + i];
+                if (run < (unsigned)remaining && run + c >= (unsigned)remaining) { s_bin = b0 + i; s_before = run; }
+                run += c;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && remaining > 0) {
+        SelState s = st[q];
+        s.prefix |= ((unsigned)s_bin) << shift;
+        s.mask |= ((unsigned)(nb - 1)) << shift;
+        s.remaining = remaining - (int)s_before;
+        st[q] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += SEL_THREADS) gh[i] = 0;   // ready for the next pass
+}
+
+// ---- count of candidates equal to key* per chunk ---------------------------------------------------
+__global__ __launch_bounds__(SEL_THREADS) void sel_count_eq_kernel(const float* __restrict__ D, long ldD, long C,
+                                                                   const int* __restrict__ cnts, float thr,
+                                                                   const SelState* __restrict__ st,
+                                                                   int* __restrict__ eqcnt, int nchunks) {
+    __shared__ int s_cnt;
+    const int q = blockIdx.y;
+    const long cnt = cnts ? (long)cnts[q] : C;
+    const long base = (long)blockIdx.x * SEL_CHUNK;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    if (base < cnt && st[q].kq > 0) {
+        const unsigned keystar = st[q].prefix;
+        unsigned v[SEL_EPT]; bool in[SEL_EPT];
+        load16(D + (long)q * ldD, base, cnt, v, in);
+        int mine = 0;
+#pragma unroll
+        for (int j = 0; j < SEL_EPT; j++) if (in[j] && cand_ok(v[j], thr) && f2key(v[j]) == keystar) mine++;
+        if (mine) atomicAdd(&s_cnt, mine);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) eqcnt[(long)q * nchunks + blockIdx.x] = s_cnt;
+}
+
+// exclusive prefix over chunks, one workgroup per query (in place)
+__global__ __launch_bounds__(SEL_THREADS) void sel_scan_eq_kernel(int* __restrict__ eqcnt, int nchunks) {
+    __shared__ int part[SEL_THREADS];
+    int* e = eqcnt + (long)blockIdx.x * nchunks;
+    const int per = (nchunks + SEL_THREADS - 1) / SEL_THREADS;
+    const int b0 = threadIdx.x * per;
+    int mine = 0;
+    for (int i = 0; i < per; i++) if (b0 + i < nchunks) mine += e[b0 + i];
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < SEL_THREADS; i++) { int x = part[i]; part[i] = run; run += x; } }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = 0; i < per; i++) if (b0 + i < nchunks) { int x = e[b0 + i]; e[b0 + i] = run; run += x; }
+}
+
+// ---- gather: emit composites (key<<32 | pos) of the selected candidates ---------------------------
+__global__ __launch_bounds__(SEL_THREADS) void sel_gather_kernel(const float* __restrict__ D, long ldD, long C,
+                                                                 const int* __restrict__ cnts, float thr,
+                                                                 SelState* __restrict__ st, const int* __restrict__ eqpre,
+                                                                 int nchunks, unsigned long long* __restrict__ comp, int comp_ld) {
+    __shared__ int wsum[SEL_THREADS / 64];
+    const int q = blockIdx.y;
+    const long cnt = cnts ? (long)cnts[q] : C;
+    const long base = (long)blockIdx.x * SEL_CHUNK;
+    if (base >= cnt) return;
+    const SelState s = st[q];
+    if (s.kq <= 0) return;
+    const unsigned keystar = s.prefix;
+    const int r = s.remaining;            // how many key*-equal candidates to take (in position order)
+    const int n_less = s.kq - r;          // all candidates with key < key*
+    unsigned v[SEL_EPT]; bool in[SEL_EPT];
+    load16(D + (long)q * ldD, base, cnt, v, in);
+    unsigned long long* out = comp + (long)q * comp_ld;
+    const long p0 = base + (long)threadIdx.x * SEL_EPT;
+    // pass 1: "less" candidates -> any free slot in [0, n_less) (order fixed later by the sort)
+    int my_eq = 0;
+#pragma unroll
+    for (int j = 0; j < SEL_EPT; j++) {
+        if (in[j] && cand_ok(v[j], thr)) {
+            unsigned k = f2key(v[j]);
+            if (k < keystar) {
+                int slot = atomicAdd(&st[q].less_cursor, 1);
+                out[slot] = ((unsigned long long)k << 32) | (unsigned)(p0 + j);
+            } else if (k == keystar) my_eq++;
+        }
+    }
+    // pass 2: ordered rank among equals: chunk prefix (eqpre) + threads before me + my own earlier ones
+    // wave-level inclusive scan via DPP-free shuffles, then cross-wave via LDS
+    int incl = my_eq;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { int y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    int before = eqpre[(long)q * nchunks + blockIdx.x];
+    for (int w = 0; w < wid; w++) before += wsum[w];
+    int rank = before + incl - my_eq;
+    if (my_eq && rank < r) {
+#pragma unroll
+        for (int j = 0; j < SEL_EPT; j++) {
+            if (in[j] && cand_ok(v[j], thr) && f2key(v[j]) == keystar) {
+                if (rank < r) out[n_less + rank] = ((unsigned long long)keystar << 32) | (unsigned)(p0 + j);
+                rank++;
+            }
+        }
+    }
+}
+
+// ---- final: sort K composites per query in LDS, write positions / scores / counts ------------------
+__global__ __launch_bounds__(1024) void sel_sort_kernel(const unsigned long long* __restrict__ comp, int comp_ld,
+                                                        const SelState* __restrict__ st, unsigned* __restrict__ out_pos,
+                                                        float* __restrict__ out_scores, int* __restrict__ out_counts, int k_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
+    const int q = blockIdx.x;
+    const int kq = st[q].kq;
+    int n2 = 1; while (n2 < kq) n2 <<= 1;
+    const unsigned long long* in = comp + (long)q * comp_ld;
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) sm[i] = i < kq ? in[i] : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    unsigned long long a = sm[i], b = sm[ixj];
+                    bool up = ((i & k) == 0);
+                    if ((a > b) == up) { sm[i] = b; sm[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int nw = kq < k_cap ? kq : k_cap;
+    for (int i = threadIdx.x; i < k_cap; i += blockDim.x) {
+        if (i < nw) {
+            unsigned long long c = sm[i];
+            out_pos[(long)q * k_cap + i] = (unsigned)(c & 0xFFFFFFFFull);
+            out_scores[(long)q * k_cap + i] = __uint_as_float(key2f((unsigned)(c >> 32)));
+        } else {
+            out_pos[(long)q * k_cap + i] = 0xFFFFFFFFu;
+            out_scores[(long)q * k_cap + i] = 0.0f;
+        }
+    }
+    if (threadIdx.x == 0) out_counts[q] = kq;
+}
+
+void launch_select_topk(Ctx* c, const float* D, int64_t ldD, int B, int64_t C, const int32_t* cnts, float thr, int K,
+                        uint32_t* out_pos, float* out_scores, int32_t* out_counts, int k_cap) {
+    if (B <= 0) return;
+    if (C <= 0) {  // nothing to select from: zero counts, cleared rows
+        c->zero(out_counts, sizeof(int32_t) * B);
+        HIP_CHECK(hipMemsetAsync(out_pos, 0xFF, sizeof(uint32_t) * (size_t)B * k_cap, c->stream));
+        c->zero(out_scores, sizeof(float) * (size_t)B * k_cap);
+        return;
+    }
+    const int64_t kmax = (K <= 0 || K > C) ? C : K;
+    if (kmax > SORT_MAX) COMET_FAIL(COMET_ERR_UNSUPPORTED, "top-k of %lld exceeds the on-device selection limit %d", (long long)kmax, SORT_MAX);
+    const int nchunks = (int)ceil_div(C, SEL_CHUNK);
+    SelState* st = c->salloc<SelState>(B);
+    unsigned* hist = c->salloc<unsigned>((size_t)B * SEL_BINS);
+    int* eqcnt = c->salloc<int>((size_t)B * nchunks);
+    int comp_ld = 1; while (comp_ld < kmax) comp_ld <<= 1;
+    unsigned long long* comp = c->salloc<unsigned long long>((size_t)B * comp_ld);
+    c->zero(st, sizeof(SelState) * B);
+    c->zero(hist, sizeof(unsigned) * (size_t)B * SEL_BINS);
+    dim3 grid(nchunks, B), blk(SEL_THREADS);
+    const int shifts[3] = {20, 8, 0}, bitsv[3] = {12, 12, 8};
+    for (int p = 0; p < 3; p++) {
+        { ProfScope ps(c, "select_hist");
+          sel_hist_kernel<<<grid, blk, 0, c->stream>>>(D, ldD, C, cnts, thr, st, shifts[p], bitsv[p], hist); LAUNCH_CHECK(); }
+        { ProfScope ps(c, "select_scan");
+          sel_scan_kernel<<<dim3(B), blk, 0, c->stream>>>(hist, st, shifts[p], bitsv[p], K, p == 0); LAUNCH_CHECK(); }
+    }
+    { ProfScope ps(c, "select_count_eq");
+      sel_count_eq_kernel<<<grid, blk, 0, c->stream>>>(D, ldD, C, cnts, thr, st, eqcnt, nchunks); LAUNCH_CHECK(); }
+    { ProfScope ps(c, "select_scan");
+      sel_scan_eq_kernel<<<dim3(B), blk, 0, c->stream>>>(eqcnt, nchunks); LAUNCH_CHECK(); }
+    { ProfScope ps(c, "select_gather");
+      sel_gather_kernel<<<grid, blk, 0, c->stream>>>(D, ldD, C, cnts, thr, st, eqcnt, nchunks, comp, comp_ld); LAUNCH_CHECK(); }
+    { ProfScope ps(c, "select_sort");
+      int threads = comp_ld >= 2048 ? 1024 : (comp_ld >= 512 ? 256 : 64);
+      sel_sort_kernel<<<dim3(B), dim3(threads), sizeof(unsigned long long) * comp_ld, c->stream>>>(comp, comp_ld, st, out_pos, out_scores, out_counts, k_cap);
+      LAUNCH_CHECK(); }
+}
+
+}  // namespace comet

@@ -1,0 +1,556 @@
+"""Host-side mirror of comet's index / search interfaces over the C ABI.
+
+Names and behaviour follow the reference's Go API so that the parity tests read like the reference's
+own tests:
+
+    idx = FlatIndex(ctx, 128, "l2_squared")            # comet.NewFlatIndex(128, comet.L2Squared)
+    idx.add(node_id, vector)                             # idx.Add(*NewVectorNodeWithID(id, v))
+    results = idx.new_search().with_query(q).with_k(10).execute()   # NewSearch().WithQuery().WithK().Execute()
+
+`VectorIndex` is index.go:32-63, `VectorSearch` index_search.go:141-279. What stays on the host here is
+exactly what stays in Go above the boundary: multi-query aggregation
+(aggregation.go:107-255), LimitResults / Autocut (limiter.go), argument validation. All distance
+arithmetic, list scans and top-k selection run in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Iterable, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import CometError, SearchParams, ZeroVectorError, check  # noqa: F401
+
+EUCLIDEAN, L2_SQUARED, COSINE = "l2", "l2_squared", "cosine"          # DistanceKind distance.go:19-39
+_METRIC = {EUCLIDEAN: _lib.L2, L2_SQUARED: _lib.L2SQ, COSINE: _lib.COSINE}
+SUM_AGGREGATION, MAX_AGGREGATION, MEAN_AGGREGATION = "sum", "max", "mean"  # aggregation.go
+
+
+class UnknownDistanceKind(ValueError):
+    """comet.ErrUnknownDistanceKind (distance.go:9)"""
+
+
+def _metric_code(kind: str) -> int:
+    if kind not in _METRIC:
+        raise UnknownDistanceKind("unknown distance kind")
+    return _METRIC[kind]
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Context:
+    """One GPU: HIP device + stream + scratch arena (comet_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.comet_ctx_create(int(device), C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.comet_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.lib.comet_ctx_sync(self.h))
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.comet_ctx_stream(self.h) or 0)
+
+    # raw device memory (for callers that keep queries / results resident in HBM)
+    def alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        check(self.lib.comet_dev_alloc(self.h, int(nbytes), C.byref(p)))
+        return int(p.value)
+
+    def free(self, ptr: int):
+        check(self.lib.comet_dev_free(self.h, C.c_void_p(ptr)))
+
+    def upload(self, ptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        check(self.lib.comet_memcpy_h2d(self.h, C.c_void_p(ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def download(self, ptr: int, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        check(self.lib.comet_memcpy_d2h(self.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes))
+        return out
+
+    def synth_fill(self, ptr: int, seed: int, offset: int, n: int):
+        check(self.lib.comet_synth_fill_dev(self.h, C.c_uint64(seed), C.c_uint64(offset), C.c_uint64(n), C.c_void_p(ptr)))
+
+    # profiling
+    def profile(self, on: bool = True):
+        check(self.lib.comet_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self.lib.comet_profile_reset(self.h))
+
+    def profile_get(self, prefix: str) -> tuple[float, int]:
+        ms, n = C.c_double(), C.c_int64()
+        check(self.lib.comet_profile_get(self.h, prefix.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def profile_dump(self) -> dict[str, tuple[float, int]]:
+        buf = C.create_string_buffer(1 << 16)
+        check(self.lib.comet_profile_dump(self.h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, n = line.rsplit(" ", 2)
+            out[name] = (float(ms), int(n))
+        return out
+
+    # comet.Distance singletons (distance.go:50-81) evaluated by the device kernels
+    def distance(self, kind: str, a, b) -> float:
+        a, b = _f32(a), _f32(b)
+        out = C.c_float()
+        check(self.lib.comet_distance(self.h, _metric_code(kind), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                      int(a.shape[0]), C.byref(out)))
+        return np.float32(out.value)
+
+    def distance_batch(self, kind: str, queries, target) -> np.ndarray:
+        q, t = _f32(queries), _f32(target)
+        out = np.empty(q.shape[0], dtype=np.float32)
+        check(self.lib.comet_distance_batch(self.h, _metric_code(kind), q.ctypes.data_as(C.c_void_p), int(q.shape[0]),
+                                            t.ctypes.data_as(C.c_void_p), int(t.shape[0]), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def preprocess(self, kind: str, x) -> np.ndarray:
+        x = _f32(x)
+        out = np.empty_like(x)
+        check(self.lib.comet_preprocess(self.h, _metric_code(kind), x.ctypes.data_as(C.c_void_p), int(x.shape[0]),
+                                        out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def kmeans(self, vectors, k: int, kind: str = L2_SQUARED, max_iter: int = 20):
+        """KMeans / KMeansSubspace (clustering.go:60,112). Returns (centroids, assignments) or (None, None)."""
+        v = _f32(vectors)
+        if v.ndim != 2 or v.shape[0] == 0 or k <= 0:
+            return None, None
+        n, d = v.shape
+        ke = min(k, n)
+        cent = np.empty((ke, d), dtype=np.float32)
+        assign = np.empty(n, dtype=np.int32)
+        kout = C.c_int32()
+        check(self.lib.comet_kmeans(self.h, v.ctypes.data_as(C.c_void_p), n, d, k, _metric_code(kind), max_iter,
+                                    cent.ctypes.data_as(C.c_void_p), assign.ctypes.data_as(C.c_void_p), C.byref(kout)))
+        return cent[:kout.value], assign
+
+    def nearest_centroid(self, vectors, centroids, kind: str) -> np.ndarray:
+        v, cts = _f32(vectors), _f32(centroids)
+        if v.ndim == 1:
+            v = v[None, :]
+        out = np.empty(v.shape[0], dtype=np.int32)
+        check(self.lib.comet_nearest_centroid(self.h, v.ctypes.data_as(C.c_void_p), v.shape[0], v.shape[1],
+                                              cts.ctypes.data_as(C.c_void_p), cts.shape[0], _metric_code(kind),
+                                              out.ctypes.data_as(C.c_void_p)))
+        return out
+
+
+@dataclass
+class VectorResult:
+    """VectorResult{Node, Score} index_search.go:84-90 (the node is identified by its id)."""
+    id: int
+    score: np.float32
+
+
+# ---- host-side post-processing that the reference also runs on the host ----------------------------
+def sanitize_k(k: int, max_results: int) -> int:           # limiter.go:12-17
+    return max_results if (k <= 0 or k > max_results) else k
+
+
+def autocut(y: Sequence[float], cutoff: int) -> int:        # limiter.go:81-118
+    y = np.asarray(y, dtype=np.float32)
+    n = len(y)
+    if n <= 1:
+        return n
+    step = np.float32(1.0) / (np.float32(n) - np.float32(1.0))
+    with np.errstate(all="ignore"):
+        diff = [(y[i] - y[0]) / (y[n - 1] - y[0]) - (np.float32(0.0) + np.float32(i) * step) for i in range(n)]
+    extrema = 0
+    for i in range(1, n):
+        if i == n - 1:
+            if i - 2 < 0:
+                continue
+            hit = diff[i] > diff[i - 1] and diff[i] > diff[i - 2]
+        else:
+            hit = diff[i] > diff[i - 1] and diff[i] > diff[i + 1]
+        if hit:
+            extrema += 1
+            if extrema >= cutoff:
+                return i
+    return n
+
+
+def aggregate(results: list[VectorResult], kind: str) -> list[VectorResult]:   # aggregation.go:107-255
+    if not results:
+        return results
+    order, scores = [], {}
+    for r in results:
+        if r.id not in scores:
+            scores[r.id] = []
+            order.append(r.id)
+        scores[r.id].append(np.float32(r.score))
+    out = []
+    for i in order:
+        s = scores[i]
+        if kind == SUM_AGGREGATION:
+            v = np.float32(0)
+            for x in s:
+                v = np.float32(v + x)
+        elif kind == MAX_AGGREGATION:
+            v = s[0]
+            for x in s[1:]:
+                if x > v:
+                    v = x
+        elif kind == MEAN_AGGREGATION:
+            v = np.float32(0)
+            for x in s:
+                v = np.float32(v + x)
+            v = np.float32(v / np.float32(len(s)))
+        else:
+            raise ValueError(f"unknown aggregation kind: {kind}")
+        out.append(VectorResult(i, v))
+    out.sort(key=lambda r: r.score)   # stable; the reference's order among ties is undefined
+    return out
+
+
+class VectorSearch:
+    """Fluent search builder (VectorSearch, index_search.go:141-279)."""
+
+    def __init__(self, index: "VectorIndex"):
+        self.index = index
+        self.queries: list[np.ndarray] = []
+        self.node_ids: list[int] = []
+        self.k = 10                      # defaults: flat_index.go:305-311
+        self.nprobes = index.default_nprobes()
+        self.ef_search = 0
+        self.threshold = 0.0
+        self.aggregation = ""
+        self.cutoff = -1
+        self.document_ids: list[int] = []
+        self.mode = 0
+
+    def with_query(self, *queries) -> "VectorSearch":
+        self.queries = [np.asarray(q, dtype=np.float32) for q in queries]
+        return self
+
+    def with_node(self, *node_ids) -> "VectorSearch":
+        self.node_ids = [int(i) for i in node_ids]
+        return self
+
+    def with_k(self, k: int) -> "VectorSearch":
+        self.k = int(k)
+        return self
+
+    def with_n_probes(self, n: int) -> "VectorSearch":
+        self.nprobes = int(n)
+        return self
+
+    def with_ef_search(self, ef: int) -> "VectorSearch":
+        self.ef_search = int(ef)
+        return self
+
+    def with_threshold(self, t: float) -> "VectorSearch":
+        self.threshold = float(t)
+        return self
+
+    def with_score_aggregation(self, kind: str) -> "VectorSearch":
+        self.aggregation = kind
+        return self
+
+    def with_cutoff(self, cutoff: int) -> "VectorSearch":
+        self.cutoff = int(cutoff)
+        return self
+
+    def with_document_ids(self, *ids) -> "VectorSearch":
+        self.document_ids = [int(i) for i in ids]
+        return self
+
+    def with_mode(self, mode: int) -> "VectorSearch":
+        """0 auto, 1 strict exact-arithmetic kernels, 2 force the fast path (backend knob, not in the reference)."""
+        self.mode = int(mode)
+        return self
+
+    def execute(self) -> list[VectorResult]:
+        # flat_index_search.go:109-165 (identical shells in the IVF / PQ / IVFPQ / HNSW searches)
+        if not self.queries and not self.node_ids:
+            raise ValueError("must specify either queries or node IDs")
+        agg = self.aggregation or SUM_AGGREGATION
+        if agg not in (SUM_AGGREGATION, MAX_AGGREGATION, MEAN_AGGREGATION):
+            raise ValueError(f"unknown aggregation kind: {agg}")
+        all_q = list(self.queries)
+        if self.node_ids:
+            all_q += self.index._lookup_node_vectors(self.node_ids)
+        for q in all_q:
+            if q.ndim != 1 or q.shape[0] != self.index.dim:
+                raise ValueError(f"query dimension mismatch: expected {self.index.dim}, got {q.shape[0] if q.ndim == 1 else q.shape}")
+        self.index._check_searchable()
+        k_cap = self.index._k_cap(self.k, self.nprobes)
+        ids, scores, counts = self.index.search_batch(np.stack(all_q), self.k, threshold=self.threshold, nprobes=self.nprobes,
+                                                      ef_search=self.ef_search, document_ids=self.document_ids, k_cap=k_cap,
+                                                      mode=self.mode)
+        all_results = [VectorResult(int(ids[b, i]), np.float32(scores[b, i])) for b in range(len(all_q)) for i in range(min(counts[b], k_cap))]
+        res = aggregate(all_results, agg)
+        res = res[:sanitize_k(self.k, len(res))]                 # LimitResults limiter.go:28
+        if self.cutoff != -1 and res:                            # AutocutResults limiter.go:52
+            res = res[:autocut([r.score for r in res], self.cutoff)]
+        return res
+
+
+class VectorIndex:
+    """Common part of the GPU indexes (VectorIndex, index.go:32-63)."""
+
+    kind_name = "?"
+
+    def __init__(self, ctx: Context, dim: int, distance_kind: str):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.dim = int(dim)
+        self.distance_kind_ = distance_kind
+        self.h = C.c_void_p()
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.comet_index_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- VectorIndex surface --
+    def dimensions(self) -> int:
+        return int(self.lib.comet_index_dim(self.h))
+
+    def distance_kind(self) -> str:
+        return self.distance_kind_
+
+    def kind(self) -> str:
+        return self.kind_name
+
+    def trained(self) -> bool:
+        return bool(self.lib.comet_index_trained(self.h))
+
+    def __len__(self) -> int:
+        return int(self.lib.comet_index_size(self.h))
+
+    def default_nprobes(self) -> int:
+        return int(self.lib.comet_index_default_nprobes(self.h))
+
+    def train(self, vectors) -> None:
+        v = _f32(vectors)
+        if v.ndim != 2 or (v.shape[0] and v.shape[1] != self.dim):
+            raise ValueError(f"vector dimension mismatch: expected {self.dim}, got {v.shape[-1] if v.size else 0}")
+        check(self.lib.comet_index_train(self.h, v.ctypes.data_as(C.c_void_p), v.shape[0]))
+
+    def add(self, node_id: int, vector, write_back: bool = True) -> None:
+        """VectorIndex.Add. Like the reference (flat_index.go:182) a cosine index normalises the caller's
+        float32 array in place when `vector` is a writable float32 ndarray."""
+        v = np.asarray(vector, dtype=np.float32)
+        if v.ndim != 1 or v.shape[0] != self.dim:
+            raise ValueError(f"vector dimension mismatch: expected {self.dim}, got {v.shape[0] if v.ndim == 1 else v.shape}")
+        out = self.add_batch(np.array([node_id], dtype=np.uint32), v[None, :], return_normalized=True)
+        if write_back and isinstance(vector, np.ndarray) and vector.dtype == np.float32 and vector.flags.writeable:
+            vector[...] = out[0]
+
+    def add_batch(self, ids, vectors, return_normalized: bool = False):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        v = _f32(vectors)
+        if v.ndim != 2 or v.shape[1] != self.dim:
+            raise ValueError(f"vector dimension mismatch: expected {self.dim}, got {v.shape[-1]}")
+        if ids.shape[0] != v.shape[0]:
+            raise ValueError("ids / vectors length mismatch")
+        added = C.c_int64()
+        norm = np.empty_like(v) if return_normalized else None
+        rc = self.lib.comet_index_add(self.h, ids.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), v.shape[0],
+                                      C.byref(added), norm.ctypes.data_as(C.c_void_p) if norm is not None else None)
+        self.last_added = added.value
+        check(rc)
+        return norm
+
+    def remove(self, node_id: int) -> None:
+        check(self.lib.comet_index_remove(self.h, C.c_uint32(int(node_id))))
+
+    def flush(self) -> None:
+        check(self.lib.comet_index_flush(self.h))
+
+    def new_search(self) -> VectorSearch:
+        return VectorSearch(self)
+
+    # -- batched entry (one call = B independent queries) --
+    def search_batch(self, queries, k: int, threshold: float = 0.0, nprobes: int = 0, ef_search: int = 0,
+                     document_ids: Iterable[int] = (), k_cap: int | None = None, mode: int = 0):
+        q = _f32(queries)
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"query dimension mismatch: expected {self.dim}, got {q.shape[-1]}")
+        B = q.shape[0]
+        if k_cap is None:
+            k_cap = self._k_cap(k, nprobes)
+        flt = np.ascontiguousarray(list(document_ids), dtype=np.uint32)
+        p = SearchParams(k=int(k), threshold=float(threshold), nprobes=int(nprobes), ef_search=int(ef_search),
+                         filter_ids=flt.ctypes.data_as(C.POINTER(C.c_uint32)) if flt.size else None, n_filter=int(flt.size), mode=int(mode))
+        ids = np.zeros((B, k_cap), dtype=np.uint32)
+        scores = np.zeros((B, k_cap), dtype=np.float32)
+        counts = np.zeros(B, dtype=np.int32)
+        check(self.lib.comet_index_search(self.h, q.ctypes.data_as(C.c_void_p), B, C.byref(p), ids.ctypes.data_as(C.c_void_p),
+                                          scores.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), k_cap))
+        return ids, scores, counts
+
+    def search_batch_dev(self, q_dev: int, B: int, k: int, out_ids_dev: int, out_scores_dev: int, out_counts_dev: int,
+                         k_cap: int, threshold: float = 0.0, nprobes: int = 0, ef_search: int = 0, mode: int = 0):
+        """Device-resident queries and outputs; asynchronous on the context's stream."""
+        p = SearchParams(k=int(k), threshold=float(threshold), nprobes=int(nprobes), ef_search=int(ef_search),
+                         filter_ids=None, n_filter=0, mode=int(mode))
+        check(self.lib.comet_index_search_dev(self.h, C.c_void_p(q_dev), int(B), C.byref(p), C.c_void_p(out_ids_dev),
+                                              C.c_void_p(out_scores_dev), C.c_void_p(out_counts_dev), int(k_cap)))
+
+    # -- helpers --
+    def _k_cap(self, k: int, nprobes: int) -> int:
+        n = len(self)
+        return max(1, n if (k <= 0 or k > n) else k)
+
+    def _check_searchable(self) -> None:
+        pass
+
+    def list_size(self, lst: int = 0) -> int:
+        out = C.c_int64()
+        check(self.lib.comet_index_list_size(self.h, int(lst), C.byref(out)))
+        return out.value
+
+    def list_read(self, lst: int = 0, codes_width: int = 0, want_vectors: bool = False):
+        n = self.list_size(lst)
+        ids = np.empty(n, dtype=np.uint32)
+        codes = np.empty((n, codes_width), dtype=np.uint8) if codes_width else None
+        vecs = np.empty((n, self.dim), dtype=np.float32) if want_vectors else None
+        check(self.lib.comet_index_list_read(self.h, int(lst), ids.ctypes.data_as(C.c_void_p),
+                                             codes.ctypes.data_as(C.c_void_p) if codes is not None else None,
+                                             vecs.ctypes.data_as(C.c_void_p) if vecs is not None else None))
+        return ids, codes, vecs
+
+    def _lookup_node_vectors(self, node_ids: list[int]) -> list[np.ndarray]:
+        # flatIndexSearch.lookupNodeVectors flat_index_search.go:171-196
+        raise NotImplementedError
+
+
+class FlatIndex(VectorIndex):
+    """comet.NewFlatIndex(dim, distanceKind) — flat_index.go:127."""
+    kind_name = "flat"
+
+    def __init__(self, ctx: Context, dim: int, distance_kind: str):
+        if dim <= 0:
+            raise ValueError("dimension must be positive")
+        super().__init__(ctx, dim, distance_kind)
+        check(self.lib.comet_flat_create(ctx.h, dim, _metric_code(distance_kind), C.byref(self.h)))
+        self._deleted: set[int] = set()
+
+    def remove(self, node_id: int) -> None:
+        super().remove(node_id)
+        self._deleted.add(int(node_id))
+
+    def flush(self) -> None:
+        super().flush()
+        self._deleted.clear()
+
+    def _lookup_node_vectors(self, node_ids):
+        ids, _, vecs = self.list_read(0, want_vectors=True)
+        out = []
+        for nid in node_ids:
+            hits = np.nonzero(ids == np.uint32(nid))[0]
+            if hits.size == 0:
+                raise KeyError(f"node ID {nid} not found in index")
+            if nid in self._deleted:
+                raise KeyError(f"node ID {nid} not found in index (deleted)")
+            out.append(vecs[hits[0]].copy())
+        return out
+
+
+class _TrainedIndex(VectorIndex):
+    not_trained_msg = "index must be trained before searching"
+
+    def _check_searchable(self) -> None:
+        if not self.trained():
+            raise RuntimeError(self.not_trained_msg)
+
+    def centroids(self, nlist: int) -> np.ndarray:
+        out = np.empty((nlist, self.dim), dtype=np.float32)
+        check(self.lib.comet_index_get_centroids(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def codebooks(self, M: int, ksub: int, dsub: int) -> np.ndarray:
+        out = np.empty((M, ksub, dsub), dtype=np.float32)
+        check(self.lib.comet_index_get_codebooks(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+
+class IVFIndex(_TrainedIndex):
+    """comet.NewIVFIndex(dim, distanceKind, nlist) — ivf_index.go:140."""
+    kind_name = "ivf"
+
+    def __init__(self, ctx: Context, dim: int, distance_kind: str, nlist: int):
+        if dim <= 0:
+            raise ValueError("dimension must be positive")
+        if nlist <= 0:
+            raise ValueError("nlist must be positive")
+        super().__init__(ctx, dim, distance_kind)
+        self.nlist = nlist
+        check(self.lib.comet_ivf_create(ctx.h, dim, _metric_code(distance_kind), nlist, C.byref(self.h)))
+
+    def _k_cap(self, k, nprobes):
+        return max(1, len(self) if (k <= 0 or k > len(self)) else k)
+
+
+class PQIndex(_TrainedIndex):
+    """comet.NewPQIndex(dim, distanceKind, M, Nbits) — pq_index.go:135."""
+    kind_name = "pq"
+    not_trained_msg = "index not trained"     # pq_index_search.go:224
+
+    def __init__(self, ctx: Context, dim: int, distance_kind: str, M: int, nbits: int):
+        _validate_pq(dim, M, nbits)
+        super().__init__(ctx, dim, distance_kind)
+        self.M, self.nbits, self.ksub, self.dsub = M, nbits, 1 << nbits, dim // M
+        check(self.lib.comet_pq_create(ctx.h, dim, _metric_code(distance_kind), M, nbits, C.byref(self.h)))
+
+
+class IVFPQIndex(_TrainedIndex):
+    """comet.NewIVFPQIndex(dim, distanceKind, nlist, m, nbits) — ivfpq_index.go:113."""
+    kind_name = "ivfpq"
+
+    def __init__(self, ctx: Context, dim: int, distance_kind: str, nlist: int, M: int, nbits: int):
+        if dim <= 0:
+            raise ValueError("dimension must be positive")
+        if nlist <= 0:
+            raise ValueError("nlist must be positive")
+        _validate_pq(dim, M, nbits)
+        super().__init__(ctx, dim, distance_kind)
+        self.nlist, self.M, self.nbits, self.ksub, self.dsub = nlist, M, nbits, 1 << nbits, dim // M
+        check(self.lib.comet_ivfpq_create(ctx.h, dim, _metric_code(distance_kind), nlist, M, nbits, C.byref(self.h)))
+
+
+def _validate_pq(dim: int, M: int, nbits: int) -> None:   # pq_index.go:135-155
+    if dim <= 0:
+        raise ValueError("dimension must be positive")
+    if M <= 0:
+        raise ValueError("parameter M must be positive")
+    if dim % M != 0:
+        raise ValueError(f"dimension {dim} must be divisible by M {M}")
+    if nbits <= 0 or nbits > 16:
+        raise ValueError("parameter Nbits must be in [1,16]")
+
+
+def default_nprobes(nlist: int) -> int:    # ivf_index.go:406-413
+    return int(math.sqrt(float(nlist)))

@@ -1,0 +1,173 @@
+/* comet_gpu.h — C ABI of the MI355X (gfx950) backend for wizenheimer/comet's vector-search hot path.
+ *
+ * This is the drop-in boundary: the entry points a cgo shim binds to implement comet's own Go
+ * interfaces (`VectorIndex` index.go:32-63, `VectorSearch` index_search.go:141-279, `TextIndex`
+ * index.go:65-81, `Distance` distance.go:50-81) on top of hand-written HIP kernels. Plain pointers
+ * and sizes only; no torch / C++ types. The Go-side binding is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns a comet_status (0 = OK); comet_last_error() gives a thread-local
+ *    message whose text mirrors the reference's fmt.Errorf strings where one exists.
+ *  - host-pointer entry points copy their inputs before returning (cgo may not retain Go pointers).
+ *  - `*_dev` entry points take DEVICE pointers (memory from comet_dev_alloc or any HIP allocation on
+ *    the context's device) and run asynchronously on the context's stream; comet_ctx_sync() waits.
+ *  - one search call = B independent queries -> B result rows (the Go shim maps the reference's
+ *    "multi-query Execute() aggregates into one list" semantics onto it, flat_index_search.go:143-153).
+ *  - result rows are sorted ascending by score; exact score ties are ordered by scan order (the
+ *    reference's own order among ties is undefined: unstable sort.Slice, flat_index_search.go:277).
+ *  - threading: any number of concurrent searches per index; mutators (train/add/remove/flush)
+ *    must be externally serialised against searches (the Go shim's RWMutex, flat_index.go:93).
+ */
+#ifndef COMET_GPU_H
+#define COMET_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COMET_API __attribute__((visibility("default")))
+
+typedef struct comet_ctx comet_ctx;     /* one per GPU (HIP device + stream + scratch arena) */
+typedef struct comet_index comet_index; /* Flat / IVF / PQ / IVFPQ / HNSW / BM25 */
+
+/* DistanceKind, distance.go:19-39 ("l2", "l2_squared", "cosine") */
+typedef enum { COMET_L2 = 0, COMET_L2SQ = 1, COMET_COSINE = 2 } comet_metric;
+
+/* VectorIndexKind, index.go */
+typedef enum { COMET_KIND_FLAT = 0, COMET_KIND_IVF = 1, COMET_KIND_PQ = 2, COMET_KIND_IVFPQ = 3,
+               COMET_KIND_HNSW = 4, COMET_KIND_BM25 = 5 } comet_kind;
+
+typedef enum {
+    COMET_OK = 0,
+    COMET_ERR_INVALID_ARG = 1,     /* constructor / argument validation (e.g. "dimension must be positive") */
+    COMET_ERR_DIM_MISMATCH = 2,    /* "query dimension mismatch: expected %d, got %d" flat_index_search.go:227 */
+    COMET_ERR_ZERO_VECTOR = 3,     /* ErrZeroVector distance.go:12 */
+    COMET_ERR_NOT_TRAINED = 4,     /* "index must be trained before searching" ivf_index_search.go:223 */
+    COMET_ERR_NOT_FOUND = 5,       /* "vector with ID %d not found" flat_index.go:233 */
+    COMET_ERR_ALREADY_DELETED = 6, /* "vector with ID %d already deleted" flat_index.go:236 */
+    COMET_ERR_TRAIN_DATA = 7,      /* "need at least %d vectors for training" ivfpq_index.go:186 */
+    COMET_ERR_HIP = 8,             /* HIP runtime failure */
+    COMET_ERR_NO_DEVICE = 9,       /* no usable gfx950 device */
+    COMET_ERR_UNSUPPORTED = 10,
+    COMET_ERR_UNKNOWN_METRIC = 11  /* ErrUnknownDistanceKind distance.go:9 */
+} comet_status;
+
+COMET_API const char* comet_last_error(void);
+COMET_API const char* comet_version(void);
+COMET_API int comet_device_count(int* out_count);
+
+/* ---- context ------------------------------------------------------------------------------ */
+COMET_API int comet_ctx_create(int device_id, comet_ctx** out);
+COMET_API int comet_ctx_destroy(comet_ctx* ctx);
+COMET_API int comet_ctx_sync(comet_ctx* ctx);
+/* raw HIP stream handle (hipStream_t) searches are enqueued on — for HIP-event timing by the caller */
+COMET_API void* comet_ctx_stream(comet_ctx* ctx);
+COMET_API int comet_dev_alloc(comet_ctx* ctx, size_t bytes, void** out_dev);
+COMET_API int comet_dev_free(comet_ctx* ctx, void* dev);
+COMET_API int comet_memcpy_h2d(comet_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+COMET_API int comet_memcpy_d2h(comet_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* SplitMix64 synthetic data, value = 2*((next>>40)*2^-24)-1 in [-1,1); element i of the stream uses
+ * counter (offset+i) — bit-identical to the oracle's orc_synth_fill. */
+COMET_API int comet_synth_fill_dev(comet_ctx* ctx, uint64_t seed, uint64_t offset, uint64_t n, float* out_dev);
+
+/* per-kernel timing (HIP events recorded on the context's stream around each launch) */
+COMET_API int comet_profile_enable(comet_ctx* ctx, int on);
+COMET_API int comet_profile_reset(comet_ctx* ctx);
+/* total milliseconds and launch count of kernels whose name starts with `prefix` since the last reset */
+COMET_API int comet_profile_get(comet_ctx* ctx, const char* prefix, double* out_total_ms, int64_t* out_launches);
+/* writes a '\n'-separated "name total_ms launches" listing into buf */
+COMET_API int comet_profile_dump(comet_ctx* ctx, char* buf, size_t cap);
+
+/* ---- Distance singletons (comet.Distance, distance.go:50-81) -------------------------------- */
+/* Calculate(a, b): distance.go:114/158/201 */
+COMET_API int comet_distance(comet_ctx* ctx, int metric, const float* a, const float* b, int d, float* out);
+/* CalculateBatch(queries, target): distance.go:123/167/218 */
+COMET_API int comet_distance_batch(comet_ctx* ctx, int metric, const float* queries, int nq, const float* target,
+                                   int d, float* out);
+/* Preprocess / PreprocessInPlace (out may alias x): distance.go:138-147,182-191,244-290 */
+COMET_API int comet_preprocess(comet_ctx* ctx, int metric, const float* x, int d, float* out);
+
+/* ---- k-means (clustering.go:60,112,259) ---------------------------------------------------- */
+/* KMeans / KMeansSubspace. out_centroids: min(k,n) x d; out_assign: n int32; *out_k = effective k */
+COMET_API int comet_kmeans(comet_ctx* ctx, const float* vecs, int64_t n, int d, int k, int metric, int max_iter,
+                           float* out_centroids, int32_t* out_assign, int* out_k);
+/* FindNearestCentroidIndex for a batch of vectors */
+COMET_API int comet_nearest_centroid(comet_ctx* ctx, const float* vecs, int64_t n, int d, const float* centroids,
+                                     int k, int metric, int32_t* out_index);
+
+/* ---- index lifecycle ------------------------------------------------------------------------ */
+COMET_API int comet_flat_create(comet_ctx* ctx, int dim, int metric, comet_index** out);  /* NewFlatIndex flat_index.go:127 */
+COMET_API int comet_ivf_create(comet_ctx* ctx, int dim, int metric, int nlist, comet_index** out); /* NewIVFIndex ivf_index.go:140 */
+COMET_API int comet_pq_create(comet_ctx* ctx, int dim, int metric, int M, int nbits, comet_index** out); /* NewPQIndex pq_index.go:135 */
+COMET_API int comet_ivfpq_create(comet_ctx* ctx, int dim, int metric, int nlist, int M, int nbits,
+                                 comet_index** out); /* NewIVFPQIndex ivfpq_index.go:113 */
+COMET_API int comet_index_destroy(comet_index* idx);
+
+COMET_API int comet_index_kind(const comet_index* idx);
+COMET_API int comet_index_dim(const comet_index* idx);
+COMET_API int comet_index_metric(const comet_index* idx);
+COMET_API int comet_index_trained(const comet_index* idx);
+COMET_API int64_t comet_index_size(const comet_index* idx); /* stored vectors incl. soft-deleted */
+/* default nprobes = floor(sqrt(nlist)) ivf_index.go:406-413; 0 for non-IVF kinds */
+COMET_API int comet_index_default_nprobes(const comet_index* idx);
+
+/* Train (VectorIndex.Train): vecs n x dim, host memory. No-op for Flat. */
+COMET_API int comet_index_train(comet_index* idx, const float* vecs, int64_t n);
+COMET_API int comet_index_train_dev(comet_index* idx, const float* vecs_dev, int64_t n);
+/* Add (VectorIndex.Add) for a batch; processed in order, stops at the first failing vector
+ * (*out_added = vectors added before the failure, like n sequential reference Add calls).
+ * If normalized_out != NULL (host API only) the preprocessed vectors are written back — the reference
+ * normalises the caller's slice in place for cosine (flat_index.go:182). */
+COMET_API int comet_index_add(comet_index* idx, const uint32_t* ids, const float* vecs, int64_t n,
+                              int64_t* out_added, float* normalized_out);
+COMET_API int comet_index_add_dev(comet_index* idx, const uint32_t* ids_dev, const float* vecs_dev, int64_t n,
+                                  int64_t* out_added);
+/* Remove (soft delete) one id — flat_index.go:216-249 */
+COMET_API int comet_index_remove(comet_index* idx, uint32_t id);
+/* Flush (hard-delete soft-deleted rows) — flat_index.go:268-296 */
+COMET_API int comet_index_flush(comet_index* idx);
+
+/* ---- search --------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t k;                  /* WithK; <=0 or > candidates => all (limiter.go:12-17) */
+    float threshold;            /* WithThreshold; active only if > 0 (flat_index_search.go:269) */
+    int32_t nprobes;            /* WithNProbes; <=0 or > nlist => nlist (ivf_index_search.go:233-236) */
+    int32_t ef_search;          /* WithEfSearch; <=0 => index default (hnsw_index_search.go:302-305) */
+    const uint32_t* filter_ids; /* WithDocumentIDs; NULL/0 => no filter (document_filter.go:27-30). HOST pointer. */
+    int32_t n_filter;
+    int32_t mode;               /* 0 = auto, 1 = strict exact-arithmetic kernels only, 2 = force fast path */
+} comet_search_params;
+
+/* B queries (B x dim, host) -> out_ids / out_scores (B x k_cap, host), out_counts[B] = number of
+ * results the reference would return for that query (rows hold min(count, k_cap) entries). */
+COMET_API int comet_index_search(comet_index* idx, const float* queries, int32_t B, const comet_search_params* p,
+                                 uint32_t* out_ids, float* out_scores, int32_t* out_counts, int32_t k_cap);
+/* Same with device-resident queries and outputs; asynchronous on the context's stream. */
+COMET_API int comet_index_search_dev(comet_index* idx, const float* queries_dev, int32_t B,
+                                     const comet_search_params* p, uint32_t* out_ids_dev, float* out_scores_dev,
+                                     int32_t* out_counts_dev, int32_t k_cap);
+
+/* ---- multi-GPU merge (the step after the RCCL all-gather of per-shard top-K; the reference's
+ * analogue is mergeResults storage_merge.go:13-46) -------------------------------------------- */
+/* in: R shards x B queries x k_cap (ids, scores ascending), counts R x B. Ties: lower shard first. */
+COMET_API int comet_merge_topk_dev(comet_ctx* ctx, const uint32_t* ids_dev, const float* scores_dev,
+                                   const int32_t* counts_dev, int32_t R, int32_t B, int32_t k_cap, int32_t k,
+                                   uint32_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev);
+
+/* ---- introspection --------------------------------------------------------------------------- */
+/* Read back trained state (host copies). centroids: nlist x dim, codebooks: M x Ksub x dsub. */
+COMET_API int comet_index_get_centroids(const comet_index* idx, float* out);
+COMET_API int comet_index_get_codebooks(const comet_index* idx, float* out);
+COMET_API int comet_index_list_size(const comet_index* idx, int32_t list, int64_t* out);
+/* ids (and, for PQ/IVFPQ, M-byte codes; for Flat/IVF, dim-float vectors) of one inverted list in Add
+ * order; list = 0 for Flat/PQ. Any output pointer may be NULL. */
+COMET_API int comet_index_list_read(const comet_index* idx, int32_t list, uint32_t* out_ids, uint8_t* out_codes,
+                                    float* out_vecs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMET_GPU_H */
