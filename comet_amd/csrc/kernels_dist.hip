@@ -23,6 +23,11 @@ namespace comet {
 // per-element steps — written as separate statements so each product / difference is rounded to
 // float32 before the add, exactly like the Go source.
 // ------------------------------------------------------------------------------------------------
+// float32(math.Sqrt(float64(x))) (distance.go:120,258): evaluated literally in binary64 — the f64 sqrt is
+// correctly rounded and 53 >= 2*24+2 bits make the second rounding innocuous, so this is the correctly
+// rounded float32 square root. (The f32 v_sqrt_f32 path hipcc emits for sqrtf is only 1-ulp accurate.)
+__device__ __forceinline__ float go_sqrt32(float x) { return (float)__builtin_sqrt((double)x); }
+
 template <int METRIC> __device__ __forceinline__ float acc_step(float acc, float q, float x) {
     if constexpr (METRIC == COMET_COSINE) {
         float p = q * x;          // dot += a[i] * b[i]  (distance.go:204-206)
@@ -38,7 +43,7 @@ template <int METRIC> __device__ __forceinline__ float acc_finish(float acc) {
         if (acc > 1.0f) acc = 1.0f; else if (acc < -1.0f) acc = -1.0f;   // distance.go:209-213
         return 1.0f - acc;
     } else if constexpr (METRIC == COMET_L2) {
-        return __fsqrt_rn(acc);   // float32(math.Sqrt(float64(sum))) == correctly-rounded sqrtf (53 >= 2*24+2)
+        return go_sqrt32(acc);
     } else {
         return acc;
     }
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(256) void ingest_rows_kernel(int metric, const floa
     if (metric == COMET_COSINE) {
         float sum = 0.0f;
         for (int i = 0; i < d; i++) { float p = s[i] * s[i]; sum = sum + p; }   // distance.go:247-250
-        float norm = __fsqrt_rn(sum);
+        float norm = go_sqrt32(sum);
         if (norm == 0.0f) zf = 1;
         else scale = 1.0f / norm;                                              // distance.go:258 (float32 divide)
     }
