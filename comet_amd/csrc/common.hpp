@@ -147,6 +147,13 @@ struct Ctx {
     }
 };
 
+// RAII: release scratch taken inside a scope (same-stream ordering makes immediate reuse safe).
+struct ScratchMark {
+    Ctx* c; void* arena; size_t off;
+    explicit ScratchMark(Ctx* c_) : c(c_), arena(c_->scratch), off(c_->scratch_off) {}
+    ~ScratchMark() { if (c->scratch == arena) c->scratch_off = off; }
+};
+
 // RAII: time one kernel launch under a name when profiling is on.
 struct ProfScope {
     Ctx* c;

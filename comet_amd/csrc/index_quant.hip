@@ -1,12 +1,558 @@
-// index_quant.hip — IVF / PQ / IVFPQ indexes.
+// index_quant.hip — k-means driver and the IVF / PQ / IVFPQ indexes (reference: clustering.go,
+// ivf_index.go + ivf_index_search.go, pq_index.go + pq_index_search.go, ivfpq_index.go +
+// ivfpq_index_search.go).
+//
+// HBM layout
+//   * vectors / centroids: padded row-major fp32 (kernels.hpp ROW_PAD);
+//   * inverted lists: elements are kept in arrival (Add) order and "compiled" lazily into list-major
+//     SLOTS — a stable counting sort by list, so each list keeps the reference's append order. For the
+//     raw-vector IVF a slot indexes the arrival-order row (row indirection is free in the gather kernel);
+//     for PQ / IVFPQ each list is padded to 64-code blocks and its codes are stored word-interleaved per
+//     block so a wave reads 256 contiguous bytes per load (see adc_scan_kernel).
 #include "index.hpp"
+
 namespace comet {
-comet_index* make_ivf(Ctx*, int, int, int) { COMET_FAIL(COMET_ERR_UNSUPPORTED, "IVF not built yet"); }
-comet_index* make_pq(Ctx*, int, int, int, int) { COMET_FAIL(COMET_ERR_UNSUPPORTED, "PQ not built yet"); }
-comet_index* make_ivfpq(Ctx*, int, int, int, int, int) { COMET_FAIL(COMET_ERR_UNSUPPORTED, "IVFPQ not built yet"); }
+
+// ------------------------------------------------------------------------------------------------
+// exact nearest-centroid assignment and k-means (clustering.go:119-272)
+// ------------------------------------------------------------------------------------------------
+// out_idx[v] = FindNearestCentroidIndex(V[v], C) for n padded rows (device). Lowest index wins ties.
+static void assign_nearest(Ctx* c, int metric, const float* V, int64_t n, int ld, const float* C, int k, int32_t* out_idx) {
+    if (n <= 0) return;
+    ScratchMark sm(c);
+    const int64_t vchunk = std::min<int64_t>(n, 262144);
+    const int64_t ldD = round_up(vchunk, 16);
+    const size_t budget = (size_t)1 << 30;
+    int kb = (int)std::min<int64_t>(k, std::max<int64_t>(16, (int64_t)(budget / ((size_t)ldD * 4)) / 16 * 16));
+    float* D = c->salloc<float>((size_t)kb * ldD);
+    float* best = c->salloc<float>(vchunk);
+    for (int64_t v0 = 0; v0 < n; v0 += vchunk) {
+        const int64_t nv = std::min(vchunk, n - v0);
+        for (int c0 = 0; c0 < k; c0 += kb) {
+            const int kn = std::min(kb, k - c0);
+            ScratchMark sm2(c);
+            // Calculate(vector, centroid): (v-c)^2 == (c-v)^2 and v*c == c*v bitwise, so the centroid block
+            // plays the "query" role of the exact distance kernel and the vectors the "row" role.
+            launch_dist_exact(c, metric, V + (size_t)v0 * ld, nv, ld, C + (size_t)c0 * ld, kn, D, ldD, nullptr);
+            launch_argmin_update(c, D, ldD, kn, c0, nv, best, out_idx + v0, c0 == 0);
+        }
+    }
 }
+
+// kmeansInternal (clustering.go:119-243). V: n x ld padded rows on device. centroids: >= min(k,n) x ld,
+// assign: n int32 (device). Returns the effective k (0 for the reference's (nil, nil) cases).
+static int kmeans_device(Ctx* c, int metric, const float* V, int64_t n, int ld, int k, int max_iter, float* centroids, int32_t* assign) {
+    if (n <= 0 || k <= 0) return 0;
+    if (k > n) k = (int)n;
+    if (max_iter <= 0) max_iter = 20;   // DefaultMaxIter clustering.go:14
+    ScratchMark sm(c);
+    {   // uniform-stride initialisation clustering.go:147-162
+        int64_t step = n / k; if (step == 0) step = 1;
+        std::vector<int32_t> idx(k);
+        for (int i = 0; i < k; i++) { int64_t vi = (int64_t)i * step; if (vi >= n) vi = n - 1; idx[i] = (int32_t)vi; }
+        int32_t* didx = c->salloc<int32_t>(k);
+        c->h2d(didx, idx.data(), k * sizeof(int32_t));
+        launch_gather_rows(c, V, ld, didx, k, centroids);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    launch_fill_i32(c, assign, n, -1);   // UnassignedCluster
+    int32_t* new_idx = c->salloc<int32_t>(n);
+    int32_t* changed = c->salloc<int32_t>(1);
+    for (int it = 0; it < max_iter; it++) {
+        assign_nearest(c, metric, V, n, ld, centroids, k, new_idx);
+        c->zero(changed, sizeof(int32_t));
+        launch_apply_assign(c, new_idx, assign, n, changed);
+        int32_t h = 0;
+        c->d2h(&h, changed, sizeof(int32_t));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (!h) break;                    // converged (clustering.go:203)
+        ScratchMark sm2(c);
+        launch_kmeans_update(c, V, n, ld, assign, k, centroids);
+    }
+    return k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// list layout shared by IVF / PQ / IVFPQ
+// ------------------------------------------------------------------------------------------------
+struct ListLayout {
+    int nlist = 1, align = 1;
+    std::vector<uint32_t> ids;       // arrival order
+    std::vector<int32_t> list_of;    // arrival order
+    int64_t n = 0;
+    bool dirty = true;
+    // compiled (host)
+    std::vector<int32_t> len_h; std::vector<int64_t> base_h; std::vector<uint32_t> row_of_slot_h;
+    int64_t nslots = 0; int max_len = 0;
+    // compiled (device)
+    DevBuf row_of_slot, ids_slot, list_base, list_len;
+    std::unordered_map<uint32_t, int> id_count;
+
+    void append(const uint32_t* new_ids, const int32_t* lists, int64_t m) {
+        ids.insert(ids.end(), new_ids, new_ids + m);
+        if (lists) list_of.insert(list_of.end(), lists, lists + m); else list_of.insert(list_of.end(), m, 0);
+        for (int64_t i = 0; i < m; i++) id_count[new_ids[i]]++;
+        n += m; dirty = true;
+    }
+    // stable counting sort by list -> slots
+    void compile(Ctx* c) {
+        if (!dirty) return;
+        len_h.assign(nlist, 0);
+        for (int64_t i = 0; i < n; i++) len_h[list_of[i]]++;
+        base_h.assign(nlist, 0);
+        int64_t run = 0; max_len = 0;
+        for (int l = 0; l < nlist; l++) { base_h[l] = run; run += round_up(len_h[l], align); max_len = std::max(max_len, len_h[l]); }
+        nslots = run;
+        row_of_slot_h.assign(std::max<int64_t>(nslots, 1), 0xFFFFFFFFu);
+        std::vector<uint32_t> ids_slot_h(std::max<int64_t>(nslots, 1), 0);
+        std::vector<int64_t> cur(base_h);
+        for (int64_t i = 0; i < n; i++) { int64_t s = cur[list_of[i]]++; row_of_slot_h[s] = (uint32_t)i; ids_slot_h[s] = ids[i]; }
+        row_of_slot.reserve(row_of_slot_h.size() * 4, c->stream, 0);
+        ids_slot.reserve(ids_slot_h.size() * 4, c->stream, 0);
+        list_base.reserve((size_t)nlist * 8, c->stream, 0);
+        list_len.reserve((size_t)nlist * 4, c->stream, 0);
+        c->h2d(row_of_slot.p, row_of_slot_h.data(), row_of_slot_h.size() * 4);
+        c->h2d(ids_slot.p, ids_slot_h.data(), ids_slot_h.size() * 4);
+        c->h2d(list_base.p, base_h.data(), (size_t)nlist * 8);
+        c->h2d(list_len.p, len_h.data(), (size_t)nlist * 4);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        dirty = false;
+    }
+    // upper bound on the candidates of one query probing `np` lists: the np longest lists
+    int64_t max_candidates(int np) const {
+        std::vector<int32_t> l(len_h);
+        if (np >= nlist) { int64_t s = 0; for (auto x : l) s += x; return s; }
+        std::partial_sort(l.begin(), l.begin() + np, l.end(), std::greater<int32_t>());
+        int64_t s = 0; for (int i = 0; i < np; i++) s += l[i];
+        return s;
+    }
+    // rows (arrival indices) surviving a flush, in arrival order
+    std::vector<int64_t> survivors(const std::unordered_set<uint32_t>& deleted) const {
+        std::vector<int64_t> keep;
+        for (int64_t i = 0; i < n; i++) if (!deleted.count(ids[i])) keep.push_back(i);
+        return keep;
+    }
+    void keep_rows(const std::vector<int64_t>& keep) {
+        std::vector<uint32_t> nid(keep.size()); std::vector<int32_t> nl(keep.size());
+        for (size_t i = 0; i < keep.size(); i++) { nid[i] = ids[keep[i]]; nl[i] = list_of[keep[i]]; }
+        ids.swap(nid); list_of.swap(nl); n = (int64_t)keep.size();
+        id_count.clear(); for (auto id : ids) id_count[id]++;
+        dirty = true;
+    }
+};
+
+// compact the surviving rows of a row-major device buffer (row_bytes each) into a fresh buffer
+static void compact_rows(Ctx* c, DevBuf& buf, size_t row_bytes, const std::vector<int64_t>& keep) {
+    DevBuf nb;
+    nb.reserve(std::max<size_t>(4, keep.size() * row_bytes), c->stream, 0);
+    size_t i = 0;
+    while (i < keep.size()) {
+        size_t j = i;
+        while (j + 1 < keep.size() && keep[j + 1] == keep[j] + 1) j++;
+        c->d2d((char*)nb.p + i * row_bytes, (char*)buf.p + (size_t)keep[i] * row_bytes, (j - i + 1) * row_bytes);
+        i = j + 1;
+    }
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::swap(buf.p, nb.p); std::swap(buf.cap, nb.cap);
+}
+
+// coarse step shared by IVF and IVFPQ (ivf_index_search.go:246-261): rank all centroids, keep nprobes.
+// probe_list[q][0..np) = centroid indices sorted by (distance, index).
+static void coarse_probe(Ctx* c, int metric, const float* centroids, int nlist, int ld, const float* Qp, int B, int np, uint32_t* probe_list) {
+    const int64_t ldDc = round_up(nlist, 16);
+    float* Dc = c->salloc<float>((size_t)B * ldDc);
+    launch_dist_exact(c, metric, centroids, nlist, ld, Qp, B, Dc, ldDc, nullptr);
+    float* psc = c->salloc<float>((size_t)B * np);
+    int32_t* pcnt = c->salloc<int32_t>(B);
+    launch_select_topk(c, Dc, ldDc, B, nlist, nullptr, 0.0f, np, probe_list, psc, pcnt, np);
+}
+static int sanitize_nprobes(int nprobes, int nlist) { return (nprobes <= 0 || nprobes > nlist) ? nlist : nprobes; }  // ivf_index_search.go:233-236
+
+// raw training vectors (dense n x dim on device) -> padded rows without preprocessing
+// (Train uses the vectors as given, even for cosine: ivf_index.go:217-224)
+static float* pad_raw(Ctx* c, const float* vecs_dev, int64_t n, int dim, int ld) {
+    float* V = c->salloc<float>((size_t)std::max<int64_t>(n, 1) * ld);
+    launch_ingest_rows(c, COMET_L2SQ, vecs_dev, n, dim, V, ld, nullptr);
+    return V;
+}
+
+// ------------------------------------------------------------------------------------------------
+// IVFIndex
+// ------------------------------------------------------------------------------------------------
+struct IVFIndex : comet_index {
+    int nlist = 0;
+    DevBuf centroids;   // nlist x ld
+    DevBuf V;           // arrival-order rows, n x ld
+    ListLayout lay;
+
+    int64_t size() const override { return lay.n; }
+    int default_nprobes() const override { return (int)std::sqrt((double)nlist); }   // ivf_index.go:406-413
+    bool contains_id(uint32_t id) const override { return lay.id_count.count(id) != 0; }
+
+    // IVFIndex.Train ivf_index.go:206-235
+    void train_dev(const float* vecs_dev, int64_t n) override {
+        if (n < nlist) COMET_FAIL(COMET_ERR_TRAIN_DATA, "need at least %d training vectors for %d clusters (got %lld)", nlist, nlist, (long long)n);
+        float* Vt = pad_raw(c, vecs_dev, n, dim, ld);
+        centroids.reserve((size_t)nlist * ld * sizeof(float), c->stream, 0);
+        int32_t* assign = c->salloc<int32_t>(n);
+        if (kmeans_device(c, metric, Vt, n, ld, nlist, 20, centroids.as<float>(), assign) == 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "k-means clustering failed");
+        trained = true;
+    }
+    // IVFIndex.Add ivf_index.go:251-280
+    int64_t add_dev(const uint32_t*, const uint32_t* ids_h, const float* vecs_dev, int64_t m, int64_t* zero_at, float* normalized_dev) override {
+        *zero_at = -1;
+        if (!trained) COMET_FAIL(COMET_ERR_NOT_TRAINED, "index must be trained before adding vectors");
+        if (m <= 0) return 0;
+        V.reserve((size_t)(lay.n + m) * ld * sizeof(float), c->stream, (size_t)lay.n * ld * sizeof(float));
+        float* dst = V.as<float>() + (size_t)lay.n * ld;
+        int32_t* zf = c->salloc<int32_t>(m);
+        launch_ingest_rows(c, metric, vecs_dev, m, dim, dst, ld, zf);
+        int64_t added = m;
+        if (metric == COMET_COSINE) {
+            std::vector<int32_t> h(m);
+            c->d2h(h.data(), zf, m * sizeof(int32_t));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            for (int64_t i = 0; i < m; i++) if (h[i]) { *zero_at = i; added = i; break; }
+        }
+        if (added > 0) {
+            int32_t* a = c->salloc<int32_t>(added);
+            assign_nearest(c, metric, dst, added, ld, centroids.as<float>(), nlist, a);   // FindNearestCentroidIndex
+            std::vector<int32_t> ah(added);
+            c->d2h(ah.data(), a, added * sizeof(int32_t));
+            if (normalized_dev) launch_unpad_rows(c, dst, added, ld, normalized_dev, dim);
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            lay.append(ids_h, ah.data(), added);
+        }
+        return added;
+    }
+    void flush() override {
+        if (deleted.empty()) return;
+        auto keep = lay.survivors(deleted);
+        compact_rows(c, V, (size_t)ld * sizeof(float), keep);
+        lay.keep_rows(keep);
+        deleted.clear(); deleted_dirty = true;
+    }
+    // ivfIndexSearch.searchSingleQuery ivf_index_search.go:217-322
+    void search_dev(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
+                    int32_t* out_counts, int k_cap) override {
+        if (!trained) COMET_FAIL(COMET_ERR_NOT_TRAINED, "index must be trained before searching");
+        lay.compile(c);
+        float* Qp; int32_t* zflag;
+        prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag);
+        const int np = sanitize_nprobes(p.nprobes, nlist);
+        uint32_t* probe_list = c->salloc<uint32_t>((size_t)B * np);
+        coarse_probe(c, metric, centroids.as<float>(), nlist, ld, Qp, B, np, probe_list);
+        int32_t* seg_off = c->salloc<int32_t>((size_t)B * (np + 1));
+        int32_t* cnts = c->salloc<int32_t>(B);
+        launch_probe_segments(c, probe_list, np, nullptr, lay.list_len.as<int32_t>(), B, np, seg_off, cnts);
+        const int64_t Cmax = lay.max_candidates(np);
+        uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
+        if (Cmax > 0) {
+            const uint8_t* elig = nullptr;
+            int nf = 0;
+            const uint32_t* flt = filter_sorted_scratch(p, &nf);
+            const uint32_t* del = deleted.empty() ? nullptr : deleted_sorted_dev();
+            const int nd = deleted.empty() ? 0 : n_deleted_dev;
+            if (nd > 0 || nf > 0) {
+                uint8_t* e = c->salloc<uint8_t>(lay.nslots);
+                launch_build_elig(c, lay.ids_slot.as<uint32_t>(), lay.nslots, del, nd, flt, nf, e);
+                elig = e;
+            }
+            const int64_t ldR = round_up(Cmax, 16);
+            const size_t budget = (size_t)2 << 30;
+            int qb = (int)std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(budget / ((size_t)ldR * 8))));
+            uint32_t* rowidx = c->salloc<uint32_t>((size_t)qb * ldR);
+            float* D = c->salloc<float>((size_t)qb * ldR);
+            for (int b0 = 0; b0 < B; b0 += qb) {
+                const int bn = std::min(qb, B - b0);
+                launch_cand_rows(c, probe_list + (size_t)b0 * np, np, seg_off + (size_t)b0 * (np + 1), np, lay.list_base.as<int64_t>(),
+                                 lay.row_of_slot.as<uint32_t>(), elig, cnts + b0, bn, rowidx, ldR);
+                launch_dist_gather(c, metric, V.as<float>(), ld, Qp + (size_t)b0 * ld, bn, rowidx, ldR, cnts + b0, Cmax, D, ldR);
+                launch_select_topk(c, D, ldR, bn, Cmax, cnts + b0, p.threshold, p.k, pos + (size_t)b0 * k_cap,
+                                   out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);
+            }
+        } else {
+            launch_select_topk(c, nullptr, 0, B, 0, nullptr, 0.0f, p.k, pos, out_scores, out_counts, k_cap);
+        }
+        launch_finalize_probe(c, pos, B, k_cap, probe_list, np, seg_off, np, lay.list_base.as<int64_t>(), lay.ids_slot.as<uint32_t>(),
+                              zflag, out_ids, out_counts);
+    }
+    void get_centroids(float* out) const override {
+        if (!trained) COMET_FAIL(COMET_ERR_NOT_TRAINED, "index must be trained");
+        float* tmp = c->salloc<float>((size_t)nlist * dim);
+        launch_unpad_rows(c, centroids.as<float>(), nlist, ld, tmp, dim);
+        c->d2h(out, tmp, (size_t)nlist * dim * sizeof(float));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    int64_t list_size(int l) const override { const_cast<ListLayout&>(lay).compile(c); return (l >= 0 && l < nlist) ? lay.len_h[l] : 0; }
+    void list_read(int l, uint32_t* oids, uint8_t*, float* ovecs) const override {
+        auto& L = const_cast<ListLayout&>(lay); L.compile(c);
+        if (l < 0 || l >= nlist) COMET_FAIL(COMET_ERR_INVALID_ARG, "list out of range");
+        const int len = L.len_h[l];
+        std::vector<float> row(ld);
+        for (int j = 0; j < len; j++) {
+            uint32_t r = L.row_of_slot_h[L.base_h[l] + j];
+            if (oids) oids[j] = L.ids[r];
+            if (ovecs) { c->d2h(row.data(), V.as<float>() + (size_t)r * ld, (size_t)ld * 4); HIP_CHECK(hipStreamSynchronize(c->stream)); std::copy(row.begin(), row.begin() + dim, ovecs + (size_t)j * dim); }
+        }
+    }
+};
+
+comet_index* make_ivf(Ctx* c, int dim, int metric, int nlist) {
+    auto* f = new IVFIndex();
+    f->c = c; f->kind = COMET_KIND_IVF; f->dim = dim; f->ld = padded_dim(dim); f->metric = metric; f->nlist = nlist;
+    f->lay.nlist = nlist; f->lay.align = 1;
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PQIndex and IVFPQIndex share one implementation: PQ is the one-list, no-centroid case.
+// ------------------------------------------------------------------------------------------------
+struct PQFamilyIndex : comet_index {
+    bool ivf = false;
+    int nlist = 1, M = 0, nbits = 0, Ksub = 0, dsub = 0, M4 = 0;
+    DevBuf centroids;   // nlist x ld (IVFPQ only)
+    DevBuf codebooks;   // M x Ksub x dsub dense fp32 (pq_index.go:99-101 layout)
+    DevBuf codes_arr;   // arrival-order codes, n x M4 words (byte m of a row = code[m])
+    DevBuf codes_il;    // compiled, block-interleaved
+    ListLayout lay;
+
+    int64_t size() const override { return lay.n; }
+    int default_nprobes() const override { return ivf ? (int)std::sqrt((double)nlist) : 0; }   // ivfpq_index.go:442-449
+    bool contains_id(uint32_t id) const override { return lay.id_count.count(id) != 0; }
+
+    // learn M codebooks on the rows of R (n x ld): KMeansSubspace per subspace (pq_index.go:218-246, ivfpq_index.go:232-256)
+    void train_codebooks(const float* R, int64_t n) {
+        codebooks.reserve((size_t)M * Ksub * dsub * sizeof(float), c->stream, 0);
+        const int lds = padded_dim(dsub);
+        float* sub = c->salloc<float>((size_t)n * lds);
+        float* cent = c->salloc<float>((size_t)std::min<int64_t>(Ksub, n) * lds);
+        int32_t* assign = c->salloc<int32_t>(n);
+        for (int m = 0; m < M; m++) {
+            launch_extract_sub(c, R, ld, n, m * dsub, dsub, sub, lds);
+            int k = kmeans_device(c, COMET_L2SQ, sub, n, lds, Ksub, 20, cent, assign);
+            if (k == 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "k-means failed for subspace %d", m);
+            if (k < Ksub) COMET_FAIL(COMET_ERR_TRAIN_DATA, "need at least %d vectors for training", Ksub);  // the reference would index past the centroids slice
+            launch_unpad_rows(c, cent, Ksub, lds, codebooks.as<float>() + (size_t)m * Ksub * dsub, dsub);
+        }
+    }
+    void train_dev(const float* vecs_dev, int64_t n) override {
+        if (ivf) {   // IVFPQIndex.Train ivfpq_index.go:180-259
+            if (n < (int64_t)nlist * 10) COMET_FAIL(COMET_ERR_TRAIN_DATA, "need at least %d vectors for training", nlist * 10);
+            float* Vt = pad_raw(c, vecs_dev, n, dim, ld);
+            centroids.reserve((size_t)nlist * ld * sizeof(float), c->stream, 0);
+            int32_t* assign = c->salloc<int32_t>(n);
+            if (kmeans_device(c, metric, Vt, n, ld, nlist, 20, centroids.as<float>(), assign) == 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "IVF k-means failed");
+            assign_nearest(c, metric, Vt, n, ld, centroids.as<float>(), nlist, assign);       // STEP 2 (:205-208)
+            float* R = c->salloc<float>((size_t)n * ld);
+            launch_residual_rows(c, Vt, ld, n, centroids.as<float>(), assign, R);              // STEP 3 (:213-224)
+            train_codebooks(R, n);                                                              // STEP 4
+        } else {     // PQIndex.Train pq_index.go:193-250
+            if (n < Ksub) COMET_FAIL(COMET_ERR_TRAIN_DATA, "need at least %d vectors for training", Ksub);
+            float* Vt = pad_raw(c, vecs_dev, n, dim, ld);
+            train_codebooks(Vt, n);
+        }
+        trained = true;
+    }
+    // PQIndex.Add pq_index.go:263-289 / IVFPQIndex.Add ivfpq_index.go:279-319
+    int64_t add_dev(const uint32_t*, const uint32_t* ids_h, const float* vecs_dev, int64_t m, int64_t* zero_at, float* normalized_dev) override {
+        *zero_at = -1;
+        if (!trained) COMET_FAIL(COMET_ERR_NOT_TRAINED, "index must be trained before adding");
+        if (m <= 0) return 0;
+        float* P = c->salloc<float>((size_t)m * ld);
+        int32_t* zf = c->salloc<int32_t>(m);
+        launch_ingest_rows(c, metric, vecs_dev, m, dim, P, ld, zf);
+        int64_t added = m;
+        if (metric == COMET_COSINE) {
+            std::vector<int32_t> h(m);
+            c->d2h(h.data(), zf, m * sizeof(int32_t));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            for (int64_t i = 0; i < m; i++) if (h[i]) { *zero_at = i; added = i; break; }
+        }
+        if (added <= 0) return 0;
+        codes_arr.reserve((size_t)(lay.n + added) * M4 * 4, c->stream, (size_t)lay.n * M4 * 4);
+        uint8_t* dst = (uint8_t*)codes_arr.p + (size_t)lay.n * M4 * 4;
+        c->zero(dst, (size_t)added * M4 * 4);
+        std::vector<int32_t> ah;
+        if (ivf) {
+            int32_t* a = c->salloc<int32_t>(added);
+            assign_nearest(c, metric, P, added, ld, centroids.as<float>(), nlist, a);
+            float* R = c->salloc<float>((size_t)added * ld);
+            launch_residual_rows(c, P, ld, added, centroids.as<float>(), a, R);
+            launch_pq_encode(c, R, ld, added, codebooks.as<float>(), M, Ksub, dsub, dst, M4 * 4);
+            ah.resize(added);
+            c->d2h(ah.data(), a, added * sizeof(int32_t));
+        } else {
+            launch_pq_encode(c, P, ld, added, codebooks.as<float>(), M, Ksub, dsub, dst, M4 * 4);
+        }
+        if (normalized_dev) launch_unpad_rows(c, P, added, ld, normalized_dev, dim);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        lay.append(ids_h, ivf ? ah.data() : nullptr, added);
+        return added;
+    }
+    void flush() override {
+        if (deleted.empty()) return;
+        auto keep = lay.survivors(deleted);
+        compact_rows(c, codes_arr, (size_t)M4 * 4, keep);
+        lay.keep_rows(keep);
+        deleted.clear(); deleted_dirty = true;
+    }
+    void compile() {
+        if (!lay.dirty) return;
+        lay.compile(c);
+        codes_il.reserve(std::max<size_t>(4, (size_t)lay.nslots * M4 * 4), c->stream, 0);
+        launch_interleave_codes(c, codes_arr.as<uint32_t>(), M4, lay.row_of_slot.as<uint32_t>(), lay.nslots, codes_il.as<uint32_t>());
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    // pqIndexSearch.searchSingleQuery pq_index_search.go:218-325 / ivfpqIndexSearch.searchSingleQuery ivfpq_index_search.go:231-341
+    void search_dev(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
+                    int32_t* out_counts, int k_cap) override {
+        if (!trained) { if (ivf) COMET_FAIL(COMET_ERR_NOT_TRAINED, "index must be trained before searching"); COMET_FAIL(COMET_ERR_NOT_TRAINED, "index not trained"); }
+        compile();
+        float* Qp; int32_t* zflag;
+        prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag);
+        const int np = ivf ? sanitize_nprobes(p.nprobes, nlist) : 1;
+        uint32_t* probe_list = c->salloc<uint32_t>((size_t)B * np);
+        if (ivf) coarse_probe(c, metric, centroids.as<float>(), nlist, ld, Qp, B, np, probe_list);
+        else c->zero(probe_list, sizeof(uint32_t) * (size_t)B);
+        int32_t* seg_off = c->salloc<int32_t>((size_t)B * (np + 1));
+        int32_t* cnts = c->salloc<int32_t>(B);
+        launch_probe_segments(c, probe_list, np, nullptr, lay.list_len.as<int32_t>(), B, np, seg_off, cnts);
+        const int64_t Cmax = lay.max_candidates(np);
+        uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
+        if (Cmax > 0) {
+            const uint8_t* elig = nullptr;
+            int nf = 0;
+            const uint32_t* flt = filter_sorted_scratch(p, &nf);
+            const uint32_t* del = deleted.empty() ? nullptr : deleted_sorted_dev();
+            const int nd = deleted.empty() ? 0 : n_deleted_dev;
+            if (nd > 0 || nf > 0) {
+                uint8_t* e = c->salloc<uint8_t>(lay.nslots);
+                launch_build_elig(c, lay.ids_slot.as<uint32_t>(), lay.nslots, del, nd, flt, nf, e);
+                elig = e;
+            }
+            const int64_t ldD = round_up(Cmax, 16);
+            const size_t budget = (size_t)2 << 30;
+            const int qb = (int)std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(budget / ((size_t)ldD * 4))));
+            float* D = c->salloc<float>((size_t)qb * ldD);
+            for (int b0 = 0; b0 < B; b0 += qb) {
+                const int bn = std::min(qb, B - b0);
+                launch_adc_scan(c, Qp + (size_t)b0 * ld, ld, dim, ivf ? centroids.as<float>() : nullptr, codebooks.as<float>(), M, Ksub, dsub,
+                                codes_il.as<uint32_t>(), M4, lay.list_base.as<int64_t>(), lay.list_len.as<int32_t>(),
+                                probe_list + (size_t)b0 * np, np, np, seg_off + (size_t)b0 * (np + 1), elig, bn, lay.max_len, D, ldD);
+                launch_select_topk(c, D, ldD, bn, Cmax, cnts + b0, p.threshold, p.k, pos + (size_t)b0 * k_cap,
+                                   out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);
+            }
+        } else {
+            launch_select_topk(c, nullptr, 0, B, 0, nullptr, 0.0f, p.k, pos, out_scores, out_counts, k_cap);
+        }
+        launch_finalize_probe(c, pos, B, k_cap, probe_list, np, seg_off, np, lay.list_base.as<int64_t>(), lay.ids_slot.as<uint32_t>(),
+                              zflag, out_ids, out_counts);
+    }
+    void get_centroids(float* out) const override {
+        if (!ivf) COMET_FAIL(COMET_ERR_UNSUPPORTED, "PQ index has no centroids");
+        if (!trained) COMET_FAIL(COMET_ERR_NOT_TRAINED, "index must be trained");
+        float* tmp = c->salloc<float>((size_t)nlist * dim);
+        launch_unpad_rows(c, centroids.as<float>(), nlist, ld, tmp, dim);
+        c->d2h(out, tmp, (size_t)nlist * dim * sizeof(float));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    void get_codebooks(float* out) const override {
+        if (!trained) COMET_FAIL(COMET_ERR_NOT_TRAINED, "index must be trained");
+        c->d2h(out, codebooks.p, (size_t)M * Ksub * dsub * sizeof(float));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    int64_t list_size(int l) const override { const_cast<ListLayout&>(lay).compile(c); return (l >= 0 && l < nlist) ? lay.len_h[l] : 0; }
+    void list_read(int l, uint32_t* oids, uint8_t* ocodes, float*) const override {
+        auto& L = const_cast<ListLayout&>(lay); L.compile(c);
+        if (l < 0 || l >= nlist) COMET_FAIL(COMET_ERR_INVALID_ARG, "list out of range");
+        const int len = L.len_h[l];
+        std::vector<uint8_t> all;
+        if (ocodes && L.n > 0) { all.resize((size_t)L.n * M4 * 4); c->d2h(all.data(), codes_arr.p, all.size()); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+        for (int j = 0; j < len; j++) {
+            uint32_t r = L.row_of_slot_h[L.base_h[l] + j];
+            if (oids) oids[j] = L.ids[r];
+            if (ocodes) std::copy(all.begin() + (size_t)r * M4 * 4, all.begin() + (size_t)r * M4 * 4 + M, ocodes + (size_t)j * M);
+        }
+    }
+};
+
+static comet_index* make_pq_family(Ctx* c, bool ivf, int dim, int metric, int nlist, int M, int nbits) {
+    auto* f = new PQFamilyIndex();
+    f->c = c; f->kind = ivf ? COMET_KIND_IVFPQ : COMET_KIND_PQ; f->dim = dim; f->ld = padded_dim(dim); f->metric = metric;
+    f->ivf = ivf; f->nlist = ivf ? nlist : 1; f->M = M; f->nbits = nbits; f->Ksub = 1 << nbits; f->dsub = dim / M; f->M4 = (M + 3) / 4;
+    f->lay.nlist = f->nlist; f->lay.align = 64;
+    return f;
+}
+comet_index* make_pq(Ctx* c, int dim, int metric, int M, int nbits) { return make_pq_family(c, false, dim, metric, 1, M, nbits); }
+comet_index* make_ivfpq(Ctx* c, int dim, int metric, int nlist, int M, int nbits) { return make_pq_family(c, true, dim, metric, nlist, M, nbits); }
+
+}  // namespace comet
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: k-means, nearest centroid, multi-GPU merge
+// ------------------------------------------------------------------------------------------------
+using namespace comet;
+
 extern "C" {
-int comet_kmeans(comet_ctx*, const float*, int64_t, int, int, int, int, float*, int32_t*, int*) { return comet::set_error(COMET_ERR_UNSUPPORTED, "kmeans not built yet"); }
-int comet_nearest_centroid(comet_ctx*, const float*, int64_t, int, const float*, int, int, int32_t*) { return comet::set_error(COMET_ERR_UNSUPPORTED, "not built yet"); }
-int comet_merge_topk_dev(comet_ctx*, const uint32_t*, const float*, const int32_t*, int32_t, int32_t, int32_t, int32_t, uint32_t*, float*, int32_t*) { return comet::set_error(COMET_ERR_UNSUPPORTED, "not built yet"); }
+
+int comet_kmeans(comet_ctx* c, const float* vecs, int64_t n, int d, int k, int metric, int max_iter, float* out_centroids,
+                 int32_t* out_assign, int* out_k) {
+    return guarded([&] {
+        if (out_k) *out_k = 0;
+        if (metric < COMET_L2 || metric > COMET_COSINE) COMET_FAIL(COMET_ERR_UNKNOWN_METRIC, "unknown distance kind");
+        if (n <= 0 || k <= 0 || d <= 0) return (int)COMET_OK;   // (nil, nil) clustering.go:123-129
+        std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->scratch_reset();
+        const int ld = padded_dim(d);
+        float* raw = c->salloc<float>((size_t)n * d);
+        c->h2d(raw, vecs, (size_t)n * d * sizeof(float));
+        float* V = c->salloc<float>((size_t)n * ld);
+        launch_ingest_rows(c, COMET_L2SQ, raw, n, d, V, ld, nullptr);
+        const int ke = (int)std::min<int64_t>(k, n);
+        float* cent = c->salloc<float>((size_t)ke * ld);
+        int32_t* assign = c->salloc<int32_t>(n);
+        const int kk = kmeans_device(c, metric, V, n, ld, k, max_iter, cent, assign);
+        float* dense = c->salloc<float>((size_t)ke * d);
+        launch_unpad_rows(c, cent, kk, ld, dense, d);
+        c->d2h(out_centroids, dense, (size_t)kk * d * sizeof(float));
+        c->d2h(out_assign, assign, (size_t)n * sizeof(int32_t));
+        c->sync();
+        if (out_k) *out_k = kk;
+        return (int)COMET_OK;
+    });
 }
+
+int comet_nearest_centroid(comet_ctx* c, const float* vecs, int64_t n, int d, const float* centroids, int k, int metric, int32_t* out_index) {
+    return guarded([&] {
+        if (metric < COMET_L2 || metric > COMET_COSINE) COMET_FAIL(COMET_ERR_UNKNOWN_METRIC, "unknown distance kind");
+        if (n <= 0) return (int)COMET_OK;
+        if (k <= 0 || d <= 0) { for (int64_t i = 0; i < n; i++) out_index[i] = 0; return (int)COMET_OK; }
+        std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->scratch_reset();
+        const int ld = padded_dim(d);
+        float* raw = c->salloc<float>((size_t)n * d);
+        float* rawc = c->salloc<float>((size_t)k * d);
+        c->h2d(raw, vecs, (size_t)n * d * sizeof(float));
+        c->h2d(rawc, centroids, (size_t)k * d * sizeof(float));
+        float* V = c->salloc<float>((size_t)n * ld);
+        float* C = c->salloc<float>((size_t)k * ld);
+        launch_ingest_rows(c, COMET_L2SQ, raw, n, d, V, ld, nullptr);
+        launch_ingest_rows(c, COMET_L2SQ, rawc, k, d, C, ld, nullptr);
+        int32_t* a = c->salloc<int32_t>(n);
+        assign_nearest(c, metric, V, n, ld, C, k, a);
+        c->d2h(out_index, a, (size_t)n * sizeof(int32_t));
+        c->sync();
+        return (int)COMET_OK;
+    });
+}
+
+int comet_merge_topk_dev(comet_ctx* c, const uint32_t* ids_dev, const float* scores_dev, const int32_t* counts_dev, int32_t R, int32_t B,
+                         int32_t k_cap, int32_t k, uint32_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev) {
+    return guarded([&] {
+        if (R <= 0 || B < 0 || k_cap <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "bad merge shape");
+        std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind();
+        launch_merge_topk(c, ids_dev, scores_dev, counts_dev, R, B, k_cap, k, out_ids_dev, out_scores_dev, out_counts_dev);
+        return (int)COMET_OK;
+    });
+}
+
+}  // extern "C"

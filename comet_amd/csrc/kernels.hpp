@@ -22,6 +22,10 @@ void launch_unpad_rows(Ctx* c, const float* src, int64_t n, int ld, float* dst, 
 // elig (nullable): per-row eligibility bytes; ineligible rows get the EXCLUDED sentinel in D.
 void launch_dist_exact(Ctx* c, int metric, const float* X, int64_t n, int ld, const float* Q, int B, float* D, int64_t ldD,
                        const uint8_t* elig);
+// Per-query candidate rows: D[q][pos] = Calculate(Q[q], X[rowidx[q][pos]]) for pos < cnts[q]
+// (rowidx == 0xFFFFFFFF -> EXCLUDED). rowidx: B x ldR, D: B x ldD, Cmax >= max cnts.
+void launch_dist_gather(Ctx* c, int metric, const float* X, int ld, const float* Q, int B, const uint32_t* rowidx, int64_t ldR,
+                        const int32_t* cnts, int64_t Cmax, float* D, int64_t ldD);
 // Bit pattern written into a distance matrix for candidates that must not be returned (soft-deleted,
 // filtered out). A negative quiet NaN with all payload bits set — never produced by the arithmetic here.
 constexpr uint32_t EXCLUDED_BITS = 0xFFFFFFFFu;
@@ -43,7 +47,34 @@ void launch_gather_u32(Ctx* c, const uint32_t* table, const uint32_t* idx, int64
 //   K   : <= 0 -> all. Results: out_pos/out_scores [B x k_cap] sorted; out_counts[q] = min(K_q, #eligible)
 //         (number of results; rows hold min(count, k_cap)). Requires min(K, C) <= select_max_k().
 int select_max_k();
+// merge R per-shard sorted top-k lists per query (ties: lower shard, then lower position). R*k_cap <= select_max_k().
+void launch_merge_topk(Ctx* c, const uint32_t* ids, const float* scores, const int32_t* counts, int R, int B, int k_cap, int k,
+                       uint32_t* out_ids, float* out_scores, int32_t* out_counts);
 void launch_select_topk(Ctx* c, const float* D, int64_t ldD, int B, int64_t C, const int32_t* cnts, float thr, int K,
                         uint32_t* out_pos, float* out_scores, int32_t* out_counts, int k_cap);
+
+
+// ---- kernels_quant.hip ------------------------------------------------------------------------
+void launch_gather_rows(Ctx* c, const float* src, int ld, const int32_t* idx, int64_t k, float* dst);
+void launch_argmin_update(Ctx* c, const float* D, int64_t ldD, int kb, int c0, int64_t n, float* best, int32_t* best_idx, bool first);
+void launch_apply_assign(Ctx* c, const int32_t* new_idx, int32_t* assign, int64_t n, int32_t* changed);
+void launch_fill_i32(Ctx* c, int32_t* p, int64_t n, int32_t v);
+// centroid update step of k-means (clustering.go:213-239), member sums in ascending vector order
+void launch_kmeans_update(Ctx* c, const float* V, int64_t n, int ld, const int32_t* assign, int k, float* centroids);
+void launch_extract_sub(Ctx* c, const float* src, int ld_src, int64_t n, int col0, int dsub, float* dst, int ld_dst);
+void launch_residual_rows(Ctx* c, const float* V, int ld, int64_t n, const float* C, const int32_t* assign, float* R);
+void launch_pq_encode(Ctx* c, const float* R, int ld, int64_t n, const float* codebooks, int M, int Ksub, int dsub,
+                      uint8_t* codes, int code_stride);
+void launch_interleave_codes(Ctx* c, const uint32_t* src_words, int M4, const uint32_t* row_of_slot, int64_t nslots, uint32_t* dst);
+void launch_probe_segments(Ctx* c, const uint32_t* probe_list, int ldp, const int32_t* probe_cnt, const int32_t* list_len, int B, int np,
+                           int32_t* seg_off, int32_t* cnts);
+void launch_cand_rows(Ctx* c, const uint32_t* probe_list, int ldp, const int32_t* seg_off, int np, const int64_t* list_base,
+                      const uint32_t* row_of_slot, const uint8_t* elig, const int32_t* cnts, int B, uint32_t* rowidx, int64_t ldR);
+void launch_finalize_probe(Ctx* c, const uint32_t* pos, int B, int k_cap, const uint32_t* probe_list, int ldp, const int32_t* seg_off, int np,
+                           const int64_t* list_base, const uint32_t* ids_of_slot, const int32_t* zflag, uint32_t* out_ids, int32_t* counts);
+size_t adc_lds_bytes(int M, int Ksub, int dim);
+void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* centroids, const float* codebooks, int M, int Ksub, int dsub,
+                     const uint32_t* codes, int M4, const int64_t* list_base, const int32_t* list_len, const uint32_t* probe_list, int ldp,
+                     int np, const int32_t* seg_off, const uint8_t* elig, int B, int max_list_len, float* D, int64_t ldD);
 
 }  // namespace comet

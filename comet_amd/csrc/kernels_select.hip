@@ -318,4 +318,65 @@ void launch_select_topk(Ctx* c, const float* D, int64_t ldD, int B, int64_t C, c
       LAUNCH_CHECK(); }
 }
 
+
+// ---- multi-GPU merge: R sorted per-shard lists per query -> global top-k ----------------------------
+// (the reference's analogue is mergeResults, storage_merge.go:13-46). Exact because the top-k of a
+// union is the top-k of the per-part top-ks. Composite key = (score key, shard, position).
+__global__ __launch_bounds__(1024) void merge_topk_kernel(const unsigned* __restrict__ ids, const float* __restrict__ scores,
+                                                          const int* __restrict__ counts, int R, int B, int k_cap, int k,
+                                                          unsigned* __restrict__ out_ids, float* __restrict__ out_scores,
+                                                          int* __restrict__ out_counts, int n2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
+    const int q = blockIdx.x;
+    int total = 0;
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+        unsigned long long v = ~0ull;
+        if (i < R * k_cap) {
+            const int r = i / k_cap, j = i - r * k_cap;
+            int cnt = counts[(long)r * B + q]; if (cnt > k_cap) cnt = k_cap;
+            if (j < cnt) v = ((unsigned long long)f2key(__float_as_uint(scores[((long)r * B + q) * k_cap + j])) << 32) | (unsigned)i;
+        }
+        sm[i] = v;
+    }
+    for (int r = 0; r < R; r++) { int cnt = counts[(long)r * B + q]; if (cnt < 0) { total = cnt; break; } total += cnt < k_cap ? cnt : k_cap; }
+    __syncthreads();
+    for (int kk = 2; kk <= n2; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    unsigned long long a = sm[i], b = sm[ixj];
+                    bool up = ((i & kk) == 0);
+                    if ((a > b) == up) { sm[i] = b; sm[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int kq = total < 0 ? 0 : ((k <= 0 || k > total) ? total : k);
+    if (kq > k_cap) kq = k_cap;
+    for (int i = threadIdx.x; i < k_cap; i += blockDim.x) {
+        unsigned id = 0; float sc = 0.0f;
+        if (i < kq) {
+            unsigned long long cmp = sm[i];
+            unsigned src = (unsigned)(cmp & 0xFFFFFFFFull);
+            const int r = src / k_cap, j = src - r * k_cap;
+            id = ids[((long)r * B + q) * k_cap + j];
+            sc = __uint_as_float(key2f((unsigned)(cmp >> 32)));
+        }
+        out_ids[(long)q * k_cap + i] = id; out_scores[(long)q * k_cap + i] = sc;
+    }
+    if (threadIdx.x == 0) out_counts[q] = total < 0 ? total : kq;
+}
+void launch_merge_topk(Ctx* c, const uint32_t* ids, const float* scores, const int32_t* counts, int R, int B, int k_cap, int k,
+                       uint32_t* out_ids, float* out_scores, int32_t* out_counts) {
+    if (B <= 0) return;
+    int n2 = 1; while (n2 < R * k_cap) n2 <<= 1;
+    if (n2 > 2 * SORT_MAX) COMET_FAIL(COMET_ERR_UNSUPPORTED, "merge of %d x %d candidates exceeds the on-device limit", R, k_cap);
+    ProfScope ps(c, "merge_topk");
+    int threads = n2 >= 2048 ? 1024 : (n2 >= 512 ? 256 : 64);
+    merge_topk_kernel<<<dim3(B), dim3(threads), sizeof(unsigned long long) * n2, c->stream>>>(ids, scores, counts, R, B, k_cap, k, out_ids, out_scores, out_counts, n2);
+    LAUNCH_CHECK();
+}
+
 }  // namespace comet

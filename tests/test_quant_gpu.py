@@ -1,0 +1,280 @@
+"""Parity of k-means, IVF, PQ and IVFPQ (train / add / search) on the GPU against the CPU oracle.
+Everything is compared bit-exactly: centroids, codebooks, list membership, PQ codes, result ids and scores.
+Reference: clustering.go, ivf_index*.go, pq_index*.go, ivfpq_index*.go; fixture shapes from
+ivfpq_index_search_test.go:9-72 and pq_index_search_test.go:9-53."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from comet_amd import COSINE, EUCLIDEAN, L2_SQUARED, CometError, IVFIndex, IVFPQIndex, PQIndex
+
+pytestmark = pytest.mark.gpu
+KATS = json.loads((Path(__file__).parent / "golden" / "reference_kats.json").read_text())
+METRICS = [EUCLIDEAN, L2_SQUARED, COSINE]
+
+
+def synth(seed, n, d):
+    return orc.synth(seed, 0, n * d).reshape(n, d)
+
+
+def clustered(seed, n, d, ncl, sigma=0.15):
+    """mixture of `ncl` gaussian-ish blobs built from the deterministic synthetic stream"""
+    centers = synth(seed, ncl, d)
+    noise = synth(seed + 1, n, d) * np.float32(sigma)
+    return (centers[np.arange(n) % ncl] + noise).astype(np.float32)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def check_search(g, o, Q, k, nprobes=0, **kw):
+    ids, sc, cnt = g.search_batch(Q, k, nprobes=nprobes, threshold=kw.get("threshold", 0.0), document_ids=kw.get("filter_ids", ()))
+    for b, q in enumerate(Q):
+        if nprobes is None:
+            n, oi, os_ = o.search(q, k, threshold=kw.get("threshold", 0.0), filter_ids=kw.get("filter_ids", ()))
+        else:
+            n, oi, os_ = o.search(q, k, nprobes, threshold=kw.get("threshold", 0.0), filter_ids=kw.get("filter_ids", ()))
+        assert cnt[b] == n, (b, cnt[b], n)
+        assert np.array_equal(ids[b, :n], oi), (b, ids[b, :n], oi)
+        assert np.array_equal(bits(sc[b, :n]), bits(os_)), (b, sc[b, :n], os_)
+
+
+# ---------------------------------------------------------------------------------------------- k-means
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("n,d,k", [(500, 16, 8), (1500, 40, 33), (300, 3, 300), (2100, 96, 64)])
+def test_kmeans_bit_exact(ctx, metric, n, d, k):
+    X = clustered(11 + n, n, d, max(2, k // 2))
+    gc, ga = ctx.kmeans(X, k, metric, 20)
+    oc, oa = orc.kmeans(X, k, metric, 20)
+    assert gc.shape == oc.shape
+    assert np.array_equal(ga, oa)
+    assert np.array_equal(bits(gc), bits(oc))
+
+
+def test_kmeans_reference_fixtures(ctx):
+    for name in ("kmeans_basic", "kmeans_convergence", "kmeans_centroid_accuracy"):
+        b = KATS[name]
+        gc, ga = ctx.kmeans(b["vectors"], b["k"], L2_SQUARED, b.get("max_iter", 20))
+        oc, oa = orc.kmeans(b["vectors"], b["k"], "l2_squared", b.get("max_iter", 20))
+        assert np.array_equal(ga, oa) and np.array_equal(bits(gc), bits(oc))
+        for grp in b.get("same_cluster_groups", []):
+            assert len({int(ga[i]) for i in grp}) == 1
+    b = KATS["kmeans_k_greater_than_n"]
+    gc, ga = ctx.kmeans(b["vectors"], b["k"])
+    assert gc.shape[0] == b["expected_k"] and len(set(ga.tolist())) == b["unique_clusters"]
+    assert ctx.kmeans(np.zeros((0, 2), np.float32), 2) == (None, None)
+    assert ctx.kmeans([[1.0, 2.0]], 0) == (None, None)
+    # max_iter <= 0 -> DefaultMaxIter
+    X = clustered(5, 400, 8, 5)
+    assert np.array_equal(bits(ctx.kmeans(X, 5, L2_SQUARED, 0)[0]), bits(orc.kmeans(X, 5, "l2_squared", 0)[0]))
+    # iteration cap honoured
+    assert np.array_equal(bits(ctx.kmeans(X, 7, L2_SQUARED, 2)[0]), bits(orc.kmeans(X, 7, "l2_squared", 2)[0]))
+
+
+def test_nearest_centroid(ctx):
+    b = KATS["nearest_centroid_tie"]
+    assert ctx.nearest_centroid(b["v"], b["centroids"], L2_SQUARED)[0] == b["source_says"]
+    X, C = synth(1, 700, 24), synth(2, 50, 24)
+    for m in METRICS:
+        got = ctx.nearest_centroid(X, C, m)
+        want = [orc.nearest_centroid(x, C, m) for x in X]
+        assert got.tolist() == want
+
+
+# ---------------------------------------------------------------------------------------------- IVF
+def build_ivf(ctx, metric, X, train, nlist):
+    n, d = X.shape
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    g = IVFIndex(ctx, d, metric, nlist)
+    o = orc.IVF(d, metric, nlist)
+    g.train(train); assert o.train(train) == 0
+    assert g.trained()
+    assert np.array_equal(bits(g.centroids(nlist)), bits(o.centroids()))
+    g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
+    assert [g.list_size(l) for l in range(nlist)] == o.list_sizes()
+    return g, o
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_ivf_matches_oracle(ctx, metric):
+    n, d, nlist = 3000, 48, 24
+    X = clustered(31, n, d, 20)
+    Q = clustered(31, 12, d, 20) + np.float32(0.01)
+    g, o = build_ivf(ctx, metric, X, X[:1200], nlist)
+    assert g.default_nprobes() == 4                       # floor(sqrt(24)) ivf_index.go:406-413
+    for nprobes in (1, 4, 24, 0, 100):                    # <=0 or > nlist -> nlist (ivf_index_search.go:233-236)
+        check_search(g, o, Q, 10, nprobes)
+    check_search(g, o, Q, 0, 3)                           # k = 0 -> all candidates of the probed lists
+    ref = o.search(Q[0], 40, 6)[2]
+    check_search(g, o, Q, 40, 6, threshold=float(ref[15]))
+    check_search(g, o, Q, 15, 6, filter_ids=list(range(1, 1500, 2)))
+    for i in (5, 6, 1000, 2999):
+        g.remove(i); assert o.remove(i) == 0
+    check_search(g, o, Q, 15, 6)
+    with pytest.raises(CometError):
+        g.remove(5)
+    # fluent API uses the index default nprobes
+    res = g.new_search().with_query(Q[1]).with_k(5).execute()
+    n_, oi, os_ = o.search(Q[1], 5, 4)
+    assert [r.id for r in res] == oi.tolist()
+
+
+def test_ivf_untrained_and_training_errors(ctx):
+    g = IVFIndex(ctx, 8, L2_SQUARED, 10)
+    with pytest.raises(RuntimeError, match="index must be trained before searching"):
+        g.new_search().with_query(np.zeros(8, np.float32)).execute()
+    with pytest.raises(CometError, match="need at least 10 training vectors"):
+        g.train(synth(1, 5, 8))
+    with pytest.raises(CometError, match="must be trained"):
+        g.add(1, np.ones(8, np.float32))
+    with pytest.raises(ValueError):
+        IVFIndex(ctx, 8, L2_SQUARED, 0)
+
+
+# ---------------------------------------------------------------------------------------------- PQ
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("d,M,nbits", [(32, 8, 4), (48, 6, 6), (20, 5, 3), (64, 64, 2)])
+def test_pq_matches_oracle(ctx, metric, d, M, nbits):
+    n = 1200
+    X = clustered(41, n, d, 30)
+    Q = clustered(41, 7, d, 30) + np.float32(0.02)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    g = PQIndex(ctx, d, metric, M, nbits)
+    o = orc.PQ(d, metric, M, nbits)
+    g.train(X[:600]); assert o.train(X[:600]) == 0
+    assert np.array_equal(bits(g.codebooks(M, 1 << nbits, d // M)), bits(o.codebooks()))
+    g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
+    gi, gcodes, _ = g.list_read(0, codes_width=M)
+    assert np.array_equal(gi, ids) and np.array_equal(gcodes, o.codes())
+    check_search(g, o, Q, 10, None)
+    check_search(g, o, Q, 0, None)                        # all results
+    ref = o.search(Q[0], 50)[2]
+    check_search(g, o, Q, 50, None, threshold=float(ref[10]))
+    check_search(g, o, Q, 9, None, filter_ids=list(range(100, 400)))
+    for i in (1, 2, 777):
+        g.remove(i); assert o.remove(i) == 0
+    check_search(g, o, Q, 9, None)
+    g.flush()
+    assert len(g) == n - 3
+
+
+def test_pq_reference_fixture_shape(ctx):
+    """pq_index_search_test.go:9-53: dim 8, M 4, nbits 4 (Ksub 16), vec[j] = (i*dim+j) % 10 — heavy ties."""
+    d, M, nbits, n = 8, 4, 4, 100
+    X = np.array([[(i * d + j) % 10 for j in range(d)] for i in range(n)], np.float32)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    g, o = PQIndex(ctx, d, EUCLIDEAN, M, nbits), orc.PQ(d, "l2", M, nbits)
+    g.train(X); assert o.train(X) == 0
+    g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
+    assert np.array_equal(g.list_read(0, codes_width=M)[1], o.codes())
+    check_search(g, o, X[:5], 5, None)
+    check_search(g, o, X[:5], 100, None)
+    # errors
+    with pytest.raises(CometError, match="need at least 16 vectors for training"):
+        PQIndex(ctx, d, EUCLIDEAN, M, nbits).train(X[:10])
+    with pytest.raises(RuntimeError, match="index not trained"):
+        PQIndex(ctx, d, EUCLIDEAN, M, nbits).new_search().with_query(X[0]).execute()
+    with pytest.raises(ValueError, match="must be divisible"):
+        PQIndex(ctx, 10, EUCLIDEAN, 4, 8)
+    with pytest.raises(ValueError, match="Nbits"):
+        PQIndex(ctx, 8, EUCLIDEAN, 4, 17)
+    assert PQIndex(ctx, d, EUCLIDEAN, M, nbits).train(X) is None
+    g2 = PQIndex(ctx, d, EUCLIDEAN, M, nbits); g2.train(X)
+    assert g2.new_search().with_query(X[0]).execute() == []           # trained but empty (pq_index_search.go:232-234)
+
+
+# ---------------------------------------------------------------------------------------------- IVFPQ
+def build_ivfpq(ctx, metric, X, train, nlist, M, nbits):
+    n, d = X.shape
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    g = IVFPQIndex(ctx, d, metric, nlist, M, nbits)
+    o = orc.IVFPQ(d, metric, nlist, M, nbits)
+    g.train(train); assert o.train(train) == 0
+    assert np.array_equal(bits(g.centroids(nlist)), bits(o.centroids()))
+    assert np.array_equal(bits(g.codebooks(M, 1 << nbits, d // M)), bits(o.codebooks()))
+    g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
+    for l in range(nlist):
+        gi, gc, _ = g.list_read(l, codes_width=M)
+        assert np.array_equal(gi, o.list_ids(l)), l
+        assert np.array_equal(gc, o.list_codes(l)), l
+    return g, o
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_ivfpq_matches_oracle(ctx, metric):
+    n, d, nlist, M, nbits = 2500, 32, 12, 8, 5
+    X = clustered(51, n, d, 16)
+    Q = clustered(51, 9, d, 16) + np.float32(0.015)
+    g, o = build_ivfpq(ctx, metric, X, X[:1000], nlist, M, nbits)
+    assert g.default_nprobes() == 3
+    for nprobes in (1, 3, 12, 0, 50):
+        check_search(g, o, Q, 10, nprobes)
+    check_search(g, o, Q, 0, 2)
+    ref = o.search(Q[0], 60, 4)[2]
+    check_search(g, o, Q, 60, 4, threshold=float(ref[20]))
+    check_search(g, o, Q, 12, 4, filter_ids=list(range(3, 2000, 3)))
+    for i in (9, 10, 11, 2500):
+        g.remove(i); assert o.remove(i) == 0
+    check_search(g, o, Q, 12, 4)
+    check_search(g, o, Q, 12, 4, filter_ids=list(range(3, 2000, 3)), threshold=float(ref[20]))
+    g.flush()
+    assert len(g) == n - 4
+    check_search(g, o, Q, 12, 4)
+
+
+def test_ivfpq_reference_fixture_shape(ctx):
+    """ivfpq_index_search_test.go:9-72: dim 8, nlist 2, M 4, nbits 4, 100 ramp training vectors vec[j] = i*dim + j."""
+    d, nlist, M, nbits, n = 8, 2, 4, 4, 100
+    X = np.array([[i * d + j for j in range(d)] for i in range(n)], np.float32)
+    g, o = build_ivfpq(ctx, L2_SQUARED, X, X, nlist, M, nbits)
+    check_search(g, o, X[:6] + np.float32(0.5), 5, 1)
+    check_search(g, o, X[:6] + np.float32(0.5), 10, 2)
+    with pytest.raises(CometError, match="need at least 20 vectors for training"):
+        IVFPQIndex(ctx, d, L2_SQUARED, nlist, M, nbits).train(X[:19])
+    with pytest.raises(RuntimeError, match="index must be trained before searching"):
+        IVFPQIndex(ctx, d, L2_SQUARED, nlist, M, nbits).new_search().with_query(X[0]).execute()
+
+
+def test_ivfpq_wide_codes_m96(ctx):
+    """The C4 code shape (M = 96, nbits = 8, dsub = 8 -> 96 KiB lookup table in LDS) at a size the oracle can train."""
+    n, d, nlist, M, nbits = 3000, 768, 8, 96, 8
+    X = clustered(61, n, d, 12, sigma=0.3)
+    Q = clustered(61, 4, d, 12, sigma=0.3) + np.float32(0.01)
+    g, o = build_ivfpq(ctx, L2_SQUARED, X, X[:600], nlist, M, nbits)
+    check_search(g, o, Q, 10, 3)
+    check_search(g, o, Q, 10, 8)
+
+
+def test_merge_topk(ctx):
+    """comet_merge_topk_dev: merging per-shard Flat results equals searching the unsharded index."""
+    import ctypes as C
+    from comet_amd import FlatIndex
+    from comet_amd._lib import check
+    n, d, B, k, R = 4000, 32, 6, 20, 4
+    X = synth(71, n, d); Q = synth(72, B, d)
+    X[n // 2 + 3] = X[5]; X[n - 1] = X[5]                      # cross-shard score ties
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    full = orc.Flat(d, "l2_squared"); full.add_batch(ids, X)
+    all_ids = np.zeros((R, B, k), np.uint32); all_sc = np.zeros((R, B, k), np.float32); all_cn = np.zeros((R, B), np.int32)
+    for r in range(R):
+        lo, hi = n * r // R, n * (r + 1) // R
+        sh = FlatIndex(ctx, d, L2_SQUARED); sh.add_batch(ids[lo:hi], X[lo:hi])
+        all_ids[r], all_sc[r], all_cn[r] = sh.search_batch(np.vstack([Q[:-1], X[5:6]]), k)
+    Qm = np.vstack([Q[:-1], X[5:6]])
+    bufs = [ctx.alloc(a.nbytes) for a in (all_ids, all_sc, all_cn)]
+    for p, a in zip(bufs, (all_ids, all_sc, all_cn)):
+        ctx.upload(p, a)
+    o_ids, o_sc, o_cn = ctx.alloc(B * k * 4), ctx.alloc(B * k * 4), ctx.alloc(B * 4)
+    check(ctx.lib.comet_merge_topk_dev(ctx.h, C.c_void_p(bufs[0]), C.c_void_p(bufs[1]), C.c_void_p(bufs[2]), R, B, k, k,
+                                       C.c_void_p(o_ids), C.c_void_p(o_sc), C.c_void_p(o_cn)))
+    ctx.sync()
+    mi, ms, mc = ctx.download(o_ids, (B, k), np.uint32), ctx.download(o_sc, (B, k), np.float32), ctx.download(o_cn, (B,), np.int32)
+    for b in range(B):
+        cnt, oi, os_ = full.search(Qm[b], k)
+        assert mc[b] == cnt and np.array_equal(mi[b, :cnt], oi) and np.array_equal(bits(ms[b, :cnt]), bits(os_))
+    for p in bufs + [o_ids, o_sc, o_cn]:
+        ctx.free(p)
