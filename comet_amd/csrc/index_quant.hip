@@ -315,6 +315,7 @@ struct PQFamilyIndex : comet_index {
     DevBuf codebooks;   // M x Ksub x dsub dense fp32 (pq_index.go:99-101 layout)
     DevBuf codes_arr;   // arrival-order codes, n x M4 words (byte m of a row = code[m])
     DevBuf codes_il;    // compiled, block-interleaved
+    bool il_dirty = true;
     ListLayout lay;
 
     int64_t size() const override { return lay.n; }
@@ -388,6 +389,7 @@ struct PQFamilyIndex : comet_index {
         if (normalized_dev) launch_unpad_rows(c, P, added, ld, normalized_dev, dim);
         HIP_CHECK(hipStreamSynchronize(c->stream));
         lay.append(ids_h, ivf ? ah.data() : nullptr, added);
+        il_dirty = true;
         return added;
     }
     void flush() override {
@@ -395,11 +397,13 @@ struct PQFamilyIndex : comet_index {
         auto keep = lay.survivors(deleted);
         compact_rows(c, codes_arr, (size_t)M4 * 4, keep);
         lay.keep_rows(keep);
+        il_dirty = true;
         deleted.clear(); deleted_dirty = true;
     }
     void compile() {
-        if (!lay.dirty) return;
         lay.compile(c);
+        if (!il_dirty) return;
+        il_dirty = false;
         codes_il.reserve(std::max<size_t>(4, (size_t)lay.nslots * M4 * 4), c->stream, 0);
         launch_interleave_codes(c, codes_arr.as<uint32_t>(), M4, lay.row_of_slot.as<uint32_t>(), lay.nslots, codes_il.as<uint32_t>());
         HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -32,7 +32,7 @@ def bits(a):
 
 
 def check_search(g, o, Q, k, nprobes=0, **kw):
-    ids, sc, cnt = g.search_batch(Q, k, nprobes=nprobes, threshold=kw.get("threshold", 0.0), document_ids=kw.get("filter_ids", ()))
+    ids, sc, cnt = g.search_batch(Q, k, nprobes=(nprobes or 0), threshold=kw.get("threshold", 0.0), document_ids=kw.get("filter_ids", ()))
     for b, q in enumerate(Q):
         if nprobes is None:
             n, oi, os_ = o.search(q, k, threshold=kw.get("threshold", 0.0), filter_ids=kw.get("filter_ids", ()))
