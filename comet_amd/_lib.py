@@ -109,6 +109,7 @@ def load() -> C.CDLL:
         "comet_index_get_codebooks": (i32, [p, p]),
         "comet_index_list_size": (i32, [p, i32, C.POINTER(i64)]),
         "comet_index_list_read": (i32, [p, i32, p, p, p]),
+        "comet_index_get_stat": (i32, [p, C.c_char_p, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

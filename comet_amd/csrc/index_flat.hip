@@ -2,6 +2,8 @@
 // helpers every index kind shares (query preprocessing, position -> id finalisation).
 #include "index.hpp"
 
+#include <cmath>
+
 namespace comet {
 
 // ------------------------------------------------------------------------------------------------
@@ -41,6 +43,12 @@ struct FlatIndex : comet_index {
     std::vector<uint32_t> ids;  // host mirror of the ids (Remove / lookup)
     std::unordered_map<uint32_t, int> id_count;
     int64_t n = 0;
+    // fp16 shadow for the MFMA fast path (kernels_fast.hip): rows, squared norms, magnitude statistics
+    int ldh = 0;
+    DevBuf Xh, rn, stats_dev;
+    float xmax_abs = 0.0f, xmax_norm2 = 0.0f;
+    // counters of the last fast-path search (bench / tests)
+    int64_t st_candidates = 0, st_overflows = 0, st_expansions = 0, st_fast_queries = 0, st_strict_queries = 0;
 
     int64_t size() const override { return n; }
     bool contains_id(uint32_t id) const override { return id_count.count(id) != 0; }
@@ -66,7 +74,18 @@ struct FlatIndex : comet_index {
             if (ids_d) c->d2d(ids_dev.as<uint32_t>() + n, ids_d, added * 4);
             else c->h2d(ids_dev.as<uint32_t>() + n, ids_h, added * 4);
             if (normalized_dev) launch_unpad_rows(c, dst, added, ld, normalized_dev, dim);
+            // half-precision shadow of the new rows + their squared norms and magnitude statistics
+            Xh.reserve((size_t)(n + added) * ldh * 2, c->stream, (size_t)n * ldh * 2);
+            rn.reserve((size_t)(n + added) * 4, c->stream, (size_t)n * 4);
+            stats_dev.reserve(8, c->stream, 0);
+            c->zero(stats_dev.p, 8);
+            launch_to_half_rows(c, dst, added, ld, (char*)Xh.p + (size_t)n * ldh * 2, ldh, rn.as<float>() + n, stats_dev.as<uint32_t>());
+            uint32_t hs[2] = {0, 0};
+            c->d2h(hs, stats_dev.p, 8);
             HIP_CHECK(hipStreamSynchronize(c->stream));
+            float fa, fn; std::memcpy(&fa, &hs[0], 4); std::memcpy(&fn, &hs[1], 4);
+            if (!(fa <= xmax_abs)) xmax_abs = fa;       // NaN-propagating max
+            if (!(fn <= xmax_norm2)) xmax_norm2 = fn;
             ids.insert(ids.end(), ids_h, ids_h + added);
             for (int64_t i = 0; i < added; i++) id_count[ids_h[i]]++;
             n += added;
@@ -98,9 +117,93 @@ struct FlatIndex : comet_index {
         HIP_CHECK(hipStreamSynchronize(c->stream));
         std::swap(X.p, nx.p); std::swap(X.cap, nx.cap);
         std::swap(ids_dev.p, nid.p); std::swap(ids_dev.cap, nid.cap);
+        {   // rebuild the fp16 shadow from the compacted rows
+            Xh.reserve(std::max<size_t>(1, nk) * ldh * 2, c->stream, 0);
+            rn.reserve(std::max<size_t>(1, nk) * 4, c->stream, 0);
+            launch_to_half_rows(c, X.as<float>(), (int64_t)nk, ld, Xh.p, ldh, rn.as<float>(), nullptr);
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
         ids.swap(nids); n = (int64_t)nk;
         id_count.clear(); for (auto id : ids) id_count[id]++;
         deleted.clear(); deleted_dirty = true;
+    }
+
+    // exact-arithmetic scan + radix top-K for `bn` prepared queries (the strict path; also the fallback)
+    void search_strict(const float* Qp, int bn, const comet_search_params& p, const uint8_t* elig, uint32_t* pos, float* out_scores,
+                       int32_t* out_counts, int k_cap) {
+        ScratchMark sm(c);
+        const int64_t ldD = round_up(n, 16);
+        const size_t budget = (size_t)2 << 30;   // bound the distance-matrix scratch: slices of queries
+        int qb = (int)std::max<int64_t>(1, std::min<int64_t>(bn, (int64_t)(budget / ((size_t)ldD * sizeof(float)))));
+        if (qb >= 16) qb = qb / 16 * 16;
+        float* D = c->salloc<float>((size_t)qb * ldD);
+        for (int b0 = 0; b0 < bn; b0 += qb) {
+            const int m = std::min(qb, bn - b0);
+            ScratchMark sm2(c);
+            launch_dist_exact(c, metric, X.as<float>(), n, ld, Qp + (size_t)b0 * ld, m, D, ldD, elig);
+            launch_select_topk(c, D, ldD, m, n, nullptr, p.threshold, p.k, pos + (size_t)b0 * k_cap,
+                               out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);
+        }
+        st_strict_queries += bn;
+    }
+
+    bool fast_usable(int B, const comet_search_params& p) const {
+        if (p.mode == 1) return false;
+        const int64_t keff = (p.k <= 0 || p.k > n) ? n : p.k;
+        const bool ok = std::isfinite(xmax_abs) && xmax_abs <= 60000.0f && std::isfinite(xmax_norm2) && keff <= 1024 && n >= 1;
+        if (p.mode == 2) return ok;
+        // auto: small batches are HBM-bound on the exact kernel anyway; the tile-top-2 proposal needs many more
+        // 256-row tiles than requested results to be selective
+        return ok && B >= 32 && n >= (int64_t)flat_fast_tile_rows() * 24 * keff;
+    }
+
+    // MFMA fast path for up to 256 prepared queries; writes candidate positions `pos` as ROW indices
+    void search_fast(const float* Qp, int bn, const comet_search_params& p, const uint8_t* elig, uint32_t* pos, float* out_scores,
+                     int32_t* out_counts, int k_cap) {
+        ScratchMark sm(c);
+        const int64_t n_tiles = ceil_div(n, flat_fast_tile_rows());
+        const int64_t ldS = round_up(2 * n_tiles, 16), ldB = round_up(n_tiles, 16);
+        const int NB = flat_fast_batch();
+        void* Qh = c->scratch_alloc((size_t)NB * ldh * 2);
+        float* qn = c->salloc<float>(NB);
+        float* err = c->salloc<float>(NB);
+        const int fmode = metric == COMET_COSINE ? 0 : 1;
+        launch_prep_queries_fast(c, Qp, bn, ld, dim, Qh, ldh, qn, err, fmode, metric == COMET_COSINE ? 1.0002f : xmax_norm2);
+        float* S0 = c->salloc<float>((size_t)NB * ldS);
+        float* bound = c->salloc<float>((size_t)NB * ldB);
+        launch_flat_scan_f16(c, fmode, Xh.p, n, ldh, Qh, rn.as<float>(), qn, elig, S0, ldS, bound, ldB);
+        // kappa: exact K-th smallest emitted key per query
+        const int64_t keff = (p.k <= 0 || p.k > n) ? n : p.k;
+        const int Kq = (int)std::min<int64_t>(keff, 2 * n_tiles);
+        uint32_t* kpos = c->salloc<uint32_t>((size_t)bn * Kq);
+        float* kkeys = c->salloc<float>((size_t)bn * Kq);
+        int32_t* kcnt = c->salloc<int32_t>(bn);
+        launch_select_topk(c, S0, ldS, bn, 2 * n_tiles, nullptr, 0.0f, Kq, kpos, kkeys, kcnt, Kq);
+        const int cap = 4096;
+        uint32_t* cand = c->salloc<uint32_t>((size_t)bn * cap);
+        int32_t* ccnt = c->salloc<int32_t>(bn);
+        int32_t* ovf = c->salloc<int32_t>(bn);
+        int32_t* st = c->salloc<int32_t>(4);
+        c->zero(st, 16);
+        // if the tile keys cannot even supply K values (tiny index / huge K) tau = +inf: every tile is expanded
+        launch_flat_collect(c, S0, ldS, bound, ldB, n_tiles, n, elig, kkeys, Kq, kcnt, (Kq == keff) ? Kq : 0x7fffffff, err, bn, cand, cap, ccnt, ovf, st);
+        float* D2 = c->salloc<float>((size_t)bn * cap);
+        launch_dist_gather(c, metric, X.as<float>(), ld, Qp, bn, cand, cap, ccnt, cap, D2, cap);
+        uint32_t* pos2 = c->salloc<uint32_t>((size_t)bn * k_cap);
+        launch_select_topk(c, D2, cap, bn, cap, ccnt, p.threshold, p.k, pos2, out_scores, out_counts, k_cap);
+        launch_gather_indirect(c, cand, cap, pos2, bn, k_cap, pos);
+        // overflowed queries (candidate list > cap): strict path
+        std::vector<int32_t> hov(bn), hst(4);
+        c->d2h(hov.data(), ovf, bn * sizeof(int32_t));
+        c->d2h(hst.data(), st, 16);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        st_candidates += hst[0]; st_overflows += hst[1]; st_expansions += hst[2];
+        int nfast = bn;
+        for (int q = 0; q < bn; q++) if (hov[q]) {
+            nfast--;
+            search_strict(Qp + (size_t)q * ld, 1, p, elig, pos + (size_t)q * k_cap, out_scores + (size_t)q * k_cap, out_counts + q, k_cap);
+        }
+        st_fast_queries += nfast;
     }
 
     // flatIndexSearch.searchSingleQuery flat_index_search.go:221-294 for B queries at once.
@@ -108,8 +211,9 @@ struct FlatIndex : comet_index {
                     int32_t* out_counts, int k_cap) override {
         float* Qp; int32_t* zflag;
         prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag);
+        st_candidates = st_overflows = st_expansions = st_fast_queries = st_strict_queries = 0;
+        uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
         if (n == 0) {   // empty index: zero results (sanitizeK(k, 0) == 0)
-            uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
             launch_select_topk(c, nullptr, 0, B, 0, nullptr, 0.0f, p.k, pos, out_scores, out_counts, k_cap);
             launch_finalize(c, nullptr, pos, B, k_cap, zflag, out_ids, out_counts);
             return;
@@ -125,22 +229,31 @@ struct FlatIndex : comet_index {
             launch_build_elig(c, ids_dev.as<uint32_t>(), n, del, nd, flt, nf, e);
             elig = e;
         }
-        const int64_t ldD = round_up(n, 16);
-        // bound the distance-matrix scratch: process the batch in slices of queries
-        const size_t budget = (size_t)2 << 30;
-        int qb = (int)std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(budget / ((size_t)ldD * sizeof(float)))));
-        if (qb >= 16) qb = qb / 16 * 16;
-        float* D = c->salloc<float>((size_t)qb * ldD);
-        uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
-        for (int b0 = 0; b0 < B; b0 += qb) {
-            const int bn = std::min(qb, B - b0);
-            launch_dist_exact(c, metric, X.as<float>(), n, ld, Qp + (size_t)b0 * ld, bn, D, ldD, elig);
-            launch_select_topk(c, D, ldD, bn, n, nullptr, p.threshold, p.k, pos + (size_t)b0 * k_cap,
-                               out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);
+        if (p.mode == 2 && !fast_usable(B, p)) COMET_FAIL(COMET_ERR_UNSUPPORTED, "fast path unavailable for this index / k (values beyond fp16 range or k > 1024)");
+        if (fast_usable(B, p)) {
+            const int NB = flat_fast_batch();
+            for (int b0 = 0; b0 < B; b0 += NB) {
+                const int bn = std::min(NB, B - b0);
+                search_fast(Qp + (size_t)b0 * ld, bn, p, elig, pos + (size_t)b0 * k_cap, out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);
+            }
+        } else {
+            search_strict(Qp, B, p, elig, pos, out_scores, out_counts, k_cap);
         }
         launch_finalize(c, ids_dev.as<uint32_t>(), pos, B, k_cap, zflag, out_ids, out_counts);
     }
 
+    bool get_stat(const char* name, double* out) const override {
+        std::string k(name);
+        if (k == "fast_candidates") *out = (double)st_candidates;
+        else if (k == "fast_overflows") *out = (double)st_overflows;
+        else if (k == "fast_expansions") *out = (double)st_expansions;
+        else if (k == "fast_queries") *out = (double)st_fast_queries;
+        else if (k == "strict_queries") *out = (double)st_strict_queries;
+        else if (k == "max_abs") *out = (double)xmax_abs;
+        else if (k == "max_norm2") *out = (double)xmax_norm2;
+        else return false;
+        return true;
+    }
     void list_read(int, uint32_t* oids, uint8_t*, float* ovecs) const override {
         if (oids) std::copy(ids.begin(), ids.end(), oids);
         if (ovecs && n > 0) {
@@ -154,7 +267,7 @@ struct FlatIndex : comet_index {
 
 comet_index* make_flat(Ctx* c, int dim, int metric) {
     auto* f = new FlatIndex();
-    f->c = c; f->kind = COMET_KIND_FLAT; f->dim = dim; f->ld = padded_dim(dim); f->metric = metric; f->trained = true;
+    f->c = c; f->kind = COMET_KIND_FLAT; f->dim = dim; f->ld = padded_dim(dim); f->ldh = (int)round_up(dim, 64); f->metric = metric; f->trained = true;
     return f;
 }
 

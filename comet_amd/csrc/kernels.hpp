@@ -39,6 +39,8 @@ void launch_build_elig(Ctx* c, const uint32_t* ids, int64_t n, const uint32_t* d
 // out[i] = table[idx[i]] (ids gather), idx == 0xFFFFFFFF -> 0
 void launch_gather_u32(Ctx* c, const uint32_t* table, const uint32_t* idx, int64_t n, uint32_t* out);
 
+void launch_gather_indirect(Ctx* c, const uint32_t* table, int64_t ldt, const uint32_t* idx, int B, int k, uint32_t* out);
+
 // ---- kernels_select.hip -----------------------------------------------------------------------
 // Exact top-K by (score asc, position asc) over per-query candidate rows D[q][0..C_q).
 //   cnts: per-query candidate counts (device, int32) or nullptr -> every query has C candidates.
@@ -76,5 +78,19 @@ size_t adc_lds_bytes(int M, int Ksub, int dim);
 void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* centroids, const float* codebooks, int M, int Ksub, int dsub,
                      const uint32_t* codes, int M4, const int64_t* list_base, const int32_t* list_len, const uint32_t* probe_list, int ldp,
                      int np, const int32_t* seg_off, const uint8_t* elig, int B, int max_list_len, float* D, int64_t ldD);
+
+// ---- kernels_fast.hip (MFMA fast path of the Flat scan) ------------------------------------------
+int flat_fast_tile_rows();
+int flat_fast_batch();
+// fp32 padded rows -> fp16 shadow rows (ldh halves per row, zero padded); rn[row] = sum x^2 (nullable);
+// stats[0] = max |x| bits, stats[1] = max row norm^2 bits (atomicMax; caller zero-initialises)
+void launch_to_half_rows(Ctx* c, const float* X, int64_t n, int ld, void* Xh, int ldh, float* rn, uint32_t* stats);
+// mode 0 cosine / 1 L2 family. Qh: 256 x ldh fp16. S0: 256 x ldS (2 packed keys per 256-row tile), bound: 256 x ldB.
+void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, const float* rn, const float* qn,
+                          const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB);
+void launch_flat_collect(Ctx* c, const float* S0, int64_t ldS, const float* bound, int64_t ldB, int64_t n_tiles, int64_t n, const uint8_t* elig,
+                         const float* kth_keys, int kcap, const int32_t* kth_cnt, int K, const float* err_abs, int B, uint32_t* cand, int cap,
+                         int32_t* cand_cnt, int32_t* overflow, int32_t* stats);
+void launch_prep_queries_fast(Ctx* c, const float* Qp, int B, int ld, int dim, void* Qh, int ldh, float* qn, float* err_abs, int mode, float xmax_norm2);
 
 }  // namespace comet

@@ -368,4 +368,18 @@ void launch_gather_u32(Ctx* c, const uint32_t* table, const uint32_t* idx, int64
     LAUNCH_CHECK();
 }
 
+// out[q][i] = table[q][idx[q][i]] (per-query table of width ldt); idx == 0xFFFFFFFF stays 0xFFFFFFFF
+__global__ __launch_bounds__(256) void gather_indirect_kernel(const unsigned* __restrict__ table, long ldt, const unsigned* __restrict__ idx, int B, int k, unsigned* __restrict__ out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * k) return;
+    const long q = i / k;
+    const unsigned p = idx[i];
+    out[i] = p == 0xFFFFFFFFu ? p : table[q * ldt + p];
+}
+void launch_gather_indirect(Ctx* c, const uint32_t* table, int64_t ldt, const uint32_t* idx, int B, int k, uint32_t* out) {
+    if (B <= 0 || k <= 0) return;
+    gather_indirect_kernel<<<dim3((unsigned)ceil_div((long)B * k, 256)), dim3(256), 0, c->stream>>>(table, ldt, idx, B, k, out);
+    LAUNCH_CHECK();
+}
+
 }  // namespace comet

@@ -427,6 +427,11 @@ class VectorIndex:
     def _check_searchable(self) -> None:
         pass
 
+    def stat(self, name: str) -> float:
+        out = C.c_double()
+        check(self.lib.comet_index_get_stat(self.h, name.encode(), C.byref(out)))
+        return out.value
+
     def list_size(self, lst: int = 0) -> int:
         out = C.c_int64()
         check(self.lib.comet_index_list_size(self.h, int(lst), C.byref(out)))

@@ -167,6 +167,10 @@ COMET_API int comet_index_list_size(const comet_index* idx, int32_t list, int64_
 COMET_API int comet_index_list_read(const comet_index* idx, int32_t list, uint32_t* out_ids, uint8_t* out_codes,
                                     float* out_vecs);
 
+/* named counters of the last search / of the index (bench + tests): "fast_candidates", "fast_overflows",
+ * "fast_expansions", "fast_queries", "strict_queries", "max_abs", "max_norm2". Unknown name -> INVALID_ARG. */
+COMET_API int comet_index_get_stat(const comet_index* idx, const char* name, double* out);
+
 #ifdef __cplusplus
 }
 #endif
