@@ -202,11 +202,18 @@ def main():
         dom_name, (dom_ms, dom_n) = dom
         rows_local = hi - lo
         launches_per_step = max(1, dom_n // args.steps)
-        # algorithmic bytes of one launch of the scan kernel: every stored row once (fp32)
-        alg_bytes = rows_local * args.dim * 4 * (B / launches_per_step / B)
-        alg_bytes = rows_local * args.dim * 4
         avg_ms = dom_ms / max(1, dom_n)
+        ldh = (args.dim + 63) // 64 * 64
+        if dom_name == "flat_scan_f16":
+            # algorithmic bytes of one launch: the fp16 shadow of every stored row once + the 256-query fp16 tile
+            alg_bytes = rows_local * ldh * 2 + 256 * ldh * 2
+            flops = 2.0 * 256 * rows_local * ldh
+        else:
+            # exact-arithmetic scan: every stored fp32 row once per launch (N*d*4)
+            alg_bytes = rows_local * args.dim * 4
+            flops = 0.0
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        mfma_tflops = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         line = {
             "metric": "queries/sec, Flat 1Mx768 scan (recall@K = 1.0: exact search, ids bit-identical to the CPU reference path)",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -217,8 +224,10 @@ def main():
                        "mode": {0: "auto", 1: "strict", 2: "fast"}[args.mode], "sharding": f"rows/{world}", "build_s": round(build_s, 2)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": avg_ms,
-                         "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": alg_bytes},
+                         "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": alg_bytes,
+                         "mfma_tflops": mfma_tflops, "mfma_frac_of_2500": mfma_tflops / 2500.0},
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
+            "fast_path": {k: idx.stat(k) for k in ("fast_queries", "strict_queries", "fast_candidates", "fast_expansions", "fast_overflows")},
         }
         if world == 1 and not args.no_cpu_baseline:
             ids = ctx.download(out_ids, (B, K), np.uint32)

@@ -188,7 +188,7 @@ struct FlatIndex : comet_index {
         // if the tile keys cannot even supply K values (tiny index / huge K) tau = +inf: every tile is expanded
         launch_flat_collect(c, S0, ldS, bound, ldB, n_tiles, n, elig, kkeys, Kq, kcnt, (Kq == keff) ? Kq : 0x7fffffff, err, bn, cand, cap, ccnt, ovf, st);
         float* D2 = c->salloc<float>((size_t)bn * cap);
-        launch_dist_gather(c, metric, X.as<float>(), ld, Qp, bn, cand, cap, ccnt, cap, D2, cap);
+        launch_rescore_exact(c, metric, X.as<float>(), ld, Qp, bn, cand, cap, ccnt, cap, D2, cap);
         uint32_t* pos2 = c->salloc<uint32_t>((size_t)bn * k_cap);
         launch_select_topk(c, D2, cap, bn, cap, ccnt, p.threshold, p.k, pos2, out_scores, out_counts, k_cap);
         launch_gather_indirect(c, cand, cap, pos2, bn, k_cap, pos);

@@ -26,6 +26,10 @@ void launch_dist_exact(Ctx* c, int metric, const float* X, int64_t n, int ld, co
 // (rowidx == 0xFFFFFFFF -> EXCLUDED). rowidx: B x ldR, D: B x ldD, Cmax >= max cnts.
 void launch_dist_gather(Ctx* c, int metric, const float* X, int ld, const float* Q, int B, const uint32_t* rowidx, int64_t ldR,
                         const int32_t* cnts, int64_t Cmax, float* D, int64_t ldD);
+// Same contract as launch_dist_gather but for a FEW valid candidates per query (no EXCLUDED entries
+// below cnts[q]); wave-per-4-candidates mapping that hides HBM latency (fast path re-scoring).
+void launch_rescore_exact(Ctx* c, int metric, const float* X, int ld, const float* Q, int B, const uint32_t* cand, int64_t ldc,
+                          const int32_t* cnts, int64_t Cmax, float* D, int64_t ldD);
 // Bit pattern written into a distance matrix for candidates that must not be returned (soft-deleted,
 // filtered out). A negative quiet NaN with all payload bits set — never produced by the arithmetic here.
 constexpr uint32_t EXCLUDED_BITS = 0xFFFFFFFFu;

@@ -72,9 +72,49 @@ __global__ __launch_bounds__(256) void ingest_rows_kernel(int metric, const floa
     for (int i = d; i < ld; i++) o[i] = 0.0f;
     if (zero_flag) zero_flag[r] = zf;
 }
+// wave-per-row variant: coalesced row load, squares staged in LDS, lane 0 runs the serial float32 sum
+// (same order as the Go loop), all lanes write the scaled row. Used when the row fits the LDS budget.
+constexpr int INGEST_MAX_D = 2048;
+__global__ __launch_bounds__(256) void ingest_rows_wave_kernel(int metric, const float* __restrict__ src, long n, int d, float* __restrict__ dst,
+                                                               int ld, int* __restrict__ zero_flag) {
+    extern __shared__ __attribute__((aligned(16))) float sq[];   // [4 waves][dpad]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long r = (long)blockIdx.x * 4 + w;
+    if (r >= n) return;
+    const int dpad = (d + 3) & ~3;
+    float* my = sq + (long)w * dpad;
+    const float* s = src + r * (long)d;
+    float* o = dst + r * (long)ld;
+    float scale = 1.0f; int zf = 0;
+    if (metric == COMET_COSINE) {
+        for (int i = lane; i < dpad; i += 64) { float v = i < d ? s[i] : 0.0f; my[i] = v * v; }
+        __builtin_amdgcn_s_waitcnt(0);   // this wave's LDS writes are complete before lane 0 reads them back
+        __builtin_amdgcn_wave_barrier();
+        float sum = 0.0f;
+        if (lane == 0) {
+            for (int i = 0; i < dpad; i += 4) {
+                const f32x4 p = *reinterpret_cast<const f32x4*>(&my[i]);
+                sum = sum + p[0]; sum = sum + p[1]; sum = sum + p[2]; sum = sum + p[3];   // trailing pad terms are +0
+            }
+        }
+        sum = __shfl(sum, 0, 64);
+        const float norm = go_sqrt32(sum);
+        if (norm == 0.0f) zf = 1; else scale = 1.0f / norm;
+    }
+    if (metric == COMET_COSINE && !zf) { for (int i = lane; i < d; i += 64) o[i] = s[i] * scale; }
+    else { for (int i = lane; i < d; i += 64) o[i] = s[i]; }
+    for (int i = d + lane; i < ld; i += 64) o[i] = 0.0f;
+    if (zero_flag && lane == 0) zero_flag[r] = zf;
+}
 void launch_ingest_rows(Ctx* c, int metric, const float* src, int64_t n, int d, float* dst, int ld, int32_t* zero_flag) {
     if (n <= 0) return;
     ProfScope ps(c, "ingest_rows");
+    if (d <= INGEST_MAX_D) {
+        const size_t lds = (size_t)4 * ((d + 3) & ~3) * sizeof(float);
+        ingest_rows_wave_kernel<<<dim3((unsigned)ceil_div(n, 4)), dim3(256), lds, c->stream>>>(metric, src, n, d, dst, ld, zero_flag);
+        LAUNCH_CHECK();
+        return;
+    }
     ingest_rows_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, c->stream>>>(metric, src, n, d, dst, ld, zero_flag);
     LAUNCH_CHECK();
 }
@@ -284,6 +324,80 @@ void launch_dist_gather(Ctx* c, int metric, const float* X, int ld, const float*
         case COMET_L2SQ: dist_gather_kernel<COMET_L2SQ><<<grid, blk, 0, c->stream>>>(X, ld, Q, rowidx, ldR, cnts, D, ldD); break;
         default: dist_gather_kernel<COMET_COSINE><<<grid, blk, 0, c->stream>>>(X, ld, Q, rowidx, ldR, cnts, D, ldD); break;
     }
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact re-scoring of a FEW candidates per query (the fast path's step 3): latency- not throughput-bound,
+// so the mapping is different from the scan kernels. A wave takes 4 candidates: all 64 lanes fetch each
+// candidate row coalesced and compute the per-element terms (diff^2 or product: independent, exactly
+// rounded), park them in LDS, then lanes 0..3 each run one candidate's serial float32 sum in index order.
+// ------------------------------------------------------------------------------------------------
+constexpr int RS_CPW = 4;        // candidates per wave
+constexpr int RS_CHUNK = 1024;   // max floats of a row staged per pass
+template <int METRIC>
+__global__ __launch_bounds__(256) void rescore_exact_kernel(const float* __restrict__ X, int ld, const float* __restrict__ Q,
+                                                            const unsigned* __restrict__ cand, long ldc, const int* __restrict__ cnts,
+                                                            float* __restrict__ D, long ldD, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) float terms_all[];   // [4 waves][RS_CPW][chunk]
+    const int q = blockIdx.y;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int cnt = cnts[q];
+    float* terms = terms_all + (long)w * RS_CPW * chunk;
+    const float* __restrict__ qv = Q + (long)q * ld;
+    // the grid covers a fixed number of candidate groups per query; longer lists loop
+    for (int c0 = (blockIdx.x * 4 + w) * RS_CPW; c0 < cnt; c0 += gridDim.x * 4 * RS_CPW) {
+        unsigned rows[RS_CPW];
+#pragma unroll
+        for (int j = 0; j < RS_CPW; j++) rows[j] = (c0 + j < cnt) ? cand[(long)q * ldc + c0 + j] : 0u;
+        float acc = 0.0f;   // lanes 0..3: running sum of candidate `lane`
+        for (int k0 = 0; k0 < ld; k0 += chunk) {
+            const int kn = min(chunk, ld - k0);   // multiple of 32
+#pragma unroll
+            for (int j = 0; j < RS_CPW; j++) {
+                const float* __restrict__ x = X + (long)rows[j] * ld + k0;
+                for (int i = lane * 4; i < kn; i += 256) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
+                    const f32x4 qq = *reinterpret_cast<const f32x4*>(qv + k0 + i);
+                    f32x4 t;
+                    if constexpr (METRIC == COMET_COSINE) { t[0] = qq[0] * xv[0]; t[1] = qq[1] * xv[1]; t[2] = qq[2] * xv[2]; t[3] = qq[3] * xv[3]; }
+                    else {
+                        const float d0 = qq[0] - xv[0], d1 = qq[1] - xv[1], d2 = qq[2] - xv[2], d3 = qq[3] - xv[3];
+                        t[0] = d0 * d0; t[1] = d1 * d1; t[2] = d2 * d2; t[3] = d3 * d3;
+                    }
+                    *reinterpret_cast<f32x4*>(&terms[j * chunk + i]) = t;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < RS_CPW) {
+                const float* tp = terms + lane * chunk;
+#pragma unroll 8
+                for (int i = 0; i < kn; i += 4) {
+                    const f32x4 p = *reinterpret_cast<const f32x4*>(tp + i);
+                    acc = acc + p[0]; acc = acc + p[1]; acc = acc + p[2]; acc = acc + p[3];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane < RS_CPW && c0 + lane < cnt) D[(long)q * ldD + c0 + lane] = acc_finish<METRIC>(acc);
+    }
+}
+void launch_rescore_exact(Ctx* c, int metric, const float* X, int ld, const float* Q, int B, const uint32_t* cand, int64_t ldc,
+                          const int32_t* cnts, int64_t Cmax, float* D, int64_t ldD) {
+    if (B <= 0 || Cmax <= 0) return;
+    ProfScope ps(c, "rescore_exact");
+    const int chunk = std::min(ld, RS_CHUNK);
+    const size_t lds = (size_t)4 * RS_CPW * chunk * sizeof(float);
+    const int groups = (int)std::min<int64_t>(ceil_div(Cmax, 4 * RS_CPW), 16);   // 256 candidates per sweep; longer lists loop
+    dim3 grid(groups, B), blk(256);
+#define RS(M) do { if (lds > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)rescore_exact_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                   rescore_exact_kernel<M><<<grid, blk, lds, c->stream>>>(X, ld, Q, cand, ldc, cnts, D, ldD, chunk); } while (0)
+    switch (metric) {
+        case COMET_L2: RS(COMET_L2); break;
+        case COMET_L2SQ: RS(COMET_L2SQ); break;
+        default: RS(COMET_COSINE); break;
+    }
+#undef RS
     LAUNCH_CHECK();
 }
 

@@ -300,10 +300,11 @@ __global__ __launch_bounds__(COLLECT_THREADS) void flat_collect_kernel(const flo
         if (threadIdx.x == 0) { overflow[q] = 1; cand_cnt[q] = 0; if (stats) { atomicAdd(&stats[1], 1); } }
         return;
     }
-    // ascending row order = the canonical tie order of the strict path
-    for (int k = 2; k <= cap2; k <<= 1) {
+    // ascending row order = the canonical tie order of the strict path (sort only the used prefix)
+    int n2 = 64; while (n2 < cnt) n2 <<= 1;
+    for (int k = 2; k <= n2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < cap2; i += COLLECT_THREADS) {
+            for (int i = threadIdx.x; i < n2; i += COLLECT_THREADS) {
                 int ixj = i ^ j;
                 if (ixj > i) {
                     unsigned a = lst[i], b = lst[ixj];

@@ -25,7 +25,7 @@ constexpr int SEL_CHUNK = SEL_THREADS * SEL_EPT;    // 4096 candidates per workg
 constexpr int SEL_BINS = 4096;
 constexpr int SORT_MAX = 4096;                      // max K sorted in LDS
 
-int select_max_k() { return SORT_MAX; }
+int select_max_k() { return SORT_MAX; }   // for candidate rows longer than SMALL_MAX; shorter rows have no limit
 
 struct SelState {
     unsigned prefix;     // bits of key* decided so far
@@ -279,6 +279,154 @@ __global__ __launch_bounds__(1024) void sel_sort_kernel(const unsigned long long
     if (threadIdx.x == 0) out_counts[q] = kq;
 }
 
+// ---- small candidate rows (C <= 8192): one workgroup per query, everything in LDS ---------------------
+// Same result as the multi-pass path (composite = order-preserving key << 32 | position, ascending), one
+// launch instead of nine: used for IVF / IVFPQ candidate lists, the fast path's tile keys and rescoring.
+//   * up to 1024 candidates: bitonic sort of the composites;
+//   * more: two 12-bit radix histogram passes in LDS locate the 24-bit prefix of the K-th key, the
+//     candidates at or below that prefix are compacted (typically K + a handful) and only those are sorted;
+//     if the compaction would exceed its buffer (heavy ties) the whole row is sorted instead.
+constexpr int SMALL_MAX = 8192;
+constexpr int SMALL_LIST = 2048;
+
+__device__ __forceinline__ void bitonic_sort_lds(unsigned long long* sm, int n2) {
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    unsigned long long a = sm[i], b = sm[ixj];
+                    bool up = ((i & k) == 0);
+                    if ((a > b) == up) { sm[i] = b; sm[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+// block-wide: find the bin of a 4096-bin LDS histogram holding the `rank`-th element (1-based);
+// returns bin in *bin_out and the number of elements in lower bins in *before_out. blockDim.x == 1024.
+__device__ __forceinline__ void find_bin_4096(const unsigned* hist, int rank, unsigned* wsum /*16*/, int* bin_out, int* before_out) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const unsigned h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+    const unsigned mine = h0 + h1 + h2 + h3;
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { unsigned y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    unsigned before = incl - mine;
+    for (int i = 0; i < w; i++) before += wsum[i];
+    const unsigned r = (unsigned)rank;
+    if (before < r && before + mine >= r) {
+        unsigned run = before; int b = 4 * t;
+        if (run + h0 >= r) { b = 4 * t; }
+        else { run += h0; if (run + h1 >= r) { b = 4 * t + 1; } else { run += h1; if (run + h2 >= r) { b = 4 * t + 2; } else { run += h2; b = 4 * t + 3; } } }
+        *bin_out = b; *before_out = (int)run;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void select_small_kernel(const float* __restrict__ D, long ldD, long C, const int* __restrict__ cnts, float thr,
+                                                            int K, unsigned* __restrict__ out_pos, float* __restrict__ out_scores,
+                                                            int* __restrict__ out_counts, int k_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];   // 64 KiB when C > 1024, else 8 * n2 bytes
+    __shared__ int s_valid, s_bin, s_before, s_m;
+    __shared__ unsigned wsum[16];
+    const int q = blockIdx.x;
+    long cnt = cnts ? (long)cnts[q] : C;
+    if (cnt > C) cnt = C;
+    if (threadIdx.x == 0) { s_valid = 0; s_m = 0; }
+    __syncthreads();
+    const float* row = D + (long)q * ldD;
+    unsigned long long* sorted = sm;
+    int kq = 0;
+    if (cnt <= 1024 || blockDim.x < 1024) {
+        // ---- direct sort ----
+        int n2 = 64; while (n2 < cnt) n2 <<= 1;
+        int mine = 0;
+        for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+            unsigned long long v = ~0ull;
+            if (i < cnt) { const unsigned bits = __float_as_uint(row[i]); if (cand_ok(bits, thr)) { v = ((unsigned long long)f2key(bits) << 32) | (unsigned)i; mine++; } }
+            sm[i] = v;
+        }
+        if (mine) atomicAdd(&s_valid, mine);
+        __syncthreads();
+        bitonic_sort_lds(sm, n2);
+        const int valid = s_valid;
+        kq = (K <= 0 || K > valid) ? valid : K;    // sanitizeK limiter.go:12-17
+    } else {
+        // ---- radix-compaction ----
+        unsigned* keys = reinterpret_cast<unsigned*>(sm);            // 8192 keys   (32 KiB)
+        unsigned* hist = keys + SMALL_MAX;                            // 4096 bins   (16 KiB)
+        unsigned long long* list = sm + (SMALL_MAX + 4096) / 2;       // 2048 composites (16 KiB)
+        int mine = 0;
+        for (int i = threadIdx.x; i < SMALL_MAX; i += 1024) {
+            unsigned k = 0xFFFFFFFFu;
+            if (i < cnt) { const unsigned bits = __float_as_uint(row[i]); if (cand_ok(bits, thr)) { k = f2key(bits); mine++; } }
+            keys[i] = k;   // note: a real key of 0xFFFFFFFF (a negative NaN) is indistinguishable from "invalid"; dropped
+        }
+        for (int i = threadIdx.x; i < 4096; i += 1024) hist[i] = 0;
+        if (mine) atomicAdd(&s_valid, mine);
+        __syncthreads();
+        const int valid = s_valid;
+        kq = (K <= 0 || K > valid) ? valid : K;
+        bool full_sort = kq > SMALL_LIST;
+        unsigned prefix24 = 0;
+        if (!full_sort && kq > 0) {
+            for (int i = threadIdx.x; i < cnt; i += 1024) { const unsigned k = keys[i]; if (k != 0xFFFFFFFFu) atomicAdd(&hist[k >> 20], 1u); }
+            __syncthreads();
+            find_bin_4096(hist, kq, wsum, &s_bin, &s_before);
+            const int bin1 = s_bin, before1 = s_before;
+            __syncthreads();
+            for (int i = threadIdx.x; i < 4096; i += 1024) hist[i] = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < cnt; i += 1024) { const unsigned k = keys[i]; if (k != 0xFFFFFFFFu && (int)(k >> 20) == bin1) atomicAdd(&hist[(k >> 8) & 4095u], 1u); }
+            __syncthreads();
+            find_bin_4096(hist, kq - before1, wsum, &s_bin, &s_before);
+            prefix24 = ((unsigned)bin1 << 12) | (unsigned)s_bin;
+            __syncthreads();
+            // compact every candidate whose 24-bit prefix is <= the K-th key's prefix
+            for (int i = threadIdx.x; i < cnt; i += 1024) {
+                const unsigned k = keys[i];
+                if (k != 0xFFFFFFFFu && (k >> 8) <= prefix24) { int s = atomicAdd(&s_m, 1); if (s < SMALL_LIST) list[s] = ((unsigned long long)k << 32) | (unsigned)i; }
+            }
+            __syncthreads();
+            if (s_m > SMALL_LIST) full_sort = true;
+        }
+        if (full_sort) {
+            __syncthreads();
+            int n2 = 64; while (n2 < cnt) n2 <<= 1;
+            for (int i = threadIdx.x; i < n2; i += 1024) {
+                unsigned long long v = ~0ull;
+                if (i < cnt) { const unsigned bits = __float_as_uint(row[i]); if (cand_ok(bits, thr)) v = ((unsigned long long)f2key(bits) << 32) | (unsigned)i; }
+                sm[i] = v;
+            }
+            __syncthreads();
+            bitonic_sort_lds(sm, n2);
+        } else if (kq > 0) {
+            const int m = s_m;
+            int n2 = 64; while (n2 < m) n2 <<= 1;
+            for (int i = m + threadIdx.x; i < n2; i += 1024) list[i] = ~0ull;
+            __syncthreads();
+            bitonic_sort_lds(list, n2);
+            sorted = list;
+        }
+    }
+    const int nw = kq < k_cap ? kq : k_cap;
+    for (int i = threadIdx.x; i < k_cap; i += blockDim.x) {
+        if (i < nw) {
+            unsigned long long c = sorted[i];
+            out_pos[(long)q * k_cap + i] = (unsigned)(c & 0xFFFFFFFFull);
+            out_scores[(long)q * k_cap + i] = __uint_as_float(key2f((unsigned)(c >> 32)));
+        } else {
+            out_pos[(long)q * k_cap + i] = 0xFFFFFFFFu;
+            out_scores[(long)q * k_cap + i] = 0.0f;
+        }
+    }
+    if (threadIdx.x == 0) out_counts[q] = kq;
+}
+
 void launch_select_topk(Ctx* c, const float* D, int64_t ldD, int B, int64_t C, const int32_t* cnts, float thr, int K,
                         uint32_t* out_pos, float* out_scores, int32_t* out_counts, int k_cap) {
     if (B <= 0) return;
@@ -286,6 +434,16 @@ void launch_select_topk(Ctx* c, const float* D, int64_t ldD, int B, int64_t C, c
         c->zero(out_counts, sizeof(int32_t) * B);
         HIP_CHECK(hipMemsetAsync(out_pos, 0xFF, sizeof(uint32_t) * (size_t)B * k_cap, c->stream));
         c->zero(out_scores, sizeof(float) * (size_t)B * k_cap);
+        return;
+    }
+    if (C <= SMALL_MAX) {
+        int n2 = 64; while (n2 < C) n2 <<= 1;
+        ProfScope ps(c, "select_small");
+        const int threads = C > 1024 ? 1024 : (n2 >= 512 ? 256 : 64);
+        const size_t lds = C > 1024 ? (size_t)64 * 1024 : sizeof(unsigned long long) * n2;
+        if (lds > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)select_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        select_small_kernel<<<dim3(B), dim3(threads), lds, c->stream>>>(D, ldD, C, cnts, thr, K, out_pos, out_scores, out_counts, k_cap);
+        LAUNCH_CHECK();
         return;
     }
     const int64_t kmax = (K <= 0 || K > C) ? C : K;
