@@ -109,6 +109,14 @@ def load() -> C.CDLL:
         "comet_index_get_codebooks": (i32, [p, p]),
         "comet_index_list_size": (i32, [p, i32, C.POINTER(i64)]),
         "comet_index_list_read": (i32, [p, i32, p, p, p]),
+        "comet_bm25_create": (i32, [p, pp]),
+        "comet_bm25_destroy": (i32, [p]),
+        "comet_bm25_add": (i32, [p, C.c_uint32, p, i32]),
+        "comet_bm25_remove": (i32, [p, C.c_uint32]),
+        "comet_bm25_flush": (i32, [p]),
+        "comet_bm25_num_docs": (i64, [p]),
+        "comet_bm25_avg_doc_len": (C.c_double, [p]),
+        "comet_bm25_search": (i32, [p, p, p, i32, i32, p, i32, p, p, p, p, i32]),
         "comet_index_get_stat": (i32, [p, C.c_char_p, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():

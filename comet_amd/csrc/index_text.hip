@@ -1,0 +1,358 @@
+// index_text.hip — BM25 on the GPU (reference: bm25_index.go, bm25_index_search.go:278-397).
+//
+// Tokenisation / NFKC / lower-casing stay in Go (third-party uax29, x/text): documents and queries
+// arrive as token ids. The host keeps the reference's structures (postings in ascending doc-id order,
+// term frequencies, document lengths, running average); a CSR snapshot lives in HBM. Scoring is
+// term-at-a-time in float64 exactly like the reference: one launch per query-token POSITION, so the
+// accumulation order `scores[doc] += score` (bm25_index_search.go:325) is the query-token order, and
+// within one launch every posting of a term touches a different document (no atomics, no reordering).
+// Selection keeps the reference's "top-k by float64 score, descending" with the canonical tie order
+// (ascending doc id) in one workgroup per query: 8 radix passes on the order-preserving 64-bit key.
+#include <map>
+#include <unordered_map>
+#include <unordered_set>
+#include <algorithm>
+#include <cmath>
+
+#include "kernels.hpp"
+
+struct comet_ctx : comet::Ctx {};
+
+namespace comet {
+
+// math.Log as Go's portable implementation computes it (FreeBSD e_log.c; src/math/log.go) — restated so
+// idf matches the reference bit for bit instead of depending on the host libm.
+static double go_log(double x) {
+    const double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10;
+    const double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01,
+                 L4 = 2.222219843214978396e-01, L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+                 L7 = 1.479819860511658591e-01;
+    if (std::isnan(x) || (std::isinf(x) && x > 0)) return x;
+    if (x < 0) return std::nan("");
+    if (x == 0) return -INFINITY;
+    int ki; double f1 = std::frexp(x, &ki);
+    if (f1 < 0.70710678118654752440) { f1 *= 2; ki--; }
+    const double f = f1 - 1, k = (double)ki;
+    const double s = f / (2 + f), s2 = s * s, s4 = s2 * s2;
+    const double t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7)));
+    const double t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
+    const double R = t1 + t2, hfsq = 0.5 * f * f;
+    return k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
+}
+
+// ---- scoring: one launch per query-token position ---------------------------------------------------
+struct TermRef { int off; int df; double idf; };   // per (query, position); df == 0 -> no such term / padding
+
+__global__ __launch_bounds__(256) void bm25_score_kernel(const TermRef* __restrict__ refs /*[B]*/, const int* __restrict__ post_doc,
+                                                         const int* __restrict__ post_tf, const int* __restrict__ doc_len,
+                                                         const unsigned char* __restrict__ elig, double avg_doc_len,
+                                                         double* __restrict__ acc, long nd) {
+    const int q = blockIdx.y;
+    const TermRef r = refs[q];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= r.df) return;
+    const int doc = post_doc[r.off + i];
+    if (elig && !elig[doc]) return;                       // deleted / filtered documents are skipped (:312-319)
+    const double tfv = (double)post_tf[r.off + i];
+    const double dl = (double)doc_len[doc];
+    // score := idf * (tfVal * (K1 + 1)) / (tfVal + K1*(1-B+B*(docLen/avgDocLen)))  (:321-324), K1=1.2, B=0.75;
+    // the untyped constants K1+1 and 1-B fold exactly to 2.2 and 0.25. Compiled with -ffp-contract=off.
+    const double ratio = dl / avg_doc_len;
+    const double inner = 0.25 + 0.75 * ratio;
+    const double den = tfv + 1.2 * inner;
+    const double num = r.idf * (tfv * 2.2);
+    const double score = num / den;
+    acc[(long)q * nd + doc] = acc[(long)q * nd + doc] + score;
+}
+
+// ---- top-k by (score desc, doc index asc) on float64 ------------------------------------------------
+// key = ~ordered(score): ascending key == descending score; untouched documents (acc == 0) are skipped
+__device__ __forceinline__ unsigned long long d2key_desc(double v) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    u = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+    return ~u;
+}
+__device__ __forceinline__ double key2d_desc(unsigned long long k) {
+    unsigned long long u = ~k;
+    u = (u & 0x8000000000000000ull) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u;
+    return __longlong_as_double((long long)u);
+}
+constexpr int BM_THREADS = 1024;
+constexpr int BM_KMAX = 2048;
+struct KP { unsigned long long key; unsigned pos; unsigned pad; };
+
+__global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(const double* __restrict__ acc, long nd, int K, const unsigned* __restrict__ doc_ids,
+                                                               unsigned* __restrict__ out_ids, float* __restrict__ out_scores,
+                                                               double* __restrict__ out_scores64, int* __restrict__ out_counts, int k_cap) {
+    __shared__ unsigned hist[256];
+    __shared__ int s_total, s_bin, s_before, s_less, s_eqbase;
+    __shared__ int wsum[BM_THREADS / 64];
+    __shared__ KP sel[BM_KMAX];
+    const int q = blockIdx.x, t = threadIdx.x;
+    const double* row = acc + (long)q * nd;
+    // pass 0: count touched documents
+    if (t == 0) { s_total = 0; s_less = 0; s_eqbase = 0; }
+    __syncthreads();
+    int mine = 0;
+    for (long i = t; i < nd; i += BM_THREADS) mine += (row[i] != 0.0);
+    if (mine) atomicAdd(&s_total, mine);
+    __syncthreads();
+    const int total = s_total;
+    int kq = (K <= 0 || K >= total) ? total : K;          // `k <= 0 || k >= len(scores)` -> all (:330)
+    if (kq > BM_KMAX) kq = BM_KMAX;                        // caller guarantees k_cap <= BM_KMAX
+    if (kq > 0) {
+        unsigned long long prefix = 0, mask = 0; int remaining = kq;
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            if (t < 256) hist[t] = 0;
+            __syncthreads();
+            for (long i = t; i < nd; i += BM_THREADS) {
+                const double v = row[i];
+                if (v != 0.0) { const unsigned long long k = d2key_desc(v); if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255ull], 1u); }
+            }
+            __syncthreads();
+            if (t == 0) {
+                int run = 0, b = 0;
+                for (b = 0; b < 256; b++) { if (run + (int)hist[b] >= remaining) break; run += (int)hist[b]; }
+                s_bin = b; s_before = run;
+            }
+            __syncthreads();
+            prefix |= ((unsigned long long)s_bin) << shift; mask |= 255ull << shift; remaining -= s_before;
+            __syncthreads();
+        }
+        const unsigned long long keystar = prefix;
+        const int r = remaining;            // equal-to-key* documents to take, lowest doc index first
+        const int n_less = kq - r;
+        // ordered sweep in chunks of BM_THREADS documents
+        for (long base = 0; base < nd; base += BM_THREADS) {
+            const long i = base + t;
+            unsigned long long k = ~0ull; bool lt = false, eq = false;
+            if (i < nd) { const double v = row[i]; if (v != 0.0) { k = d2key_desc(v); lt = k < keystar; eq = k == keystar; } }
+            if (lt) { int s = atomicAdd(&s_less, 1); sel[s].key = k; sel[s].pos = (unsigned)i; }
+            // rank among equals: block prefix
+            int e = eq ? 1 : 0, incl = e;
+            const int lane = t & 63, w = t >> 6;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { int y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
+            if (lane == 63) wsum[w] = incl;
+            __syncthreads();
+            int before = s_eqbase;
+            for (int j = 0; j < w; j++) before += wsum[j];
+            const int rank = before + incl - e;
+            if (eq && rank < r) { sel[n_less + rank].key = k; sel[n_less + rank].pos = (unsigned)i; }
+            __syncthreads();
+            if (t == BM_THREADS - 1) s_eqbase = before + incl;
+            __syncthreads();
+        }
+        // sort the kq selected (key, pos) pairs
+        int n2 = 1; while (n2 < kq) n2 <<= 1;
+        for (int i = kq + t; i < n2; i += BM_THREADS) { sel[i].key = ~0ull; sel[i].pos = 0xFFFFFFFFu; }
+        __syncthreads();
+        for (int k2 = 2; k2 <= n2; k2 <<= 1) {
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int i = t; i < n2; i += BM_THREADS) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        KP a = sel[i], b = sel[ixj];
+                        const bool gt = (a.key > b.key) || (a.key == b.key && a.pos > b.pos);
+                        const bool up = ((i & k2) == 0);
+                        if (gt == up) { sel[i] = b; sel[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    for (int i = t; i < k_cap; i += BM_THREADS) {
+        if (i < kq) {
+            const double s = key2d_desc(sel[i].key);
+            out_ids[(long)q * k_cap + i] = doc_ids[sel[i].pos];
+            out_scores[(long)q * k_cap + i] = (float)s;                 // Score: float32(r.Score) (:392)
+            if (out_scores64) out_scores64[(long)q * k_cap + i] = s;
+        } else {
+            out_ids[(long)q * k_cap + i] = 0; out_scores[(long)q * k_cap + i] = 0.0f;
+            if (out_scores64) out_scores64[(long)q * k_cap + i] = 0.0;
+        }
+    }
+    if (t == 0) out_counts[q] = (K <= 0 || K >= total) ? total : K;
+}
+
+}  // namespace comet
+
+using namespace comet;
+
+struct comet_text_index {
+    Ctx* c = nullptr;
+    // host structures (bm25_index.go:101-114)
+    std::map<uint32_t, std::vector<uint32_t>> postings;                       // term -> ascending doc ids
+    std::unordered_map<uint32_t, std::unordered_map<uint32_t, int>> tf;       // term -> doc -> tf
+    std::unordered_map<uint32_t, int> doc_len;
+    std::unordered_map<uint32_t, std::vector<uint32_t>> doc_tokens;
+    std::unordered_set<uint32_t> deleted;
+    uint32_t num_docs = 0; long total_tokens = 0; double avg_doc_len = 0;
+    // device snapshot
+    bool dirty = true;
+    std::vector<uint32_t> doc_ids_h; std::unordered_map<uint32_t, int> term_index; std::vector<int> term_off_h;
+    DevBuf doc_ids, doc_len_dev, post_doc, post_tf, deleted_dev;
+    int64_t nd = 0;
+
+    void update_avg() { avg_doc_len = num_docs == 0 ? 0 : (double)total_tokens / (double)num_docs; }   // bm25_index.go updateAvgDocLen
+    void remove_internal(uint32_t id) {                                                                 // bm25_index.go removeInternal
+        auto it = doc_tokens.find(id); if (it == doc_tokens.end()) return;
+        const int dl = doc_len[id];
+        for (uint32_t t : it->second) {
+            auto pit = postings.find(t);
+            if (pit != postings.end()) { auto& v = pit->second; auto f = std::lower_bound(v.begin(), v.end(), id); if (f != v.end() && *f == id) v.erase(f); if (v.empty()) postings.erase(pit); }
+            auto tit = tf.find(t);
+            if (tit != tf.end()) { tit->second.erase(id); if (tit->second.empty()) tf.erase(tit); }
+        }
+        doc_tokens.erase(it); doc_len.erase(id); num_docs--; total_tokens -= dl;
+        if (num_docs > 0) update_avg(); else { avg_doc_len = 0; total_tokens = 0; }
+        dirty = true;
+    }
+    void compile() {
+        if (!dirty) return;
+        doc_ids_h.clear();
+        for (auto& kv : doc_len) doc_ids_h.push_back(kv.first);
+        std::sort(doc_ids_h.begin(), doc_ids_h.end());
+        nd = (int64_t)doc_ids_h.size();
+        std::unordered_map<uint32_t, int> didx; didx.reserve(nd * 2);
+        std::vector<int> dl(nd);
+        for (int64_t i = 0; i < nd; i++) { didx[doc_ids_h[i]] = (int)i; dl[i] = doc_len[doc_ids_h[i]]; }
+        term_index.clear(); term_off_h.assign(1, 0);
+        std::vector<int> pd, pt;
+        for (auto& kv : postings) {
+            term_index[kv.first] = (int)term_off_h.size() - 1;
+            auto& tfm = tf[kv.first];
+            for (uint32_t d : kv.second) { pd.push_back(didx[d]); pt.push_back(tfm[d]); }
+            term_off_h.push_back((int)pd.size());
+        }
+        doc_ids.reserve(std::max<size_t>(4, nd * 4), c->stream, 0); doc_len_dev.reserve(std::max<size_t>(4, nd * 4), c->stream, 0);
+        post_doc.reserve(std::max<size_t>(4, pd.size() * 4), c->stream, 0); post_tf.reserve(std::max<size_t>(4, pt.size() * 4), c->stream, 0);
+        c->h2d(doc_ids.p, doc_ids_h.data(), nd * 4); c->h2d(doc_len_dev.p, dl.data(), nd * 4);
+        c->h2d(post_doc.p, pd.data(), pd.size() * 4); c->h2d(post_tf.p, pt.data(), pt.size() * 4);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        dirty = false;
+    }
+};
+
+extern "C" {
+
+int comet_bm25_create(comet_ctx* c, comet_text_index** out) {
+    return guarded([&] { c->bind(); auto* t = new comet_text_index(); t->c = c; *out = t; return (int)COMET_OK; });
+}
+int comet_bm25_destroy(comet_text_index* idx) {
+    return guarded([&] { if (!idx) return (int)COMET_OK; Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); (void)hipStreamSynchronize(c->stream); delete idx; return (int)COMET_OK; });
+}
+// BM25SearchIndex.Add bm25_index.go:168-201 with the text already tokenised into ids
+int comet_bm25_add(comet_text_index* ix, uint32_t id, const uint32_t* tokens, int32_t n) {
+    return guarded([&] {
+        std::lock_guard<std::recursive_mutex> lk(ix->c->mu);
+        if (ix->doc_tokens.count(id)) ix->remove_internal(id);
+        ix->doc_tokens[id].assign(tokens, tokens + n);
+        ix->doc_len[id] = n; ix->num_docs++; ix->total_tokens += n;
+        for (int i = 0; i < n; i++) {
+            auto& v = ix->postings[tokens[i]];
+            auto f = std::lower_bound(v.begin(), v.end(), id);
+            if (f == v.end() || *f != id) v.insert(f, id);
+            ix->tf[tokens[i]][id]++;
+        }
+        ix->update_avg(); ix->dirty = true;
+        return (int)COMET_OK;
+    });
+}
+// Remove: soft delete bm25_index.go:203-222
+int comet_bm25_remove(comet_text_index* ix, uint32_t id) {
+    return guarded([&] { std::lock_guard<std::recursive_mutex> lk(ix->c->mu); if (ix->doc_tokens.count(id)) ix->deleted.insert(id); return (int)COMET_OK; });
+}
+// Flush bm25_index.go:374-400
+int comet_bm25_flush(comet_text_index* ix) {
+    return guarded([&] {
+        std::lock_guard<std::recursive_mutex> lk(ix->c->mu);
+        std::vector<uint32_t> d(ix->deleted.begin(), ix->deleted.end()); std::sort(d.begin(), d.end());
+        for (uint32_t id : d) ix->remove_internal(id);
+        ix->deleted.clear();
+        return (int)COMET_OK;
+    });
+}
+int64_t comet_bm25_num_docs(const comet_text_index* ix) { return ix->num_docs; }
+double comet_bm25_avg_doc_len(const comet_text_index* ix) { return ix->avg_doc_len; }
+
+// bm25TextSearch.searchSingleQuery bm25_index_search.go:278-397 for B tokenised queries
+int comet_bm25_search(comet_text_index* ix, const uint32_t* q_tokens, const int32_t* q_offsets, int32_t B, int32_t k,
+                      const uint32_t* filter_ids, int32_t n_filter, uint32_t* out_ids, float* out_scores, double* out_scores64,
+                      int32_t* out_counts, int32_t k_cap) {
+    return guarded([&] {
+        if (B <= 0) return (int)COMET_OK;
+        if (k_cap <= 0 || k_cap > BM_KMAX) COMET_FAIL(COMET_ERR_UNSUPPORTED, "k_cap must be in [1,%d]", BM_KMAX);
+        Ctx* c = ix->c;
+        std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->scratch_reset();
+        ix->compile();
+        const int64_t nd = ix->nd;
+        uint32_t* d_ids = c->salloc<uint32_t>((size_t)B * k_cap);
+        float* d_sc = c->salloc<float>((size_t)B * k_cap);
+        double* d_sc64 = c->salloc<double>((size_t)B * k_cap);
+        int32_t* d_cn = c->salloc<int32_t>(B);
+        const double N = (double)ix->num_docs;
+        if (nd == 0 || N == 0) {   // `if N == 0 { return nil, nil }` (:290)
+            std::fill(out_counts, out_counts + B, 0);
+            return (int)COMET_OK;
+        }
+        // eligibility: soft deletes + document filter (by id)
+        const uint8_t* elig = nullptr;
+        std::vector<uint32_t> del(ix->deleted.begin(), ix->deleted.end()); std::sort(del.begin(), del.end());
+        std::vector<uint32_t> flt;
+        if (filter_ids && n_filter > 0) { flt.assign(filter_ids, filter_ids + n_filter); std::sort(flt.begin(), flt.end()); flt.erase(std::unique(flt.begin(), flt.end()), flt.end()); }
+        if (!del.empty() || !flt.empty()) {
+            uint32_t* dd = c->salloc<uint32_t>(std::max<size_t>(1, del.size())); uint32_t* df = c->salloc<uint32_t>(std::max<size_t>(1, flt.size()));
+            c->h2d(dd, del.data(), del.size() * 4); c->h2d(df, flt.data(), flt.size() * 4);
+            uint8_t* e = c->salloc<uint8_t>(nd);
+            launch_build_elig(c, ix->doc_ids.as<uint32_t>(), nd, dd, (int)del.size(), df, (int)flt.size(), e);
+            elig = e;
+        }
+        double* acc = c->salloc<double>((size_t)B * nd);
+        c->zero(acc, sizeof(double) * (size_t)B * nd);
+        int maxlen = 0;
+        for (int b = 0; b < B; b++) maxlen = std::max(maxlen, q_offsets[b + 1] - q_offsets[b]);
+        std::vector<TermRef> refs((size_t)std::max(1, maxlen) * B);
+        int maxdf = 0;
+        for (int j = 0; j < maxlen; j++)
+            for (int b = 0; b < B; b++) {
+                TermRef r{0, 0, 0.0};
+                const int len = q_offsets[b + 1] - q_offsets[b];
+                if (j < len) {
+                    auto it = ix->term_index.find(q_tokens[q_offsets[b] + j]);
+                    if (it != ix->term_index.end()) {
+                        r.off = ix->term_off_h[it->second];
+                        r.df = ix->term_off_h[it->second + 1] - r.off;
+                        const double df = (double)r.df;
+                        r.idf = go_log((N - df + 0.5) / (df + 0.5) + 1.0);     // :306
+                        maxdf = std::max(maxdf, r.df);
+                    }
+                }
+                refs[(size_t)j * B + b] = r;
+            }
+        TermRef* drefs = c->salloc<TermRef>(refs.size());
+        c->h2d(drefs, refs.data(), refs.size() * sizeof(TermRef));
+        if (maxdf > 0) {
+            for (int j = 0; j < maxlen; j++) {
+                ProfScope ps(c, "bm25_score");
+                bm25_score_kernel<<<dim3((unsigned)ceil_div(maxdf, 256), B), dim3(256), 0, c->stream>>>(drefs + (size_t)j * B, ix->post_doc.as<int>(), ix->post_tf.as<int>(),
+                                                                                                   ix->doc_len_dev.as<int>(), elig, ix->avg_doc_len, acc, nd);
+                LAUNCH_CHECK();
+            }
+        }
+        {
+            ProfScope ps(c, "bm25_topk");
+            bm25_topk_kernel<<<dim3(B), dim3(BM_THREADS), 0, c->stream>>>(acc, nd, k, ix->doc_ids.as<uint32_t>(), d_ids, d_sc, d_sc64, d_cn, k_cap);
+            LAUNCH_CHECK();
+        }
+        c->d2h(out_ids, d_ids, (size_t)B * k_cap * 4);
+        c->d2h(out_scores, d_sc, (size_t)B * k_cap * 4);
+        if (out_scores64) c->d2h(out_scores64, d_sc64, (size_t)B * k_cap * 8);
+        c->d2h(out_counts, d_cn, (size_t)B * 4);
+        c->sync();
+        return (int)COMET_OK;
+    });
+}
+
+}  // extern "C"

@@ -559,3 +559,145 @@ def _validate_pq(dim: int, M: int, nbits: int) -> None:   # pq_index.go:135-155
 
 def default_nprobes(nlist: int) -> int:    # ivf_index.go:406-413
     return int(math.sqrt(float(nlist)))
+
+
+# ---------------------------------------------------------------------------------------------------
+# BM25 text index (TextIndex index.go:65-81; TextSearch index_search.go:358-430)
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class TextResult:
+    """TextResult{Id, Score} index_search.go:306-312"""
+    id: int
+    score: np.float32
+
+
+def aggregate_text(results: list[TextResult], kind: str) -> list[TextResult]:
+    """Text aggregation (aggregation.go: text*Aggregation): by doc id, sorted by score DESCENDING."""
+    if not results:
+        return results
+    order, scores = [], {}
+    for r in results:
+        if r.id not in scores:
+            scores[r.id] = []
+            order.append(r.id)
+        scores[r.id].append(np.float32(r.score))
+    out = []
+    for i in order:
+        s = scores[i]
+        if kind == SUM_AGGREGATION:
+            v = np.float32(0)
+            for x in s:
+                v = np.float32(v + x)
+        elif kind == MAX_AGGREGATION:
+            v = max(s)
+        elif kind == MEAN_AGGREGATION:
+            v = np.float32(0)
+            for x in s:
+                v = np.float32(v + x)
+            v = np.float32(v / np.float32(len(s)))
+        else:
+            raise ValueError(f"unknown aggregation kind: {kind}")
+        out.append(TextResult(i, v))
+    out.sort(key=lambda r: -float(r.score))
+    return out
+
+
+class TextSearch:
+    """Fluent text search builder (TextSearch, index_search.go:358-430) over token-id queries."""
+
+    def __init__(self, index: "BM25SearchIndex"):
+        self.index = index
+        self.queries: list[list[int]] = []
+        self.k = 10
+        self.aggregation = ""
+        self.cutoff = -1
+        self.document_ids: list[int] = []
+
+    def with_query(self, *token_lists) -> "TextSearch":
+        self.queries = [list(map(int, t)) for t in token_lists]
+        return self
+
+    def with_k(self, k: int) -> "TextSearch":
+        self.k = int(k)
+        return self
+
+    def with_score_aggregation(self, kind: str) -> "TextSearch":
+        self.aggregation = kind
+        return self
+
+    def with_cutoff(self, cutoff: int) -> "TextSearch":
+        self.cutoff = int(cutoff)
+        return self
+
+    def with_document_ids(self, *ids) -> "TextSearch":
+        self.document_ids = [int(i) for i in ids]
+        return self
+
+    def execute(self) -> list[TextResult]:
+        if not self.queries:
+            raise ValueError("must specify either queries or node IDs")
+        agg = self.aggregation or SUM_AGGREGATION
+        k_cap = max(1, min(2048, self.k if self.k > 0 else 2048))
+        ids, sc, _, cnt = self.index.search_batch(self.queries, self.k, document_ids=self.document_ids, k_cap=k_cap)
+        allr = [TextResult(int(ids[b, i]), np.float32(sc[b, i])) for b in range(len(self.queries)) for i in range(min(cnt[b], k_cap))]
+        res = aggregate_text(allr, agg)
+        res = res[:sanitize_k(self.k, len(res))]
+        if self.cutoff != -1 and res:
+            res = res[:autocut([r.score for r in res], self.cutoff)]
+        return res
+
+
+class BM25SearchIndex:
+    """comet.NewBM25SearchIndex() with documents / queries given as token ids (tokenisation stays in Go)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.h = C.c_void_p()
+        check(self.lib.comet_bm25_create(ctx.h, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.comet_bm25_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add(self, doc_id: int, tokens) -> None:
+        t = np.ascontiguousarray(list(tokens), dtype=np.uint32)
+        check(self.lib.comet_bm25_add(self.h, C.c_uint32(int(doc_id)), t.ctypes.data_as(C.c_void_p), int(t.size)))
+
+    def remove(self, doc_id: int) -> None:
+        check(self.lib.comet_bm25_remove(self.h, C.c_uint32(int(doc_id))))
+
+    def flush(self) -> None:
+        check(self.lib.comet_bm25_flush(self.h))
+
+    def num_docs(self) -> int:
+        return int(self.lib.comet_bm25_num_docs(self.h))
+
+    def avg_doc_len(self) -> float:
+        return float(self.lib.comet_bm25_avg_doc_len(self.h))
+
+    def new_search(self) -> TextSearch:
+        return TextSearch(self)
+
+    def search_batch(self, queries, k: int, document_ids: Iterable[int] = (), k_cap: int | None = None):
+        B = len(queries)
+        k_cap = k_cap or max(1, min(2048, k if k > 0 else 2048))
+        offs = np.zeros(B + 1, dtype=np.int32)
+        for i, qt in enumerate(queries):
+            offs[i + 1] = offs[i] + len(qt)
+        toks = np.ascontiguousarray([t for qt in queries for t in qt], dtype=np.uint32)
+        flt = np.ascontiguousarray(list(document_ids), dtype=np.uint32)
+        ids = np.zeros((B, k_cap), np.uint32)
+        sc = np.zeros((B, k_cap), np.float32)
+        sc64 = np.zeros((B, k_cap), np.float64)
+        cnt = np.zeros(B, np.int32)
+        check(self.lib.comet_bm25_search(self.h, toks.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), B, int(k),
+                                         flt.ctypes.data_as(C.c_void_p) if flt.size else None, int(flt.size), ids.ctypes.data_as(C.c_void_p),
+                                         sc.ctypes.data_as(C.c_void_p), sc64.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p), k_cap))
+        return ids, sc, sc64, cnt

@@ -167,6 +167,24 @@ COMET_API int comet_index_list_size(const comet_index* idx, int32_t list, int64_
 COMET_API int comet_index_list_read(const comet_index* idx, int32_t list, uint32_t* out_ids, uint8_t* out_codes,
                                     float* out_vecs);
 
+/* ---- BM25 text index (TextIndex index.go:65-81, bm25_index.go, bm25_index_search.go) ----------------
+ * Tokenisation / NFKC / lower-casing stay in Go (third-party uax29, x/text): documents and queries are
+ * passed as token ids. Scoring is float64, term-at-a-time in query-token order like the reference. */
+typedef struct comet_text_index comet_text_index;
+COMET_API int comet_bm25_create(comet_ctx* ctx, comet_text_index** out);                 /* NewBM25SearchIndex */
+COMET_API int comet_bm25_destroy(comet_text_index* idx);
+COMET_API int comet_bm25_add(comet_text_index* idx, uint32_t doc_id, const uint32_t* tokens, int32_t n); /* Add bm25_index.go:168 */
+COMET_API int comet_bm25_remove(comet_text_index* idx, uint32_t doc_id);                 /* soft delete bm25_index.go:203 */
+COMET_API int comet_bm25_flush(comet_text_index* idx);                                   /* Flush bm25_index.go:374 */
+COMET_API int64_t comet_bm25_num_docs(const comet_text_index* idx);
+COMET_API double comet_bm25_avg_doc_len(const comet_text_index* idx);
+/* B queries: tokens of query b are q_tokens[q_offsets[b] .. q_offsets[b+1]). k <= 0 or >= hits => all.
+ * out_scores: float32(score) like TextResult.Score; out_scores64 (nullable): the float64 accumulators.
+ * Rows are sorted by score descending (ties: ascending doc id). k_cap <= 2048. All pointers are HOST memory. */
+COMET_API int comet_bm25_search(comet_text_index* idx, const uint32_t* q_tokens, const int32_t* q_offsets, int32_t B, int32_t k,
+                                const uint32_t* filter_ids, int32_t n_filter, uint32_t* out_ids, float* out_scores,
+                                double* out_scores64, int32_t* out_counts, int32_t k_cap);
+
 /* named counters of the last search / of the index (bench + tests): "fast_candidates", "fast_overflows",
  * "fast_expansions", "fast_queries", "strict_queries", "max_abs", "max_norm2". Unknown name -> INVALID_ARG. */
 COMET_API int comet_index_get_stat(const comet_index* idx, const char* name, double* out);

@@ -364,3 +364,37 @@ class IVFPQ(_Index):
 
     def search(self, q, k, nprobes, threshold=0.0, filter_ids=(), cap=None):
         return self._do_search(lib().orc_ivfpq_search, q, k, [int(nprobes)], threshold, filter_ids, cap)
+
+
+class BM25:
+    def __init__(self):
+        self.h = lib().orc_bm25_new()
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_bm25_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def add(self, doc_id, tokens):
+        t = np.ascontiguousarray(list(tokens), np.uint32)
+        return lib().orc_bm25_add(self.h, int(doc_id), _p(t), int(t.size))
+
+    def remove(self, doc_id):
+        return lib().orc_bm25_remove(self.h, int(doc_id))
+
+    def num_docs(self):
+        return lib().orc_bm25_num_docs(self.h)
+
+    def avg_doc_len(self):
+        return lib().orc_bm25_avg_doc_len(self.h)
+
+    def search(self, qtokens, k, filter_ids=(), cap=4096):
+        q = np.ascontiguousarray(list(qtokens), np.uint32)
+        flt = np.ascontiguousarray(list(filter_ids), np.uint32)
+        ids = np.zeros(cap, np.uint32); sc = np.zeros(cap, np.float32); sc64 = np.zeros(cap, np.float64)
+        n = lib().orc_bm25_search(self.h, _p(q), int(q.size), int(k), _p(flt) if flt.size else None, int(flt.size), _p(ids), _p(sc), _p(sc64), cap)
+        m = min(n, cap)
+        return n, ids[:m], sc[:m], sc64[:m]
