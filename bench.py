@@ -121,7 +121,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("COMET_BENCH_FORCE_DIST") == "1"   # the env knob exercises the RCCL path at world size 1
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -139,40 +140,24 @@ def main():
     q_dev = ctx.alloc(B * args.dim * 4)
     ctx.synth_fill(q_dev, QUERY_SEED, 0, B * args.dim)
 
-    if world > 1:
+    if use_dist:
         import torch
+        from comet_amd.dist import TopKExchange
         dev = torch.device("cuda", local_rank)
-        ids_t = torch.zeros((B, K), dtype=torch.int32, device=dev)
-        sc_t = torch.zeros((B, K), dtype=torch.float32, device=dev)
-        cn_t = torch.zeros((B,), dtype=torch.int32, device=dev)
-        g_ids = torch.zeros((world, B, K), dtype=torch.int32, device=dev)
-        g_sc = torch.zeros((world, B, K), dtype=torch.float32, device=dev)
-        g_cn = torch.zeros((world, B), dtype=torch.int32, device=dev)
-        m_ids = torch.zeros((B, K), dtype=torch.int32, device=dev)
-        m_sc = torch.zeros((B, K), dtype=torch.float32, device=dev)
-        m_cn = torch.zeros((B,), dtype=torch.int32, device=dev)
-        out_ids, out_sc, out_cn = ids_t.data_ptr(), sc_t.data_ptr(), cn_t.data_ptr()
+        ex = TopKExchange(B, K, dev, ctx=ctx)
+        out_ids, out_sc, out_cn = ex.local_ptrs()
     else:
         out_ids, out_sc, out_cn = ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)
 
-    import ctypes as C
-    from comet_amd._lib import check
-
     def step():
         idx.search_batch_dev(q_dev, B, K, out_ids, out_sc, out_cn, K, mode=args.mode)
-        if world > 1:
-            ctx.sync()
-            dist.all_gather_into_tensor(g_ids, ids_t)
-            dist.all_gather_into_tensor(g_sc, sc_t)
-            dist.all_gather_into_tensor(g_cn, cn_t)
-            torch.cuda.synchronize()
-            check(ctx.lib.comet_merge_topk_dev(ctx.h, C.c_void_p(g_ids.data_ptr()), C.c_void_p(g_sc.data_ptr()),
-                                               C.c_void_p(g_cn.data_ptr()), world, B, K, K, C.c_void_p(m_ids.data_ptr()),
-                                               C.c_void_p(m_sc.data_ptr()), C.c_void_p(m_cn.data_ptr())))
+        if use_dist:
+            ctx.sync()                      # shard results complete before RCCL reads them
+            ex.exchange_and_merge(K)        # one all-gather per array + merge kernel on every rank
 
     def barrier():
         ctx.sync()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -189,7 +174,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_dump()
     ctx.profile(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -237,7 +222,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

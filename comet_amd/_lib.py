@@ -89,6 +89,8 @@ def load() -> C.CDLL:
         "comet_ivf_create": (i32, [p, i32, i32, i32, pp]),
         "comet_pq_create": (i32, [p, i32, i32, i32, i32, pp]),
         "comet_ivfpq_create": (i32, [p, i32, i32, i32, i32, i32, pp]),
+        "comet_hnsw_create": (i32, [p, i32, i32, i32, i32, i32, pp]),
+        "comet_hnsw_load_graph": (i32, [p, i64, p, p, p, p, p, C.c_uint32, i32]),
         "comet_index_destroy": (i32, [p]),
         "comet_index_kind": (i32, [p]),
         "comet_index_dim": (i32, [p]),

@@ -1,0 +1,387 @@
+// index_hnsw.hip — HNSW search on the GPU (reference: hnsw_index_search.go:248-354 and
+// HNSWIndex.searchLayer hnsw_index.go:565-629).
+//
+// One wave per query. Graph traversal is a serial pointer chase whose order is fixed by the two Go
+// container/heap structures (candidates min-heap, result max-heap); to return the reference's results —
+// including its behaviour on equal distances — lane 0 executes exactly those heap operations (same
+// up/down sift code as Go's stdlib) on LDS arrays. What is data-parallel is the neighbour batch: the
+// up-to-64 neighbours of the node being expanded are filtered (soft-deleted, visited bitmap) and their
+// exact float32 distances computed one lane per neighbour from an LDS-transposed tile (coalesced
+// 256-byte row pieces, conflict-free ds_read_b128), after which lane 0 replays the reference's
+// sequential push/pop decisions over the batch in edge order.
+//
+// Graph construction (insertNode, hnsw_index.go:493-552) is not on the GPU yet: a graph built by the
+// reference (or the oracle) is loaded with comet_hnsw_load_graph.
+#include "index.hpp"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace comet {
+
+__device__ __forceinline__ float hn_sqrt32(float x) { return (float)__builtin_sqrt((double)x); }
+template <int METRIC> __device__ __forceinline__ float hn_step(float acc, float q, float x) {
+    if constexpr (METRIC == COMET_COSINE) { float p = q * x; return acc + p; }
+    else { float diff = q - x; float sq = diff * diff; return acc + sq; }
+}
+template <int METRIC> __device__ __forceinline__ float hn_finish(float acc) {
+    if constexpr (METRIC == COMET_COSINE) { if (acc > 1.0f) acc = 1.0f; else if (acc < -1.0f) acc = -1.0f; return 1.0f - acc; }
+    else if constexpr (METRIC == COMET_L2) return hn_sqrt32(acc);
+    else return acc;
+}
+
+constexpr int HN_TD = 64;            // floats of each row staged per pass (256 B)
+constexpr int HN_LD = HN_TD + 4;     // LDS row stride
+constexpr int HN_CAND_CAP = 4096;    // candidates min-heap capacity (LDS)
+constexpr int HN_EF_MAX = 1024;
+constexpr unsigned HN_NONE = 0xFFFFFFFFu;
+
+struct HC { unsigned id; float d; };
+
+// Go container/heap on an LDS array (heap.go: up / down / Push / Pop)
+template <bool MAXHEAP> __device__ __forceinline__ bool hless(const HC& a, const HC& b) { return MAXHEAP ? (a.d > b.d) : (a.d < b.d); }
+template <bool MAXHEAP> __device__ void heap_push(HC* h, int& n, HC x) {
+    h[n] = x; int j = n; n++;
+    for (;;) { int i = (j - 1) / 2; if (i == j || !hless<MAXHEAP>(h[j], h[i])) break; HC t = h[i]; h[i] = h[j]; h[j] = t; j = i; }
+}
+template <bool MAXHEAP> __device__ HC heap_pop(HC* h, int& n) {
+    const int m = n - 1;
+    { HC t = h[0]; h[0] = h[m]; h[m] = t; }
+    int i = 0;
+    for (;;) {
+        int j1 = 2 * i + 1; if (j1 >= m || j1 < 0) break;
+        int j = j1; const int j2 = j1 + 1;
+        if (j2 < m && hless<MAXHEAP>(h[j2], h[j1])) j = j2;
+        if (!hless<MAXHEAP>(h[j], h[i])) break;
+        HC t = h[i]; h[i] = h[j]; h[j] = t; i = j;
+    }
+    n = m;
+    return h[m];
+}
+
+// exact distances from the query to up to 64 rows (rows[j] == HN_NONE -> skipped); lane j gets row j's distance
+template <int METRIC>
+__device__ __forceinline__ float wave_dists(const float* __restrict__ V, int ld, const float* __restrict__ qv, const unsigned* rows, int cnt, float* tile) {
+    const int lane = threadIdx.x;
+    float acc = 0.0f;
+    const int lrow = lane >> 4, lc = (lane & 15) * 4;      // loader: 4 rows x 16 float4 per instruction
+    for (int k0 = 0; k0 < ld; k0 += HN_TD) {
+        const int kn = min(HN_TD, ld - k0);                // multiple of 32
+        for (int r0 = 0; r0 < cnt; r0 += 4) {
+            const int r = r0 + lrow;
+            if (r < cnt && lc < kn) {
+                unsigned row = rows[r]; if (row == HN_NONE) row = 0;
+                *reinterpret_cast<f32x4*>(&tile[r * HN_LD + lc]) = *reinterpret_cast<const f32x4*>(V + (long)row * ld + k0 + lc);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < cnt) {
+#pragma unroll 4
+            for (int i = 0; i < kn; i += 4) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(&tile[lane * HN_LD + i]);
+                acc = hn_step<METRIC>(acc, qv[k0 + i + 0], x[0]);
+                acc = hn_step<METRIC>(acc, qv[k0 + i + 1], x[1]);
+                acc = hn_step<METRIC>(acc, qv[k0 + i + 2], x[2]);
+                acc = hn_step<METRIC>(acc, qv[k0 + i + 3], x[3]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return hn_finish<METRIC>(acc);
+}
+
+struct HnswGraph {
+    const float* V; int ld; long n;
+    const int* level; const long* slot_base; const long* edge_off; const unsigned* edges;
+    unsigned entry; int max_level;
+    const unsigned* deleted;   // bitmap over dense node indices (nullable)
+};
+__device__ __forceinline__ bool bit_get(const unsigned* bm, unsigned i) { return bm && ((bm[i >> 5] >> (i & 31)) & 1u); }
+
+template <int METRIC>
+__global__ __launch_bounds__(64) void hnsw_search_kernel(HnswGraph g, const float* __restrict__ Qp, int ef, unsigned* __restrict__ visited /*[B][vwords]*/,
+                                                         long vwords, unsigned* __restrict__ res_idx, float* __restrict__ res_dist,
+                                                         int* __restrict__ res_cnt, int* __restrict__ status, unsigned long long* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    HC* cand = reinterpret_cast<HC*>(smem);                                  // HN_CAND_CAP
+    HC* res = cand + HN_CAND_CAP;                                            // ef + 1
+    float* tile = reinterpret_cast<float*>(res + (HN_EF_MAX + 1));           // 64 x HN_LD
+    unsigned* rows = reinterpret_cast<unsigned*>(tile + 64 * HN_LD);         // 64
+    float* dd = reinterpret_cast<float*>(rows + 64);                         // 64
+    __shared__ unsigned s_cur; __shared__ int s_flag; __shared__ float s_dist;
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const float* __restrict__ qv = Qp + (long)q * g.ld;
+    unsigned* vis = visited + (long)q * vwords;
+    unsigned long long n_eval = 0, n_exp = 0;
+
+    // ---- phase 1: greedy descent through the upper layers (hnsw_index_search.go:271-296) ----
+    unsigned curr = g.entry;
+    if (lane == 0) rows[0] = curr;
+    __builtin_amdgcn_wave_barrier();
+    float d0 = wave_dists<METRIC>(g.V, g.ld, qv, rows, 1, tile);
+    float curr_dist = __shfl(d0, 0, 64);
+    n_eval += 1;
+    for (int lc = g.max_level; lc > 0; lc--) {
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            const unsigned node = curr;                 // `node := s.index.nodes[curr]` — its edge list is scanned to the end
+            if (lc <= g.level[node]) {                  // `if lc < len(node.Edges)`
+                const long s = g.slot_base[node] + lc;
+                const long off = g.edge_off[s]; const int deg = (int)(g.edge_off[s + 1] - off);
+                for (int b0 = 0; b0 < deg; b0 += 64) {
+                    const int cnt = min(64, deg - b0);
+                    unsigned nb = HN_NONE;
+                    if (lane < cnt) { nb = g.edges[off + b0 + lane]; if (bit_get(g.deleted, nb)) nb = HN_NONE; }   // deleted neighbours are skipped
+                    rows[lane] = nb;
+                    __builtin_amdgcn_wave_barrier();
+                    const float d = wave_dists<METRIC>(g.V, g.ld, qv, rows, cnt, tile);
+                    dd[lane] = d;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) {
+                        unsigned c = curr; float cd = curr_dist; int ch = 0;
+                        for (int j = 0; j < cnt; j++) if (rows[j] != HN_NONE && dd[j] < cd) { cd = dd[j]; c = rows[j]; ch = 1; }
+                        s_cur = c; s_flag = ch; s_dist = cd;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    curr = s_cur; curr_dist = s_dist; if (s_flag) changed = true;
+                    __builtin_amdgcn_wave_barrier();
+                    n_eval += cnt;
+                }
+            }
+        }
+    }
+
+    // ---- phase 2: searchLayer(query, curr, ef, 0) (hnsw_index.go:565-629) ----
+    int ncand = 0, nres = 0, overflow = 0;
+    {
+        const bool dead = bit_get(g.deleted, curr);
+        if (lane == 0) rows[0] = curr;
+        __builtin_amdgcn_wave_barrier();
+        const float d = wave_dists<METRIC>(g.V, g.ld, qv, rows, 1, tile);
+        if (lane == 0) {
+            if (!dead) { HC x{curr, d}; heap_push<false>(cand, ncand, x); heap_push<true>(res, nres, x); }
+            atomicOr(&vis[curr >> 5], 1u << (curr & 31));
+        }
+        n_eval += 1;
+    }
+    for (;;) {
+        if (lane == 0) {
+            int stop = 0; unsigned cid = 0;
+            if (ncand == 0) stop = 1;
+            else {
+                HC cur = heap_pop<false>(cand, ncand);
+                if (nres >= ef && cur.d > res[0].d) stop = 1;      // early termination hnsw_index.go:592-594
+                cid = cur.id;
+            }
+            s_flag = stop; s_cur = cid;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int stop = s_flag; const unsigned cid = s_cur;
+        __builtin_amdgcn_wave_barrier();
+        if (stop) break;
+        n_exp += 1;
+        const long s = g.slot_base[cid];
+        const long off = g.edge_off[s]; const int deg = (int)(g.edge_off[s + 1] - off);
+        for (int b0 = 0; b0 < deg; b0 += 64) {
+            const int cnt = min(64, deg - b0);
+            unsigned nb = HN_NONE;
+            if (lane < cnt) {
+                nb = g.edges[off + b0 + lane];
+                if (bit_get(g.deleted, nb)) nb = HN_NONE;                                  // SOFT DELETE CHECK
+                else {
+                    const unsigned old = atomicOr(&vis[nb >> 5], 1u << (nb & 31));          // !visited.Contains -> visited.Add
+                    if ((old >> (nb & 31)) & 1u) nb = HN_NONE;
+                }
+            }
+            rows[lane] = nb;
+            __builtin_amdgcn_wave_barrier();
+            const float d = wave_dists<METRIC>(g.V, g.ld, qv, rows, cnt, tile);
+            dd[lane] = d;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                for (int j = 0; j < cnt; j++) {
+                    if (rows[j] == HN_NONE) continue;
+                    const float dj = dd[j];
+                    if (nres < ef || dj < res[0].d) {
+                        if (ncand >= HN_CAND_CAP) { overflow = 1; continue; }
+                        HC x{rows[j], dj};
+                        heap_push<false>(cand, ncand, x);
+                        heap_push<true>(res, nres, x);
+                        if (nres > ef) (void)heap_pop<true>(res, nres);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            n_eval += cnt;
+        }
+    }
+    // drain the result heap into an ascending array (hnsw_index.go:623-626)
+    if (lane == 0) {
+        const int n = nres;
+        for (int i = n - 1; i >= 0; i--) { HC x = heap_pop<true>(res, nres); res_idx[(long)q * ef + i] = x.id; res_dist[(long)q * ef + i] = x.d; }
+        res_cnt[q] = n;
+        if (overflow) *status = 1;
+        if (stats) { atomicAdd(&stats[0], n_eval); atomicAdd(&stats[1], n_exp); }
+    }
+}
+
+// D[q][i] = res_dist[q][i] unless the node is filtered out (hnsw_index_search.go:321-325)
+__global__ __launch_bounds__(256) void hnsw_mask_kernel(const unsigned* __restrict__ res_idx, const float* __restrict__ res_dist, const int* __restrict__ res_cnt,
+                                                        int ef, int B, const unsigned char* __restrict__ elig, float* __restrict__ D) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * ef) return;
+    const int q = (int)(i / ef), j = (int)(i - (long)q * ef);
+    float v = __uint_as_float(EXCLUDED_BITS);
+    if (j < res_cnt[q]) { const unsigned n = res_idx[i]; if (!elig || elig[n]) v = res_dist[i]; }
+    D[i] = v;
+}
+
+struct HNSWIndex : comet_index {
+    int M = 16, efC = 200, efS = 200;
+    int64_t n = 0; int max_level = -1; uint32_t entry = 0;
+    DevBuf V, ids_dev, level, slot_base, edge_off, edges, del_bm;
+    std::vector<uint32_t> ids; std::unordered_map<uint32_t, uint32_t> id2idx;
+    bool del_dirty = true;
+    uint64_t st_evals = 0, st_exp = 0;
+
+    int64_t size() const override { return n; }
+    bool contains_id(uint32_t id) const override { return id2idx.count(id) != 0; }
+    int64_t add_dev(const uint32_t*, const uint32_t*, const float*, int64_t, int64_t*, float*) override {
+        COMET_FAIL(COMET_ERR_UNSUPPORTED, "HNSW graph construction on the GPU is not built yet: load a graph with comet_hnsw_load_graph");
+    }
+    void flush() override { if (!deleted.empty()) COMET_FAIL(COMET_ERR_UNSUPPORTED, "HNSW Flush (graph repair) is not built yet"); }
+
+    void load(int64_t nn, const uint32_t* ids_h, const int32_t* levels, const float* vecs, const int64_t* eoff, const uint32_t* edge_ids,
+              uint32_t entry_id, int maxl) {
+        n = nn; max_level = maxl;
+        ids.assign(ids_h, ids_h + nn); id2idx.clear();
+        for (int64_t i = 0; i < nn; i++) id2idx[ids[i]] = (uint32_t)i;
+        std::vector<int64_t> sb(nn + 1); int64_t slots = 0;
+        for (int64_t i = 0; i < nn; i++) { sb[i] = slots; slots += levels[i] + 1; }
+        sb[nn] = slots;
+        const int64_t ne = eoff[slots];
+        std::vector<uint32_t> eidx(std::max<int64_t>(ne, 1));
+        for (int64_t e = 0; e < ne; e++) {
+            auto it = id2idx.find(edge_ids[e]);
+            if (it == id2idx.end()) COMET_FAIL(COMET_ERR_INVALID_ARG, "edge references unknown node id %u", edge_ids[e]);
+            eidx[e] = it->second;
+        }
+        if (nn > 0) { auto it = id2idx.find(entry_id); if (it == id2idx.end()) COMET_FAIL(COMET_ERR_INVALID_ARG, "entry point %u is not a node", entry_id); entry = it->second; }
+        V.reserve(std::max<size_t>(4, (size_t)nn * ld * 4), c->stream, 0);
+        float* raw = c->salloc<float>(std::max<size_t>(1, (size_t)nn * dim));
+        c->h2d(raw, vecs, (size_t)nn * dim * 4);
+        launch_ingest_rows(c, COMET_L2SQ, raw, nn, dim, V.as<float>(), ld, nullptr);   // stored vectors are already preprocessed
+        ids_dev.reserve(std::max<size_t>(4, nn * 4), c->stream, 0); level.reserve(std::max<size_t>(4, nn * 4), c->stream, 0);
+        slot_base.reserve((nn + 1) * 8, c->stream, 0); edge_off.reserve((slots + 1) * 8, c->stream, 0); edges.reserve(eidx.size() * 4, c->stream, 0);
+        c->h2d(ids_dev.p, ids.data(), nn * 4); c->h2d(level.p, levels, nn * 4);
+        c->h2d(slot_base.p, sb.data(), (nn + 1) * 8); c->h2d(edge_off.p, eoff, (slots + 1) * 8); c->h2d(edges.p, eidx.data(), eidx.size() * 4);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        trained = true; del_dirty = true;
+    }
+    const uint32_t* deleted_bitmap() {
+        if (deleted.empty()) return nullptr;
+        if (del_dirty || deleted_dirty) {
+            std::vector<uint32_t> bm((n + 31) / 32, 0);
+            for (uint32_t id : deleted) { auto it = id2idx.find(id); if (it != id2idx.end()) bm[it->second >> 5] |= 1u << (it->second & 31); }
+            del_bm.reserve(bm.size() * 4, c->stream, 0);
+            c->h2d(del_bm.p, bm.data(), bm.size() * 4);
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            del_dirty = false;
+        }
+        return del_bm.as<uint32_t>();
+    }
+    // hnswIndexSearch.searchSingleQuery hnsw_index_search.go:248-354
+    void search_dev(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
+                    int32_t* out_counts, int k_cap) override {
+        float* Qp; int32_t* zflag;
+        prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag);
+        uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
+        if (n == 0 || max_level == -1) {      // empty graph -> [] (:258)
+            launch_select_topk(c, nullptr, 0, B, 0, nullptr, 0.0f, p.k, pos, out_scores, out_counts, k_cap);
+            launch_finalize(c, nullptr, pos, B, k_cap, zflag, out_ids, out_counts);
+            return;
+        }
+        int ef = p.ef_search > 0 ? p.ef_search : efS;    // :302-305
+        if (ef > HN_EF_MAX) COMET_FAIL(COMET_ERR_UNSUPPORTED, "efSearch %d exceeds the on-device limit %d", ef, HN_EF_MAX);
+        const int64_t vwords = (n + 31) / 32;
+        uint32_t* vis = c->salloc<uint32_t>((size_t)B * vwords);
+        c->zero(vis, (size_t)B * vwords * 4);
+        uint32_t* res_idx = c->salloc<uint32_t>((size_t)B * ef);
+        float* res_dist = c->salloc<float>((size_t)B * ef);
+        int32_t* res_cnt = c->salloc<int32_t>(B);
+        int32_t* status = c->salloc<int32_t>(1);
+        unsigned long long* st = c->salloc<unsigned long long>(2);
+        c->zero(status, 4); c->zero(st, 16);
+        HnswGraph g{V.as<float>(), ld, n, level.as<int>(), (const long*)slot_base.p, (const long*)edge_off.p, edges.as<uint32_t>(), entry, max_level, deleted_bitmap()};
+        const size_t lds = sizeof(HC) * (HN_CAND_CAP + HN_EF_MAX + 1) + sizeof(float) * 64 * HN_LD + 64 * 4 + 64 * 4 + 64;
+        {
+            ProfScope ps(c, "hnsw_search");
+#define HS(MT) do { HIP_CHECK(hipFuncSetAttribute((const void*)hnsw_search_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                    hnsw_search_kernel<MT><<<dim3(B), dim3(64), lds, c->stream>>>(g, Qp, ef, vis, vwords, res_idx, res_dist, res_cnt, status, st); } while (0)
+            switch (metric) { case COMET_L2: HS(COMET_L2); break; case COMET_L2SQ: HS(COMET_L2SQ); break; default: HS(COMET_COSINE); break; }
+#undef HS
+            LAUNCH_CHECK();
+        }
+        // phase 3: document filter + threshold applied AFTER the search (can return < k), sort, top-k (:321-351)
+        const uint8_t* elig = nullptr;
+        int nf = 0;
+        const uint32_t* flt = filter_sorted_scratch(p, &nf);
+        if (nf > 0) { uint8_t* e = c->salloc<uint8_t>(n); launch_build_elig(c, ids_dev.as<uint32_t>(), n, nullptr, 0, flt, nf, e); elig = e; }
+        float* D = c->salloc<float>((size_t)B * ef);
+        hnsw_mask_kernel<<<dim3((unsigned)ceil_div((int64_t)B * ef, 256)), dim3(256), 0, c->stream>>>(res_idx, res_dist, res_cnt, ef, B, elig, D);
+        LAUNCH_CHECK();
+        uint32_t* pos2 = c->salloc<uint32_t>((size_t)B * k_cap);
+        launch_select_topk(c, D, ef, B, ef, res_cnt, p.threshold, p.k, pos2, out_scores, out_counts, k_cap);
+        launch_gather_indirect(c, res_idx, ef, pos2, B, k_cap, pos);
+        launch_finalize(c, ids_dev.as<uint32_t>(), pos, B, k_cap, zflag, out_ids, out_counts);
+        int32_t hs = 0; unsigned long long hst[2];
+        c->d2h(&hs, status, 4); c->d2h(hst, st, 16);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        st_evals = hst[0]; st_exp = hst[1];
+        if (hs) COMET_FAIL(COMET_ERR_UNSUPPORTED, "HNSW candidate heap overflow (more than %d live candidates): lower efSearch", HN_CAND_CAP);
+    }
+    bool get_stat(const char* name, double* out) const override {
+        std::string k(name);
+        if (k == "hnsw_distance_evals") *out = (double)st_evals;
+        else if (k == "hnsw_expansions") *out = (double)st_exp;
+        else return false;
+        return true;
+    }
+};
+
+}  // namespace comet
+
+using namespace comet;
+
+extern "C" {
+
+// NewHNSWIndex hnsw_index.go:160-202 (defaults: M 16, efConstruction 200, efSearch = efConstruction)
+int comet_hnsw_create(comet_ctx* c, int dim, int metric, int m, int ef_construction, int ef_search, comet_index** out) {
+    return guarded([&] {
+        *out = nullptr;
+        if (dim <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "dimension must be positive");
+        if (metric < COMET_L2 || metric > COMET_COSINE) COMET_FAIL(COMET_ERR_UNKNOWN_METRIC, "unknown distance kind");
+        if (m <= 0) m = 16;
+        if (ef_construction <= 0) ef_construction = 200;
+        if (ef_search <= 0) ef_search = ef_construction;
+        c->bind();
+        auto* h = new HNSWIndex();
+        h->c = c; h->kind = COMET_KIND_HNSW; h->dim = dim; h->ld = padded_dim(dim); h->metric = metric; h->M = m; h->efC = ef_construction; h->efS = ef_search;
+        h->trained = true;
+        *out = h;
+        return (int)COMET_OK;
+    });
+}
+
+int comet_hnsw_load_graph(comet_index* idx, int64_t n, const uint32_t* ids, const int32_t* levels, const float* vecs,
+                          const int64_t* edge_offsets, const uint32_t* edges, uint32_t entry_id, int32_t max_level) {
+    return guarded([&] {
+        if (idx->kind != COMET_KIND_HNSW) COMET_FAIL(COMET_ERR_INVALID_ARG, "not an HNSW index");
+        Ctx* c = idx->c;
+        std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->scratch_reset();
+        static_cast<HNSWIndex*>(idx)->load(n, ids, levels, vecs, edge_offsets, edges, entry_id, max_level);
+        return (int)COMET_OK;
+    });
+}
+
+}  // extern "C"

@@ -701,3 +701,29 @@ class BM25SearchIndex:
                                          flt.ctypes.data_as(C.c_void_p) if flt.size else None, int(flt.size), ids.ctypes.data_as(C.c_void_p),
                                          sc.ctypes.data_as(C.c_void_p), sc64.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p), k_cap))
         return ids, sc, sc64, cnt
+
+
+class HNSWIndex(VectorIndex):
+    """comet.NewHNSWIndex(dim, distanceKind, m, efConstruction, efSearch) — hnsw_index.go:160.
+    Search runs on the GPU; the graph is loaded (built by the reference / the oracle), see load_graph."""
+    kind_name = "hnsw"
+
+    def __init__(self, ctx: Context, dim: int, distance_kind: str, m: int = 0, ef_construction: int = 0, ef_search: int = 0):
+        if dim <= 0:
+            raise ValueError("dimension must be positive")
+        super().__init__(ctx, dim, distance_kind)
+        check(self.lib.comet_hnsw_create(ctx.h, dim, _metric_code(distance_kind), m, ef_construction, ef_search, C.byref(self.h)))
+
+    def load_graph(self, ids, levels, vectors, edge_offsets, edges, entry_id: int, max_level: int) -> None:
+        ids = np.ascontiguousarray(ids, np.uint32)
+        levels = np.ascontiguousarray(levels, np.int32)
+        v = _f32(vectors)
+        eo = np.ascontiguousarray(edge_offsets, np.int64)
+        ed = np.ascontiguousarray(edges, np.uint32)
+        check(self.lib.comet_hnsw_load_graph(self.h, ids.shape[0], ids.ctypes.data_as(C.c_void_p), levels.ctypes.data_as(C.c_void_p),
+                                             v.ctypes.data_as(C.c_void_p), eo.ctypes.data_as(C.c_void_p), ed.ctypes.data_as(C.c_void_p),
+                                             C.c_uint32(int(entry_id)), int(max_level)))
+
+    def _k_cap(self, k, nprobes):
+        n = len(self)
+        return max(1, min(1024, n if (k <= 0 or k > n) else k))

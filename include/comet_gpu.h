@@ -104,6 +104,14 @@ COMET_API int comet_ivf_create(comet_ctx* ctx, int dim, int metric, int nlist, c
 COMET_API int comet_pq_create(comet_ctx* ctx, int dim, int metric, int M, int nbits, comet_index** out); /* NewPQIndex pq_index.go:135 */
 COMET_API int comet_ivfpq_create(comet_ctx* ctx, int dim, int metric, int nlist, int M, int nbits,
                                  comet_index** out); /* NewIVFPQIndex ivfpq_index.go:113 */
+/* NewHNSWIndex hnsw_index.go:160 (m / ef_construction / ef_search <= 0 -> 16 / 200 / ef_construction) */
+COMET_API int comet_hnsw_create(comet_ctx* ctx, int dim, int metric, int m, int ef_construction, int ef_search, comet_index** out);
+/* Load a graph built by the reference (or the oracle): n nodes in any order with their ids, levels
+ * (hnswNode.Level), stored (already preprocessed) vectors n x dim, and for every (node, layer <= level) in
+ * node-major order an edge list: edge_offsets has sum(level+1)+1 entries into `edges` (neighbour NODE IDS,
+ * hnswNode.Edges hnsw_index.go:50-61). Graph construction on the GPU (insertNode) is not built yet. */
+COMET_API int comet_hnsw_load_graph(comet_index* idx, int64_t n, const uint32_t* ids, const int32_t* levels, const float* vecs,
+                                    const int64_t* edge_offsets, const uint32_t* edges, uint32_t entry_id, int32_t max_level);
 COMET_API int comet_index_destroy(comet_index* idx);
 
 COMET_API int comet_index_kind(const comet_index* idx);

@@ -398,3 +398,50 @@ class BM25:
         n = lib().orc_bm25_search(self.h, _p(q), int(q.size), int(k), _p(flt) if flt.size else None, int(flt.size), _p(ids), _p(sc), _p(sc64), cap)
         m = min(n, cap)
         return n, ids[:m], sc[:m], sc64[:m]
+
+
+class HNSW(_Index):
+    _free = "orc_hnsw_free"
+
+    def __init__(self, dim, metric, m=0, efc=0, efs=0, seed=12345):
+        self.dim, self.metric = dim, metric
+        self.h = lib().orc_hnsw_new(dim, METRIC[metric], m, efc, efs, C.c_uint64(seed))
+
+    def add(self, i, v, level=-1):
+        v = _f32(v)
+        return lib().orc_hnsw_add_with_level(self.h, int(i), _p(v), int(level))
+
+    def add_batch(self, ids, X):
+        for i, v in zip(ids, _f32(X)):
+            rc = self.add(i, v)
+            if rc:
+                return rc
+        return 0
+
+    def remove(self, i):
+        return lib().orc_hnsw_remove(self.h, int(i))
+
+    def capacity(self):
+        return lib().orc_hnsw_size(self.h)
+
+    def max_level(self):
+        return lib().orc_hnsw_max_level(self.h)
+
+    def entry(self):
+        return lib().orc_hnsw_entry(self.h)
+
+    def stats(self, reset=True):
+        a, b = C.c_uint64(), C.c_uint64()
+        lib().orc_hnsw_stats(self.h, C.byref(a), C.byref(b), 1 if reset else 0)
+        return a.value, b.value
+
+    def export(self):
+        slots, ne = C.c_int64(), C.c_int64()
+        n = lib().orc_hnsw_export(self.h, None, None, None, None, None, C.byref(slots), C.byref(ne))
+        ids = np.zeros(n, np.uint32); levels = np.zeros(n, np.int32); vecs = np.zeros((n, self.dim), np.float32)
+        eoff = np.zeros(slots.value + 1, np.int64); edges = np.zeros(max(1, ne.value), np.uint32)
+        lib().orc_hnsw_export(self.h, _p(ids), _p(levels), _p(vecs), _p(eoff), _p(edges), None, None)
+        return ids, levels, vecs, eoff, edges[:ne.value]
+
+    def search(self, q, k, ef=0, threshold=0.0, filter_ids=(), cap=None):
+        return self._do_search(lib().orc_hnsw_search, q, k, [int(ef)], threshold, filter_ids, cap)
