@@ -171,7 +171,7 @@ struct FlatIndex : comet_index {
         launch_prep_queries_fast(c, Qp, bn, ld, dim, Qh, ldh, qn, err, fmode, metric == COMET_COSINE ? 1.0002f : xmax_norm2);
         float* S0 = c->salloc<float>((size_t)NB * ldS);
         float* bound = c->salloc<float>((size_t)NB * ldB);
-        launch_flat_scan_f16(c, fmode, Xh.p, n, ldh, Qh, rn.as<float>(), qn, elig, S0, ldS, bound, ldB);
+        launch_flat_scan_f16(c, fmode, Xh.p, n, ldh, Qh, bn, rn.as<float>(), qn, elig, S0, ldS, bound, ldB);
         // kappa: exact K-th smallest emitted key per query
         const int64_t keff = (p.k <= 0 || p.k > n) ? n : p.k;
         const int Kq = (int)std::min<int64_t>(keff, 2 * n_tiles);

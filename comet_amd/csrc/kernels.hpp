@@ -90,7 +90,7 @@ int flat_fast_batch();
 // stats[0] = max |x| bits, stats[1] = max row norm^2 bits (atomicMax; caller zero-initialises)
 void launch_to_half_rows(Ctx* c, const float* X, int64_t n, int ld, void* Xh, int ldh, float* rn, uint32_t* stats);
 // mode 0 cosine / 1 L2 family. Qh: 256 x ldh fp16. S0: 256 x ldS (2 packed keys per 256-row tile), bound: 256 x ldB.
-void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, const float* rn, const float* qn,
+void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, int nq_used, const float* rn, const float* qn,
                           const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB);
 void launch_flat_collect(Ctx* c, const float* S0, int64_t ldS, const float* bound, int64_t ldB, int64_t n_tiles, int64_t n, const uint8_t* elig,
                          const float* kth_keys, int kcap, const int32_t* kth_cnt, int K, const float* err_abs, int B, uint32_t* cand, int cap,
