@@ -198,6 +198,16 @@ def main():
             alg_bytes = rows_local * args.dim * 4
             flops = 0.0
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel from the PMC counters: a separate rocprofv3 --pmc pass
+        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), committed under profiles/ and scaled by the row count
+        traffic = None
+        try:
+            pm = json.loads((ROOT / "profiles" / "r01_flat_fast_pmc_traffic.json").read_text())
+            for kname, kv in pm["kernels"].items():
+                if dom_name in kname:
+                    traffic = (kv["hbm_read_bytes_per_launch_corrected"] + kv["hbm_write_bytes_per_launch_uncalibrated"]) * rows_local / 1_000_000
+        except Exception:
+            traffic = None
         mfma_tflops = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         line = {
             "metric": "queries/sec, Flat 1Mx768 scan (recall@K = 1.0: exact search, ids bit-identical to the CPU reference path)",
@@ -208,7 +218,7 @@ def main():
                        "rows": args.rows, "dim": args.dim, "batch": B, "k": K, "metric": args.metric,
                        "mode": {0: "auto", 1: "strict", 2: "fast"}[args.mode], "sharding": f"rows/{world}", "build_s": round(build_s, 2)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": avg_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_ms": avg_ms,
                          "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": alg_bytes,
                          "mfma_tflops": mfma_tflops, "mfma_frac_of_2500": mfma_tflops / 2500.0},
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},

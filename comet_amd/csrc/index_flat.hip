@@ -75,11 +75,16 @@ struct FlatIndex : comet_index {
             else c->h2d(ids_dev.as<uint32_t>() + n, ids_h, added * 4);
             if (normalized_dev) launch_unpad_rows(c, dst, added, ld, normalized_dev, dim);
             // half-precision shadow of the new rows + their squared norms and magnitude statistics
-            Xh.reserve((size_t)(n + added) * ldh * 2, c->stream, (size_t)n * ldh * 2);
+            {   // tiled shadow: whole 256-row tiles, new tiles zero-initialised (padding rows must read as zeros)
+                const size_t tile_bytes = (size_t)256 * ldh * 2;
+                const size_t old_tiles = (size_t)ceil_div(n, 256), new_tiles = (size_t)ceil_div(n + added, 256);
+                Xh.reserve(new_tiles * tile_bytes, c->stream, old_tiles * tile_bytes);
+                if (new_tiles > old_tiles) c->zero((char*)Xh.p + old_tiles * tile_bytes, (new_tiles - old_tiles) * tile_bytes);
+            }
             rn.reserve((size_t)(n + added) * 4, c->stream, (size_t)n * 4);
             stats_dev.reserve(8, c->stream, 0);
             c->zero(stats_dev.p, 8);
-            launch_to_half_rows(c, dst, added, ld, (char*)Xh.p + (size_t)n * ldh * 2, ldh, rn.as<float>() + n, stats_dev.as<uint32_t>());
+            launch_to_half_rows(c, dst, added, ld, Xh.p, ldh, n, rn.as<float>() + n, stats_dev.as<uint32_t>());
             uint32_t hs[2] = {0, 0};
             c->d2h(hs, stats_dev.p, 8);
             HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -118,9 +123,11 @@ struct FlatIndex : comet_index {
         std::swap(X.p, nx.p); std::swap(X.cap, nx.cap);
         std::swap(ids_dev.p, nid.p); std::swap(ids_dev.cap, nid.cap);
         {   // rebuild the fp16 shadow from the compacted rows
-            Xh.reserve(std::max<size_t>(1, nk) * ldh * 2, c->stream, 0);
+            const size_t tiles = std::max<size_t>(1, (size_t)ceil_div((int64_t)nk, 256));
+            Xh.reserve(tiles * 256 * ldh * 2, c->stream, 0);
+            c->zero(Xh.p, tiles * 256 * ldh * 2);
             rn.reserve(std::max<size_t>(1, nk) * 4, c->stream, 0);
-            launch_to_half_rows(c, X.as<float>(), (int64_t)nk, ld, Xh.p, ldh, rn.as<float>(), nullptr);
+            launch_to_half_rows(c, X.as<float>(), (int64_t)nk, ld, Xh.p, ldh, 0, rn.as<float>(), nullptr);
             HIP_CHECK(hipStreamSynchronize(c->stream));
         }
         ids.swap(nids); n = (int64_t)nk;

@@ -86,9 +86,11 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
 // ---- kernels_fast.hip (MFMA fast path of the Flat scan) ------------------------------------------
 int flat_fast_tile_rows();
 int flat_fast_batch();
-// fp32 padded rows -> fp16 shadow rows (ldh halves per row, zero padded); rn[row] = sum x^2 (nullable);
+// fp32 padded rows -> fp16 shadow in the TILED layout [256-row tile][64-half K step][row][64] (each (tile, K step)
+// slab is 32 KiB contiguous). X / rn point at the first new row whose global row index is row_base; the shadow
+// buffer must hold whole tiles (zero-initialised padding rows). rn[row] = sum x^2 (nullable);
 // stats[0] = max |x| bits, stats[1] = max row norm^2 bits (atomicMax; caller zero-initialises)
-void launch_to_half_rows(Ctx* c, const float* X, int64_t n, int ld, void* Xh, int ldh, float* rn, uint32_t* stats);
+void launch_to_half_rows(Ctx* c, const float* X, int64_t n, int ld, void* Xh, int ldh, int64_t row_base, float* rn, uint32_t* stats);
 // mode 0 cosine / 1 L2 family. Qh: 256 x ldh fp16. S0: 256 x ldS (2 packed keys per 256-row tile), bound: 256 x ldB.
 void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, int nq_used, const float* rn, const float* qn,
                           const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB);
