@@ -119,6 +119,7 @@ def load() -> C.CDLL:
         "comet_bm25_num_docs": (i64, [p]),
         "comet_bm25_avg_doc_len": (C.c_double, [p]),
         "comet_bm25_search": (i32, [p, p, p, i32, i32, p, i32, p, p, p, p, i32]),
+        "comet_index_export": (i32, [p, p, p, p]),
         "comet_index_get_stat": (i32, [p, C.c_char_p, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():

@@ -292,6 +292,9 @@ int comet_index_list_read(const comet_index* idx, int32_t list, uint32_t* out_id
     return guarded([&] { CallGuard g(idx->c); idx->list_read(list, out_ids, out_codes, out_vecs); return (int)COMET_OK; });
 }
 
+int comet_index_export(const comet_index* idx, uint32_t* out_ids, int32_t* out_lists, uint8_t* out_codes) {
+    return guarded([&] { CallGuard g(idx->c); idx->export_all(out_ids, out_lists, out_codes); return (int)COMET_OK; });
+}
 int comet_index_get_stat(const comet_index* idx, const char* name, double* out) {
     return guarded([&] { if (!idx->get_stat(name, out)) COMET_FAIL(COMET_ERR_INVALID_ARG, "unknown stat '%s'", name); return (int)COMET_OK; });
 }

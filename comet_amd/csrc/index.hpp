@@ -34,6 +34,7 @@ struct comet_index {
                             float* out_scores, int32_t* out_counts, int k_cap) = 0;
     virtual int64_t list_size(int /*list*/) const { return size(); }
     virtual void list_read(int /*list*/, uint32_t* /*ids*/, uint8_t* /*codes*/, float* /*vecs*/) const {}
+    virtual void export_all(uint32_t* /*ids*/, int32_t* /*lists*/, uint8_t* /*codes*/) const { COMET_FAIL(COMET_ERR_UNSUPPORTED, "export not supported for this index kind"); }
     virtual bool get_stat(const char* /*name*/, double* /*out*/) const { return false; }
     virtual void get_centroids(float*) const { COMET_FAIL(COMET_ERR_UNSUPPORTED, "index has no centroids"); }
     virtual void get_codebooks(float*) const { COMET_FAIL(COMET_ERR_UNSUPPORTED, "index has no codebooks"); }

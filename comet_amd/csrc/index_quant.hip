@@ -461,10 +461,25 @@ struct PQFamilyIndex : comet_index {
         c->d2h(out, tmp, (size_t)nlist * dim * sizeof(float));
         HIP_CHECK(hipStreamSynchronize(c->stream));
     }
+    void export_all(uint32_t* oids, int32_t* olists, uint8_t* ocodes) const override {
+        if (oids) std::copy(lay.ids.begin(), lay.ids.end(), oids);
+        if (olists) std::copy(lay.list_of.begin(), lay.list_of.end(), olists);
+        if (ocodes && lay.n > 0) {
+            std::vector<uint8_t> all((size_t)lay.n * M4 * 4);
+            c->d2h(all.data(), codes_arr.p, all.size());
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            for (int64_t i = 0; i < lay.n; i++) std::copy(all.begin() + (size_t)i * M4 * 4, all.begin() + (size_t)i * M4 * 4 + M, ocodes + (size_t)i * M);
+        }
+    }
     void get_codebooks(float* out) const override {
         if (!trained) COMET_FAIL(COMET_ERR_NOT_TRAINED, "index must be trained");
         c->d2h(out, codebooks.p, (size_t)M * Ksub * dsub * sizeof(float));
         HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    bool get_stat(const char* name, double* out) const override {
+        std::string k(name);
+        if (k == "max_list_len") { const_cast<ListLayout&>(lay).compile(c); *out = (double)lay.max_len; return true; }
+        return false;
     }
     int64_t list_size(int l) const override { const_cast<ListLayout&>(lay).compile(c); return (l >= 0 && l < nlist) ? lay.len_h[l] : 0; }
     void list_read(int l, uint32_t* oids, uint8_t* ocodes, float*) const override {

@@ -332,28 +332,37 @@ void launch_finalize_probe(Ctx* c, const uint32_t* pos, int B, int k_cap, const 
 //      reference's serial float32 sum), takes the correctly-rounded sqrt and writes the distance.
 // LDS holds the table (96 KiB at M=96, Ksub=256: fits because gfx950 has 160 KiB per CU).
 // ------------------------------------------------------------------------------------------------
-constexpr int ADC_THREADS = 512;
+constexpr int ADC_THREADS = 1024;
+typedef float f32x4q __attribute__((ext_vector_type(4)));
 
-template <bool HAS_CENTROID>
+template <bool HAS_CENTROID, int DSUB>
 __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const float* __restrict__ Qp, int ld, int dim,
                                                                const float* __restrict__ centroids, const float* __restrict__ codebooks,
                                                                int M, int Ksub, int KL, int dsub, const unsigned* __restrict__ codes, int M4,
                                                                const long* __restrict__ list_base, const int* __restrict__ list_len,
                                                                const unsigned* __restrict__ probe_list, int ldp, int np,
                                                                const int* __restrict__ seg_off, const unsigned char* __restrict__ elig,
-                                                               float* __restrict__ D, long ldD, int segs_per_list, int seg_codes) {
+                                                               float* __restrict__ D, long ldD, int segs_per_list, int seg_codes, int n_queries) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lut = lds;               // M * KL
     float* res = lds + (long)M * KL;  // dim
-    const int q = blockIdx.y;
-    const int p = blockIdx.x / segs_per_list;
-    const int s = blockIdx.x - p * segs_per_list;
+    // persistent workgroups: the 96 KiB table allows one workgroup per CU, so re-launching one per work item
+    // would expose the dispatch gap ~30 times per CU; instead each resident workgroup walks the item list
+    // (query, probe, segment) with a grid stride.
+    const int items_per_q = np * segs_per_list;
+    const long n_items = (long)n_queries * items_per_q;
+  for (long item = blockIdx.x; item < n_items; item += gridDim.x) {
+    __syncthreads();                 // previous item's table no longer in use
+    const int q = (int)(item / items_per_q);
+    const int rem = (int)(item - (long)q * items_per_q);
+    const int p = rem / segs_per_list;
+    const int s = rem - p * segs_per_list;
     const int so = seg_off[(long)q * (np + 1) + p];
-    if (seg_off[(long)q * (np + 1) + p + 1] == so) return;   // empty list or probe slot not used by this query
+    if (seg_off[(long)q * (np + 1) + p + 1] == so) continue;   // empty list or probe slot not used by this query
     const unsigned L = probe_list[(long)q * ldp + p];
     const int len = list_len[L];
     const int start = s * seg_codes;
-    if (start >= len) return;
+    if (start >= len) continue;
     const int end = min(len, start + seg_codes);
 
     const float* __restrict__ qv = Qp + (long)q * ld;
@@ -363,41 +372,124 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const float* __re
     }
     __syncthreads();
     const int n_ent = M * KL;
-    for (int e = threadIdx.x; e < n_ent; e += ADC_THREADS) {
-        const int m = e / KL, k = e - m * KL;
-        const float* __restrict__ cb = codebooks + ((long)m * Ksub + k) * dsub;
-        const float* r = res + m * dsub;
-        float dist = 0.0f;
-        for (int i = 0; i < dsub; i++) { float diff = r[i] - cb[i]; float sq = diff * diff; dist = dist + sq; }
-        lut[e] = dist;
+    if constexpr (DSUB > 0) {
+        // table build, specialised on the subspace width. The codebook is L2-resident and re-read by every workgroup
+        // (786 KiB per (query, list) at M=96), so the loop is software-pipelined: the codebook rows of the NEXT group
+        // of U entries are already in flight (16-byte loads) while the current group is reduced. The per-entry
+        // float32 sum keeps the reference's dimension order (ivfpq_index_search.go:365-371).
+        constexpr int U = (DSUB <= 4) ? 8 : (DSUB <= 8 ? 4 : 2);
+        // entry e = m * KL + k with KL a power of two dividing the workgroup size: a thread keeps one codeword index k
+        // and walks the subspaces m = m0, m0 + mstep, ... with constant pointer strides (no per-entry address math)
+        const int kl_shift = 31 - __builtin_clz((unsigned)KL);
+        const int k = threadIdx.x & (KL - 1), m0 = threadIdx.x >> kl_shift, mstep = ADC_THREADS >> kl_shift;
+        const float* __restrict__ cbp = codebooks + ((long)m0 * Ksub + k) * DSUB;
+        const long cstride = (long)mstep * Ksub * DSUB;
+        const int n_j = (M - m0 + mstep - 1) / mstep;       // entries owned by this thread (m0 < M iff n_j > 0)
+        float cur[U][DSUB], nxt[U][DSUB];
+        auto fetch = [&](float (&dst)[U][DSUB], int j0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                int j = j0 + u; if (j > n_j - 1) j = n_j - 1; if (j < 0) j = 0;      // clamped re-read, never stored
+                const float* __restrict__ cb = cbp + (long)j * cstride;
+                if constexpr (DSUB % 4 == 0) {
+#pragma unroll
+                    for (int i = 0; i < DSUB; i += 4) { const f32x4q v = *reinterpret_cast<const f32x4q*>(cb + i); dst[u][i] = v[0]; dst[u][i + 1] = v[1]; dst[u][i + 2] = v[2]; dst[u][i + 3] = v[3]; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < DSUB; i++) dst[u][i] = cb[i];
+                }
+            }
+        };
+        if (m0 < M) {
+            fetch(cur, 0);
+            for (int j0 = 0; j0 < n_j; j0 += U) {
+                fetch(nxt, j0 + U);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int j = j0 + u;
+                    if (j < n_j) {
+                        const int m = m0 + j * mstep;
+                        const float* r = res + m * DSUB;
+                        float dsum = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < DSUB; i++) { float diff = r[i] - cur[u][i]; float sq = diff * diff; dsum = dsum + sq; }
+                        lut[m * KL + k] = dsum;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int i = 0; i < DSUB; i++) cur[u][i] = nxt[u][i];
+            }
+        }
+    } else {
+        for (int e = threadIdx.x; e < n_ent; e += ADC_THREADS) {
+            const int m = e / KL, k = e - m * KL;
+            const float* __restrict__ cb = codebooks + ((long)m * Ksub + k) * dsub;
+            const float* r = res + m * dsub;
+            float dist = 0.0f;
+            for (int i = 0; i < dsub; i++) { float diff = r[i] - cb[i]; float sq = diff * diff; dist = dist + sq; }
+            lut[e] = dist;
+        }
     }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const long base_slot = list_base[L];            // multiple of 64
-    const int Mfull = M >> 2, Mtail = M & 3;
-    for (int blk = (start >> 6) + wid; blk * 64 < end; blk += ADC_THREADS / 64) {
-        const int j = blk * 64 + lane;
-        const long slot = base_slot + j;
-        const unsigned* __restrict__ cw = codes + ((base_slot >> 6) + blk) * (long)M4 * 64 + lane;
-        float acc = 0.0f;
-        int m = 0;
-        for (int w = 0; w < Mfull; w++, m += 4) {
-            const unsigned word = cw[(long)w * 64];
-            acc = acc + lut[(m + 0) * KL + (word & 255u)];
-            acc = acc + lut[(m + 1) * KL + ((word >> 8) & 255u)];
-            acc = acc + lut[(m + 2) * KL + ((word >> 16) & 255u)];
-            acc = acc + lut[(m + 3) * KL + (word >> 24)];
+    // scan: a lane owns one code of each of TWO 64-code blocks (two independent serial float32 chains in flight);
+    // the M4 code words are fetched eight at a time, the next group requested before the current one is consumed,
+    // and the 32 table lookups of a group are issued as straight-line code so the LDS reads overlap the add chain.
+    constexpr int G = 4;
+    const int nblk_end = (end + 63) >> 6;
+    for (int blk = (start >> 6) + 2 * wid; blk < nblk_end; blk += 2 * (ADC_THREADS / 64)) {
+        const bool has1 = (blk + 1) < nblk_end;
+        const unsigned* __restrict__ cw0 = codes + ((base_slot >> 6) + blk) * (long)M4 * 64 + lane;
+        const unsigned* __restrict__ cw1 = has1 ? cw0 + (long)M4 * 64 : cw0;
+        float acc0 = 0.0f, acc1 = 0.0f;
+        unsigned cur0[G], cur1[G], nxt0[G], nxt1[G];
+#pragma unroll
+        for (int i = 0; i < G; i++) { cur0[i] = (i < M4) ? cw0[(long)i * 64] : 0u; cur1[i] = (i < M4) ? cw1[(long)i * 64] : 0u; }
+        for (int w0 = 0; w0 < M4; w0 += G) {
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                const bool in = (w0 + G + i) < M4;
+                nxt0[i] = in ? cw0[(long)(w0 + G + i) * 64] : 0u;
+                nxt1[i] = in ? cw1[(long)(w0 + G + i) * 64] : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                const int m = (w0 + i) * 4;
+                if (m + 3 < M) {            // wave-uniform
+                    const unsigned wa = cur0[i], wb = cur1[i];
+                    const float* l0 = lut + (long)m * KL;
+                    const float a0 = l0[wa & 255u], a1 = l0[KL + ((wa >> 8) & 255u)], a2 = l0[2 * KL + ((wa >> 16) & 255u)], a3 = l0[3 * KL + (wa >> 24)];
+                    const float b0 = l0[wb & 255u], b1 = l0[KL + ((wb >> 8) & 255u)], b2 = l0[2 * KL + ((wb >> 16) & 255u)], b3 = l0[3 * KL + (wb >> 24)];
+                    acc0 = acc0 + a0; acc1 = acc1 + b0;
+                    acc0 = acc0 + a1; acc1 = acc1 + b1;
+                    acc0 = acc0 + a2; acc1 = acc1 + b2;
+                    acc0 = acc0 + a3; acc1 = acc1 + b3;
+                } else if (m < M) {         // last, partial word (M not a multiple of 4)
+                    const unsigned wa = cur0[i], wb = cur1[i];
+                    for (int bb = 0; m + bb < M; bb++) {
+                        acc0 = acc0 + lut[(m + bb) * KL + ((wa >> (8 * bb)) & 255u)];
+                        acc1 = acc1 + lut[(m + bb) * KL + ((wb >> (8 * bb)) & 255u)];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < G; i++) { cur0[i] = nxt0[i]; cur1[i] = nxt1[i]; }
         }
-        if (Mtail) {
-            const unsigned word = cw[(long)Mfull * 64];
-            for (int b = 0; b < Mtail; b++) acc = acc + lut[(m + b) * KL + ((word >> (8 * b)) & 255u)];
+        const int j0 = blk * 64 + lane, j1 = j0 + 64;
+        if (j0 >= start && j0 < end) {
+            const bool ok = elig ? (elig[base_slot + j0] != 0) : true;
+            D[(long)q * ldD + so + j0] = ok ? go_sqrt32q(acc0) : __uint_as_float(EXCLUDED_BITS);
         }
-        if (j >= start && j < end) {
-            const bool ok = elig ? (elig[slot] != 0) : true;
-            D[(long)q * ldD + so + j] = ok ? go_sqrt32q(acc) : __uint_as_float(EXCLUDED_BITS);
+        if (has1 && j1 >= start && j1 < end) {
+            const bool ok = elig ? (elig[base_slot + j1] != 0) : true;
+            D[(long)q * ldD + so + j1] = ok ? go_sqrt32q(acc1) : __uint_as_float(EXCLUDED_BITS);
         }
     }
+  }   // item loop
 }
 size_t adc_lds_bytes(int M, int Ksub, int dim) { int KL = Ksub < 256 ? Ksub : 256; return ((size_t)M * KL + dim) * sizeof(float); }
 void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* centroids, const float* codebooks, int M, int Ksub, int dsub,
@@ -409,17 +501,18 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
     if (lds > 160 * 1024) COMET_FAIL(COMET_ERR_UNSUPPORTED, "PQ lookup table (%zu bytes) exceeds the 160 KiB LDS of a gfx950 CU", lds);
     const int seg_codes = 8192;
     const int segs = (int)ceil_div(max_list_len, seg_codes);
-    dim3 grid((unsigned)(np * segs), B), blk(ADC_THREADS);
+    const long n_items = (long)B * np * segs;
+    dim3 grid((unsigned)std::min<long>(n_items, (long)c->prop.multiProcessorCount)), blk(ADC_THREADS);
     ProfScope ps(c, "adc_scan");
-    if (centroids) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        adc_scan_kernel<true><<<grid, blk, lds, c->stream>>>(Qp, ld, dim, centroids, codebooks, M, Ksub, KL, dsub, codes, M4, (const long*)list_base,
-                                                           list_len, probe_list, ldp, np, seg_off, elig, D, ldD, segs, seg_codes);
-    } else {
-        HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        adc_scan_kernel<false><<<grid, blk, lds, c->stream>>>(Qp, ld, dim, nullptr, codebooks, M, Ksub, KL, dsub, codes, M4, (const long*)list_base,
-                                                            list_len, probe_list, ldp, np, seg_off, elig, D, ldD, segs, seg_codes);
-    }
+#define ADC_LAUNCH(HC, DS) do { \
+        HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan_kernel<HC, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        adc_scan_kernel<HC, DS><<<grid, blk, lds, c->stream>>>(Qp, ld, dim, centroids, codebooks, M, Ksub, KL, dsub, codes, M4, (const long*)list_base, \
+                                                              list_len, probe_list, ldp, np, seg_off, elig, D, ldD, segs, seg_codes, B); } while (0)
+#define ADC_DS(HC) do { switch (dsub) { case 2: ADC_LAUNCH(HC, 2); break; case 4: ADC_LAUNCH(HC, 4); break; case 8: ADC_LAUNCH(HC, 8); break; \
+                                       case 16: ADC_LAUNCH(HC, 16); break; default: ADC_LAUNCH(HC, 0); break; } } while (0)
+    if (centroids) ADC_DS(true); else ADC_DS(false);
+#undef ADC_DS
+#undef ADC_LAUNCH
     LAUNCH_CHECK();
 }
 

@@ -1,0 +1,120 @@
+"""Hybrid search above the boundary (config 5: IVF + BM25 + Reciprocal Rank Fusion).
+
+This is orchestration that stays on the host in the reference too (hybrid_search_index.go:477-615,
+fusion.go:174-243): both sub-searches run on the GPU through their index objects, are cut to k BEFORE fusion
+(:518, :555), and the fused scores are sorted descending and cut to k. Metadata filtering (roaring / BSI) is out of
+scope; pre-computed candidate ids can be passed with `with_document_ids` and are pushed down to both sub-searches
+exactly like the reference pushes metadata candidates (:531-533, :560-562).
+
+Ties: the reference ranks with an exchange sort over Go-map iteration order, so equal scores have no defined rank;
+here insertion order (best-first lists from the sub-searches) is kept.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+RECIPROCAL_RANK_FUSION, WEIGHTED_SUM_FUSION, MAX_FUSION, MIN_FUSION = "reciprocal_rank", "weighted_sum", "max", "min"
+
+
+@dataclass
+class HybridSearchResult:
+    id: int
+    score: float
+
+
+def score_map_to_ranks(scores: dict[int, float], ascending: bool) -> dict[int, int]:
+    """scoreMapToRanks fusion.go:205-243 (O(n^2) exchange sort; 0-based ranks)."""
+    s = list(scores.items())
+    n = len(s)
+    for i in range(n - 1):
+        for j in range(i + 1, n):
+            swap = s[i][1] > s[j][1] if ascending else s[i][1] < s[j][1]
+            if swap:
+                s[i], s[j] = s[j], s[i]
+    return {doc: rank for rank, (doc, _) in enumerate(s)}
+
+
+def reciprocal_rank_fusion(vector: dict[int, float], text: dict[int, float], k: float = 60.0) -> dict[int, float]:
+    """reciprocalRankFusion.Combine fusion.go:174-203: vector ranks ascending (distances), text descending."""
+    out: dict[int, float] = {}
+    for doc, r in score_map_to_ranks(vector, True).items():
+        out[doc] = 1.0 / (k + float(r))
+    for doc, r in score_map_to_ranks(text, False).items():
+        v = 1.0 / (k + float(r))
+        out[doc] = out[doc] + v if doc in out else v
+    return out
+
+
+def weighted_sum_fusion(vector: dict[int, float], text: dict[int, float], wv: float = 1.0, wt: float = 1.0) -> dict[int, float]:
+    """weightedSumFusion.Combine (the reference's default, hybrid_search_index.go:237): wv*vector + wt*text."""
+    out = {d: wv * s for d, s in vector.items()}
+    for d, s in text.items():
+        out[d] = out.get(d, 0.0) + wt * s
+    return out
+
+
+class HybridSearch:
+    """hybridSearch builder (hybrid_search_index.go:326-365) over a GPU vector index and a GPU BM25 index."""
+
+    def __init__(self, vector_index=None, text_index=None):
+        self.vector_index, self.text_index = vector_index, text_index
+        self.vector_query = None
+        self.text_queries: list[list[int]] = []
+        self.k = 10
+        self.n_probes = 1            # hybrid default nProbes = 1 (hybrid_search_index.go:236)
+        self.ef_search = 0
+        self.threshold = 0.0
+        self.fusion_kind = WEIGHTED_SUM_FUSION
+        self.rrf_k = 60.0
+        self.document_ids: list[int] = []
+
+    def with_vector(self, q): self.vector_query = q; return self
+    def with_text(self, *token_lists): self.text_queries = [list(t) for t in token_lists]; return self
+    def with_k(self, k): self.k = int(k); return self
+    def with_n_probes(self, n): self.n_probes = int(n); return self
+    def with_ef_search(self, ef): self.ef_search = int(ef); return self
+    def with_threshold(self, t): self.threshold = float(t); return self
+    def with_fusion_kind(self, kind, rrf_k: float = 60.0): self.fusion_kind = kind; self.rrf_k = rrf_k; return self
+    def with_document_ids(self, *ids): self.document_ids = [int(i) for i in ids]; return self
+
+    def execute(self) -> list[HybridSearchResult]:
+        vres: dict[int, float] = {}
+        tres: dict[int, float] = {}
+        if self.vector_query is not None:
+            if self.vector_index is None:
+                raise ValueError("vector query specified but no vector index configured")
+            s = self.vector_index.new_search().with_query(self.vector_query).with_k(self.k)
+            if self.n_probes > 0:
+                s = s.with_n_probes(self.n_probes)
+            if self.ef_search > 0:
+                s = s.with_ef_search(self.ef_search)
+            if self.threshold > 0:
+                s = s.with_threshold(self.threshold)
+            if self.document_ids:
+                s = s.with_document_ids(*self.document_ids)
+            vres = {r.id: float(r.score) for r in s.execute()}
+        if self.text_queries:
+            if self.text_index is None:
+                raise ValueError("text query specified but no text index configured")
+            s = self.text_index.new_search().with_query(*self.text_queries).with_k(self.k)
+            if self.document_ids:
+                s = s.with_document_ids(*self.document_ids)
+            tres = {r.id: float(r.score) for r in s.execute()}
+        if vres and tres:
+            if self.fusion_kind == RECIPROCAL_RANK_FUSION:
+                comb = reciprocal_rank_fusion(vres, tres, self.rrf_k)
+            elif self.fusion_kind == WEIGHTED_SUM_FUSION:
+                comb = weighted_sum_fusion(vres, tres)
+            elif self.fusion_kind == MAX_FUSION:
+                comb = {d: max(vres.get(d, float("-inf")), tres.get(d, float("-inf"))) for d in {**vres, **tres}}
+            elif self.fusion_kind == MIN_FUSION:
+                comb = {d: min(vres.get(d, float("inf")), tres.get(d, float("inf"))) for d in {**vres, **tres}}
+            else:
+                raise ValueError(f"unknown fusion kind: {self.fusion_kind}")
+        else:
+            comb = vres or tres
+        if not comb and self.document_ids:
+            comb = {i: 1.0 for i in self.document_ids}
+        res = [HybridSearchResult(i, s) for i, s in comb.items()]
+        res.sort(key=lambda r: -r.score)      # sort.Slice(desc) hybrid_search_index.go:603
+        return res[:self.k] if len(res) > self.k else res

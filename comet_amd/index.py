@@ -432,6 +432,15 @@ class VectorIndex:
         check(self.lib.comet_index_get_stat(self.h, name.encode(), C.byref(out)))
         return out.value
 
+    def export(self, codes_width: int = 0):
+        """(ids, list index, PQ codes) of every stored element in Add order."""
+        n = len(self)
+        ids = np.empty(n, np.uint32); lists = np.empty(n, np.int32)
+        codes = np.empty((n, codes_width), np.uint8) if codes_width else None
+        check(self.lib.comet_index_export(self.h, ids.ctypes.data_as(C.c_void_p), lists.ctypes.data_as(C.c_void_p),
+                                          codes.ctypes.data_as(C.c_void_p) if codes is not None else None))
+        return ids, lists, codes
+
     def list_size(self, lst: int = 0) -> int:
         out = C.c_int64()
         check(self.lib.comet_index_list_size(self.h, int(lst), C.byref(out)))

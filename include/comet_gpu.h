@@ -193,6 +193,11 @@ COMET_API int comet_bm25_search(comet_text_index* idx, const uint32_t* q_tokens,
                                 const uint32_t* filter_ids, int32_t n_filter, uint32_t* out_ids, float* out_scores,
                                 double* out_scores64, int32_t* out_counts, int32_t k_cap);
 
+/* Bulk export in arrival (Add) order: ids[n], list index per element lists[n] (0 for Flat / PQ), and M-byte
+ * PQ codes codes[n*M] (PQ / IVFPQ only). Any pointer may be NULL. Used to hand a GPU-built index to the CPU
+ * reference path (the CPU baseline searches the index the GPU built). */
+COMET_API int comet_index_export(const comet_index* idx, uint32_t* out_ids, int32_t* out_lists, uint8_t* out_codes);
+
 /* named counters of the last search / of the index (bench + tests): "fast_candidates", "fast_overflows",
  * "fast_expansions", "fast_queries", "strict_queries", "max_abs", "max_norm2". Unknown name -> INVALID_ARG. */
 COMET_API int comet_index_get_stat(const comet_index* idx, const char* name, double* out);

@@ -1,0 +1,52 @@
+"""Host-side fusion (fusion.go) — CPU test against the reference's KAT — and the config-5 hybrid path on the GPU
+(IVF + BM25 + RRF) against the oracle's restatement of the same pipeline."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from comet_amd.hybrid import RECIPROCAL_RANK_FUSION, HybridSearch, reciprocal_rank_fusion, score_map_to_ranks
+
+KATS = json.loads((Path(__file__).parent / "golden" / "reference_kats.json").read_text())
+
+
+def test_rrf_reference_kat():
+    b = KATS["rrf"]
+    got = reciprocal_rank_fusion({int(k): v for k, v in b["vector"].items()}, {int(k): v for k, v in b["text"].items()}, b["K"])
+    for k, e in b["expected"].items():
+        assert abs(got[int(k)] - e) <= b["tolerance"]
+    assert got[1] > max(got[2], got[3], got[4])
+    assert score_map_to_ranks({1: 0.1, 2: 0.3, 3: 0.5}, True) == {1: 0, 2: 1, 3: 2}       # fusion_test.go:394-438
+    assert score_map_to_ranks({1: 20.0, 2: 15.0, 4: 10.0}, False) == {1: 0, 2: 1, 4: 2}
+
+
+@pytest.mark.gpu
+def test_config5_hybrid_ivf_bm25_rrf(ctx):
+    import ctypes as C
+    import oracle_lib as orc
+    from comet_amd import BM25SearchIndex, IVFIndex, L2_SQUARED
+    n, d, nlist, k = 4000, 32, 16, 10
+    X = orc.synth(3, 0, n * d).reshape(n, d)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    g = IVFIndex(ctx, d, L2_SQUARED, nlist); o = orc.IVF(d, "l2_squared", nlist)
+    g.train(X[:1000]); o.train(X[:1000]); g.add_batch(ids, X); o.add_batch(ids, X)
+    rng = np.random.default_rng(4)
+    tg, to = BM25SearchIndex(ctx), orc.BM25()
+    for i in range(1, n + 1):
+        toks = np.minimum((rng.pareto(1.1, int(rng.integers(8, 40))) * 3).astype(np.int64), 199).astype(np.uint32)
+        tg.add(i, toks); to.add(i, toks)
+    for qi in range(5):
+        q = X[qi * 37] + np.float32(0.01)
+        terms = [int(t) for t in rng.integers(0, 20, 3)]
+        res = HybridSearch(g, tg).with_vector(q).with_text(terms).with_k(k).with_n_probes(4).with_fusion_kind(RECIPROCAL_RANK_FUSION).execute()
+        # oracle pipeline: both sub-searches cut to k, then RRF (orc_rrf), sort desc, cut to k
+        nv, vi, vs = o.search(q, k, 4)
+        nt, ti, ts32, ts = to.search(terms, k)
+        vsd, tsd = vs.astype(np.float64), ts32.astype(np.float64)       # float64(result.GetScore()) of float32 scores
+        oi, os_ = np.zeros(2 * k, np.uint32), np.zeros(2 * k, np.float64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        m = orc.lib().orc_rrf(C.c_double(60.0), p(vi), p(vsd), nv, p(ti), p(tsd), nt, p(oi), p(os_))
+        want = sorted(zip(os_[:m].tolist(), oi[:m].tolist()), key=lambda t: -t[0])[:k]
+        assert sorted(r.score for r in res) == sorted(s for s, _ in want)
+        assert {r.id for r in res if r.score > want[-1][0]} == {i for s, i in want if s > want[-1][0]}
