@@ -140,20 +140,33 @@ def main():
     q_dev = ctx.alloc(B * args.dim * 4)
     ctx.synth_fill(q_dev, QUERY_SEED, 0, B * args.dim)
 
+    # two result-buffer sets: batch i+1 is enqueued before batch i is finalised / exchanged (software pipeline)
     if use_dist:
         import torch
         from comet_amd.dist import TopKExchange
         dev = torch.device("cuda", local_rank)
-        ex = TopKExchange(B, K, dev, ctx=ctx)
-        out_ids, out_sc, out_cn = ex.local_ptrs()
+        sets = [TopKExchange(B, K, dev, ctx=ctx) for _ in range(2)]
+        ptrs = [e.local_ptrs() for e in sets]
     else:
-        out_ids, out_sc, out_cn = ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)
+        sets = [None, None]
+        ptrs = [(ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)) for _ in range(2)]
+    out_ids, out_sc, out_cn = ptrs[0]
 
-    def step():
-        idx.search_batch_dev(q_dev, B, K, out_ids, out_sc, out_cn, K, mode=args.mode)
+    def finish(ticket, which):
+        idx.search_wait(ticket)                 # results of that batch final (device side complete)
         if use_dist:
-            ctx.sync()                      # shard results complete before RCCL reads them
-            ex.exchange_and_merge(K)        # one all-gather per array + merge kernel on every rank
+            sets[which].exchange_and_merge(K)   # one all-gather per array (RCCL) + merge kernel on every rank
+
+    def run(nsteps):
+        prev = None
+        for i in range(nsteps):
+            w = i & 1
+            t = idx.search_batch_dev_async(q_dev, B, K, ptrs[w][0], ptrs[w][1], ptrs[w][2], K, mode=args.mode)
+            if prev is not None:
+                finish(*prev)
+            prev = (t, w)
+        if prev is not None:
+            finish(*prev)
 
     def barrier():
         ctx.sync()
@@ -162,14 +175,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run(max(1, args.warmup))
     barrier()
     ctx.profile(True)
     ctx.profile_reset()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_dump()
@@ -225,9 +236,10 @@ def main():
             "fast_path": {k: idx.stat(k) for k in ("fast_queries", "strict_queries", "fast_candidates", "fast_expansions", "fast_overflows")},
         }
         if world == 1 and not args.no_cpu_baseline:
-            ids = ctx.download(out_ids, (B, K), np.uint32)
-            sc = ctx.download(out_sc, (B, K), np.float32)
-            cn = ctx.download(out_cn, (B,), np.int32)
+            last = ptrs[(args.steps - 1) & 1]
+            ids = ctx.download(last[0], (B, K), np.uint32)
+            sc = ctx.download(last[1], (B, K), np.float32)
+            cn = ctx.download(last[2], (B,), np.int32)
             line["cpu_baseline"] = cpu_baseline(args, ids, sc, cn)
         else:
             line["cpu_baseline"] = None

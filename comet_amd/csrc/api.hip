@@ -284,6 +284,26 @@ int comet_index_search(comet_index* idx, const float* queries, int32_t B, const 
     });
 }
 
+int comet_index_search_dev_async(comet_index* idx, const float* queries_dev, int32_t B, const comet_search_params* p,
+                                 uint32_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev, int32_t k_cap, uint64_t* out_ticket) {
+    return guarded([&] {
+        check_search_args(idx, B, p, k_cap);
+        if (out_ticket) *out_ticket = 0;
+        if (B == 0) return (int)COMET_OK;
+        CallGuard g(idx->c);
+        uint64_t t = idx->search_begin(queries_dev, B, *p, out_ids_dev, out_scores_dev, out_counts_dev, k_cap);
+        if (out_ticket) *out_ticket = t;
+        return (int)COMET_OK;
+    });
+}
+int comet_index_search_wait(comet_index* idx, uint64_t ticket) {
+    return guarded([&] {
+        std::lock_guard<std::recursive_mutex> lk(idx->c->mu); idx->c->bind();
+        idx->search_finish(ticket);
+        return (int)COMET_OK;
+    });
+}
+
 // ---- introspection -----------------------------------------------------------------------------
 int comet_index_get_centroids(const comet_index* idx, float* out) { return guarded([&] { CallGuard g(idx->c); idx->get_centroids(out); return (int)COMET_OK; }); }
 int comet_index_get_codebooks(const comet_index* idx, float* out) { return guarded([&] { CallGuard g(idx->c); idx->get_codebooks(out); return (int)COMET_OK; }); }

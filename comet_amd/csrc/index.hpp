@@ -32,6 +32,11 @@ struct comet_index {
     virtual void flush() = 0;
     virtual void search_dev(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids,
                             float* out_scores, int32_t* out_counts, int k_cap) = 0;
+    // asynchronous form: begin enqueues the search and returns a ticket; finish(ticket) makes the results final
+    // (index kinds without deferred work run everything in begin)
+    virtual uint64_t search_begin(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
+                                  int32_t* out_counts, int k_cap) { search_dev(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap); return 0; }
+    virtual void search_finish(uint64_t /*ticket*/) {}
     virtual int64_t list_size(int /*list*/) const { return size(); }
     virtual void list_read(int /*list*/, uint32_t* /*ids*/, uint8_t* /*codes*/, float* /*vecs*/) const {}
     virtual void export_all(uint32_t* /*ids*/, int32_t* /*lists*/, uint8_t* /*codes*/) const { COMET_FAIL(COMET_ERR_UNSUPPORTED, "export not supported for this index kind"); }

@@ -49,6 +49,22 @@ struct FlatIndex : comet_index {
     float xmax_abs = 0.0f, xmax_norm2 = 0.0f;
     // counters of the last fast-path search (bench / tests)
     int64_t st_candidates = 0, st_overflows = 0, st_expansions = 0, st_fast_queries = 0, st_strict_queries = 0;
+    // Deferred verification of fast-path searches: the candidate-overflow flags of a search are copied to pinned host
+    // memory asynchronously; search_finish() waits for the search's event, and re-runs the (rare) overflowed queries on
+    // the strict kernels. This keeps the stream busy across batches (no host round trip inside a search).
+    struct Pending {
+        bool active = false; uint64_t ticket = 0; hipEvent_t ev = nullptr;
+        int B = 0, k_cap = 0, nfast_slices = 0;
+        const float* queries = nullptr; comet_search_params p{}; std::vector<uint32_t> flt;
+        uint32_t* out_ids = nullptr; float* out_scores = nullptr; int32_t* out_counts = nullptr;
+        int32_t* flags = nullptr;   // pinned: per fast slice [256 overflow flags | 4 stats]
+    };
+    static constexpr int kRing = 8, kSliceInts = 260, kMaxSlices = 64;
+    Pending ring[kRing];
+    uint64_t next_ticket = 1;
+    ~FlatIndex() override {
+        for (auto& r : ring) { if (r.ev) (void)hipEventDestroy(r.ev); if (r.flags) (void)hipHostFree(r.flags); }
+    }
 
     int64_t size() const override { return n; }
     bool contains_id(uint32_t id) const override { return id_count.count(id) != 0; }
@@ -166,7 +182,7 @@ struct FlatIndex : comet_index {
 
     // MFMA fast path for up to 256 prepared queries; writes candidate positions `pos` as ROW indices
     void search_fast(const float* Qp, int bn, const comet_search_params& p, const uint8_t* elig, uint32_t* pos, float* out_scores,
-                     int32_t* out_counts, int k_cap) {
+                     int32_t* out_counts, int k_cap, Pending* pend) {
         ScratchMark sm(c);
         const int64_t n_tiles = ceil_div(n, flat_fast_tile_rows());
         const int64_t ldS = round_up(2 * n_tiles, 16), ldB = round_up(n_tiles, 16);
@@ -199,26 +215,18 @@ struct FlatIndex : comet_index {
         uint32_t* pos2 = c->salloc<uint32_t>((size_t)bn * k_cap);
         launch_select_topk(c, D2, cap, bn, cap, ccnt, p.threshold, p.k, pos2, out_scores, out_counts, k_cap);
         launch_gather_indirect(c, cand, cap, pos2, bn, k_cap, pos);
-        // overflowed queries (candidate list > cap): strict path
-        std::vector<int32_t> hov(bn), hst(4);
-        c->d2h(hov.data(), ovf, bn * sizeof(int32_t));
-        c->d2h(hst.data(), st, 16);
-        HIP_CHECK(hipStreamSynchronize(c->stream));
-        st_candidates += hst[0]; st_overflows += hst[1]; st_expansions += hst[2];
-        int nfast = bn;
-        for (int q = 0; q < bn; q++) if (hov[q]) {
-            nfast--;
-            search_strict(Qp + (size_t)q * ld, 1, p, elig, pos + (size_t)q * k_cap, out_scores + (size_t)q * k_cap, out_counts + q, k_cap);
-        }
-        st_fast_queries += nfast;
+        // overflow flags + statistics go to pinned host memory asynchronously; search_finish() acts on them
+        int32_t* hf = pend->flags + (size_t)pend->nfast_slices * kSliceInts;
+        c->d2h(hf, ovf, bn * sizeof(int32_t));
+        c->d2h(hf + 256, st, 16);
+        pend->nfast_slices++;
     }
 
-    // flatIndexSearch.searchSingleQuery flat_index_search.go:221-294 for B queries at once.
-    void search_dev(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
-                    int32_t* out_counts, int k_cap) override {
+    // flatIndexSearch.searchSingleQuery flat_index_search.go:221-294 for B queries at once (enqueue only).
+    void search_core(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
+                     int32_t* out_counts, int k_cap, Pending* pend) {
         float* Qp; int32_t* zflag;
         prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag);
-        st_candidates = st_overflows = st_expansions = st_fast_queries = st_strict_queries = 0;
         uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
         if (n == 0) {   // empty index: zero results (sanitizeK(k, 0) == 0)
             launch_select_topk(c, nullptr, 0, B, 0, nullptr, 0.0f, p.k, pos, out_scores, out_counts, k_cap);
@@ -237,16 +245,71 @@ struct FlatIndex : comet_index {
             elig = e;
         }
         if (p.mode == 2 && !fast_usable(B, p)) COMET_FAIL(COMET_ERR_UNSUPPORTED, "fast path unavailable for this index / k (values beyond fp16 range or k > 1024)");
-        if (fast_usable(B, p)) {
-            const int NB = flat_fast_batch();
+        const int NB = flat_fast_batch();
+        if (pend && fast_usable(B, p) && ceil_div(B, NB) <= kMaxSlices) {
             for (int b0 = 0; b0 < B; b0 += NB) {
                 const int bn = std::min(NB, B - b0);
-                search_fast(Qp + (size_t)b0 * ld, bn, p, elig, pos + (size_t)b0 * k_cap, out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);
+                search_fast(Qp + (size_t)b0 * ld, bn, p, elig, pos + (size_t)b0 * k_cap, out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap, pend);
             }
         } else {
             search_strict(Qp, B, p, elig, pos, out_scores, out_counts, k_cap);
         }
         launch_finalize(c, ids_dev.as<uint32_t>(), pos, B, k_cap, zflag, out_ids, out_counts);
+    }
+
+    uint64_t search_begin(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
+                          int32_t* out_counts, int k_cap) override {
+        // pick a free ring slot (retire the oldest if all are in use)
+        Pending* slot = nullptr;
+        for (auto& r : ring) if (!r.active) { slot = &r; break; }
+        if (!slot) {
+            Pending* oldest = &ring[0];
+            for (auto& r : ring) if (r.ticket < oldest->ticket) oldest = &r;
+            search_finish(oldest->ticket);
+            slot = oldest;
+        }
+        if (!slot->ev) HIP_CHECK(hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
+        if (!slot->flags) HIP_CHECK(hipHostMalloc((void**)&slot->flags, sizeof(int32_t) * kSliceInts * kMaxSlices, hipHostMallocDefault));
+        slot->ticket = next_ticket++; slot->B = B; slot->k_cap = k_cap; slot->nfast_slices = 0; slot->queries = queries_dev;
+        slot->p = p; slot->flt.clear();
+        if (p.filter_ids && p.n_filter > 0) { slot->flt.assign(p.filter_ids, p.filter_ids + p.n_filter); slot->p.filter_ids = slot->flt.data(); }
+        slot->out_ids = out_ids; slot->out_scores = out_scores; slot->out_counts = out_counts;
+        st_candidates = st_overflows = st_expansions = st_fast_queries = st_strict_queries = 0;
+        search_core(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap, slot);
+        HIP_CHECK(hipEventRecord(slot->ev, c->stream));
+        slot->active = true;
+        return slot->ticket;
+    }
+
+    void search_finish(uint64_t ticket) override {
+        Pending* slot = nullptr;
+        for (auto& r : ring) if (r.active && r.ticket == ticket) { slot = &r; break; }
+        if (!slot) return;     // already finished (or never deferred)
+        HIP_CHECK(hipEventSynchronize(slot->ev));
+        slot->active = false;
+        const int NB = flat_fast_batch();
+        std::vector<int> redo;
+        for (int sl = 0; sl < slot->nfast_slices; sl++) {
+            const int32_t* hf = slot->flags + (size_t)sl * kSliceInts;
+            const int bn = std::min(NB, slot->B - sl * NB);
+            st_candidates += hf[256]; st_overflows += hf[257]; st_expansions += hf[258];
+            int nfast = bn;
+            for (int q = 0; q < bn; q++) if (hf[q]) { redo.push_back(sl * NB + q); nfast--; }
+            st_fast_queries += nfast;
+        }
+        // overflowed queries (candidate list > cap: adversarial clustering / mass ties): strict kernels, one query at a time
+        comet_search_params sp = slot->p; sp.mode = 1;
+        for (int q : redo) {
+            ScratchMark sm(c);   // on top of whatever the arena holds (the host API keeps queries / outputs of this call there)
+            search_core(slot->queries + (size_t)q * dim, 1, sp, slot->out_ids + (size_t)q * slot->k_cap, slot->out_scores + (size_t)q * slot->k_cap,
+                        slot->out_counts + q, slot->k_cap, nullptr);
+        }
+        if (!redo.empty()) HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+
+    void search_dev(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
+                    int32_t* out_counts, int k_cap) override {
+        search_finish(search_begin(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap));
     }
 
     bool get_stat(const char* name, double* out) const override {

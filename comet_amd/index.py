@@ -419,6 +419,19 @@ class VectorIndex:
         check(self.lib.comet_index_search_dev(self.h, C.c_void_p(q_dev), int(B), C.byref(p), C.c_void_p(out_ids_dev),
                                               C.c_void_p(out_scores_dev), C.c_void_p(out_counts_dev), int(k_cap)))
 
+    def search_batch_dev_async(self, q_dev: int, B: int, k: int, out_ids_dev: int, out_scores_dev: int, out_counts_dev: int,
+                               k_cap: int, threshold: float = 0.0, nprobes: int = 0, ef_search: int = 0, mode: int = 0) -> int:
+        """Enqueue only; returns a ticket for search_wait(). Buffers must stay untouched until the wait returns."""
+        p = SearchParams(k=int(k), threshold=float(threshold), nprobes=int(nprobes), ef_search=int(ef_search),
+                         filter_ids=None, n_filter=0, mode=int(mode))
+        t = C.c_uint64()
+        check(self.lib.comet_index_search_dev_async(self.h, C.c_void_p(q_dev), int(B), C.byref(p), C.c_void_p(out_ids_dev),
+                                                    C.c_void_p(out_scores_dev), C.c_void_p(out_counts_dev), int(k_cap), C.byref(t)))
+        return t.value
+
+    def search_wait(self, ticket: int) -> None:
+        check(self.lib.comet_index_search_wait(self.h, C.c_uint64(int(ticket))))
+
     # -- helpers --
     def _k_cap(self, k: int, nprobes: int) -> int:
         n = len(self)

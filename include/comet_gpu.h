@@ -158,6 +158,16 @@ COMET_API int comet_index_search_dev(comet_index* idx, const float* queries_dev,
                                      const comet_search_params* p, uint32_t* out_ids_dev, float* out_scores_dev,
                                      int32_t* out_counts_dev, int32_t k_cap);
 
+/* Pipelined form: `_async` only ENQUEUES the search on the context's stream and returns a ticket;
+ * comet_index_search_wait(ticket) blocks until that search has finished on the device and makes its results final
+ * (the Flat fast path re-runs the rare queries whose candidate list overflowed on the exact kernels there).
+ * Queries and output buffers must stay untouched until the wait returns. Several searches may be in flight;
+ * they complete in order. comet_index_search_dev == async + wait. */
+COMET_API int comet_index_search_dev_async(comet_index* idx, const float* queries_dev, int32_t B, const comet_search_params* p,
+                                           uint32_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev, int32_t k_cap,
+                                           uint64_t* out_ticket);
+COMET_API int comet_index_search_wait(comet_index* idx, uint64_t ticket);
+
 /* ---- multi-GPU merge (the step after the RCCL all-gather of per-shard top-K; the reference's
  * analogue is mergeResults storage_merge.go:13-46) -------------------------------------------- */
 /* in: R shards x B queries x k_cap (ids, scores ascending), counts R x B. Ties: lower shard first. */

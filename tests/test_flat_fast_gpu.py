@@ -109,3 +109,27 @@ def test_auto_mode_picks_fast_for_big_batches(ctx):
     assert g.stat("fast_queries") == 0
     g.search_batch(synth(15, 64, d), 100)        # too few tiles per requested result: exact kernel
     assert g.stat("fast_queries") == 0
+
+
+def test_async_pipeline_equals_sync(ctx):
+    """comet_index_search_dev_async / comet_index_search_wait: several searches in flight on the stream give the same
+    rows as the synchronous call, including batches whose queries overflow to the strict path at wait time."""
+    n, d, B, k = 60000, 64, 128, 5
+    base = synth(31, 16, d)
+    X = np.concatenate([np.repeat(base[:4], 400, axis=0), synth(32, n - 1600, d)])       # 4 x 400 duplicates -> overflows
+    g = FlatIndex(ctx, d, L2_SQUARED)
+    g.add_batch(np.arange(1, n + 1, dtype=np.uint32), X)
+    batches = [np.concatenate([base[:4] + np.float32(1e-3), synth(40 + i, B - 4, d)]) for i in range(4)]
+    want = [g.search_batch(Qb, k, mode=1) for Qb in batches]
+    qd = [ctx.alloc(B * d * 4) for _ in batches]
+    outs = [(ctx.alloc(B * k * 4), ctx.alloc(B * k * 4), ctx.alloc(B * 4)) for _ in batches]
+    for p, Qb in zip(qd, batches):
+        ctx.upload(p, Qb)
+    tickets = [g.search_batch_dev_async(qd[i], B, k, outs[i][0], outs[i][1], outs[i][2], k, mode=2) for i in range(4)]
+    for i in (0, 1, 2, 3):
+        g.search_wait(tickets[i])
+        got = (ctx.download(outs[i][0], (B, k), np.uint32), ctx.download(outs[i][1], (B, k), np.float32), ctx.download(outs[i][2], (B,), np.int32))
+        same(got, want[i])
+    g.search_wait(tickets[0])          # waiting twice is a no-op
+    for p in qd + [x for o in outs for x in o]:
+        ctx.free(p)
