@@ -329,12 +329,12 @@ void launch_dist_gather(Ctx* c, int metric, const float* X, int ld, const float*
 
 // ------------------------------------------------------------------------------------------------
 // exact re-scoring of a FEW candidates per query (the fast path's step 3): latency- not throughput-bound,
-// so the mapping is different from the scan kernels. A wave takes 4 candidates: all 64 lanes fetch each
+// so the mapping is different from the scan kernels. A wave takes 16 candidates: all 64 lanes fetch each
 // candidate row coalesced and compute the per-element terms (diff^2 or product: independent, exactly
-// rounded), park them in LDS, then lanes 0..3 each run one candidate's serial float32 sum in index order.
+// rounded), park them in LDS, then lanes 0..15 each run one candidate's serial float32 sum in index order.
 // ------------------------------------------------------------------------------------------------
-constexpr int RS_CPW = 4;        // candidates per wave
-constexpr int RS_CHUNK = 1024;   // max floats of a row staged per pass
+constexpr int RS_CPW = 16;       // candidates per wave (lanes 0..15 run the serial sums)
+constexpr int RS_CHUNK = 256;    // max floats of a row staged per pass
 template <int METRIC>
 __global__ __launch_bounds__(256) void rescore_exact_kernel(const float* __restrict__ X, int ld, const float* __restrict__ Q,
                                                             const unsigned* __restrict__ cand, long ldc, const int* __restrict__ cnts,
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void rescore_exact_kernel(const float* __restr
         unsigned rows[RS_CPW];
 #pragma unroll
         for (int j = 0; j < RS_CPW; j++) rows[j] = (c0 + j < cnt) ? cand[(long)q * ldc + c0 + j] : 0u;
-        float acc = 0.0f;   // lanes 0..3: running sum of candidate `lane`
+        float acc = 0.0f;   // lanes 0..RS_CPW-1: running sum of candidate `lane`
         for (int k0 = 0; k0 < ld; k0 += chunk) {
             const int kn = min(chunk, ld - k0);   // multiple of 32
 #pragma unroll
@@ -388,7 +388,7 @@ void launch_rescore_exact(Ctx* c, int metric, const float* X, int ld, const floa
     ProfScope ps(c, "rescore_exact");
     const int chunk = std::min(ld, RS_CHUNK);
     const size_t lds = (size_t)4 * RS_CPW * chunk * sizeof(float);
-    const int groups = (int)std::min<int64_t>(ceil_div(Cmax, 4 * RS_CPW), 16);   // 256 candidates per sweep; longer lists loop
+    const int groups = (int)std::min<int64_t>(ceil_div(Cmax, 4 * RS_CPW), 4);    // 256 candidates per sweep; longer lists loop
     dim3 grid(groups, B), blk(256);
 #define RS(M) do { if (lds > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)rescore_exact_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                    rescore_exact_kernel<M><<<grid, blk, lds, c->stream>>>(X, ld, Q, cand, ldc, cnts, D, ldD, chunk); } while (0)

@@ -1,0 +1,77 @@
+"""CPU-side tests of the host mirror's own logic (no GPU, no HIP calls): the pieces that stay above the C ABI in the
+reference too — sanitizeK / LimitResults / Autocut (limiter.go), multi-query aggregation (aggregation.go), argument
+validation of the fluent builders — checked against the reference's known-answer tests and against the oracle."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from comet_amd.index import (MAX_AGGREGATION, MEAN_AGGREGATION, SUM_AGGREGATION, TextResult, VectorResult, aggregate,
+                             aggregate_text, autocut, default_nprobes, sanitize_k, _metric_code, UnknownDistanceKind, _validate_pq)
+
+KATS = json.loads((Path(__file__).parent / "golden" / "reference_kats.json").read_text())
+
+
+def test_sanitize_k_matches_reference_and_oracle():
+    # flat_index_search_test.go:348-389: k = 0 / -1 / 3 / 5 / 100 / 1 over 5 results
+    for c in KATS["flat_search_k_bounds"]["cases"]:
+        assert sanitize_k(c["k"], 5) == c["len"] == orc.lib().orc_sanitize_k(c["k"], 5)
+
+
+def test_autocut_kats_and_oracle():
+    for c in KATS["autocut"]["cases"]:
+        assert autocut(c["scores"], c["cutoff"]) == c["expected"], c
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        y = np.sort(rng.random(int(rng.integers(2, 30)))).astype(np.float32)
+        cut = int(rng.integers(1, 4))
+        assert autocut(y, cut) == orc.autocut(y, cut)
+
+
+def test_vector_aggregation_kats():
+    b = KATS["sum_aggregation"]
+    res = [VectorResult(i, np.float32(s)) for i, s in zip(b["ids"], b["scores"])]
+    agg = aggregate(res, SUM_AGGREGATION)
+    assert len(agg) == b["unique"]
+    assert {r.id: r.score for r in agg}[1] == np.float32(b["node1_expected"])          # the reference compares with ==
+    assert all(agg[i].score <= agg[i + 1].score for i in range(len(agg) - 1))
+    # max / mean (aggregation_test.go:54-115)
+    res = [VectorResult(1, np.float32(0.1)), VectorResult(2, np.float32(0.2)), VectorResult(1, np.float32(0.3))]
+    assert {r.id: r.score for r in aggregate(res, MAX_AGGREGATION)} == {1: np.float32(0.3), 2: np.float32(0.2)}
+    assert {r.id: r.score for r in aggregate(res, MEAN_AGGREGATION)}[1] == np.float32((np.float32(0.1) + np.float32(0.3)) / np.float32(2))
+    with pytest.raises(ValueError):
+        aggregate(res, "median")
+    assert aggregate([], SUM_AGGREGATION) == []
+
+
+def test_aggregation_matches_oracle_on_random_lists():
+    import ctypes as C
+    rng = np.random.default_rng(1)
+    for kind_i, kind in enumerate((SUM_AGGREGATION, MAX_AGGREGATION, MEAN_AGGREGATION)):
+        ids = rng.integers(1, 20, 60).astype(np.uint32)
+        sc = rng.random(60).astype(np.float32)
+        got = aggregate([VectorResult(int(i), s) for i, s in zip(ids, sc)], kind)
+        oi, os_ = np.zeros(60, np.uint32), np.zeros(60, np.float32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        n = orc.lib().orc_aggregate(kind_i, p(ids), p(sc), 60, p(oi), p(os_))
+        assert [r.id for r in got] == oi[:n].tolist()
+        assert np.array_equal(np.array([r.score for r in got], np.float32).view(np.uint32), os_[:n].view(np.uint32))
+
+
+def test_text_aggregation_is_descending():
+    res = [TextResult(1, np.float32(2.0)), TextResult(2, np.float32(3.0)), TextResult(1, np.float32(0.5))]
+    agg = aggregate_text(res, SUM_AGGREGATION)          # bm25_index_search_test.go:449-563: 2.5 / 3.0
+    assert [(r.id, float(r.score)) for r in agg] == [(2, 3.0), (1, 2.5)]
+    assert [(r.id, float(r.score)) for r in aggregate_text(res, MAX_AGGREGATION)] == [(2, 3.0), (1, 2.0)]
+
+
+def test_constructor_validation_and_defaults():
+    assert default_nprobes(4096) == 64 and default_nprobes(10) == 3            # int(sqrt(nlist)) ivf_index.go:406-413
+    with pytest.raises(UnknownDistanceKind):
+        _metric_code("manhattan")                                               # ErrUnknownDistanceKind distance.go:9
+    for bad in ((0, 4, 8), (8, 0, 8), (10, 4, 8), (8, 4, 0), (8, 4, 17)):
+        with pytest.raises(ValueError):
+            _validate_pq(*bad)                                                  # pq_index.go:135-155
+    _validate_pq(8, 4, 16)
