@@ -81,7 +81,7 @@ void launch_finalize_probe(Ctx* c, const uint32_t* pos, int B, int k_cap, const 
 size_t adc_lds_bytes(int M, int Ksub, int dim);
 void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* centroids, const float* codebooks, int M, int Ksub, int dsub,
                      const uint32_t* codes, int M4, const int64_t* list_base, const int32_t* list_len, const uint32_t* probe_list, int ldp,
-                     int np, const int32_t* seg_off, const uint8_t* elig, int B, int max_list_len, float* D, int64_t ldD);
+                     int np, const int32_t* seg_off, const uint8_t* elig, int B, int nlist, int max_list_len, float* D, int64_t ldD);
 
 // ---- kernels_fast.hip (MFMA fast path of the Flat scan) ------------------------------------------
 int flat_fast_tile_rows();

@@ -320,200 +320,329 @@ void launch_finalize_probe(Ctx* c, const uint32_t* pos, int B, int k_cap, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// fused PQ lookup-table build + asymmetric-distance scan (pq_index_search.go:243-306,
-// ivfpq_index_search.go:285-321,350-390).
+// PQ asymmetric-distance search (pq_index_search.go:243-306, ivfpq_index_search.go:285-321,350-390), three kernels:
 //
-// One workgroup = one (query, probed list, segment of that list). It
-//   1. forms the query residual r = q - centroid[list] in LDS (IVFPQ; r = q for plain PQ),
-//   2. builds the M x KL table LUT[m][k] = sum_i (r[m*dsub+i] - cb[m][k][i])^2 in LDS (KL = min(Ksub,256):
-//      codes are uint8, so entries >= 256 can never be addressed), exact float32, dimension order,
-//   3. streams the list's codes — stored as 64-code blocks, word-interleaved so that a wave reads
-//      256 contiguous bytes per load — and for each code sums LUT[m][code[m]] in m order (the
-//      reference's serial float32 sum), takes the correctly-rounded sqrt and writes the distance.
-// LDS holds the table (96 KiB at M=96, Ksub=256: fits because gfx950 has 160 KiB per CU).
+//  pq_lut_kernel      builds, for every (query, probed list) PAIR, the M x KL table
+//                       LUT[m][k] = sum_i ((q[m*dsub+i] - centroid[m*dsub+i]) - cb[m][k][i])^2
+//                     (KL = min(Ksub,256): codes are uint8, entries >= 256 can never be addressed) in exact float32,
+//                     dimension order, and stores it to HBM. A thread keeps ONE codeword in registers and walks the
+//                     pairs, so the codebook is read once per 32 pairs instead of once per pair (a fused build re-reads
+//                     all 786 KiB of codebooks per pair and is L2-bandwidth bound: 15 us per pair on the whole chip).
+//  order_pairs_kernel sorts the pairs of a sub-batch by probed list: workgroups scanning the same inverted list then run
+//                     at the same time and the list's codes come from L2 / Infinity Cache for all but the first.
+//  adc_scan_kernel    persistent 1024-thread workgroups pull (pair, segment) items from eight XCD-affine queues
+//                     (adjacent sorted pairs share an XCD and therefore an L2), DMA the pair's table into LDS (96 KiB at
+//                     M=96, Ksub=256: fits because gfx950 has 160 KiB per CU), and stream the list's codes — stored as
+//                     64-code blocks, word-interleaved so that a wave reads 256 contiguous bytes per load. A lane owns
+//                     one code of up to four blocks (four independent serial float32 chains), sums LUT[m][code[m]] in m
+//                     order (the reference's serial sum), takes the correctly-rounded sqrt and writes the distance.
 // ------------------------------------------------------------------------------------------------
 constexpr int ADC_THREADS = 1024;
+constexpr int ADC_WAVES = ADC_THREADS / 64;
+constexpr int ADC_CHAINS = 4;
+constexpr int ADC_SEG_CODES = ADC_WAVES * ADC_CHAINS * 64;     // codes one workgroup takes per item
+constexpr int ADC_XCD_CHUNK = 4;                               // adjacent sorted pairs kept on one XCD
+constexpr int LUT_PAIRS_PER_WG = 32;
+constexpr int ORDER_MAX_LISTS = 36 * 1024;                     // counting-sort bins that fit in LDS
 typedef float f32x4q __attribute__((ext_vector_type(4)));
 
 template <bool HAS_CENTROID, int DSUB>
-__global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const float* __restrict__ Qp, int ld, int dim,
-                                                               const float* __restrict__ centroids, const float* __restrict__ codebooks,
-                                                               int M, int Ksub, int KL, int dsub, const unsigned* __restrict__ codes, int M4,
+__global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ Qp, int ld, const float* __restrict__ centroids,
+                                                     const float* __restrict__ codebooks, int M, int Ksub, int KL, int kl_shift, int dsub,
+                                                     const unsigned* __restrict__ probe_list, int ldp, int np,
+                                                     const int* __restrict__ seg_off, int n_pairs, int ppw, float* __restrict__ lut) {
+    // workgroup = (256 >> kl_shift) consecutive subspaces x KL codewords, `ppw` consecutive pairs.
+    extern __shared__ __attribute__((aligned(16))) float rs[];  // [ppw][mw * d] residual slices, then [ppw] live flags (as int)
+    const int d = DSUB > 0 ? DSUB : dsub;
+    const int mw = 256 >> kl_shift;                             // subspaces per workgroup
+    const int m_base = blockIdx.x * mw;
+    const int wcols = min(mw, M - m_base) * d;                  // residual columns this workgroup needs
+    const int p0 = blockIdx.y * ppw, pn = min(n_pairs, p0 + ppw) - p0;
+    int* live = reinterpret_cast<int*>(rs + (long)ppw * mw * d);
+    // phase 1: every (pair, column) residual is formed once, all loads of the workgroup in flight together
+    for (int e = threadIdx.x; e < pn * wcols; e += 256) {
+        const int pl = e / wcols, col = e - pl * wcols;
+        const int pr = p0 + pl, q = pr / np, pi = pr - q * np;
+        const int* so = seg_off + (long)q * (np + 1) + pi;
+        const bool lv = so[1] != so[0];                         // empty list / unused probe slot: table never read
+        float r = 0.0f;
+        if (lv) {
+            const float qv = Qp[(long)q * ld + m_base * d + col];
+            if constexpr (HAS_CENTROID) r = qv - centroids[(long)probe_list[(long)q * ldp + pi] * ld + m_base * d + col];   // queryResidual[d] = q[d] - centroid[d]
+            else r = qv;
+        }
+        rs[(long)pl * mw * d + col] = r;
+        if (col == 0) live[pl] = lv ? 1 : 0;
+    }
+    const int k = threadIdx.x & (KL - 1), mm = threadIdx.x >> kl_shift, m = m_base + mm;
+    float cb[DSUB > 0 ? DSUB : 1];
+    const float* __restrict__ cbp = codebooks + ((long)min(m, M - 1) * Ksub + k) * d;
+    if constexpr (DSUB > 0) {
+        if constexpr (DSUB % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < DSUB; i += 4) { const f32x4q v = *reinterpret_cast<const f32x4q*>(cbp + i); cb[i] = v[0]; cb[i + 1] = v[1]; cb[i + 2] = v[2]; cb[i + 3] = v[3]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < DSUB; i++) cb[i] = cbp[i];
+        }
+    }
+    __syncthreads();
+    if (m >= M) return;
+    // phase 2: a thread keeps ONE codeword in registers and walks the pairs (LDS broadcast reads of the residual slice)
+    float* __restrict__ out = lut + ((long)p0 * M + m) * KL + k;
+    for (int pl = 0; pl < pn; pl++) {
+        if (!live[pl]) continue;
+        const float* r = rs + (long)pl * mw * d + mm * d;
+        float dsum = 0.0f;
+        if constexpr (DSUB > 0) {
+#pragma unroll
+            for (int i = 0; i < DSUB; i++) { const float diff = r[i] - cb[i]; const float sq = diff * diff; dsum = dsum + sq; }
+        } else {
+            for (int i = 0; i < d; i++) { const float diff = r[i] - cbp[i]; const float sq = diff * diff; dsum = dsum + sq; }
+        }
+        out[(long)pl * M * KL] = dsum;
+    }
+}
+
+// order[] = the pair indices grouped by probed list (counting sort in LDS; pairs with nothing to scan go last; the
+// order inside a list is whatever the atomics give — results do not depend on it). One workgroup, nlist + 1 bins in LDS.
+__global__ __launch_bounds__(1024) void order_pairs_kernel(const unsigned* __restrict__ probe_list, int ldp, int np, const int* __restrict__ seg_off,
+                                                           int n_pairs, int nlist, unsigned* __restrict__ order) {
+    extern __shared__ __attribute__((aligned(16))) int obin[];   // nlist + 1 counters
+    __shared__ int part[1024];
+    const int nb = nlist + 1, t = threadIdx.x;
+    for (int i = t; i < nb; i += 1024) obin[i] = 0;
+    __syncthreads();
+    auto key_of = [&](int i) {
+        const int q = i / np, pi = i - q * np;
+        const int* so = seg_off + (long)q * (np + 1) + pi;
+        return (so[1] == so[0]) ? nlist : (int)min(probe_list[(long)q * ldp + pi], (unsigned)(nlist - 1));
+    };
+    for (int i = t; i < n_pairs; i += 1024) atomicAdd(&obin[key_of(i)], 1);
+    __syncthreads();
+    const int per = (nb + 1023) / 1024, lo = t * per, hi = min(nb, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; i++) s += obin[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;                                      // exclusive prefix of this thread's bins
+    for (int i = lo; i < hi; i++) { const int cnt = obin[i]; obin[i] = run; run += cnt; }
+    __syncthreads();
+    for (int i = t; i < n_pairs; i += 1024) order[atomicAdd(&obin[key_of(i)], 1)] = (unsigned)i;
+}
+__global__ __launch_bounds__(256) void iota_kernel(unsigned* __restrict__ p, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (unsigned)i;
+}
+
+// one wave, C blocks (wid, wid+16, ...) of the segment: C serial float32 chains per lane
+template <int C>
+__device__ __forceinline__ void adc_chains(const float* __restrict__ lut, int M, int M4, int KL, const unsigned* __restrict__ cw, long blk_stride16,
+                                           float (&acc)[ADC_CHAINS]) {
+    constexpr int G = 4;
+    unsigned cur[C][G], nxt[C][G];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        acc[c] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < G; i++) cur[c][i] = cw[c * blk_stride16 + (long)min(i, M4 - 1) * 64];
+    }
+    for (int w0 = 0; w0 < M4; w0 += G) {
+#pragma unroll
+        for (int c = 0; c < C; c++)
+#pragma unroll
+            for (int i = 0; i < G; i++) nxt[c][i] = cw[c * blk_stride16 + (long)min(w0 + G + i, M4 - 1) * 64];   // clamped re-read past the end
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            const int m = (w0 + i) * 4;
+            if (m + 3 < M) {            // wave-uniform
+                const float* l0 = lut + (long)m * KL;
+                float v[C][4];
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const unsigned w = cur[c][i];
+                    v[c][0] = l0[w & 255u]; v[c][1] = l0[KL + ((w >> 8) & 255u)]; v[c][2] = l0[2 * KL + ((w >> 16) & 255u)]; v[c][3] = l0[3 * KL + (w >> 24)];
+                }
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+#pragma unroll
+                    for (int c = 0; c < C; c++) acc[c] = acc[c] + v[c][b];
+            } else if (m < M) {         // last, partial word (M not a multiple of 4)
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const unsigned w = cur[c][i];
+                    for (int bb = 0; m + bb < M; bb++) acc[c] = acc[c] + lut[(m + bb) * KL + ((w >> (8 * bb)) & 255u)];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++)
+#pragma unroll
+            for (int i = 0; i < G; i++) cur[c][i] = nxt[c][i];
+    }
+}
+
+__global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const float* __restrict__ lutg, int M, int KL, const unsigned* __restrict__ codes, int M4,
                                                                const long* __restrict__ list_base, const int* __restrict__ list_len,
                                                                const unsigned* __restrict__ probe_list, int ldp, int np,
                                                                const int* __restrict__ seg_off, const unsigned char* __restrict__ elig,
-                                                               float* __restrict__ D, long ldD, int segs_per_list, int seg_codes, int n_queries) {
+                                                               const unsigned* __restrict__ order, int n_pairs, int segs_per_list,
+                                                               int* __restrict__ queues, float* __restrict__ D, long ldD) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* lut = lds;               // M * KL
-    float* res = lds + (long)M * KL;  // dim
-    // persistent workgroups: the 96 KiB table allows one workgroup per CU, so re-launching one per work item
-    // would expose the dispatch gap ~30 times per CU; instead each resident workgroup walks the item list
-    // (query, probe, segment) with a grid stride.
-    const int items_per_q = np * segs_per_list;
-    const long n_items = (long)n_queries * items_per_q;
-  for (long item = blockIdx.x; item < n_items; item += gridDim.x) {
-    __syncthreads();                 // previous item's table no longer in use
-    const int q = (int)(item / items_per_q);
-    const int rem = (int)(item - (long)q * items_per_q);
-    const int p = rem / segs_per_list;
-    const int s = rem - p * segs_per_list;
-    const int so = seg_off[(long)q * (np + 1) + p];
-    if (seg_off[(long)q * (np + 1) + p + 1] == so) continue;   // empty list or probe slot not used by this query
-    const unsigned L = probe_list[(long)q * ldp + p];
-    const int len = list_len[L];
-    const int start = s * seg_codes;
-    if (start >= len) continue;
-    const int end = min(len, start + seg_codes);
-
-    const float* __restrict__ qv = Qp + (long)q * ld;
-    for (int i = threadIdx.x; i < dim; i += ADC_THREADS) {
-        if constexpr (HAS_CENTROID) res[i] = qv[i] - centroids[(long)L * ld + i];   // queryResidual[d] = q[d] - centroid[d]
-        else res[i] = qv[i];
-    }
-    __syncthreads();
+    float* lut = lds;                               // M * KL
+    __shared__ int s_ticket[2];                     // [0] queue, [1] ticket of the NEXT item (-1: all queues drained)
     const int n_ent = M * KL;
-    if constexpr (DSUB > 0) {
-        // table build, specialised on the subspace width. The codebook is L2-resident and re-read by every workgroup
-        // (786 KiB per (query, list) at M=96), so the loop is software-pipelined: the codebook rows of the NEXT group
-        // of U entries are already in flight (16-byte loads) while the current group is reduced. The per-entry
-        // float32 sum keeps the reference's dimension order (ivfpq_index_search.go:365-371).
-        constexpr int U = (DSUB <= 4) ? 8 : (DSUB <= 8 ? 4 : 2);
-        // entry e = m * KL + k with KL a power of two dividing the workgroup size: a thread keeps one codeword index k
-        // and walks the subspaces m = m0, m0 + mstep, ... with constant pointer strides (no per-entry address math)
-        const int kl_shift = 31 - __builtin_clz((unsigned)KL);
-        const int k = threadIdx.x & (KL - 1), m0 = threadIdx.x >> kl_shift, mstep = ADC_THREADS >> kl_shift;
-        const float* __restrict__ cbp = codebooks + ((long)m0 * Ksub + k) * DSUB;
-        const long cstride = (long)mstep * Ksub * DSUB;
-        const int n_j = (M - m0 + mstep - 1) / mstep;       // entries owned by this thread (m0 < M iff n_j > 0)
-        float cur[U][DSUB], nxt[U][DSUB];
-        auto fetch = [&](float (&dst)[U][DSUB], int j0) {
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                int j = j0 + u; if (j > n_j - 1) j = n_j - 1; if (j < 0) j = 0;      // clamped re-read, never stored
-                const float* __restrict__ cb = cbp + (long)j * cstride;
-                if constexpr (DSUB % 4 == 0) {
-#pragma unroll
-                    for (int i = 0; i < DSUB; i += 4) { const f32x4q v = *reinterpret_cast<const f32x4q*>(cb + i); dst[u][i] = v[0]; dst[u][i + 1] = v[1]; dst[u][i + 2] = v[2]; dst[u][i + 3] = v[3]; }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < DSUB; i++) dst[u][i] = cb[i];
-                }
-            }
-        };
-        if (m0 < M) {
-            fetch(cur, 0);
-            for (int j0 = 0; j0 < n_j; j0 += U) {
-                fetch(nxt, j0 + U);
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int j = j0 + u;
-                    if (j < n_j) {
-                        const int m = m0 + j * mstep;
-                        const float* r = res + m * DSUB;
-                        float dsum = 0.0f;
-#pragma unroll
-                        for (int i = 0; i < DSUB; i++) { float diff = r[i] - cur[u][i]; float sq = diff * diff; dsum = dsum + sq; }
-                        lut[m * KL + k] = dsum;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++)
-#pragma unroll
-                    for (int i = 0; i < DSUB; i++) cur[u][i] = nxt[u][i];
-            }
-        }
-    } else {
-        for (int e = threadIdx.x; e < n_ent; e += ADC_THREADS) {
-            const int m = e / KL, k = e - m * KL;
-            const float* __restrict__ cb = codebooks + ((long)m * Ksub + k) * dsub;
-            const float* r = res + m * dsub;
-            float dist = 0.0f;
-            for (int i = 0; i < dsub; i++) { float diff = r[i] - cb[i]; float sq = diff * diff; dist = dist + sq; }
-            lut[e] = dist;
-        }
-    }
-    __syncthreads();
-
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const long base_slot = list_base[L];            // multiple of 64
-    // scan: a lane owns one code of each of TWO 64-code blocks (two independent serial float32 chains in flight);
-    // the M4 code words are fetched eight at a time, the next group requested before the current one is consumed,
-    // and the 32 table lookups of a group are issued as straight-line code so the LDS reads overlap the add chain.
-    constexpr int G = 4;
-    const int nblk_end = (end + 63) >> 6;
-    for (int blk = (start >> 6) + 2 * wid; blk < nblk_end; blk += 2 * (ADC_THREADS / 64)) {
-        const bool has1 = (blk + 1) < nblk_end;
-        const unsigned* __restrict__ cw0 = codes + ((base_slot >> 6) + blk) * (long)M4 * 64 + lane;
-        const unsigned* __restrict__ cw1 = has1 ? cw0 + (long)M4 * 64 : cw0;
-        float acc0 = 0.0f, acc1 = 0.0f;
-        unsigned cur0[G], cur1[G], nxt0[G], nxt1[G];
-#pragma unroll
-        for (int i = 0; i < G; i++) { cur0[i] = (i < M4) ? cw0[(long)i * 64] : 0u; cur1[i] = (i < M4) ? cw1[(long)i * 64] : 0u; }
-        for (int w0 = 0; w0 < M4; w0 += G) {
-#pragma unroll
-            for (int i = 0; i < G; i++) {
-                const bool in = (w0 + G + i) < M4;
-                nxt0[i] = in ? cw0[(long)(w0 + G + i) * 64] : 0u;
-                nxt1[i] = in ? cw1[(long)(w0 + G + i) * 64] : 0u;
-            }
-#pragma unroll
-            for (int i = 0; i < G; i++) {
-                const int m = (w0 + i) * 4;
-                if (m + 3 < M) {            // wave-uniform
-                    const unsigned wa = cur0[i], wb = cur1[i];
-                    const float* l0 = lut + (long)m * KL;
-                    const float a0 = l0[wa & 255u], a1 = l0[KL + ((wa >> 8) & 255u)], a2 = l0[2 * KL + ((wa >> 16) & 255u)], a3 = l0[3 * KL + (wa >> 24)];
-                    const float b0 = l0[wb & 255u], b1 = l0[KL + ((wb >> 8) & 255u)], b2 = l0[2 * KL + ((wb >> 16) & 255u)], b3 = l0[3 * KL + (wb >> 24)];
-                    acc0 = acc0 + a0; acc1 = acc1 + b0;
-                    acc0 = acc0 + a1; acc1 = acc1 + b1;
-                    acc0 = acc0 + a2; acc1 = acc1 + b2;
-                    acc0 = acc0 + a3; acc1 = acc1 + b3;
-                } else if (m < M) {         // last, partial word (M not a multiple of 4)
-                    const unsigned wa = cur0[i], wb = cur1[i];
-                    for (int bb = 0; m + bb < M; bb++) {
-                        acc0 = acc0 + lut[(m + bb) * KL + ((wa >> (8 * bb)) & 255u)];
-                        acc1 = acc1 + lut[(m + bb) * KL + ((wb >> (8 * bb)) & 255u)];
-                    }
+    // Eight queues, one per XCD (workgroup b runs on XCD b % 8). Queue x holds the chunks c = x (mod 8) of ADC_XCD_CHUNK
+    // adjacent sorted pairs, each pair with its segments; a drained workgroup steals from the next queue.
+    const int n_chunks = (n_pairs + ADC_XCD_CHUNK - 1) / ADC_XCD_CHUNK;
+    auto queue_items = [&](int x) { return ((n_chunks - x + 7) >> 3) * ADC_XCD_CHUNK * segs_per_list; };
+    auto take = [&](int& xq, int& tried) -> int {   // thread 0 only
+        while (tried < 8) {
+            const int t = atomicAdd(&queues[xq], 1);
+            if (t < queue_items(xq)) return t;
+            xq = (xq + 1) & 7; tried++;
+        }
+        return -1;
+    };
+    int my_q = blockIdx.x & 7, tried = 0;
+    if (threadIdx.x == 0) { const int t = take(my_q, tried); s_ticket[0] = my_q; s_ticket[1] = t; }
+    __syncthreads();
+    while (true) {
+        const int xq = s_ticket[0], ticket = s_ticket[1];
+        if (ticket < 0) break;
+        __syncthreads();                            // everyone has read the ticket; previous table no longer in use
+        const int lsp = ticket / segs_per_list, s = ticket - lsp * segs_per_list;
+        const int sp = ((lsp / ADC_XCD_CHUNK) * 8 + xq) * ADC_XCD_CHUNK + (lsp % ADC_XCD_CHUNK);
+        bool live = sp < n_pairs;
+        int pair = 0, q = 0, so = 0, len = 0, start = 0;
+        unsigned L = 0;
+        if (live) {
+            pair = (int)order[sp];
+            q = pair / np; const int p = pair - q * np;
+            so = seg_off[(long)q * (np + 1) + p];
+            start = s * ADC_SEG_CODES;
+            if (seg_off[(long)q * (np + 1) + p + 1] == so) live = false;
+            else { L = probe_list[(long)q * ldp + p]; len = list_len[L]; live = start < len; }
+        }
+        if (live) {                                 // workgroup-uniform
+            const float* __restrict__ src = lutg + (long)pair * n_ent;
+            if ((n_ent & 3) == 0) {
+                // LDS-DMA: each wave moves 1 KiB per instruction, lane-linear destination
+                for (int e = wid * 256; e < n_ent; e += ADC_THREADS * 4) {
+                    if (e + lane * 4 < n_ent)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + e + lane * 4),
+                                                         (__attribute__((address_space(3))) void*)(lut + e), 16, 0, 0);
                 }
+            } else {
+                for (int e = threadIdx.x; e < n_ent; e += ADC_THREADS) lut[e] = src[e];
             }
+        }
+        if (threadIdx.x == 0) { const int t = take(my_q, tried); s_ticket[0] = my_q; s_ticket[1] = t; }   // overlaps the table load
+        __syncthreads();                            // table in LDS (the compiler drains vmcnt before the barrier), next ticket published
+        if (!live) continue;
+        const int end = min(len, start + ADC_SEG_CODES);
+        const int nblk = (end - start + 63) >> 6;   // blocks of this segment, 1..64
+        const int nact = wid < nblk ? (nblk - wid + ADC_WAVES - 1) / ADC_WAVES : 0;
+        const long base_slot = list_base[L];        // multiple of 64
+        const int blk0 = (start >> 6) + wid;
+        const unsigned* __restrict__ cw = codes + ((base_slot >> 6) + blk0) * (long)M4 * 64 + lane;
+        const long stride16 = (long)ADC_WAVES * M4 * 64;
+        float acc[ADC_CHAINS];
+        switch (nact) {
+            case 1: adc_chains<1>(lut, M, M4, KL, cw, stride16, acc); break;
+            case 2: adc_chains<2>(lut, M, M4, KL, cw, stride16, acc); break;
+            case 3: adc_chains<3>(lut, M, M4, KL, cw, stride16, acc); break;
+            case 4: adc_chains<4>(lut, M, M4, KL, cw, stride16, acc); break;
+            default: break;
+        }
 #pragma unroll
-            for (int i = 0; i < G; i++) { cur0[i] = nxt0[i]; cur1[i] = nxt1[i]; }
-        }
-        const int j0 = blk * 64 + lane, j1 = j0 + 64;
-        if (j0 >= start && j0 < end) {
-            const bool ok = elig ? (elig[base_slot + j0] != 0) : true;
-            D[(long)q * ldD + so + j0] = ok ? go_sqrt32q(acc0) : __uint_as_float(EXCLUDED_BITS);
-        }
-        if (has1 && j1 >= start && j1 < end) {
-            const bool ok = elig ? (elig[base_slot + j1] != 0) : true;
-            D[(long)q * ldD + so + j1] = ok ? go_sqrt32q(acc1) : __uint_as_float(EXCLUDED_BITS);
+        for (int c = 0; c < ADC_CHAINS; c++) {
+            const int j = (blk0 + c * ADC_WAVES) * 64 + lane;
+            if (c < nact && j < end) {
+                const bool ok = elig ? (elig[base_slot + j] != 0) : true;
+                D[(long)q * ldD + so + j] = ok ? go_sqrt32q(acc[c]) : __uint_as_float(EXCLUDED_BITS);
+            }
         }
     }
-  }   // item loop
 }
-size_t adc_lds_bytes(int M, int Ksub, int dim) { int KL = Ksub < 256 ? Ksub : 256; return ((size_t)M * KL + dim) * sizeof(float); }
+size_t adc_lds_bytes(int M, int Ksub, int dim) { (void)dim; int KL = Ksub < 256 ? Ksub : 256; return (size_t)M * KL * sizeof(float); }
+static size_t adc_lut_budget() {
+    static size_t b = [] { const char* e = getenv("COMET_ADC_LUT_MB"); long mb = e ? atol(e) : 1024; if (mb < 1) mb = 1; return (size_t)mb << 20; }();
+    return b;
+}
 void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* centroids, const float* codebooks, int M, int Ksub, int dsub,
                      const uint32_t* codes, int M4, const int64_t* list_base, const int32_t* list_len, const uint32_t* probe_list, int ldp,
-                     int np, const int32_t* seg_off, const uint8_t* elig, int B, int max_list_len, float* D, int64_t ldD) {
+                     int np, const int32_t* seg_off, const uint8_t* elig, int B, int nlist, int max_list_len, float* D, int64_t ldD) {
     if (B <= 0 || np <= 0 || max_list_len <= 0) return;
     const int KL = Ksub < 256 ? Ksub : 256;
+    const int kl_shift = 31 - __builtin_clz((unsigned)KL);
     const size_t lds = adc_lds_bytes(M, Ksub, dim);
-    if (lds > 160 * 1024) COMET_FAIL(COMET_ERR_UNSUPPORTED, "PQ lookup table (%zu bytes) exceeds the 160 KiB LDS of a gfx950 CU", lds);
-    const int seg_codes = 8192;
-    const int segs = (int)ceil_div(max_list_len, seg_codes);
-    const long n_items = (long)B * np * segs;
-    dim3 grid((unsigned)std::min<long>(n_items, (long)c->prop.multiProcessorCount)), blk(ADC_THREADS);
-    ProfScope ps(c, "adc_scan");
-#define ADC_LAUNCH(HC, DS) do { \
-        HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan_kernel<HC, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        adc_scan_kernel<HC, DS><<<grid, blk, lds, c->stream>>>(Qp, ld, dim, centroids, codebooks, M, Ksub, KL, dsub, codes, M4, (const long*)list_base, \
-                                                              list_len, probe_list, ldp, np, seg_off, elig, D, ldD, segs, seg_codes, B); } while (0)
-#define ADC_DS(HC) do { switch (dsub) { case 2: ADC_LAUNCH(HC, 2); break; case 4: ADC_LAUNCH(HC, 4); break; case 8: ADC_LAUNCH(HC, 8); break; \
-                                       case 16: ADC_LAUNCH(HC, 16); break; default: ADC_LAUNCH(HC, 0); break; } } while (0)
-    if (centroids) ADC_DS(true); else ADC_DS(false);
-#undef ADC_DS
-#undef ADC_LAUNCH
-    LAUNCH_CHECK();
+    if (lds > 158 * 1024) COMET_FAIL(COMET_ERR_UNSUPPORTED, "PQ lookup table (%zu bytes) exceeds the 160 KiB LDS of a gfx950 CU", lds);
+    const size_t lut_pair = (size_t)M * KL * sizeof(float);
+    // queries per sub-batch: tables of a sub-batch live in HBM between the two kernels
+    int64_t qc = std::max<int64_t>(1, (int64_t)(adc_lut_budget() / (lut_pair * (size_t)np)));
+    qc = std::min<int64_t>(qc, B);
+    ScratchMark mark(c);
+    float* lut = c->salloc<float>((size_t)qc * np * M * KL);
+    uint32_t* order = c->salloc<uint32_t>((size_t)qc * np);
+    int32_t* queues = c->salloc<int32_t>(8);
+    const int segs = (int)ceil_div(max_list_len, ADC_SEG_CODES);
+    const int mw = 256 >> kl_shift;
+    int ppw = LUT_PAIRS_PER_WG;
+    while (ppw > 1 && (size_t)ppw * mw * dsub * 4 > 48 * 1024) ppw >>= 1;
+    const size_t lut_lds = (size_t)ppw * mw * dsub * 4 + (size_t)ppw * 4;
+    if (lut_lds > 150 * 1024) COMET_FAIL(COMET_ERR_UNSUPPORTED, "PQ subspace slice too wide for the table-build kernel (%zu bytes of LDS)", lut_lds);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void*)order_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (ORDER_MAX_LISTS + 1) * 4));
+        attr_done = true;
+    }
+    for (int b0 = 0; b0 < B; b0 += (int)qc) {
+        const int bn = std::min<int>((int)qc, B - b0);
+        const int n_pairs = bn * np;
+        const float* Qb = Qp + (size_t)b0 * ld;
+        const uint32_t* pl = probe_list + (size_t)b0 * ldp;
+        const int32_t* so = seg_off + (size_t)b0 * (np + 1);
+        {
+            ProfScope ps(c, "pq_lut");
+            dim3 grid((unsigned)ceil_div(M, mw), (unsigned)ceil_div(n_pairs, ppw)), blk(256);
+#define LUT_LAUNCH(HC, DS) do { if (lut_lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)pq_lut_kernel<HC, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lut_lds)); \
+        pq_lut_kernel<HC, DS><<<grid, blk, lut_lds, c->stream>>>(Qb, ld, centroids, codebooks, M, Ksub, KL, kl_shift, dsub, pl, ldp, np, so, n_pairs, ppw, lut); } while (0)
+#define LUT_DS(HC) do { switch (dsub) { case 2: LUT_LAUNCH(HC, 2); break; case 4: LUT_LAUNCH(HC, 4); break; case 8: LUT_LAUNCH(HC, 8); break; \
+                                       case 16: LUT_LAUNCH(HC, 16); break; default: LUT_LAUNCH(HC, 0); break; } } while (0)
+            if (centroids) LUT_DS(true); else LUT_DS(false);
+#undef LUT_DS
+#undef LUT_LAUNCH
+            LAUNCH_CHECK();
+        }
+        {
+            ProfScope ps(c, "adc_order");
+            if (nlist <= ORDER_MAX_LISTS && n_pairs > 1) {
+                order_pairs_kernel<<<dim3(1), dim3(1024), (size_t)(nlist + 1) * 4, c->stream>>>(pl, ldp, np, so, n_pairs, nlist, order);
+            } else {
+                iota_kernel<<<dim3((unsigned)ceil_div(n_pairs, 256)), dim3(256), 0, c->stream>>>(order, n_pairs);
+            }
+            LAUNCH_CHECK();
+            c->zero(queues, 8 * sizeof(int32_t));
+        }
+        {
+            ProfScope ps(c, "adc_scan");
+            const long n_items = (long)n_pairs * segs;
+            long g = std::min<long>(n_items, (long)c->prop.multiProcessorCount);
+            g = std::max<long>(8, (g + 7) / 8 * 8);          // a multiple of the XCD count so that blockIdx % 8 is the XCD of every slot
+            adc_scan_kernel<<<dim3((unsigned)g), dim3(ADC_THREADS), lds, c->stream>>>(lut, M, KL, codes, M4, (const long*)list_base, list_len, pl, ldp, np, so,
+                                                                                     elig, order, n_pairs, segs, queues, D + (size_t)b0 * ldD, ldD);
+            LAUNCH_CHECK();
+        }
+    }
 }
 
 }  // namespace comet
