@@ -112,7 +112,7 @@ def main():
     cand = int(list_len[probed].sum())
     code_bytes = cand * args.M
     adc_ms, adc_n = prof.get("adc_scan", (0.0, 1))
-    adc_avg_ms = adc_ms / max(1, adc_n)
+    adc_avg_ms = adc_ms / max(1, args.steps)        # per step: one step may split the batch over several launches
     achieved = code_bytes / (adc_avg_ms * 1e-3) / 1e9 if adc_avg_ms > 0 else 0.0
 
     line = {

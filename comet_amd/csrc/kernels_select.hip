@@ -73,9 +73,10 @@ __device__ __forceinline__ void load16(const float* __restrict__ row, long base,
 __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const float* __restrict__ D, long ldD, long C,
                                                                const int* __restrict__ cnts, float thr,
                                                                const SelState* __restrict__ st, int shift, int bits,
-                                                               unsigned* __restrict__ hist /*[B][SEL_BINS]*/) {
+                                                               unsigned* __restrict__ hist /*[B][SEL_BINS]*/, const int* __restrict__ rowlist) {
     __shared__ unsigned lh[SEL_BINS];
-    const int q = blockIdx.y;
+    if (rowlist && (int)blockIdx.y >= rowlist[0]) return;          // rowlist = {n, row_0, row_1, ...}: only the rows that need the generic path
+    const int q = rowlist ? rowlist[1 + blockIdx.y] : (int)blockIdx.y;
     const long cnt = cnts ? (long)cnts[q] : C;
     const long base = (long)blockIdx.x * SEL_CHUNK;
     if (base >= cnt) return;
@@ -99,10 +100,11 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_hist_kernel(const float* __re
 
 // ---- scan: one workgroup per query; pick the bin holding the `remaining`-th candidate ---------------
 __global__ __launch_bounds__(SEL_THREADS) void sel_scan_kernel(unsigned* __restrict__ hist, SelState* __restrict__ st,
-                                                               int shift, int bits, int K, int first) {
+                                                               int shift, int bits, int K, int first, const int* __restrict__ rowlist) {
     __shared__ unsigned part[SEL_THREADS];
     __shared__ int s_bin; __shared__ unsigned s_before; __shared__ int s_remaining;
-    const int q = blockIdx.x;
+    if (rowlist && (int)blockIdx.x >= rowlist[0]) return;
+    const int q = rowlist ? rowlist[1 + blockIdx.x] : (int)blockIdx.x;
     const int nb = 1 << bits;
     unsigned* gh = hist + (long)q * SEL_BINS;
     const int per = (nb + SEL_THREADS - 1) / SEL_THREADS;   // bins per thread (contiguous)
@@ -152,9 +154,10 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_scan_kernel(unsigned* __restr
 __global__ __launch_bounds__(SEL_THREADS) void sel_count_eq_kernel(const float* __restrict__ D, long ldD, long C,
                                                                    const int* __restrict__ cnts, float thr,
                                                                    const SelState* __restrict__ st,
-                                                                   int* __restrict__ eqcnt, int nchunks) {
+                                                                   int* __restrict__ eqcnt, int nchunks, const int* __restrict__ rowlist) {
     __shared__ int s_cnt;
-    const int q = blockIdx.y;
+    if (rowlist && (int)blockIdx.y >= rowlist[0]) return;
+    const int q = rowlist ? rowlist[1 + blockIdx.y] : (int)blockIdx.y;
     const long cnt = cnts ? (long)cnts[q] : C;
     const long base = (long)blockIdx.x * SEL_CHUNK;
     if (threadIdx.x == 0) s_cnt = 0;
@@ -173,9 +176,10 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_count_eq_kernel(const float* 
 }
 
 // exclusive prefix over chunks, one workgroup per query (in place)
-__global__ __launch_bounds__(SEL_THREADS) void sel_scan_eq_kernel(int* __restrict__ eqcnt, int nchunks) {
+__global__ __launch_bounds__(SEL_THREADS) void sel_scan_eq_kernel(int* __restrict__ eqcnt, int nchunks, const int* __restrict__ rowlist) {
     __shared__ int part[SEL_THREADS];
-    int* e = eqcnt + (long)blockIdx.x * nchunks;
+    if (rowlist && (int)blockIdx.x >= rowlist[0]) return;
+    int* e = eqcnt + (long)(rowlist ? rowlist[1 + blockIdx.x] : (int)blockIdx.x) * nchunks;
     const int per = (nchunks + SEL_THREADS - 1) / SEL_THREADS;
     const int b0 = threadIdx.x * per;
     int mine = 0;
@@ -192,9 +196,11 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_scan_eq_kernel(int* __restric
 __global__ __launch_bounds__(SEL_THREADS) void sel_gather_kernel(const float* __restrict__ D, long ldD, long C,
                                                                  const int* __restrict__ cnts, float thr,
                                                                  SelState* __restrict__ st, const int* __restrict__ eqpre,
-                                                                 int nchunks, unsigned long long* __restrict__ comp, int comp_ld) {
+                                                                 int nchunks, unsigned long long* __restrict__ comp, int comp_ld,
+                                                                 const int* __restrict__ rowlist) {
     __shared__ int wsum[SEL_THREADS / 64];
-    const int q = blockIdx.y;
+    if (rowlist && (int)blockIdx.y >= rowlist[0]) return;
+    const int q = rowlist ? rowlist[1 + blockIdx.y] : (int)blockIdx.y;
     const long cnt = cnts ? (long)cnts[q] : C;
     const long base = (long)blockIdx.x * SEL_CHUNK;
     if (base >= cnt) return;
@@ -244,9 +250,11 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_gather_kernel(const float* __
 // ---- final: sort K composites per query in LDS, write positions / scores / counts ------------------
 __global__ __launch_bounds__(1024) void sel_sort_kernel(const unsigned long long* __restrict__ comp, int comp_ld,
                                                         const SelState* __restrict__ st, unsigned* __restrict__ out_pos,
-                                                        float* __restrict__ out_scores, int* __restrict__ out_counts, int k_cap) {
+                                                        float* __restrict__ out_scores, int* __restrict__ out_counts, int k_cap,
+                                                        const int* __restrict__ rowlist) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
-    const int q = blockIdx.x;
+    if (rowlist && (int)blockIdx.x >= rowlist[0]) return;
+    const int q = rowlist ? rowlist[1 + blockIdx.x] : (int)blockIdx.x;
     const int kq = st[q].kq;
     int n2 = 1; while (n2 < kq) n2 <<= 1;
     const unsigned long long* in = comp + (long)q * comp_ld;
@@ -427,6 +435,230 @@ __global__ __launch_bounds__(1024) void select_small_kernel(const float* __restr
     if (threadIdx.x == 0) out_counts[q] = kq;
 }
 
+// ---- long rows, small K: sample bound + one filtering pass --------------------------------------------
+// The three histogram passes above re-read the whole distance matrix and serialise on LDS atomics (the top key bits of
+// a row of distances are nearly all equal). For K much smaller than the row, a bound does the same job in ONE pass:
+//   sel_bound   per row: the 24-bit key prefix of the K-th smallest valid candidate among the first S candidates of
+//               the row (any subset gives an upper bound on the row's K-th smallest; for IVF-type rows the prefix is
+//               the nearest lists, i.e. a tight one),
+//   sel_filter  streams the matrix once and keeps the composites (key<<32 | position) of candidates at or below the bound,
+//   sel_final   sorts the kept composites (bitonic, LDS) and writes the row; a row that kept more than BOUND_CAP
+//               (adversarial order, heavy ties) is appended to the row list of the generic path, which then runs for
+//               those rows only (its workgroups exit at once when the list is empty).
+// Exact for the same reason the merge is: the kept set contains every candidate <= the K-th smallest.
+constexpr int BOUND_CAP = 4096;
+constexpr int BOUND_SAMPLE_MAX = 65536;
+__global__ __launch_bounds__(1024) void sel_bound_kernel(const float* __restrict__ D, long ldD, long C, const int* __restrict__ cnts, float thr,
+                                                         int K, int S, unsigned* __restrict__ bound, int* __restrict__ cursor) {
+    __shared__ unsigned hist[4096];
+    __shared__ unsigned wsum[16];
+    __shared__ int s_valid, s_bin, s_before;
+    const int q = blockIdx.x;
+    long cnt = cnts ? (long)cnts[q] : C;
+    if (cnt > C) cnt = C;
+    const int n = (int)(cnt < S ? cnt : S);
+    const float* row = D + (long)q * ldD;
+    for (int i = threadIdx.x; i < 4096; i += 1024) hist[i] = 0;
+    if (threadIdx.x == 0) { s_valid = 0; cursor[q] = 0; }
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const unsigned bits = __float_as_uint(row[i]);
+        if (cand_ok(bits, thr)) { atomicAdd(&hist[f2key(bits) >> 20], 1u); mine++; }
+    }
+    if (mine) atomicAdd(&s_valid, mine);
+    __syncthreads();
+    if (s_valid < K) { if (threadIdx.x == 0) bound[q] = 0xFFFFFFFFu; return; }   // sample too thin: keep everything valid
+    find_bin_4096(hist, K, wsum, &s_bin, &s_before);
+    const int bin1 = s_bin, before1 = s_before;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const unsigned bits = __float_as_uint(row[i]);
+        if (cand_ok(bits, thr)) { const unsigned k = f2key(bits); if ((int)(k >> 20) == bin1) atomicAdd(&hist[(k >> 8) & 4095u], 1u); }
+    }
+    __syncthreads();
+    find_bin_4096(hist, K - before1, wsum, &s_bin, &s_before);
+    if (threadIdx.x == 0) bound[q] = ((((unsigned)bin1 << 12) | (unsigned)s_bin) << 8) | 0xFFu;
+}
+__global__ __launch_bounds__(SEL_THREADS) void sel_filter_kernel(const float* __restrict__ D, long ldD, long C, const int* __restrict__ cnts, float thr,
+                                                                 const unsigned* __restrict__ bound, int* __restrict__ cursor,
+                                                                 unsigned long long* __restrict__ comp) {
+    const int q = blockIdx.y;
+    long cnt = cnts ? (long)cnts[q] : C;
+    if (cnt > C) cnt = C;
+    const long base = (long)blockIdx.x * SEL_CHUNK;
+    if (base >= cnt) return;
+    const unsigned bnd = bound[q];
+    unsigned v[SEL_EPT]; bool in[SEL_EPT];
+    load16(D + (long)q * ldD, base, cnt, v, in);
+    const long p0 = base + (long)threadIdx.x * SEL_EPT;
+    unsigned keep = 0;                               // bit j: candidate j of this thread is kept
+#pragma unroll
+    for (int j = 0; j < SEL_EPT; j++)
+        if (in[j] && cand_ok(v[j], thr) && f2key(v[j]) <= bnd) keep |= 1u << j;
+    // one global atomic per workgroup (same-address atomics of a row serialise in L2): workgroup-wide exclusive scan
+    __shared__ int wsum[SEL_THREADS / 64];
+    __shared__ int s_base;
+    const int mine = __builtin_popcount(keep);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { int y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    int before = incl - mine, total = 0;
+#pragma unroll
+    for (int w = 0; w < SEL_THREADS / 64; w++) { if (w < wid) before += wsum[w]; total += wsum[w]; }
+    if (total == 0) return;                          // workgroup-uniform
+    if (threadIdx.x == 0) s_base = atomicAdd(&cursor[q], total);
+    __syncthreads();
+    int slot = s_base + before;
+#pragma unroll
+    for (int j = 0; j < SEL_EPT; j++) {
+        if (keep & (1u << j)) {
+            if (slot < BOUND_CAP) comp[(long)q * BOUND_CAP + slot] = ((unsigned long long)f2key(v[j]) << 32) | (unsigned)(p0 + j);
+            slot++;
+        }
+    }
+}
+__global__ __launch_bounds__(1024) void sel_final_kernel(const unsigned long long* __restrict__ comp, const int* __restrict__ cursor, int K,
+                                                         unsigned* __restrict__ out_pos, float* __restrict__ out_scores, int* __restrict__ out_counts,
+                                                         int k_cap, int* __restrict__ rowlist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
+    const int q = blockIdx.x;
+    const int m = cursor[q];
+    if (m > BOUND_CAP) {                             // generic path takes this row
+        if (threadIdx.x == 0) { const int s = atomicAdd(&rowlist[0], 1); rowlist[1 + s] = q; }
+        return;
+    }
+    int n2 = 64; while (n2 < m) n2 <<= 1;
+    for (int i = threadIdx.x; i < n2; i += 1024) sm[i] = i < m ? comp[(long)q * BOUND_CAP + i] : ~0ull;
+    __syncthreads();
+    bitonic_sort_lds(sm, n2);
+    const int kq = K > m ? m : K;                    // m < K only when the whole row holds fewer than K valid candidates
+    const int nw = kq < k_cap ? kq : k_cap;
+    for (int i = threadIdx.x; i < k_cap; i += 1024) {
+        if (i < nw) {
+            const unsigned long long c = sm[i];
+            out_pos[(long)q * k_cap + i] = (unsigned)(c & 0xFFFFFFFFull);
+            out_scores[(long)q * k_cap + i] = __uint_as_float(key2f((unsigned)(c >> 32)));
+        } else {
+            out_pos[(long)q * k_cap + i] = 0xFFFFFFFFu;
+            out_scores[(long)q * k_cap + i] = 0.0f;
+        }
+    }
+    if (threadIdx.x == 0) out_counts[q] = kq;
+}
+
+// Rows the bound could not handle: ONE workgroup per such row does the whole radix selection (three histogram passes,
+// ordered gather, sort) so that the common case — no such row — costs a single near-empty launch.
+__global__ __launch_bounds__(1024) void sel_row_kernel(const float* __restrict__ D, long ldD, long C, const int* __restrict__ cnts, float thr, int K,
+                                                       const int* __restrict__ rowlist, unsigned* __restrict__ out_pos, float* __restrict__ out_scores,
+                                                       int* __restrict__ out_counts, int k_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];   // SORT_MAX composites
+    __shared__ unsigned hist[4096];
+    __shared__ unsigned wsum[16];
+    __shared__ int s_bin, s_before, s_less, s_eqbase;
+    if ((int)blockIdx.x >= rowlist[0]) return;
+    const int q = rowlist[1 + blockIdx.x];
+    long cnt = cnts ? (long)cnts[q] : C;
+    if (cnt > C) cnt = C;
+    const float* row = D + (long)q * ldD;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    unsigned prefix = 0, mask = 0;
+    int remaining = 0, kq = 0;
+    const int shifts[3] = {20, 8, 0}, bitsv[3] = {12, 12, 8};
+    for (int p = 0; p < 3; p++) {
+        const int shift = shifts[p], nb = 1 << bitsv[p];
+        for (int i = t; i < 4096; i += 1024) hist[i] = 0;
+        __syncthreads();
+        for (long i0 = 0; i0 < cnt; i0 += 1024) {
+            const long i = i0 + t;
+            bool ok = false; unsigned bin = 0;
+            if (i < cnt) { const unsigned bits = __float_as_uint(row[i]); if (cand_ok(bits, thr)) { const unsigned k = f2key(bits); if ((k & mask) == prefix) { ok = true; bin = (k >> shift) & (nb - 1); } } }
+            // the top bits of a row of distances are nearly all equal: one atomic for the lanes that agree with the first one
+            const unsigned long long act = __ballot(ok);
+            if (act) {
+                const int first = __builtin_ctzll(act);
+                const unsigned bin0 = __shfl(bin, first, 64);
+                const unsigned long long same = __ballot(ok && bin == bin0);
+                if (lane == first) atomicAdd(&hist[bin0], (unsigned)__builtin_popcountll(same));
+                if (ok && bin != bin0) atomicAdd(&hist[bin], 1u);
+            }
+        }
+        __syncthreads();
+        if (p == 0) {
+            unsigned mine = 0;
+            for (int i = t; i < 4096; i += 1024) mine += hist[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+            if (lane == 0) wsum[wid] = mine;
+            __syncthreads();
+            unsigned total = 0;
+            for (int w = 0; w < 16; w++) total += wsum[w];
+            kq = (K <= 0 || (unsigned)K > total) ? (int)total : K;     // sanitizeK limiter.go:12-17
+            remaining = kq;
+            __syncthreads();
+        }
+        if (kq <= 0) break;
+        find_bin_4096(hist, remaining, wsum, &s_bin, &s_before);
+        prefix |= ((unsigned)s_bin) << shift;
+        mask |= ((unsigned)(nb - 1)) << shift;
+        remaining -= s_before;
+        __syncthreads();
+    }
+    if (kq > 0) {
+        const unsigned keystar = prefix;
+        const int r = remaining, n_less = kq - r;    // every candidate below key*, then the first r (by position) equal to it
+        if (t == 0) { s_less = 0; s_eqbase = 0; }
+        __syncthreads();
+        for (long i0 = 0; i0 < cnt; i0 += 1024) {
+            const long i = i0 + t;
+            bool eq = false;
+            if (i < cnt) {
+                const unsigned bits = __float_as_uint(row[i]);
+                if (cand_ok(bits, thr)) {
+                    const unsigned k = f2key(bits);
+                    if (k < keystar) { const int s = atomicAdd(&s_less, 1); sm[s] = ((unsigned long long)k << 32) | (unsigned)i; }
+                    else eq = (k == keystar);
+                }
+            }
+            const int eqbase = s_eqbase;
+            if (eqbase < r) {                        // workgroup-uniform: still taking equals, in position order
+                const unsigned long long m = __ballot(eq);
+                if (lane == 0) wsum[wid] = (unsigned)__builtin_popcountll(m);
+                __syncthreads();
+                int before = eqbase;
+                for (int w = 0; w < wid; w++) before += (int)wsum[w];
+                const int rank = before + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                if (eq && rank < r) sm[n_less + rank] = ((unsigned long long)keystar << 32) | (unsigned)i;
+                __syncthreads();
+                if (t == 0) { int tot = 0; for (int w = 0; w < 16; w++) tot += (int)wsum[w]; s_eqbase = eqbase + tot; }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        int n2 = 64; while (n2 < kq) n2 <<= 1;
+        for (int i = kq + t; i < n2; i += 1024) sm[i] = ~0ull;
+        __syncthreads();
+        bitonic_sort_lds(sm, n2);
+    }
+    const int nw = kq < k_cap ? kq : k_cap;
+    for (int i = t; i < k_cap; i += 1024) {
+        if (i < nw) {
+            const unsigned long long c = sm[i];
+            out_pos[(long)q * k_cap + i] = (unsigned)(c & 0xFFFFFFFFull);
+            out_scores[(long)q * k_cap + i] = __uint_as_float(key2f((unsigned)(c >> 32)));
+        } else {
+            out_pos[(long)q * k_cap + i] = 0xFFFFFFFFu;
+            out_scores[(long)q * k_cap + i] = 0.0f;
+        }
+    }
+    if (t == 0) out_counts[q] = kq;
+}
+
 void launch_select_topk(Ctx* c, const float* D, int64_t ldD, int B, int64_t C, const int32_t* cnts, float thr, int K,
                         uint32_t* out_pos, float* out_scores, int32_t* out_counts, int k_cap) {
     if (B <= 0) return;
@@ -449,6 +681,32 @@ void launch_select_topk(Ctx* c, const float* D, int64_t ldD, int B, int64_t C, c
     const int64_t kmax = (K <= 0 || K > C) ? C : K;
     if (kmax > SORT_MAX) COMET_FAIL(COMET_ERR_UNSUPPORTED, "top-k of %lld exceeds the on-device selection limit %d", (long long)kmax, SORT_MAX);
     const int nchunks = (int)ceil_div(C, SEL_CHUNK);
+    dim3 grid(nchunks, B), blk(SEL_THREADS);
+    // sample-bound path: expected kept candidates K*C/S held near 512 (BOUND_CAP = 8x that); needs K >= 1
+    int* rowlist = nullptr;
+    static const bool bound_off = getenv("COMET_SELECT_NO_BOUND") != nullptr;
+    if (K >= 1 && !bound_off) {
+        int64_t S = std::max<int64_t>(SMALL_MAX, round_up((int64_t)K * C / 512, 1024));
+        if (S <= BOUND_SAMPLE_MAX && S * 2 <= C) {
+            unsigned* bound = c->salloc<unsigned>(B);
+            int* cursor = c->salloc<int>(B);
+            unsigned long long* kept = c->salloc<unsigned long long>((size_t)B * BOUND_CAP);
+            rowlist = c->salloc<int>(B + 1);
+            c->zero(rowlist, sizeof(int));
+            { ProfScope ps(c, "select_bound");
+              sel_bound_kernel<<<dim3(B), dim3(1024), 0, c->stream>>>(D, ldD, C, cnts, thr, K, (int)S, bound, cursor); LAUNCH_CHECK(); }
+            { ProfScope ps(c, "select_filter");
+              sel_filter_kernel<<<grid, blk, 0, c->stream>>>(D, ldD, C, cnts, thr, bound, cursor, kept); LAUNCH_CHECK(); }
+            { ProfScope ps(c, "select_final");
+              sel_final_kernel<<<dim3(B), dim3(1024), sizeof(unsigned long long) * BOUND_CAP, c->stream>>>(kept, cursor, K, out_pos, out_scores, out_counts, k_cap, rowlist);
+              LAUNCH_CHECK(); }
+            { ProfScope ps(c, "select_rows");
+              int n2 = 64; while (n2 < kmax) n2 <<= 1;
+              sel_row_kernel<<<dim3(B), dim3(1024), sizeof(unsigned long long) * n2, c->stream>>>(D, ldD, C, cnts, thr, K, rowlist, out_pos, out_scores, out_counts, k_cap);
+              LAUNCH_CHECK(); }
+            return;
+        }
+    }
     SelState* st = c->salloc<SelState>(B);
     unsigned* hist = c->salloc<unsigned>((size_t)B * SEL_BINS);
     int* eqcnt = c->salloc<int>((size_t)B * nchunks);
@@ -456,23 +714,22 @@ void launch_select_topk(Ctx* c, const float* D, int64_t ldD, int B, int64_t C, c
     unsigned long long* comp = c->salloc<unsigned long long>((size_t)B * comp_ld);
     c->zero(st, sizeof(SelState) * B);
     c->zero(hist, sizeof(unsigned) * (size_t)B * SEL_BINS);
-    dim3 grid(nchunks, B), blk(SEL_THREADS);
     const int shifts[3] = {20, 8, 0}, bitsv[3] = {12, 12, 8};
     for (int p = 0; p < 3; p++) {
         { ProfScope ps(c, "select_hist");
-          sel_hist_kernel<<<grid, blk, 0, c->stream>>>(D, ldD, C, cnts, thr, st, shifts[p], bitsv[p], hist); LAUNCH_CHECK(); }
+          sel_hist_kernel<<<grid, blk, 0, c->stream>>>(D, ldD, C, cnts, thr, st, shifts[p], bitsv[p], hist, rowlist); LAUNCH_CHECK(); }
         { ProfScope ps(c, "select_scan");
-          sel_scan_kernel<<<dim3(B), blk, 0, c->stream>>>(hist, st, shifts[p], bitsv[p], K, p == 0); LAUNCH_CHECK(); }
+          sel_scan_kernel<<<dim3(B), blk, 0, c->stream>>>(hist, st, shifts[p], bitsv[p], K, p == 0, rowlist); LAUNCH_CHECK(); }
     }
     { ProfScope ps(c, "select_count_eq");
-      sel_count_eq_kernel<<<grid, blk, 0, c->stream>>>(D, ldD, C, cnts, thr, st, eqcnt, nchunks); LAUNCH_CHECK(); }
+      sel_count_eq_kernel<<<grid, blk, 0, c->stream>>>(D, ldD, C, cnts, thr, st, eqcnt, nchunks, rowlist); LAUNCH_CHECK(); }
     { ProfScope ps(c, "select_scan");
-      sel_scan_eq_kernel<<<dim3(B), blk, 0, c->stream>>>(eqcnt, nchunks); LAUNCH_CHECK(); }
+      sel_scan_eq_kernel<<<dim3(B), blk, 0, c->stream>>>(eqcnt, nchunks, rowlist); LAUNCH_CHECK(); }
     { ProfScope ps(c, "select_gather");
-      sel_gather_kernel<<<grid, blk, 0, c->stream>>>(D, ldD, C, cnts, thr, st, eqcnt, nchunks, comp, comp_ld); LAUNCH_CHECK(); }
+      sel_gather_kernel<<<grid, blk, 0, c->stream>>>(D, ldD, C, cnts, thr, st, eqcnt, nchunks, comp, comp_ld, rowlist); LAUNCH_CHECK(); }
     { ProfScope ps(c, "select_sort");
       int threads = comp_ld >= 2048 ? 1024 : (comp_ld >= 512 ? 256 : 64);
-      sel_sort_kernel<<<dim3(B), dim3(threads), sizeof(unsigned long long) * comp_ld, c->stream>>>(comp, comp_ld, st, out_pos, out_scores, out_counts, k_cap);
+      sel_sort_kernel<<<dim3(B), dim3(threads), sizeof(unsigned long long) * comp_ld, c->stream>>>(comp, comp_ld, st, out_pos, out_scores, out_counts, k_cap, rowlist);
       LAUNCH_CHECK(); }
 }
 

@@ -221,3 +221,39 @@ def test_synth_fill_matches_oracle_stream(ctx):
     got = ctx.download(p, (n,), np.float32)
     ctx.free(p)
     assert np.array_equal(got.view(np.uint32), orc.synth(0xC0FFEE, 12345, n).view(np.uint32))
+
+
+def test_long_rows_sample_bound_and_its_generic_fallback(ctx):
+    """Rows longer than 2 x 8192 candidates take the sample-bound selection (bound from the row's prefix, one filtering
+    pass); orders that defeat the bound — distances DESCENDING along the row, or every distance equal — must fall
+    through to the multi-pass radix path on the device and still give the canonical (score, position) order."""
+    n, d = 40_000, 8
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((6, d)).astype(np.float32)
+    g, o = build_pair(ctx, L2_SQUARED, X)
+    for k in (1, 10, 64):
+        ids, sc, cnt = g.search_batch(Q, k, mode=1)
+        for b, q in enumerate(Q):
+            m, oi, os_ = o.search(q, k)
+            assert cnt[b] == m and np.array_equal(ids[b, :m], oi) and np.array_equal(sc[b, :m].view(np.uint32), os_.view(np.uint32))
+    # threshold + soft deletes on the bound path
+    ref = o.search(Q[0], 40)[2]
+    assert_same(g, o, Q, 25, threshold=float(ref[17]))
+    for i in o.search(Q[1], 5)[1].tolist():
+        g.remove(int(i)); assert o.remove(int(i)) == 0
+    assert_same(g, o, Q, 10)
+    # adversarial: the query is the origin and |x_i| decreases with i -> the best candidates are the LAST ones
+    X2 = np.zeros((n, d), np.float32); X2[:, 0] = np.linspace(1000.0, 1.0, n, dtype=np.float32)
+    g2, o2 = build_pair(ctx, L2_SQUARED, X2)
+    Z = np.zeros((3, d), np.float32); Z[1, 0] = 1.0; Z[2, 0] = 500.0
+    for k in (1, 10, 100):
+        ids, sc, cnt = g2.search_batch(Z, k, mode=1)
+        for b, q in enumerate(Z):
+            m, oi, os_ = o2.search(q, k)
+            assert cnt[b] == m and np.array_equal(ids[b, :m], oi) and np.array_equal(sc[b, :m].view(np.uint32), os_.view(np.uint32))
+    # all distances equal: ties resolved by scan position, by the generic path
+    X3 = np.ones((n, d), np.float32)
+    g3, o3 = build_pair(ctx, L2_SQUARED, X3)
+    ids, sc, cnt = g3.search_batch(Z[:1], 10, mode=1)
+    assert ids[0, :10].tolist() == list(range(1, 11)) == o3.search(Z[0], 10)[1].tolist()
