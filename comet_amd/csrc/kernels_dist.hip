@@ -243,10 +243,15 @@ static void launch_dist_exact_t(Ctx* c, const float* X, int64_t n, int ld, const
 template <int METRIC>
 static void launch_dist_exact_m(Ctx* c, const float* X, int64_t n, int ld, const float* Q, int B, float* D, int64_t ldD,
                                 const uint8_t* elig) {
+    // queries per workgroup: 16 amortises the LDS transpose best, but a short matrix (coarse centroids, small indexes)
+    // then gives fewer workgroups than the chip has CUs — halve the query group until the grid covers ~2 per CU
+    int qt = 16;
+    const int64_t tiles = ceil_div(n, TILE_ROWS);
+    while (qt > 4 && tiles * ceil_div(B, qt) < 2 * (int64_t)c->prop.multiProcessorCount) qt >>= 1;
     if (B <= 1) launch_dist_exact_t<METRIC, 1>(c, X, n, ld, Q, B, D, ldD, elig);
     else if (B <= 2) launch_dist_exact_t<METRIC, 2>(c, X, n, ld, Q, B, D, ldD, elig);
-    else if (B <= 4) launch_dist_exact_t<METRIC, 4>(c, X, n, ld, Q, B, D, ldD, elig);
-    else if (B <= 8) launch_dist_exact_t<METRIC, 8>(c, X, n, ld, Q, B, D, ldD, elig);
+    else if (B <= 4 || qt == 4) launch_dist_exact_t<METRIC, 4>(c, X, n, ld, Q, B, D, ldD, elig);
+    else if (B <= 8 || qt == 8) launch_dist_exact_t<METRIC, 8>(c, X, n, ld, Q, B, D, ldD, elig);
     else launch_dist_exact_t<METRIC, 16>(c, X, n, ld, Q, B, D, ldD, elig);
 }
 void launch_dist_exact(Ctx* c, int metric, const float* X, int64_t n, int ld, const float* Q, int B, float* D, int64_t ldD,

@@ -441,50 +441,51 @@ __global__ __launch_bounds__(256) void iota_kernel(unsigned* __restrict__ p, int
     if (i < n) p[i] = (unsigned)i;
 }
 
-// one wave, C blocks (wid, wid+16, ...) of the segment: C serial float32 chains per lane
+// one wave, C blocks (wid, wid+16, ...) of the segment: C serial float32 chains per lane. `cur` holds the code words of
+// the first group (requested by the caller before the table barrier). The main loop runs over groups of ADC_G FULL words
+// (4 codes each) without a branch so that the next group's loads and this group's 16*C table reads overlap the add chains;
+// words past the last full group (M not a multiple of 16) are handled one code at a time.
+constexpr int ADC_G = 4;
 template <int C>
 __device__ __forceinline__ void adc_chains(const float* __restrict__ lut, int M, int M4, int KL, const unsigned* __restrict__ cw, long blk_stride16,
-                                           float (&acc)[ADC_CHAINS]) {
-    constexpr int G = 4;
-    unsigned cur[C][G], nxt[C][G];
+                                           unsigned (&cur)[ADC_CHAINS][ADC_G], float (&acc)[ADC_CHAINS]) {
+    constexpr int G = ADC_G;
+    const int ngroups = (M >> 2) / G;
+    unsigned nxt[C][G];
 #pragma unroll
-    for (int c = 0; c < C; c++) {
-        acc[c] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < G; i++) cur[c][i] = cw[c * blk_stride16 + (long)min(i, M4 - 1) * 64];
-    }
-    for (int w0 = 0; w0 < M4; w0 += G) {
+    for (int c = 0; c < C; c++) acc[c] = 0.0f;
+    for (int g = 0; g < ngroups; g++) {
+        const int gn = min(g + 1, ngroups - 1);      // the last iteration re-reads its own group (never used)
 #pragma unroll
         for (int c = 0; c < C; c++)
 #pragma unroll
-            for (int i = 0; i < G; i++) nxt[c][i] = cw[c * blk_stride16 + (long)min(w0 + G + i, M4 - 1) * 64];   // clamped re-read past the end
+            for (int i = 0; i < G; i++) nxt[c][i] = cw[c * blk_stride16 + (long)(gn * G + i) * 64];
+        const float* l0 = lut + (long)g * (G * 4) * KL;
 #pragma unroll
         for (int i = 0; i < G; i++) {
-            const int m = (w0 + i) * 4;
-            if (m + 3 < M) {            // wave-uniform
-                const float* l0 = lut + (long)m * KL;
-                float v[C][4];
+            float v[C][4];
 #pragma unroll
-                for (int c = 0; c < C; c++) {
-                    const unsigned w = cur[c][i];
-                    v[c][0] = l0[w & 255u]; v[c][1] = l0[KL + ((w >> 8) & 255u)]; v[c][2] = l0[2 * KL + ((w >> 16) & 255u)]; v[c][3] = l0[3 * KL + (w >> 24)];
-                }
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-#pragma unroll
-                    for (int c = 0; c < C; c++) acc[c] = acc[c] + v[c][b];
-            } else if (m < M) {         // last, partial word (M not a multiple of 4)
-#pragma unroll
-                for (int c = 0; c < C; c++) {
-                    const unsigned w = cur[c][i];
-                    for (int bb = 0; m + bb < M; bb++) acc[c] = acc[c] + lut[(m + bb) * KL + ((w >> (8 * bb)) & 255u)];
-                }
+            for (int c = 0; c < C; c++) {
+                const unsigned w = cur[c][i];
+                v[c][0] = l0[(i * 4 + 0) * KL + (w & 255u)]; v[c][1] = l0[(i * 4 + 1) * KL + ((w >> 8) & 255u)];
+                v[c][2] = l0[(i * 4 + 2) * KL + ((w >> 16) & 255u)]; v[c][3] = l0[(i * 4 + 3) * KL + (w >> 24)];
             }
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int c = 0; c < C; c++) acc[c] = acc[c] + v[c][b];
         }
 #pragma unroll
         for (int c = 0; c < C; c++)
 #pragma unroll
             for (int i = 0; i < G; i++) cur[c][i] = nxt[c][i];
+    }
+    for (int w0 = ngroups * G; w0 < M4; w0++) {      // tail words
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const unsigned w = cw[c * blk_stride16 + (long)w0 * 64];
+            for (int bb = 0; bb < 4 && w0 * 4 + bb < M; bb++) acc[c] = acc[c] + lut[(w0 * 4 + bb) * KL + ((w >> (8 * bb)) & 255u)];
+        }
     }
 }
 
@@ -531,6 +532,28 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const float* __re
             if (seg_off[(long)q * (np + 1) + p + 1] == so) live = false;
             else { L = probe_list[(long)q * ldp + p]; len = list_len[L]; live = start < len; }
         }
+        // code words of the first group are requested before the table so that both are in flight together
+        unsigned cur[ADC_CHAINS][ADC_G];
+        int end = 0, nact = 0, blk0 = 0;
+        long base_slot = 0;
+        const unsigned* __restrict__ cw = codes;
+        const long stride16 = (long)ADC_WAVES * M4 * 64;
+        if (live) {
+            end = min(len, start + ADC_SEG_CODES);
+            const int nblk = (end - start + 63) >> 6;   // blocks of this segment, 1..64
+            nact = wid < nblk ? (nblk - wid + ADC_WAVES - 1) / ADC_WAVES : 0;
+            base_slot = list_base[L];                   // multiple of 64
+            blk0 = (start >> 6) + wid;
+            cw = codes + ((base_slot >> 6) + blk0) * (long)M4 * 64 + lane;
+            if ((M >> 2) >= ADC_G) {
+#pragma unroll
+                for (int c = 0; c < ADC_CHAINS; c++)
+                    if (c < nact) {
+#pragma unroll
+                        for (int i = 0; i < ADC_G; i++) cur[c][i] = cw[c * stride16 + (long)i * 64];
+                    }
+            }
+        }
         if (live) {                                 // workgroup-uniform
             const float* __restrict__ src = lutg + (long)pair * n_ent;
             if ((n_ent & 3) == 0) {
@@ -547,19 +570,12 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const float* __re
         if (threadIdx.x == 0) { const int t = take(my_q, tried); s_ticket[0] = my_q; s_ticket[1] = t; }   // overlaps the table load
         __syncthreads();                            // table in LDS (the compiler drains vmcnt before the barrier), next ticket published
         if (!live) continue;
-        const int end = min(len, start + ADC_SEG_CODES);
-        const int nblk = (end - start + 63) >> 6;   // blocks of this segment, 1..64
-        const int nact = wid < nblk ? (nblk - wid + ADC_WAVES - 1) / ADC_WAVES : 0;
-        const long base_slot = list_base[L];        // multiple of 64
-        const int blk0 = (start >> 6) + wid;
-        const unsigned* __restrict__ cw = codes + ((base_slot >> 6) + blk0) * (long)M4 * 64 + lane;
-        const long stride16 = (long)ADC_WAVES * M4 * 64;
         float acc[ADC_CHAINS];
         switch (nact) {
-            case 1: adc_chains<1>(lut, M, M4, KL, cw, stride16, acc); break;
-            case 2: adc_chains<2>(lut, M, M4, KL, cw, stride16, acc); break;
-            case 3: adc_chains<3>(lut, M, M4, KL, cw, stride16, acc); break;
-            case 4: adc_chains<4>(lut, M, M4, KL, cw, stride16, acc); break;
+            case 1: adc_chains<1>(lut, M, M4, KL, cw, stride16, cur, acc); break;
+            case 2: adc_chains<2>(lut, M, M4, KL, cw, stride16, cur, acc); break;
+            case 3: adc_chains<3>(lut, M, M4, KL, cw, stride16, cur, acc); break;
+            case 4: adc_chains<4>(lut, M, M4, KL, cw, stride16, cur, acc); break;
             default: break;
         }
 #pragma unroll
