@@ -31,12 +31,12 @@ namespace comet {
 // ------------------------------------------------------------------------------------------------
 // fp32 padded rows -> fp16 shadow rows (+ squared norms, max |x|, max norm^2)
 // ------------------------------------------------------------------------------------------------
-// Shadow layout ("tiled"): [tile of 256 rows][K step of 64 halves][row in tile][64 halves] — the 32 KiB a
-// workgroup needs for one K step of its tile are CONTIGUOUS in HBM (whole DRAM pages stream in), instead of
-// 256 separate 128-byte pieces at a 1536-byte stride as in a row-major shadow.
+// Shadow layout ("tiled"): [tile of 256 rows][K slab of 32 halves][row in tile][32 halves] — the 16 KiB a
+// workgroup needs for one 32-wide K slab of its tile are CONTIGUOUS in HBM (whole DRAM pages stream in), instead of
+// 256 separate 64-byte pieces at a 1536-byte stride as in a row-major shadow.
 __device__ __forceinline__ long tiled_off(long row, int k, int ldh) {
     const long tile = row >> 8; const int r = (int)(row & 255);
-    return ((tile * (ldh >> 6) + (k >> 6)) * 256 + r) * 64 + (k & 63);
+    return ((tile * (ldh >> 5) + (k >> 5)) * 256 + r) * 32 + (k & 31);
 }
 __global__ __launch_bounds__(256) void to_half_rows_kernel(const float* __restrict__ X, long n, int ld, _Float16* __restrict__ Xh, int ldh, long row_base,
                                                            float* __restrict__ rn, unsigned* __restrict__ stats /*[0]=max|x| bits, [1]=max norm2 bits*/) {
@@ -84,85 +84,13 @@ __device__ __forceinline__ void ins3(float& t0, float& t1, float& t2, float a) {
     t0 = fminf(t0, a); t1 = n1; t2 = n2;
 }
 
-// MODE 0: cosine   key = max(0, 1 - s)
-// MODE 1: L2 family key = max(0, qn[q] + rn[row] - 2 s)
+// ---- epilogue shared by the scan kernels: 8 waves as 2 (rows) x 4 (queries), wave tile 128 x 64, acc[mb][nb] ----
 template <int MODE>
-__global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
-                                                                   const _Float16* __restrict__ Qh /*256 x ldh*/,
-                                                                   const float* __restrict__ rn, const float* __restrict__ qn,
-                                                                   const unsigned char* __restrict__ elig,
-                                                                   float* __restrict__ S0 /*[256][ldS]: 2 keys per tile*/, long ldS,
-                                                                   float* __restrict__ bound /*[256][ldB]*/, long ldB, long n_tiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [buf][X 32 KiB | Q 32 KiB]
+__device__ __forceinline__ void scan_epilogue(f32x16 (&acc)[4][2], unsigned char* smem, long tile, long row0, long n,
+                                              const float* __restrict__ rn, const float* __restrict__ qn, const unsigned char* __restrict__ elig,
+                                              float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 2, wn = wid & 3;
-    // XCD-aware tile order: contiguous chunks of tiles per XCD keep an XCD's L2 working on neighbouring rows
-    long tile;
-    {
-        const long L = blockIdx.x, nx = 8;
-        const long q = n_tiles / nx, r = n_tiles % nx, xcd = L % nx, idx = L / nx;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        if (idx >= (xcd < r ? q + 1 : q)) return;
-    }
-    const long row0 = tile * FB_M;
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
-
-    // ---- staging: each wave moves 4 X pieces + 4 Q pieces (8 rows x 128 B each) per K step ----
-    const int prow = lane >> 3, pslot = lane & 7;
-    const char* xsrc[4]; const char* qsrc[4]; int ldsoff[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int r = (wid * 4 + i) * 8 + prow;                 // row inside the tile (0..255)
-        const int ks = pslot ^ ((r >> 1) & 7);                  // logical slot stored at this physical slot
-        // tiled shadow: (tile, kt) slab = 256 rows x 128 B contiguous; rows past n are zero-filled padding of the last tile
-        xsrc[i] = reinterpret_cast<const char*>(Xh) + (tile * (long)(ldh >> 6) * 256 + r) * 128 + ks * 16;
-        qsrc[i] = reinterpret_cast<const char*>(Qh + (long)r * ldh) + ks * 16;
-        ldsoff[i] = (wid * 4 + i) * 8 * 128;                    // wave-uniform LDS base of the piece
-    }
-    auto stage = [&](int buf, int kt) {
-        unsigned char* xb = smem + buf * 65536;
-        unsigned char* qb = xb + 32768;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + (long)kt * (256 * 128)),
-                                             (__attribute__((address_space(3))) void*)(xb + ldsoff[i]), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc[i] + (long)kt * 128),
-                                             (__attribute__((address_space(3))) void*)(qb + ldsoff[i]), 16, 0, 0);
-        }
-    };
-
-    const int nk = ldh / FB_K;
-    stage(0, 0);
-    __syncthreads();   // compiler drains vmcnt before the barrier (LDS-DMA counts on vmcnt)
-    const int arow = wm * 128 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = lane >> 5;
-    for (int kt = 0; kt < nk; kt++) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
-        const unsigned char* xb = smem + buf * 65536;
-        const unsigned char* qb = xb + 32768;
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            half8 a[4], b[2];
-#pragma unroll
-            for (int mb = 0; mb < 4; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, ks * 2 + khalf));
-#pragma unroll
-            for (int nb = 0; nb < 2; nb++) b[nb] = *reinterpret_cast<const half8*>(qb + swz_off(brow + nb * 32, ks * 2 + khalf));
-#pragma unroll
-            for (int mb = 0; mb < 4; mb++)
-#pragma unroll
-                for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-
+    const int wm = wid >> 2, wn = wid & 3, khalf = lane >> 5;
     // ---- epilogue: per (query, tile) two smallest packed keys + third smallest (bound) ----
     // C layout of the 32x32 MFMA: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     const float INF = __builtin_inff();
@@ -231,19 +159,547 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_kernel(const _Float1
         bound[(long)tid * ldB + tile] = t2;
     }
 }
+
+// MODE 0: cosine   key = max(0, 1 - s)
+// MODE 1: L2 family key = max(0, qn[q] + rn[row] - 2 s)
+template <int MODE, int DBG, bool ILV = false>
+__global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
+                                                                   const _Float16* __restrict__ Qh /*256 x ldh*/,
+                                                                   const float* __restrict__ rn, const float* __restrict__ qn,
+                                                                   const unsigned char* __restrict__ elig,
+                                                                   float* __restrict__ S0 /*[256][ldS]: 2 keys per tile*/, long ldS,
+                                                                   float* __restrict__ bound /*[256][ldB]*/, long ldB, long n_tiles) {
+    constexpr int dbg = DBG;   // timing experiments only (COMET_SCAN_DEBUG_SKIP); 0 in production
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [buf][X 32 KiB | Q 32 KiB]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    // XCD-aware tile order: contiguous chunks of tiles per XCD keep an XCD's L2 working on neighbouring rows
+    long tile;
+    {
+        const long L = blockIdx.x, nx = 8;
+        const long q = n_tiles / nx, r = n_tiles % nx, xcd = L % nx, idx = L / nx;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        if (idx >= (xcd < r ? q + 1 : q)) return;
+    }
+    const long row0 = tile * FB_M;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    // ---- staging: each wave moves 4 X pieces + 4 Q pieces (8 rows x 128 B each) per K step ----
+    const int prow = lane >> 3, pslot = lane & 7;
+    const char* xsrc[4]; const char* qsrc[4]; int ldsoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = (wid * 4 + i) * 8 + prow;                 // row inside the tile (0..255)
+        const int ks = pslot ^ ((r >> 1) & 7);                  // logical slot stored at this physical slot
+        // tiled shadow: a 64-wide K step = two consecutive 16 KiB slabs (256 rows x 64 B); rows past n are zero-filled padding
+        xsrc[i] = reinterpret_cast<const char*>(Xh) + ((tile * (long)(ldh >> 5) + (ks >> 2)) * 256 + r) * 64 + (ks & 3) * 16;
+        qsrc[i] = reinterpret_cast<const char*>(Qh + (long)r * ldh) + ks * 16;
+        ldsoff[i] = (wid * 4 + i) * 8 * 128;                    // wave-uniform LDS base of the piece
+    }
+    auto stage = [&](int buf, int kt) {
+        unsigned char* xb = smem + buf * 65536;
+        unsigned char* qb = xb + 32768;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if constexpr (!(DBG & 1))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + (long)kt * (256 * 128)),
+                                             (__attribute__((address_space(3))) void*)(xb + ldsoff[i]), 16, 0, 0);
+            if constexpr (!(DBG & 2))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc[i] + (long)kt * 128),
+                                             (__attribute__((address_space(3))) void*)(qb + ldsoff[i]), 16, 0, 0);
+        }
+    };
+
+    const int nk = ldh / FB_K;
+    stage(0, 0);
+    __syncthreads();   // compiler drains vmcnt before the barrier (LDS-DMA counts on vmcnt)
+    const int arow = wm * 128 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = lane >> 5;
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if constexpr (!ILV) { if (kt + 1 < nk) stage(buf ^ 1, kt + 1); }   // ILV: pieces issued inside the MFMA block, unconditionally (last one redundant)
+        const unsigned char* xb = smem + buf * 65536;
+        const unsigned char* qb = xb + 32768;
+        if constexpr ((DBG & 8) != 0) {
+            half8 a[4], b[2];
+#pragma unroll
+            for (int mb = 0; mb < 4; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, khalf));
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) b[nb] = *reinterpret_cast<const half8*>(qb + swz_off(brow + nb * 32, khalf));
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+            for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+                for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+        } else if constexpr (ILV) {
+            // same work, explicit issue order: fragment reads of sub-step ks+1 and the 8 DMA pieces of the next K step are
+            // threaded one at a time between the MFMAs of sub-step ks (a burst of 8 pieces + 24 ds_read_b128 in front of
+            // the MFMAs costs 100-185 cycles per piece while the matrix pipe idles; a single piece between MFMAs ~60)
+            half8 a[2][4], b[2][2];
+            const int ktn = min(kt + 1, nk - 1);
+            unsigned char* xbn = smem + (buf ^ 1) * 65536;
+            unsigned char* qbn = xbn + 32768;
+#pragma unroll
+            for (int mb = 0; mb < 4; mb++) a[0][mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, khalf));
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) b[0][nb] = *reinterpret_cast<const half8*>(qb + swz_off(brow + nb * 32, khalf));
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                if (ks < 3) {
+#pragma unroll
+                    for (int mb = 0; mb < 4; mb++) a[(ks + 1) & 1][mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, (ks + 1) * 2 + khalf));
+#pragma unroll
+                    for (int nb = 0; nb < 2; nb++) b[(ks + 1) & 1][nb] = *reinterpret_cast<const half8*>(qb + swz_off(brow + nb * 32, (ks + 1) * 2 + khalf));
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[ks] + (long)ktn * (256 * 128)),
+                                                 (__attribute__((address_space(3))) void*)(xbn + ldsoff[ks]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc[ks] + (long)ktn * 128),
+                                                 (__attribute__((address_space(3))) void*)(qbn + ldsoff[ks]), 16, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+                    for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][mb], b[ks & 1][nb], acc[mb][nb], 0, 0, 0);
+            }
+            // order: 6 fragment reads, then per sub-step {MFMA, DS} x6 + {MFMA, VMEM} x2 (last sub-step: no reads left)
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+                for (int i = 0; i < 2; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            half8 a[4], b[2];
+#pragma unroll
+            for (int mb = 0; mb < 4; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, ks * 2 + khalf));
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) b[nb] = *reinterpret_cast<const half8*>(qb + swz_off(brow + nb * 32, ks * 2 + khalf));
+#pragma unroll
+            for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+                for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+        }
+        }
+        if constexpr (!(DBG & 16)) __syncthreads();
+    }
+    if constexpr ((DBG & 4) != 0) {
+        float s = 0.0f;
+#pragma unroll
+        for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) s += acc[mb][nb][e];
+        if (s == 12345.678f) S0[tid] = s;
+        return;
+    }
+
+    scan_epilogue<MODE>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
+}
+// ------------------------------------------------------------------------------------------------
+// ring variant: same 256 x 256 tile / 8 waves / 128 accumulators per lane, but K streamed in 32-half slabs through a
+// FIVE-stage LDS ring (5 x (16 KiB rows + 16 KiB queries) = 160 KiB, the whole LDS) with raw s_barrier and COUNTED vmcnt:
+// four stages (64 KiB of corpus rows per CU) stay in flight across every barrier. Streaming-read probes on this part
+// (tools/hbm_read_probe.hip) need >= ~100 KiB in flight per CU for 6+ TB/s; the two-stage loop above keeps 32 KiB of rows
+// in flight and is latency-bound at 3 TB/s.
+// ------------------------------------------------------------------------------------------------
+constexpr int R5_K = 32, R5_STAGES = 5, R5_STAGE_BYTES = 32768, R5_XBYTES = 16384;
+__device__ __forceinline__ int swz32_off(int row, int kslot) { return row * 64 + ((kslot ^ ((row >> 2) & 3)) << 4); }
+
+template <int MODE>
+__global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_ring_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
+                                                                        const _Float16* __restrict__ Qh /*256 x ldh*/,
+                                                                        const float* __restrict__ rn, const float* __restrict__ qn,
+                                                                        const unsigned char* __restrict__ elig,
+                                                                        float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    long tile;
+    {
+        const long L = blockIdx.x, nx = 8;
+        const long q = n_tiles / nx, r = n_tiles % nx, xcd = L % nx, idx = L / nx;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        if (idx >= (xcd < r ? q + 1 : q)) return;
+    }
+    const long row0 = tile * FB_M;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    // staging: one wave instruction moves 16 rows x 64 B; 16 row pieces + 16 query pieces per stage -> 2 + 2 per wave
+    const int prow = lane >> 2, pslot = lane & 3;
+    const char* xsrc[2]; const char* qsrc[2]; int poff[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int r = (wid * 2 + i) * 16 + prow;
+        const int ks = pslot ^ ((r >> 2) & 3);
+        xsrc[i] = reinterpret_cast<const char*>(Xh) + (tile * (long)(ldh >> 5) * 256 + r) * 64 + ks * 16;
+        qsrc[i] = reinterpret_cast<const char*>(Qh + (long)r * ldh) + ks * 16;
+        poff[i] = (wid * 2 + i) * 1024;
+    }
+    auto stage = [&](int kt) {
+        unsigned char* sb = smem + (kt % R5_STAGES) * R5_STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + (long)kt * R5_XBYTES),
+                                             (__attribute__((address_space(3))) void*)(sb + poff[i]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc[i] + (long)kt * 64),
+                                             (__attribute__((address_space(3))) void*)(sb + R5_XBYTES + poff[i]), 16, 0, 0);
+        }
+    };
+    const int nk = ldh / R5_K;
+#pragma unroll
+    for (int s = 0; s < R5_STAGES - 1; s++) if (s < nk) stage(s);
+    const int arow = wm * 128 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = lane >> 5;
+    for (int kt = 0; kt < nk; kt++) {
+        // stage kt must have landed; this wave issued 4 loads per stage, the younger stages may stay in flight
+        const int younger = min(nk - 1 - kt, R5_STAGES - 2);
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave's pieces of stage kt landed; the buffer of stage kt-1 is free
+        if (kt + R5_STAGES - 1 < nk) stage(kt + R5_STAGES - 1);
+        const unsigned char* xb = smem + (kt % R5_STAGES) * R5_STAGE_BYTES;
+        const unsigned char* qb = xb + R5_XBYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            half8 a[4], b[2];
+#pragma unroll
+            for (int mb = 0; mb < 4; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz32_off(arow + mb * 32, ks * 2 + khalf));
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) b[nb] = *reinterpret_cast<const half8*>(qb + swz32_off(brow + nb * 32, ks * 2 + khalf));
+#pragma unroll
+            for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+                for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+        }
+    }
+    __syncthreads();   // all LDS reads done before the epilogue reuses the ring
+    scan_epilogue<MODE>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ping-pong variant: the ring kernel's data flow, but the two waves that share a SIMD (waves w and w+4: row halves 0 / 1 of
+// the tile) run half a step out of phase — while one issues its 16 MFMAs of K slab k from registers, the other is in its
+// load segment (4 LDS-DMA pieces of slab k+4, 12 ds_read_b128 of its own fragments for slab k). Every segment ends in
+// an s_barrier. In the in-phase kernels both waves of a SIMD issue DMA (60-185 cycles per piece, MI355X_MICROARCH.md) and
+// fragment reads at the same time and the matrix pipe idles meanwhile: 35 % MFMA-busy at 0.5 ms, independent of ring depth.
+//   slot 2k   : group 0 LOAD(k)     | group 1 COMPUTE(k-1)
+//   slot 2k+1 : group 0 COMPUTE(k)  | group 1 LOAD(k)
+// Slab j is complete (all 8 waves' pieces landed) after the barrier that ends slot 2j-1; group 0 reads it in slot 2j,
+// group 1 in slot 2j+1, and its ring buffer is rewritten (slab j+5) no earlier than slot 2j+2.
+// ------------------------------------------------------------------------------------------------
+constexpr int PP_AHEAD = R5_STAGES - 1;     // slabs requested ahead of the one being read
+#define PP_WAIT_YOUNGER(y) do { if ((y) >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); \
+                                else if ((y) == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
+                                else if ((y) == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); \
+                                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+
+template <int MODE>
+__global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_pp_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
+                                                                      const _Float16* __restrict__ Qh /*256 x ldh*/,
+                                                                      const float* __restrict__ rn, const float* __restrict__ qn,
+                                                                      const unsigned char* __restrict__ elig,
+                                                                      float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;      // wm = phase group
+    long tile;
+    {
+        const long L = blockIdx.x, nx = 8;
+        const long q = n_tiles / nx, r = n_tiles % nx, xcd = L % nx, idx = L / nx;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        if (idx >= (xcd < r ? q + 1 : q)) return;
+    }
+    const long row0 = tile * FB_M;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    const int prow = lane >> 2, pslot = lane & 3;
+    const char* xsrc[2]; const char* qsrc[2]; int poff[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int r = (wid * 2 + i) * 16 + prow;
+        const int ks = pslot ^ ((r >> 2) & 3);
+        xsrc[i] = reinterpret_cast<const char*>(Xh) + (tile * (long)(ldh >> 5) * 256 + r) * 64 + ks * 16;
+        qsrc[i] = reinterpret_cast<const char*>(Qh + (long)r * ldh) + ks * 16;
+        poff[i] = (wid * 2 + i) * 1024;
+    }
+    auto stage = [&](int kt) {
+        unsigned char* sb = smem + (kt % R5_STAGES) * R5_STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + (long)kt * R5_XBYTES),
+                                             (__attribute__((address_space(3))) void*)(sb + poff[i]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc[i] + (long)kt * 64),
+                                             (__attribute__((address_space(3))) void*)(sb + R5_XBYTES + poff[i]), 16, 0, 0);
+        }
+    };
+    const int nk = ldh / R5_K;
+    const int arow = wm * 128 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = lane >> 5;
+    half8 fa[2][4], fb[2][2];
+    auto read_frags = [&](int kt) {
+        const unsigned char* xb = smem + (kt % R5_STAGES) * R5_STAGE_BYTES;
+        const unsigned char* qb = xb + R5_XBYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+            for (int mb = 0; mb < 4; mb++) fa[ks][mb] = *reinterpret_cast<const half8*>(xb + swz32_off(arow + mb * 32, ks * 2 + khalf));
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) fb[ks][nb] = *reinterpret_cast<const half8*>(qb + swz32_off(brow + nb * 32, ks * 2 + khalf));
+        }
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+                for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][mb], fb[ks][nb], acc[mb][nb], 0, 0, 0);
+    };
+    // end of an odd slot 2k+1: slab k+1 must have landed (this wave's pieces); younger slabs stay in flight
+    auto end_odd_slot = [&](int k) {
+        if (k + 1 < nk) { const int younger = min(nk - 1, k + PP_AHEAD) - (k + 1); PP_WAIT_YOUNGER(younger); }
+        __builtin_amdgcn_s_barrier();
+    };
+
+#pragma unroll
+    for (int s = 0; s < PP_AHEAD; s++) if (s < nk) stage(s);
+    { const int younger = min(nk - 1, PP_AHEAD - 1); PP_WAIT_YOUNGER(younger); }
+    __builtin_amdgcn_s_barrier();                      // slab 0 landed
+    if (wm == 0) {
+        for (int k = 0; k < nk; k++) {
+            // slot 2k: LOAD(k)
+            if (k + PP_AHEAD < nk) stage(k + PP_AHEAD);
+            read_frags(k);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // slot 2k+1: COMPUTE(k)
+            __builtin_amdgcn_sched_barrier(0);
+            compute();
+            __builtin_amdgcn_sched_barrier(0);
+            end_odd_slot(k);
+        }
+        __builtin_amdgcn_s_barrier();                  // slot 2nk (group 1's last compute)
+    } else {
+        __builtin_amdgcn_s_barrier();                  // slot 0: nothing to do yet
+        for (int k = 0; k < nk; k++) {
+            // slot 2k+1: LOAD(k)
+            if (k + PP_AHEAD < nk) stage(k + PP_AHEAD);
+            read_frags(k);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            end_odd_slot(k);
+            // slot 2k+2: COMPUTE(k)
+            __builtin_amdgcn_sched_barrier(0);
+            compute();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    __syncthreads();   // all LDS reads done before the epilogue reuses the ring
+    scan_epilogue<MODE>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
+}
+
+// ------------------------------------------------------------------------------------------------
+// persistent variant: one workgroup per CU walks its share of the row tiles; the LDS ring (4 x 32 KiB) never drains —
+// the slabs of the NEXT tile are already in flight while the current tile's epilogue runs, and the per-tile workgroup
+// launch (the 128-160 KiB of LDS make consecutive one-shot workgroups of a CU strictly serial: ~6 us of dispatch +
+// pipeline fill per tile, a quarter of the one-shot kernel's time with memory traffic removed) is paid once.
+// Timing breakdown of the one-shot kernel at 1M x 768, B = 256 (compile-time knock-outs, COMET_SCAN_DEBUG_SKIP):
+//   all of it 0.53 ms | no DMA 0.35 | no DMA, no epilogue 0.26 | + no fragment reads, no barriers 0.257 (MFMA only;
+//   0.157 at the 2.5 PF/s peak).
+// ------------------------------------------------------------------------------------------------
+constexpr int P7_STAGES = 4, P7_AHEAD = P7_STAGES - 1, P7_EPI_OFF = P7_STAGES * R5_STAGE_BYTES;
+
+template <int MODE, int DBG>
+__global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_persist_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
+                                                                           const _Float16* __restrict__ Qh /*256 x ldh*/,
+                                                                           const float* __restrict__ rn, const float* __restrict__ qn,
+                                                                           const unsigned char* __restrict__ elig,
+                                                                           float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    // XCD x = blockIdx % 8 owns a contiguous chunk of tiles; its workgroups (slots) take the chunk's tiles round-robin,
+    // so that the CUs of an XCD stream neighbouring rows at the same time
+    const int nx = 8, xcd = blockIdx.x % nx, slot = blockIdx.x / nx, slots = gridDim.x / nx;
+    const long tq = n_tiles / nx, tr = n_tiles % nx;
+    const long chunk0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const long chunk_n = xcd < tr ? tq + 1 : tq;
+    const long my_tiles = slot < chunk_n ? (chunk_n - slot + slots - 1) / slots : 0;
+    if (my_tiles == 0) return;
+    const int nk = ldh / R5_K;
+    const long G = my_tiles * nk;                          // slabs this workgroup streams
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    const int prow = lane >> 2, pslot = lane & 3;
+    long xoff[2]; const char* qsrc[2]; int poff[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int r = (wid * 2 + i) * 16 + prow;
+        const int ks = pslot ^ ((r >> 2) & 3);
+        xoff[i] = (long)r * 64 + ks * 16;
+        qsrc[i] = reinterpret_cast<const char*>(Qh + (long)r * ldh) + ks * 16;
+        poff[i] = (wid * 2 + i) * 1024;
+    }
+    const char* Xb = reinterpret_cast<const char*>(Xh);
+    const long tile_bytes = (long)(ldh >> 5) * R5_XBYTES;
+    // issue state: slab counter gi -> (tile ordinal, kt) kept incrementally (no divisions in the loop)
+    long gi = 0; long gi_tile = chunk0 + slot; int gi_kt = 0;
+    auto stage_next = [&]() {
+        unsigned char* sb = smem + (int)(gi % P7_STAGES) * R5_STAGE_BYTES;
+        const char* xs = Xb + gi_tile * tile_bytes + (long)gi_kt * R5_XBYTES;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            if constexpr (!(DBG & 1))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + xoff[i]),
+                                             (__attribute__((address_space(3))) void*)(sb + poff[i]), 16, 0, 0);
+            if constexpr (!(DBG & 2))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc[i] + (long)gi_kt * 64),
+                                             (__attribute__((address_space(3))) void*)(sb + R5_XBYTES + poff[i]), 16, 0, 0);
+        }
+        gi++; gi_kt++;
+        if (gi_kt == nk) { gi_kt = 0; gi_tile += slots; }
+    };
+#pragma unroll
+    for (int s = 0; s < P7_AHEAD; s++) if (gi < G) stage_next();
+    const int arow = wm * 128 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = lane >> 5;
+    long tile = chunk0 + slot; int kt = 0;
+    for (long g = 0; g < G; g++) {
+        const long younger = min(G - 1 - g, (long)(P7_AHEAD - 1));
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // slab g landed for every wave; the buffer of slab g-1 is free
+        if (gi < G) stage_next();
+        const unsigned char* xb = smem + (int)(g % P7_STAGES) * R5_STAGE_BYTES;
+        const unsigned char* qb = xb + R5_XBYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            half8 a[4], b[2];
+#pragma unroll
+            for (int mb = 0; mb < 4; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz32_off(arow + mb * 32, ks * 2 + khalf));
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) b[nb] = *reinterpret_cast<const half8*>(qb + swz32_off(brow + nb * 32, ks * 2 + khalf));
+#pragma unroll
+            for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+                for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+        }
+        if (++kt == nk) {
+            // tile finished: epilogue from registers + a private LDS scratch beyond the ring (the ring keeps filling)
+            if constexpr ((DBG & 4) != 0) {
+                float s = 0.0f;
+#pragma unroll
+                for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+                    for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) s += acc[mb][nb][e];
+                if (s == 12345.678f) S0[tid] = s;
+            } else
+            scan_epilogue<MODE>(acc, smem + P7_EPI_OFF, tile, tile * FB_M, n, rn, qn, elig, S0, ldS, bound, ldB);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores + the slabs requested before the epilogue (long landed)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+            kt = 0; tile += slots;
+        }
+    }
+}
+
 void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, int /*nq_used*/, const float* rn, const float* qn,
                           const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB) {
     const long n_tiles = ceil_div(n, FB_M);
     ProfScope ps(c, "flat_scan_f16");
-    const size_t lds = 2 * 65536;
     const long grid = round_up(n_tiles, 8);
-    if (mode == 0) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        flat_scan_f16_kernel<0><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
-    } else {
-        HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        flat_scan_f16_kernel<1><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+    static const int variant = [] { const char* e = getenv("COMET_SCAN_VARIANT"); return e ? atoi(e) : 7; }();
+    if (variant == 7) {
+        const size_t lds = (size_t)P7_EPI_OFF + 8192;
+        const long g7 = std::min<long>(round_up(n_tiles, 8), (long)c->prop.multiProcessorCount / 8 * 8);
+        static const int dbg7 = [] { const char* e = getenv("COMET_SCAN_DEBUG_SKIP"); return e ? atoi(e) : 0; }();   // timing experiments only
+#define SCAN7(M, D) do { HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_persist_kernel<M, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        flat_scan_f16_persist_kernel<M, D><<<dim3((unsigned)g7), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles); } while (0)
+        if (mode != 0) SCAN7(1, 0);
+        else switch (dbg7) { case 3: SCAN7(0, 3); break; case 7: SCAN7(0, 7); break; case 4: SCAN7(0, 4); break; case 1: SCAN7(0, 1); break; case 2: SCAN7(0, 2); break; default: SCAN7(0, 0); break; }
+#undef SCAN7
+        LAUNCH_CHECK();
+        return;
     }
+    if (variant == 6) {
+        const size_t lds = (size_t)R5_STAGES * R5_STAGE_BYTES;
+        if (mode == 0) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            flat_scan_f16_pp_kernel<0><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        } else {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_pp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            flat_scan_f16_pp_kernel<1><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        }
+        LAUNCH_CHECK();
+        return;
+    }
+    if (variant == 5) {
+        const size_t lds = (size_t)R5_STAGES * R5_STAGE_BYTES;
+        if (mode == 0) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_ring_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            flat_scan_f16_ring_kernel<0><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        } else {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_ring_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            flat_scan_f16_ring_kernel<1><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        }
+        LAUNCH_CHECK();
+        return;
+    }
+    const size_t lds = 2 * 65536;
+    static const int dbg = [] { const char* e = getenv("COMET_SCAN_DEBUG_SKIP"); return e ? atoi(e) : 0; }();   // timing experiments only (results invalid)
+#define SCAN8(M) do { HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<M, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        flat_scan_f16_kernel<M, 0, true><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles); } while (0)
+    if (variant == 8) { if (mode != 0) SCAN8(1); else SCAN8(0); LAUNCH_CHECK(); return; }
+#undef SCAN8
+#define SCAN1(M, D) do { HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<M, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        flat_scan_f16_kernel<M, D><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles); } while (0)
+    if (mode != 0) SCAN1(1, 0);
+    else switch (dbg) {
+        case 3: SCAN1(0, 3); break; case 7: SCAN1(0, 7); break; case 15: SCAN1(0, 15); break; case 31: SCAN1(0, 31); break;
+        case 4: SCAN1(0, 4); break; case 1: SCAN1(0, 1); break; case 2: SCAN1(0, 2); break;
+        default: SCAN1(0, 0); break;
+    }
+#undef SCAN1
     LAUNCH_CHECK();
 }
 int flat_fast_tile_rows() { return FB_M; }
@@ -366,6 +822,332 @@ __global__ __launch_bounds__(256) void prep_queries_fast_kernel(const float* __r
 }
 void launch_prep_queries_fast(Ctx* c, const float* Qp, int B, int ld, int dim, void* Qh, int ldh, float* qn, float* err_abs, int mode, float xmax_norm2) {
     prep_queries_fast_kernel<<<dim3(FB_N / 4), dim3(256), 0, c->stream>>>(Qp, B, ld, dim, (_Float16*)Qh, ldh, qn, err_abs, mode, xmax_norm2);
+    LAUNCH_CHECK();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// fused post-scan stage: ONE workgroup per query does what used to be five launches (K-th tile key, candidate
+// collection, exact rescoring, final selection, row gather). Each of those is a short, latency-bound, one-workgroup-
+// per-query kernel; chained through HBM they cost ~0.2 ms per 256-query batch, a quarter of the whole search step.
+//   1. tile keys of the query -> LDS; kappa = exact K-th smallest (three radix passes, 12+12+8 bits)
+//   2. tau = kappa + 2E (+ key-packing slack); candidates = emitted rows with key <= tau, plus every row of a tile whose
+//      third-smallest key (bound) is <= tau; more than POST_CAP -> overflow flag (the host re-runs that query strictly)
+//   3. candidates sorted by row (canonical tie order), exact distances in the reference's float32 order: a wave takes
+//      32 candidates, stages 32-float slices of their products in LDS, lanes 0..31 run the serial sums
+//   4. (score, row) sort, threshold + sanitizeK, rows / scores / count written
+// ------------------------------------------------------------------------------------------------
+constexpr int POST_THREADS = 1024, POST_WAVES = 16, POST_MAXKEYS = 16384, POST_CAP = 4096, POST_CPW = 32, POST_CHUNK = 32;
+constexpr int POST_LPC = POST_CHUNK / 4, POST_CPI = 64 / POST_LPC, POST_NJ = POST_CPW / POST_CPI;   // lanes per candidate slice, candidates per load instruction, instructions per slice
+constexpr size_t POST_LDS = (size_t)POST_MAXKEYS * 4 + 4096 * 4 + (size_t)POST_CAP * 4 + (size_t)POST_CAP * 4;   // keys|hist , list , scores
+
+__device__ __forceinline__ unsigned pf2key(unsigned u) { return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ unsigned pkey2f(unsigned k) { return (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; }
+
+// block-wide (1024 threads): bin of a 4096-bin LDS histogram holding the rank-th element (1-based) and the count below it
+__device__ __forceinline__ void post_find_bin(const unsigned* hist, int rank, unsigned* wsum, int* bin_out, int* before_out) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const unsigned h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+    const unsigned mine = h0 + h1 + h2 + h3;
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { unsigned y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    unsigned before = incl - mine;
+    for (int i = 0; i < w; i++) before += wsum[i];
+    const unsigned r = (unsigned)rank;
+    if (before < r && before + mine >= r) {
+        unsigned run = before; int b = 4 * t;
+        if (run + h0 >= r) { b = 4 * t; }
+        else { run += h0; if (run + h1 >= r) { b = 4 * t + 1; } else { run += h1; if (run + h2 >= r) { b = 4 * t + 2; } else { run += h2; b = 4 * t + 3; } } }
+        *bin_out = b; *before_out = (int)run;
+    }
+    __syncthreads();
+}
+template <typename T>
+__device__ __forceinline__ void post_bitonic(T* sm, int n2) {
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += POST_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) { const T a = sm[i], b = sm[ixj]; if ((a > b) == ((i & k) == 0)) { sm[i] = b; sm[ixj] = a; } }
+            }
+            __syncthreads();
+        }
+}
+
+// sort n distinct values (n <= n2, tail padded with all-ones) ascending: counting rank for short lists (one pass of
+// broadcast LDS reads, no barrier ladder), bitonic network otherwise. `tmp` must hold n values.
+template <typename T>
+__device__ __forceinline__ void post_sort(T* sm, int n, int n2, T* tmp) {
+    if (n <= 1024) {
+        const int t = threadIdx.x;
+        T me = 0; int rank = 0;
+        if (t < n) {
+            me = sm[t];
+            for (int j = 0; j < n; j++) rank += (sm[j] < me) ? 1 : 0;
+        }
+        __syncthreads();
+        if (t < n) tmp[rank] = me;
+        __syncthreads();
+        if (t < n) sm[t] = tmp[t];
+        __syncthreads();
+    } else {
+        post_bitonic(sm, n2);
+    }
+}
+// append `v` to list[] for the lanes with `want`, one LDS atomic per wave
+__device__ __forceinline__ void post_append(bool want, unsigned v, unsigned* list, int* counter, int cap) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63, leader = __builtin_ctzll(m);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, (int)__builtin_popcountll(m));
+    base = __shfl(base, leader, 64);
+    if (want) { const int s = base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull)); if (s < cap) list[s] = v; }
+}
+
+template <int METRIC, int STOP = 0>
+__global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __restrict__ S0, long ldS, const float* __restrict__ bound, long ldB,
+                                                                 long n_tiles, long n, const unsigned char* __restrict__ elig,
+                                                                 const float* __restrict__ err_abs, int K /*requested, sanitised against n*/, int kappa_rank /*0: tau = inf*/,
+                                                                 float thr, const float* __restrict__ X, int ld, const float* __restrict__ Qp,
+                                                                 unsigned* __restrict__ out_rows, float* __restrict__ out_scores, int* __restrict__ out_counts,
+                                                                 int k_cap, int* __restrict__ overflow, int* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    unsigned* keys = reinterpret_cast<unsigned*>(psm);                       // [POST_MAXKEYS]; later the rescoring slices / sort buffer
+    unsigned* hist = keys + POST_MAXKEYS;                                    // [4096]
+    unsigned* lst = hist + 4096;                                             // [POST_CAP] candidate rows
+    float* sc = reinterpret_cast<float*>(lst + POST_CAP);                    // [POST_CAP] exact scores
+    __shared__ unsigned wsum[16];
+    __shared__ int s_bin, s_before, s_cnt, s_exp, s_valid;
+    const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int nkeys = (int)(2 * n_tiles);
+    const float* s0 = S0 + (long)q * ldS;
+    const float INF = __builtin_inff();
+    if (t == 0) { s_cnt = 0; s_exp = 0; s_valid = 0; }
+    // ---- 1. kappa ----
+    float tau = INF;
+    if (kappa_rank > 0) {
+        int mine = 0;
+        for (int i = t; i < nkeys; i += POST_THREADS) { const float v = s0[i]; keys[i] = __float_as_uint(v); if (v != INF) mine++; }   // keys >= 0: bit order = value order
+        __syncthreads();
+        if (mine) atomicAdd(&s_valid, mine);
+        __syncthreads();
+        if (s_valid >= kappa_rank) {
+            // The keys of a query crowd into a few exponent bins, so radix histograms serialise on LDS atomics. Bin them
+            // LINEARLY over [min, max] instead (monotone: float subtract, multiply and floor are), locate the bin of the
+            // K-th smallest, and rank the handful of keys inside it directly.
+            float lo = INF, hi = 0.0f;
+            for (int i = t; i < nkeys; i += POST_THREADS) { const float v = __uint_as_float(keys[i]); if (v != INF) { lo = fminf(lo, v); hi = fmaxf(hi, v); } }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
+            float* wlo = reinterpret_cast<float*>(hist); float* whi = wlo + 16;
+            if (lane == 0) { wlo[wid] = lo; whi[wid] = hi; }
+            __syncthreads();
+            for (int w = 0; w < POST_WAVES; w++) { lo = fminf(lo, wlo[w]); hi = fmaxf(hi, whi[w]); }
+            __syncthreads();
+            const float scale = hi > lo ? 4095.0f / (hi - lo) : 0.0f;
+            auto bin_of = [&](unsigned k) { const int bq = (int)((__uint_as_float(k) - lo) * scale); return bq < 0 ? 0 : (bq > 4095 ? 4095 : bq); };
+            for (int i = t; i < 4096; i += POST_THREADS) hist[i] = 0;
+            __syncthreads();
+            for (int i = t; i < nkeys; i += POST_THREADS) { const unsigned k = keys[i]; if (k != 0x7F800000u) atomicAdd(&hist[bin_of(k)], 1u); }
+            __syncthreads();
+            post_find_bin(hist, kappa_rank, wsum, &s_bin, &s_before);
+            const int kbin = s_bin, rank_in = kappa_rank - s_before, members = (int)hist[kbin];
+            __syncthreads();
+            unsigned kap = 0;
+            if (members <= 1024) {
+                unsigned* mem = lst;                      // the candidate list is not in use yet
+                if (t == 0) s_cnt = 0;
+                __syncthreads();
+                for (int i = t; i < nkeys; i += POST_THREADS) { const unsigned k = keys[i]; if (k != 0x7F800000u && bin_of(k) == kbin) mem[atomicAdd(&s_cnt, 1)] = k; }
+                __syncthreads();
+                if (t < members) {
+                    const unsigned me = mem[t]; int less = 0;
+                    for (int j = 0; j < members; j++) { const unsigned o = mem[j]; less += (o < me || (o == me && j < t)) ? 1 : 0; }
+                    if (less == rank_in - 1) hist[0] = me;    // exactly one thread
+                }
+                __syncthreads();
+                kap = hist[0];
+                __syncthreads();
+                if (t == 0) s_cnt = 0;
+            } else {
+                // mass ties inside one bin: exact radix selection restricted to the bin's members
+                unsigned prefix = 0, mask = 0; int rank = rank_in;
+                const int shifts[3] = {20, 8, 0}, nbits[3] = {12, 12, 8};
+                for (int p = 0; p < 3; p++) {
+                    for (int i = t; i < 4096; i += POST_THREADS) hist[i] = 0;
+                    __syncthreads();
+                    const unsigned bm = (1u << nbits[p]) - 1u;
+                    for (int i = t; i < nkeys; i += POST_THREADS) {
+                        const unsigned k = keys[i];
+                        if (k != 0x7F800000u && bin_of(k) == kbin && (k & mask) == prefix) atomicAdd(&hist[(k >> shifts[p]) & bm], 1u);
+                    }
+                    __syncthreads();
+                    post_find_bin(hist, rank, wsum, &s_bin, &s_before);
+                    prefix |= ((unsigned)s_bin) << shifts[p]; mask |= bm << shifts[p]; rank -= s_before;
+                    __syncthreads();
+                }
+                kap = prefix;
+            }
+            const float kappa = __uint_as_float(kap);
+            tau = kappa + 2.0f * err_abs[q] + 1.0e-4f * fabsf(kappa) + 1e-30f;   // 1e-4 ~ 3 * 2^-15: key packing slack, both sides
+        }
+    }
+    __syncthreads();
+    if constexpr (STOP == 1) { if (tau == 12345.0f) out_counts[q] = 1; return; }
+    // ---- 2. candidates ----
+    const float* bd = bound + (long)q * ldB;
+    for (long t0 = 0; t0 < n_tiles; t0 += POST_THREADS) {
+        const long tl = t0 + t;
+        const bool live = tl < n_tiles;
+        const bool expand = live && bd[tl] <= tau;
+        // rare: some non-emitted row of a tile may qualify -> take the whole tile; the wave does it together, one tile at a time
+        unsigned long long em = __ballot(expand);
+        while (em) {
+            const int src = __builtin_ctzll(em); em &= em - 1ull;
+            const long te = t0 + (t & ~63) + src;      // tile of lane `src`
+            if (lane == src) atomicAdd(&s_exp, 1);
+            for (int j = lane; j < FB_M; j += 64) {
+                const long r = te * FB_M + j;
+                post_append(r < n && (!elig || elig[r]), (unsigned)r, lst, &s_cnt, POST_CAP);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float key = (live && !expand) ? s0[2 * tl + e] : INF;
+            post_append(key <= tau && key != INF, (unsigned)(tl * FB_M + (__float_as_uint(key) & 0xFFu)), lst, &s_cnt, POST_CAP);
+        }
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    if (cnt > POST_CAP) {                              // empty row; the host re-runs this query on the strict path
+        for (int i = t; i < k_cap; i += POST_THREADS) { out_rows[(long)q * k_cap + i] = 0xFFFFFFFFu; out_scores[(long)q * k_cap + i] = 0.0f; }
+        if (t == 0) { out_counts[q] = 0; overflow[q] = 1; if (stats) atomicAdd(&stats[1], 1); }
+        return;
+    }
+    int n2 = 64; while (n2 < cnt) n2 <<= 1;
+    for (int i = cnt + t; i < n2; i += POST_THREADS) lst[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    if constexpr (STOP == 2) { if (cnt == 123456) out_counts[q] = 1; return; }
+    post_sort(lst, cnt, n2, hist);                     // ascending row = canonical tie order of the strict path (hist: 16 KiB scratch)
+    if constexpr (STOP == 3) { if (lst[0] == 123456) out_counts[q] = 1; return; }
+    // ---- 3. exact distances ----
+    float* terms = reinterpret_cast<float*>(psm) + wid * (POST_CPW * POST_CHUNK);   // 4 KiB per wave over the key area
+    const float* __restrict__ qv = Qp + (long)q * ld;
+    const int sub = lane / POST_LPC, lp = lane % POST_LPC;   // a load instruction covers POST_CPI candidates x POST_CHUNK floats
+    for (int c0 = wid * POST_CPW; c0 < cnt; c0 += POST_WAVES * POST_CPW) {
+        const float* xr[POST_NJ];
+#pragma unroll
+        for (int j = 0; j < POST_NJ; j++) { const int ci = c0 + j * POST_CPI + sub; xr[j] = X + (long)lst[ci < cnt ? ci : c0] * ld + lp * 4; }
+        float acc = 0.0f;
+        // row slices are random 128-byte reads: keep POST_DEPTH slices per candidate in flight
+        constexpr int POST_DEPTH = 3;
+        f32x4v xb[POST_DEPTH][POST_NJ];
+        const int nsl = ld / POST_CHUNK;                 // ld is a multiple of 32 = POST_CHUNK
+#pragma unroll
+        for (int d = 0; d < POST_DEPTH; d++)
+#pragma unroll
+            for (int j = 0; j < POST_NJ; j++) xb[d][j] = *reinterpret_cast<const f32x4v*>(xr[j] + min(d, nsl - 1) * POST_CHUNK);
+        for (int s0i = 0; s0i < nsl; s0i += POST_DEPTH) {
+#pragma unroll
+            for (int d = 0; d < POST_DEPTH; d++) {
+                const int sl = s0i + d;
+                if (sl < nsl) {                          // wave-uniform
+                    f32x4v xv[POST_NJ];
+#pragma unroll
+                    for (int j = 0; j < POST_NJ; j++) xv[j] = xb[d][j];
+                    const int nx = min(sl + POST_DEPTH, nsl - 1);     // refill this slot (past the end: a harmless re-read)
+#pragma unroll
+                    for (int j = 0; j < POST_NJ; j++) xb[d][j] = *reinterpret_cast<const f32x4v*>(xr[j] + nx * POST_CHUNK);
+                    const f32x4v qq = *reinterpret_cast<const f32x4v*>(qv + sl * POST_CHUNK + lp * 4);
+#pragma unroll
+                    for (int j = 0; j < POST_NJ; j++) {
+                        f32x4v tt;
+                        if constexpr (METRIC == COMET_COSINE) { tt[0] = qq[0] * xv[j][0]; tt[1] = qq[1] * xv[j][1]; tt[2] = qq[2] * xv[j][2]; tt[3] = qq[3] * xv[j][3]; }
+                        else {
+                            const float d0 = qq[0] - xv[j][0], d1 = qq[1] - xv[j][1], d2 = qq[2] - xv[j][2], d3 = qq[3] - xv[j][3];
+                            tt[0] = d0 * d0; tt[1] = d1 * d1; tt[2] = d2 * d2; tt[3] = d3 * d3;
+                        }
+                        *reinterpret_cast<f32x4v*>(&terms[(j * POST_CPI + sub) * POST_CHUNK + lp * 4]) = tt;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < POST_CPW) {
+                        const float* tp = terms + lane * POST_CHUNK;
+#pragma unroll
+                        for (int i = 0; i < POST_CHUNK; i += 4) {
+                            const f32x4v p = *reinterpret_cast<const f32x4v*>(tp + i);
+                            acc = acc + p[0]; acc = acc + p[1]; acc = acc + p[2]; acc = acc + p[3];
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (lane < POST_CPW && c0 + lane < cnt) {
+            float v;
+            if constexpr (METRIC == COMET_COSINE) { float a = acc; if (a > 1.0f) a = 1.0f; else if (a < -1.0f) a = -1.0f; v = 1.0f - a; }   // distance.go:209-213
+            else if constexpr (METRIC == COMET_L2) v = (float)__builtin_sqrt((double)acc);
+            else v = acc;
+            sc[c0 + lane] = v;
+        }
+    }
+    __syncthreads();
+    if constexpr (STOP == 4) { if (sc[0] == 123456.0f) out_counts[q] = 1; return; }
+    // ---- 4. final order: (score, row position) ----
+    unsigned long long* comp = reinterpret_cast<unsigned long long*>(psm);   // POST_CAP composites (32 KiB) over the slices
+    int mine = 0;
+    for (int i = t; i < n2; i += POST_THREADS) {
+        unsigned long long v = ~0ull;
+        if (i < cnt) {
+            const unsigned bits = __float_as_uint(sc[i]);
+            const bool ok = !(thr > 0.0f && sc[i] > thr);                    // `s.threshold > 0 && dist > s.threshold`
+            if (ok) { v = ((unsigned long long)pf2key(bits) << 32) | (unsigned)i; mine++; }
+        }
+        comp[i] = v;
+    }
+    if (t == 0) s_valid = 0;
+    __syncthreads();
+    if (mine) atomicAdd(&s_valid, mine);
+    __syncthreads();
+    post_sort(comp, cnt, n2, comp + POST_CAP);           // second half of the 64 KiB key area as scratch
+    const int valid = s_valid;
+    const int kq = (K <= 0 || K > valid) ? valid : K;                          // sanitizeK limiter.go:12-17
+    const int nw = kq < k_cap ? kq : k_cap;
+    for (int i = t; i < k_cap; i += POST_THREADS) {
+        if (i < nw) {
+            const unsigned long long cc = comp[i];
+            out_rows[(long)q * k_cap + i] = lst[(unsigned)(cc & 0xFFFFFFFFull)];
+            out_scores[(long)q * k_cap + i] = __uint_as_float(pkey2f((unsigned)(cc >> 32)));
+        } else {
+            out_rows[(long)q * k_cap + i] = 0xFFFFFFFFu;
+            out_scores[(long)q * k_cap + i] = 0.0f;
+        }
+    }
+    if (t == 0) {
+        out_counts[q] = kq; overflow[q] = 0;
+        if (stats) { atomicAdd(&stats[0], cnt); atomicAdd(&stats[2], s_exp); }
+    }
+}
+bool flat_post_usable(int64_t n_tiles) { return 2 * n_tiles <= POST_MAXKEYS; }
+void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const float* bound, int64_t ldB, int64_t n_tiles, int64_t n, const uint8_t* elig,
+                      const float* err_abs, int K, int kappa_rank, float thr, const float* X, int ld, const float* Qp, int B,
+                      uint32_t* out_rows, float* out_scores, int32_t* out_counts, int k_cap, int32_t* overflow, int32_t* stats) {
+    if (B <= 0) return;
+    ProfScope ps(c, "flat_post");
+#define POST(M) do { HIP_CHECK(hipFuncSetAttribute((const void*)flat_post_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POST_LDS)); \
+        flat_post_kernel<M><<<dim3(B), dim3(POST_THREADS), POST_LDS, c->stream>>>(S0, ldS, bound, ldB, n_tiles, n, elig, err_abs, K, kappa_rank, thr, X, ld, Qp, \
+                                                                                 out_rows, out_scores, out_counts, k_cap, overflow, stats); } while (0)
+    static const int stop = [] { const char* e = getenv("COMET_POST_DEBUG_STOP"); return e ? atoi(e) : 0; }();   // timing experiments only
+#define POSTS(S) do { HIP_CHECK(hipFuncSetAttribute((const void*)flat_post_kernel<COMET_COSINE, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POST_LDS)); \
+        flat_post_kernel<COMET_COSINE, S><<<dim3(B), dim3(POST_THREADS), POST_LDS, c->stream>>>(S0, ldS, bound, ldB, n_tiles, n, elig, err_abs, K, kappa_rank, thr, X, ld, Qp, \
+                                                                                 out_rows, out_scores, out_counts, k_cap, overflow, stats); } while (0)
+    if (stop == 1) POSTS(1); else if (stop == 2) POSTS(2); else if (stop == 3) POSTS(3); else if (stop == 4) POSTS(4); else
+    switch (metric) { case COMET_L2: POST(COMET_L2); break; case COMET_L2SQ: POST(COMET_L2SQ); break; default: POST(COMET_COSINE); break; }
+#undef POSTS
+#undef POST
     LAUNCH_CHECK();
 }
 
