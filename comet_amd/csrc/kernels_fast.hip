@@ -160,6 +160,82 @@ __device__ __forceinline__ void scan_epilogue(f32x16 (&acc)[4][2], unsigned char
     }
 }
 
+// ---- the same epilogue for the producer/consumer kernel: its one workgroup barrier is a raw s_barrier that the producer waves match ----
+template <int MODE>
+__device__ __forceinline__ void scan_epilogue_pc(f32x16 (&acc)[4][2], unsigned char* smem, long tile, long row0, long n,
+                                              const float* __restrict__ rn, const float* __restrict__ qn, const unsigned char* __restrict__ elig,
+                                              float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3, khalf = lane >> 5;
+    // ---- epilogue: per (query, tile) two smallest packed keys + third smallest (bound) ----
+    // C layout of the 32x32 MFMA: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    const float INF = __builtin_inff();
+    float* trip = reinterpret_cast<float*>(smem);     // [wm][query 256][3]  (6 KiB), LDS is free now
+    const int lane_rowbits = 4 * khalf + 128 * wm;    // bits 2 and 7 of the row-in-tile
+    const long nvalid = n - row0;
+    const bool check = (nvalid < FB_M) || (elig != nullptr);   // workgroup-uniform
+    // per-lane 64-bit mask of usable rows (bit mb*16+e), only built on the slow path
+    unsigned long long okmask = ~0ull;
+    if (check) {
+        okmask = 0ull;
+        for (int mb = 0; mb < 4; mb++)
+            for (int e = 0; e < 16; e++) {
+                const long r = mb * 32 + (e & 3) + 8 * (e >> 2) + lane_rowbits;
+                bool ok = r < nvalid;
+                if (ok && elig) ok = elig[row0 + r] != 0;
+                if (ok) okmask |= 1ull << (mb * 16 + e);
+            }
+    }
+    float rnv[MODE == 1 ? 64 : 1];
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                long r = row0 + mb * 32 + (e & 3) + 8 * (e >> 2) + lane_rowbits;
+                rnv[mb * 16 + e] = rn[r < n ? r : n - 1];
+            }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) {
+        const int q = wn * 64 + nb * 32 + (lane & 31);
+        float qnv = 0.0f;
+        if constexpr (MODE == 1) qnv = qn[q];
+        float t0 = INF, t1 = INF, t2 = INF;
+#pragma unroll
+        for (int mb = 0; mb < 4; mb++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int rconst = mb * 32 + (e & 3) + 8 * (e >> 2);      // compile-time part of the row
+                float a;
+                if constexpr (MODE == 0) a = 1.0f - acc[mb][nb][e];
+                else a = (qnv + rnv[mb * 16 + e]) - 2.0f * acc[mb][nb][e];
+                a = fmaxf(a, 0.0f);
+                float key = __uint_as_float((__float_as_uint(a) & 0xFFFFFF00u) | (unsigned)rconst);   // row bits {0,1,3,4,5,6}
+                if (check) key = ((okmask >> (mb * 16 + e)) & 1ull) ? key : INF;
+                ins3(t0, t1, t2, key);
+            }
+        }
+        // add the lane-dependent row bits (2 and 7) to the survivors; inf stays inf
+        auto addbits = [&](float v) { return v == INF ? v : __uint_as_float(__float_as_uint(v) | (unsigned)lane_rowbits); };
+        t0 = addbits(t0); t1 = addbits(t1); t2 = addbits(t2);
+        // merge with the other half-wave (rows +4): exchange triples across lane ^ 32
+        const float o0 = __shfl_xor(t0, 32, 64), o1 = __shfl_xor(t1, 32, 64), o2 = __shfl_xor(t2, 32, 64);
+        ins3(t0, t1, t2, o0); ins3(t0, t1, t2, o1); ins3(t0, t1, t2, o2);
+        if (lane < 32) { float* p = trip + ((wm * 256 + q) * 3); p[0] = t0; p[1] = t1; p[2] = t2; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
+    if (tid < 256) {
+        const float* pa = trip + tid * 3;
+        const float* pb = trip + (256 + tid) * 3;
+        float t0 = pa[0], t1 = pa[1], t2 = pa[2];
+        ins3(t0, t1, t2, pb[0]); ins3(t0, t1, t2, pb[1]); ins3(t0, t1, t2, pb[2]);
+        S0[(long)tid * ldS + 2 * tile] = t0;
+        S0[(long)tid * ldS + 2 * tile + 1] = t1;
+        bound[(long)tid * ldB + tile] = t2;
+    }
+}
+
 // MODE 0: cosine   key = max(0, 1 - s)
 // MODE 1: L2 family key = max(0, qn[q] + rn[row] - 2 s)
 template <int MODE, int DBG, bool ILV = false>
@@ -294,7 +370,8 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_kernel(const _Float1
                 for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
         }
         }
-        if constexpr (!(DBG & 16)) __syncthreads();
+        if constexpr ((DBG & 32) != 0) __builtin_amdgcn_s_barrier();      // experiment: barrier without waiting for the DMA
+        else if constexpr (!(DBG & 16)) __syncthreads();
     }
     if constexpr ((DBG & 4) != 0) {
         float s = 0.0f;
@@ -643,12 +720,128 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_persist_kernel(const
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// producer/consumer variant. Knock-out timings of the kernel above (1M x 768, B = 256): 0.57 ms complete, 0.54 with the
+// DMA issued but never waited for, 0.35 with no DMA at all — the cost of the LDS-DMA is its ISSUE, not its latency or
+// bandwidth: 64 one-KiB pieces per K step queue on the CU's single texture-address path, a wave whose next instruction is
+// a piece stalls until the path accepts it, and with every wave of the workgroup both loader and MFMA issuer the matrix
+// pipe idles meanwhile (deeper rings, ping-pong phases and interleaved issue all leave this unchanged: 0.51-0.56 ms).
+// Here four extra waves (one per SIMD) do nothing but issue the pieces (16 each per step; a wave issues a piece every
+// ~100 cycles, so two loader waves could not keep up: 0.63 ms) and the eight MFMA waves never touch VMEM:
+//   consumers:  [fragment reads + 32 MFMAs on buffer k&1] -> s_barrier
+//   producers:  [64 pieces of step k+1 into buffer (k+1)&1] -> s_waitcnt vmcnt(0) -> s_barrier
+// 768 threads = 12 waves, three per SIMD: 168 VGPRs at most (the staging pointers are gone
+// from the MFMA waves, the accumulators stay at 128).
+// ------------------------------------------------------------------------------------------------
+constexpr int PC_THREADS = 768, PC_CONSUMERS = 8, PC_PRODUCERS = 4, PC_PIECES = 32 / PC_PRODUCERS;   // pieces of each operand per producer per step
+
+template <int MODE>
+__global__ __launch_bounds__(PC_THREADS) void flat_scan_f16_pc_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
+                                                                      const _Float16* __restrict__ Qh /*256 x ldh*/,
+                                                                      const float* __restrict__ rn, const float* __restrict__ qn,
+                                                                      const unsigned char* __restrict__ elig,
+                                                                      float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [buf][X 32 KiB | Q 32 KiB], rows of 128 B with the same XOR swizzle as the kernel above
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    long tile;
+    {
+        const long L = blockIdx.x, nx = 8;
+        const long q = n_tiles / nx, r = n_tiles % nx, xcd = L % nx, idx = L / nx;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        if (idx >= (xcd < r ? q + 1 : q)) return;
+    }
+    const int nk = ldh / FB_K;
+    if (wid >= PC_CONSUMERS) {
+        // ---------------- producer wave p: PC_PIECES pieces of the row tile and as many of the query tile per step ----------------
+        const int p = wid - PC_CONSUMERS;
+        const int prow = lane >> 3, pslot = lane & 7;
+        // piece i covers rows i*8 + prow; the swizzle term ((r >> 1) & 7) = (4*(i & 1) + (prow >> 1)) & 7 depends on i's parity only
+        int xlo[2], qlo[2];
+#pragma unroll
+        for (int par = 0; par < 2; par++) {
+            const int ks = pslot ^ ((4 * par + (prow >> 1)) & 7);
+            xlo[par] = (ks >> 2) * 16384 + prow * 64 + (ks & 3) * 16;          // two 16 KiB slabs per 64-wide K step
+            qlo[par] = prow * ldh * 2 + ks * 16;
+        }
+        const char* xbase = reinterpret_cast<const char*>(Xh) + tile * (long)(ldh >> 5) * 16384;
+        const char* qbase = reinterpret_cast<const char*>(Qh);
+        auto stage = [&](int buf, int kt) {
+            unsigned char* xb = smem + buf * 65536;
+            unsigned char* qb = xb + 32768;
+            const char* xs = xbase + (long)kt * 32768;
+            const char* qs = qbase + (long)kt * 128;
+#pragma unroll
+            for (int j = 0; j < PC_PIECES; j++) {
+                const int i = p * PC_PIECES + j;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + i * 512 + xlo[j & 1]),
+                                                 (__attribute__((address_space(3))) void*)(xb + i * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qs + (long)i * 8 * ldh * 2 + qlo[j & 1]),
+                                                 (__attribute__((address_space(3))) void*)(qb + i * 1024), 16, 0, 0);
+            }
+        };
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; kt++) {
+            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_barrier();              // the epilogue's barrier
+        return;
+    }
+    // ---------------- consumer waves: 2 (rows) x 4 (queries), wave tile 128 x 64 ----------------
+    const int wm = wid >> 2, wn = wid & 3;
+    const long row0 = tile * FB_M;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+    const int arow = wm * 128 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = lane >> 5;
+    __builtin_amdgcn_s_barrier();                  // step 0 landed
+    for (int kt = 0; kt < nk; kt++) {
+        const unsigned char* xb = smem + (kt & 1) * 65536;
+        const unsigned char* qb = xb + 32768;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            half8 a[4], b[2];
+#pragma unroll
+            for (int mb = 0; mb < 4; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, ks * 2 + khalf));
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) b[nb] = *reinterpret_cast<const half8*>(qb + swz_off(brow + nb * 32, ks * 2 + khalf));
+#pragma unroll
+            for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+                for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads done before the buffer is handed back
+        __builtin_amdgcn_s_barrier();
+    }
+    scan_epilogue_pc<MODE>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
+}
+
 void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, int /*nq_used*/, const float* rn, const float* qn,
                           const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB) {
     const long n_tiles = ceil_div(n, FB_M);
     ProfScope ps(c, "flat_scan_f16");
     const long grid = round_up(n_tiles, 8);
     static const int variant = [] { const char* e = getenv("COMET_SCAN_VARIANT"); return e ? atoi(e) : 7; }();
+    if (variant == 9) {
+        const size_t lds = 2 * 65536;
+        if (mode == 0) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_pc_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            flat_scan_f16_pc_kernel<0><<<dim3((unsigned)grid), dim3(PC_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        } else {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_pc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            flat_scan_f16_pc_kernel<1><<<dim3((unsigned)grid), dim3(PC_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        }
+        LAUNCH_CHECK();
+        return;
+    }
     if (variant == 7) {
         const size_t lds = (size_t)P7_EPI_OFF + 8192;
         const long g7 = std::min<long>(round_up(n_tiles, 8), (long)c->prop.multiProcessorCount / 8 * 8);
@@ -696,7 +889,7 @@ void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, 
     if (mode != 0) SCAN1(1, 0);
     else switch (dbg) {
         case 3: SCAN1(0, 3); break; case 7: SCAN1(0, 7); break; case 15: SCAN1(0, 15); break; case 31: SCAN1(0, 31); break;
-        case 4: SCAN1(0, 4); break; case 1: SCAN1(0, 1); break; case 2: SCAN1(0, 2); break;
+        case 4: SCAN1(0, 4); break; case 1: SCAN1(0, 1); break; case 2: SCAN1(0, 2); break; case 32: SCAN1(0, 32); break; case 36: SCAN1(0, 36); break;
         default: SCAN1(0, 0); break;
     }
 #undef SCAN1
