@@ -84,25 +84,26 @@ __device__ __forceinline__ void ins3(float& t0, float& t1, float& t2, float a) {
     t0 = fminf(t0, a); t1 = n1; t2 = n2;
 }
 
-// ---- epilogue shared by the scan kernels: 8 waves as 2 (rows) x 4 (queries), wave tile 128 x 64, acc[mb][nb] ----
-template <int MODE>
-__device__ __forceinline__ void scan_epilogue(f32x16 (&acc)[4][2], unsigned char* smem, long tile, long row0, long n,
+// ---- epilogue shared by the scan kernels: waves as WM (rows) x 4 (queries), wave tile MB*32 rows x 64 queries, acc[mb][nb] ----
+template <int MODE, int MB>
+__device__ __forceinline__ void scan_epilogue(f32x16 (&acc)[MB][2], unsigned char* smem, long tile, long row0, long n,
                                               const float* __restrict__ rn, const float* __restrict__ qn, const unsigned char* __restrict__ elig,
                                               float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB) {
+    constexpr int WM = FB_M / (MB * 32);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 2, wn = wid & 3, khalf = lane >> 5;
-    // ---- epilogue: per (query, tile) two smallest packed keys + third smallest (bound) ----
+    // per (query, tile): the two smallest packed keys + the third smallest (bound).
     // C layout of the 32x32 MFMA: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     const float INF = __builtin_inff();
-    float* trip = reinterpret_cast<float*>(smem);     // [wm][query 256][3]  (6 KiB), LDS is free now
-    const int lane_rowbits = 4 * khalf + 128 * wm;    // bits 2 and 7 of the row-in-tile
+    float* trip = reinterpret_cast<float*>(smem);     // [wm][query 256][3]  (3 KiB per row group), LDS is free now
+    const int lane_rowbits = 4 * khalf + MB * 32 * wm;   // the row-in-tile bits that depend on the lane / wave (disjoint from rconst's)
     const long nvalid = n - row0;
     const bool check = (nvalid < FB_M) || (elig != nullptr);   // workgroup-uniform
-    // per-lane 64-bit mask of usable rows (bit mb*16+e), only built on the slow path
+    // per-lane mask of usable rows (bit mb*16+e), only built on the slow path
     unsigned long long okmask = ~0ull;
     if (check) {
         okmask = 0ull;
-        for (int mb = 0; mb < 4; mb++)
+        for (int mb = 0; mb < MB; mb++)
             for (int e = 0; e < 16; e++) {
                 const long r = mb * 32 + (e & 3) + 8 * (e >> 2) + lane_rowbits;
                 bool ok = r < nvalid;
@@ -110,10 +111,10 @@ __device__ __forceinline__ void scan_epilogue(f32x16 (&acc)[4][2], unsigned char
                 if (ok) okmask |= 1ull << (mb * 16 + e);
             }
     }
-    float rnv[MODE == 1 ? 64 : 1];
+    float rnv[MODE == 1 ? MB * 16 : 1];
     if constexpr (MODE == 1) {
 #pragma unroll
-        for (int mb = 0; mb < 4; mb++)
+        for (int mb = 0; mb < MB; mb++)
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 long r = row0 + mb * 32 + (e & 3) + 8 * (e >> 2) + lane_rowbits;
@@ -127,7 +128,7 @@ __device__ __forceinline__ void scan_epilogue(f32x16 (&acc)[4][2], unsigned char
         if constexpr (MODE == 1) qnv = qn[q];
         float t0 = INF, t1 = INF, t2 = INF;
 #pragma unroll
-        for (int mb = 0; mb < 4; mb++) {
+        for (int mb = 0; mb < MB; mb++) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int rconst = mb * 32 + (e & 3) + 8 * (e >> 2);      // compile-time part of the row
@@ -135,12 +136,12 @@ __device__ __forceinline__ void scan_epilogue(f32x16 (&acc)[4][2], unsigned char
                 if constexpr (MODE == 0) a = 1.0f - acc[mb][nb][e];
                 else a = (qnv + rnv[mb * 16 + e]) - 2.0f * acc[mb][nb][e];
                 a = fmaxf(a, 0.0f);
-                float key = __uint_as_float((__float_as_uint(a) & 0xFFFFFF00u) | (unsigned)rconst);   // row bits {0,1,3,4,5,6}
+                float key = __uint_as_float((__float_as_uint(a) & 0xFFFFFF00u) | (unsigned)rconst);
                 if (check) key = ((okmask >> (mb * 16 + e)) & 1ull) ? key : INF;
                 ins3(t0, t1, t2, key);
             }
         }
-        // add the lane-dependent row bits (2 and 7) to the survivors; inf stays inf
+        // add the lane-dependent row bits to the survivors; inf stays inf
         auto addbits = [&](float v) { return v == INF ? v : __uint_as_float(__float_as_uint(v) | (unsigned)lane_rowbits); };
         t0 = addbits(t0); t1 = addbits(t1); t2 = addbits(t2);
         // merge with the other half-wave (rows +4): exchange triples across lane ^ 32
@@ -151,85 +152,9 @@ __device__ __forceinline__ void scan_epilogue(f32x16 (&acc)[4][2], unsigned char
     __syncthreads();
     if (tid < 256) {
         const float* pa = trip + tid * 3;
-        const float* pb = trip + (256 + tid) * 3;
         float t0 = pa[0], t1 = pa[1], t2 = pa[2];
-        ins3(t0, t1, t2, pb[0]); ins3(t0, t1, t2, pb[1]); ins3(t0, t1, t2, pb[2]);
-        S0[(long)tid * ldS + 2 * tile] = t0;
-        S0[(long)tid * ldS + 2 * tile + 1] = t1;
-        bound[(long)tid * ldB + tile] = t2;
-    }
-}
-
-// ---- the same epilogue for the producer/consumer kernel: its one workgroup barrier is a raw s_barrier that the producer waves match ----
-template <int MODE>
-__device__ __forceinline__ void scan_epilogue_pc(f32x16 (&acc)[4][2], unsigned char* smem, long tile, long row0, long n,
-                                              const float* __restrict__ rn, const float* __restrict__ qn, const unsigned char* __restrict__ elig,
-                                              float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 2, wn = wid & 3, khalf = lane >> 5;
-    // ---- epilogue: per (query, tile) two smallest packed keys + third smallest (bound) ----
-    // C layout of the 32x32 MFMA: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-    const float INF = __builtin_inff();
-    float* trip = reinterpret_cast<float*>(smem);     // [wm][query 256][3]  (6 KiB), LDS is free now
-    const int lane_rowbits = 4 * khalf + 128 * wm;    // bits 2 and 7 of the row-in-tile
-    const long nvalid = n - row0;
-    const bool check = (nvalid < FB_M) || (elig != nullptr);   // workgroup-uniform
-    // per-lane 64-bit mask of usable rows (bit mb*16+e), only built on the slow path
-    unsigned long long okmask = ~0ull;
-    if (check) {
-        okmask = 0ull;
-        for (int mb = 0; mb < 4; mb++)
-            for (int e = 0; e < 16; e++) {
-                const long r = mb * 32 + (e & 3) + 8 * (e >> 2) + lane_rowbits;
-                bool ok = r < nvalid;
-                if (ok && elig) ok = elig[row0 + r] != 0;
-                if (ok) okmask |= 1ull << (mb * 16 + e);
-            }
-    }
-    float rnv[MODE == 1 ? 64 : 1];
-    if constexpr (MODE == 1) {
 #pragma unroll
-        for (int mb = 0; mb < 4; mb++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                long r = row0 + mb * 32 + (e & 3) + 8 * (e >> 2) + lane_rowbits;
-                rnv[mb * 16 + e] = rn[r < n ? r : n - 1];
-            }
-    }
-#pragma unroll
-    for (int nb = 0; nb < 2; nb++) {
-        const int q = wn * 64 + nb * 32 + (lane & 31);
-        float qnv = 0.0f;
-        if constexpr (MODE == 1) qnv = qn[q];
-        float t0 = INF, t1 = INF, t2 = INF;
-#pragma unroll
-        for (int mb = 0; mb < 4; mb++) {
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int rconst = mb * 32 + (e & 3) + 8 * (e >> 2);      // compile-time part of the row
-                float a;
-                if constexpr (MODE == 0) a = 1.0f - acc[mb][nb][e];
-                else a = (qnv + rnv[mb * 16 + e]) - 2.0f * acc[mb][nb][e];
-                a = fmaxf(a, 0.0f);
-                float key = __uint_as_float((__float_as_uint(a) & 0xFFFFFF00u) | (unsigned)rconst);   // row bits {0,1,3,4,5,6}
-                if (check) key = ((okmask >> (mb * 16 + e)) & 1ull) ? key : INF;
-                ins3(t0, t1, t2, key);
-            }
-        }
-        // add the lane-dependent row bits (2 and 7) to the survivors; inf stays inf
-        auto addbits = [&](float v) { return v == INF ? v : __uint_as_float(__float_as_uint(v) | (unsigned)lane_rowbits); };
-        t0 = addbits(t0); t1 = addbits(t1); t2 = addbits(t2);
-        // merge with the other half-wave (rows +4): exchange triples across lane ^ 32
-        const float o0 = __shfl_xor(t0, 32, 64), o1 = __shfl_xor(t1, 32, 64), o2 = __shfl_xor(t2, 32, 64);
-        ins3(t0, t1, t2, o0); ins3(t0, t1, t2, o1); ins3(t0, t1, t2, o2);
-        if (lane < 32) { float* p = trip + ((wm * 256 + q) * 3); p[0] = t0; p[1] = t1; p[2] = t2; }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
-    if (tid < 256) {
-        const float* pa = trip + tid * 3;
-        const float* pb = trip + (256 + tid) * 3;
-        float t0 = pa[0], t1 = pa[1], t2 = pa[2];
-        ins3(t0, t1, t2, pb[0]); ins3(t0, t1, t2, pb[1]); ins3(t0, t1, t2, pb[2]);
+        for (int w = 1; w < WM; w++) { const float* pb = trip + (w * 256 + tid) * 3; ins3(t0, t1, t2, pb[0]); ins3(t0, t1, t2, pb[1]); ins3(t0, t1, t2, pb[2]); }
         S0[(long)tid * ldS + 2 * tile] = t0;
         S0[(long)tid * ldS + 2 * tile + 1] = t1;
         bound[(long)tid * ldB + tile] = t2;
@@ -238,14 +163,14 @@ __device__ __forceinline__ void scan_epilogue_pc(f32x16 (&acc)[4][2], unsigned c
 
 // MODE 0: cosine   key = max(0, 1 - s)
 // MODE 1: L2 family key = max(0, qn[q] + rn[row] - 2 s)
-template <int MODE, int DBG, bool ILV = false>
+template <int MODE, bool TRACE = false, bool PRIO = false, bool ALT = false>
 __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
                                                                    const _Float16* __restrict__ Qh /*256 x ldh*/,
                                                                    const float* __restrict__ rn, const float* __restrict__ qn,
                                                                    const unsigned char* __restrict__ elig,
                                                                    float* __restrict__ S0 /*[256][ldS]: 2 keys per tile*/, long ldS,
-                                                                   float* __restrict__ bound /*[256][ldB]*/, long ldB, long n_tiles) {
-    constexpr int dbg = DBG;   // timing experiments only (COMET_SCAN_DEBUG_SKIP); 0 in production
+                                                                   float* __restrict__ bound /*[256][ldB]*/, long ldB, long n_tiles,
+                                                                   unsigned long long* __restrict__ trace = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // [buf][X 32 KiB | Q 32 KiB]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -285,78 +210,55 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_kernel(const _Float1
         unsigned char* qb = xb + 32768;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            if constexpr (!(DBG & 1))
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + (long)kt * (256 * 128)),
                                              (__attribute__((address_space(3))) void*)(xb + ldsoff[i]), 16, 0, 0);
-            if constexpr (!(DBG & 2))
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc[i] + (long)kt * 128),
                                              (__attribute__((address_space(3))) void*)(qb + ldsoff[i]), 16, 0, 0);
         }
     };
 
+    // ALT: the row group that is NOT computing first issues all 64 pieces of the step (16 per wave), alternating every step
+    const int aprow = lane >> 3, apslot = lane & 7;
+    int axlo[2], aqlo[2];
+#pragma unroll
+    for (int par = 0; par < 2; par++) {
+        const int ks = apslot ^ ((4 * par + (aprow >> 1)) & 7);
+        axlo[par] = (ks >> 2) * 16384 + aprow * 64 + (ks & 3) * 16;
+        aqlo[par] = aprow * ldh * 2 + ks * 16;
+    }
+    auto stage_alt = [&](int buf, int kt) {
+        unsigned char* xb = smem + buf * 65536;
+        unsigned char* qb = xb + 32768;
+        const char* xs = reinterpret_cast<const char*>(Xh) + tile * (long)(ldh >> 5) * 16384 + (long)kt * 32768;
+        const char* qs = reinterpret_cast<const char*>(Qh) + (long)kt * 128;
+        const int p = wid & 3;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = p * 8 + j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + i * 512 + axlo[j & 1]),
+                                             (__attribute__((address_space(3))) void*)(xb + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qs + (long)i * 8 * ldh * 2 + aqlo[j & 1]),
+                                             (__attribute__((address_space(3))) void*)(qb + i * 1024), 16, 0, 0);
+        }
+    };
     const int nk = ldh / FB_K;
     stage(0, 0);
     __syncthreads();   // compiler drains vmcnt before the barrier (LDS-DMA counts on vmcnt)
     const int arow = wm * 128 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = lane >> 5;
+    // TRACE: s_memtime stamps of every wave of ONE workgroup (blockIdx 64), steps 2..9
+    const bool tr = TRACE && blockIdx.x == 64 && lane == 0;
+    unsigned long long t_prev = 0;
+    if (TRACE) t_prev = __builtin_amdgcn_s_memtime();
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
-        if constexpr (!ILV) { if (kt + 1 < nk) stage(buf ^ 1, kt + 1); }   // ILV: pieces issued inside the MFMA block, unconditionally (last one redundant)
+        if (PRIO) __builtin_amdgcn_s_setprio(3);
+        if (ALT) { if (kt + 1 < nk && (wid >> 2) == (kt & 1)) stage_alt(buf ^ 1, kt + 1); }
+        else if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        unsigned long long t1 = 0, t2 = 0, t3 = 0;
+        if (TRACE) { __builtin_amdgcn_sched_barrier(0); t1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         const unsigned char* xb = smem + buf * 65536;
         const unsigned char* qb = xb + 32768;
-        if constexpr ((DBG & 8) != 0) {
-            half8 a[4], b[2];
-#pragma unroll
-            for (int mb = 0; mb < 4; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, khalf));
-#pragma unroll
-            for (int nb = 0; nb < 2; nb++) b[nb] = *reinterpret_cast<const half8*>(qb + swz_off(brow + nb * 32, khalf));
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++)
-#pragma unroll
-            for (int mb = 0; mb < 4; mb++)
-#pragma unroll
-                for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
-        } else if constexpr (ILV) {
-            // same work, explicit issue order: fragment reads of sub-step ks+1 and the 8 DMA pieces of the next K step are
-            // threaded one at a time between the MFMAs of sub-step ks (a burst of 8 pieces + 24 ds_read_b128 in front of
-            // the MFMAs costs 100-185 cycles per piece while the matrix pipe idles; a single piece between MFMAs ~60)
-            half8 a[2][4], b[2][2];
-            const int ktn = min(kt + 1, nk - 1);
-            unsigned char* xbn = smem + (buf ^ 1) * 65536;
-            unsigned char* qbn = xbn + 32768;
-#pragma unroll
-            for (int mb = 0; mb < 4; mb++) a[0][mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, khalf));
-#pragma unroll
-            for (int nb = 0; nb < 2; nb++) b[0][nb] = *reinterpret_cast<const half8*>(qb + swz_off(brow + nb * 32, khalf));
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                if (ks < 3) {
-#pragma unroll
-                    for (int mb = 0; mb < 4; mb++) a[(ks + 1) & 1][mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, (ks + 1) * 2 + khalf));
-#pragma unroll
-                    for (int nb = 0; nb < 2; nb++) b[(ks + 1) & 1][nb] = *reinterpret_cast<const half8*>(qb + swz_off(brow + nb * 32, (ks + 1) * 2 + khalf));
-                }
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[ks] + (long)ktn * (256 * 128)),
-                                                 (__attribute__((address_space(3))) void*)(xbn + ldsoff[ks]), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc[ks] + (long)ktn * 128),
-                                                 (__attribute__((address_space(3))) void*)(qbn + ldsoff[ks]), 16, 0, 0);
-#pragma unroll
-                for (int mb = 0; mb < 4; mb++)
-#pragma unroll
-                    for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][mb], b[ks & 1][nb], acc[mb][nb], 0, 0, 0);
-            }
-            // order: 6 fragment reads, then per sub-step {MFMA, DS} x6 + {MFMA, VMEM} x2 (last sub-step: no reads left)
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-            for (int ks = 0; ks < 3; ks++) {
-#pragma unroll
-                for (int i = 0; i < 6; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-#pragma unroll
-                for (int i = 0; i < 2; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-        } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
             half8 a[4], b[2];
@@ -369,36 +271,28 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_kernel(const _Float1
 #pragma unroll
                 for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
         }
+        if (TRACE) { __builtin_amdgcn_sched_barrier(0); t2 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t3 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        __syncthreads();
+        if (TRACE) {
+            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+            if (tr && kt >= 2 && kt < 10) {
+                unsigned long long* o = trace + ((long)wid * 8 + (kt - 2)) * 5;
+                o[0] = t_prev; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4;
+            }
+            t_prev = t4;
         }
-        if constexpr ((DBG & 32) != 0) __builtin_amdgcn_s_barrier();      // experiment: barrier without waiting for the DMA
-        else if constexpr (!(DBG & 16)) __syncthreads();
     }
-    if constexpr ((DBG & 4) != 0) {
-        float s = 0.0f;
-#pragma unroll
-        for (int mb = 0; mb < 4; mb++)
-#pragma unroll
-            for (int nb = 0; nb < 2; nb++)
-#pragma unroll
-                for (int e = 0; e < 16; e++) s += acc[mb][nb][e];
-        if (s == 12345.678f) S0[tid] = s;
-        return;
-    }
-
-    scan_epilogue<MODE>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
+    scan_epilogue<MODE, 4>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
 }
 // ------------------------------------------------------------------------------------------------
-// ring variant: same 256 x 256 tile / 8 waves / 128 accumulators per lane, but K streamed in 32-half slabs through a
-// FIVE-stage LDS ring (5 x (16 KiB rows + 16 KiB queries) = 160 KiB, the whole LDS) with raw s_barrier and COUNTED vmcnt:
-// four stages (64 KiB of corpus rows per CU) stay in flight across every barrier. Streaming-read probes on this part
-// (tools/hbm_read_probe.hip) need >= ~100 KiB in flight per CU for 6+ TB/s; the two-stage loop above keeps 32 KiB of rows
-// in flight and is latency-bound at 3 TB/s.
+// 16-wave variant of the same tile: 4 (rows) x 4 (queries) waves, wave tile 64 x 64 (64 accumulators, <= 128 VGPRs), four
+// waves per SIMD. The cost of the LDS-DMA is its per-wave ISSUE (~100 cycles per 1 KiB piece, during which the wave issues
+// no MFMA): with 16 waves each wave issues 4 pieces per K step instead of 8, and three other waves on its SIMD can keep the
+// matrix pipe busy meanwhile. Fragment reads per MFMA rise from 0.75 to 1 KiB (the LDS array is ~15 % busy, so they fit).
 // ------------------------------------------------------------------------------------------------
-constexpr int R5_K = 32, R5_STAGES = 5, R5_STAGE_BYTES = 32768, R5_XBYTES = 16384;
-__device__ __forceinline__ int swz32_off(int row, int kslot) { return row * 64 + ((kslot ^ ((row >> 2) & 3)) << 4); }
-
+constexpr int W16_THREADS = 1024;
 template <int MODE>
-__global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_ring_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
+__global__ __launch_bounds__(W16_THREADS) void flat_scan_f16_w16_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
                                                                         const _Float16* __restrict__ Qh /*256 x ldh*/,
                                                                         const float* __restrict__ rn, const float* __restrict__ qn,
                                                                         const unsigned char* __restrict__ elig,
@@ -414,335 +308,90 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_ring_kernel(const _F
         if (idx >= (xcd < r ? q + 1 : q)) return;
     }
     const long row0 = tile * FB_M;
-    f32x16 acc[4][2];
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
-
-    // staging: one wave instruction moves 16 rows x 64 B; 16 row pieces + 16 query pieces per stage -> 2 + 2 per wave
-    const int prow = lane >> 2, pslot = lane & 3;
-    const char* xsrc[2]; const char* qsrc[2]; int poff[2];
+    // staging: each wave moves 2 X pieces + 2 Q pieces (8 rows x 128 B each) per K step
+    const int prow = lane >> 3, pslot = lane & 7;
+    const char* xsrc[2]; const char* qsrc[2]; int ldsoff[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-        const int r = (wid * 2 + i) * 16 + prow;
-        const int ks = pslot ^ ((r >> 2) & 3);
-        xsrc[i] = reinterpret_cast<const char*>(Xh) + (tile * (long)(ldh >> 5) * 256 + r) * 64 + ks * 16;
+        const int r = (wid * 2 + i) * 8 + prow;
+        const int ks = pslot ^ ((r >> 1) & 7);
+        xsrc[i] = reinterpret_cast<const char*>(Xh) + ((tile * (long)(ldh >> 5) + (ks >> 2)) * 256 + r) * 64 + (ks & 3) * 16;
         qsrc[i] = reinterpret_cast<const char*>(Qh + (long)r * ldh) + ks * 16;
-        poff[i] = (wid * 2 + i) * 1024;
+        ldsoff[i] = (wid * 2 + i) * 8 * 128;
     }
-    auto stage = [&](int kt) {
-        unsigned char* sb = smem + (kt % R5_STAGES) * R5_STAGE_BYTES;
+    auto stage = [&](int buf, int kt) {
+        unsigned char* xb = smem + buf * 65536;
+        unsigned char* qb = xb + 32768;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + (long)kt * R5_XBYTES),
-                                             (__attribute__((address_space(3))) void*)(sb + poff[i]), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc[i] + (long)kt * 64),
-                                             (__attribute__((address_space(3))) void*)(sb + R5_XBYTES + poff[i]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + (long)kt * (256 * 128)),
+                                             (__attribute__((address_space(3))) void*)(xb + ldsoff[i]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc[i] + (long)kt * 128),
+                                             (__attribute__((address_space(3))) void*)(qb + ldsoff[i]), 16, 0, 0);
         }
     };
-    const int nk = ldh / R5_K;
-#pragma unroll
-    for (int s = 0; s < R5_STAGES - 1; s++) if (s < nk) stage(s);
-    const int arow = wm * 128 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = lane >> 5;
+    const int nk = ldh / FB_K;
+    stage(0, 0);
+    __syncthreads();
+    const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = lane >> 5;
     for (int kt = 0; kt < nk; kt++) {
-        // stage kt must have landed; this wave issued 4 loads per stage, the younger stages may stay in flight
-        const int younger = min(nk - 1 - kt, R5_STAGES - 2);
-        if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // every wave's pieces of stage kt landed; the buffer of stage kt-1 is free
-        if (kt + R5_STAGES - 1 < nk) stage(kt + R5_STAGES - 1);
-        const unsigned char* xb = smem + (kt % R5_STAGES) * R5_STAGE_BYTES;
-        const unsigned char* qb = xb + R5_XBYTES;
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+        const unsigned char* xb = smem + buf * 65536;
+        const unsigned char* qb = xb + 32768;
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            half8 a[4], b[2];
+        for (int ks = 0; ks < 4; ks++) {
+            half8 a[2], b[2];
 #pragma unroll
-            for (int mb = 0; mb < 4; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz32_off(arow + mb * 32, ks * 2 + khalf));
+            for (int mb = 0; mb < 2; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, ks * 2 + khalf));
 #pragma unroll
-            for (int nb = 0; nb < 2; nb++) b[nb] = *reinterpret_cast<const half8*>(qb + swz32_off(brow + nb * 32, ks * 2 + khalf));
+            for (int nb = 0; nb < 2; nb++) b[nb] = *reinterpret_cast<const half8*>(qb + swz_off(brow + nb * 32, ks * 2 + khalf));
 #pragma unroll
-            for (int mb = 0; mb < 4; mb++)
+            for (int mb = 0; mb < 2; mb++)
 #pragma unroll
                 for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
         }
+        __syncthreads();
     }
-    __syncthreads();   // all LDS reads done before the epilogue reuses the ring
-    scan_epilogue<MODE>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
+    scan_epilogue<MODE, 2>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
 }
-
 // ------------------------------------------------------------------------------------------------
-// ping-pong variant: the ring kernel's data flow, but the two waves that share a SIMD (waves w and w+4: row halves 0 / 1 of
-// the tile) run half a step out of phase — while one issues its 16 MFMAs of K slab k from registers, the other is in its
-// load segment (4 LDS-DMA pieces of slab k+4, 12 ds_read_b128 of its own fragments for slab k). Every segment ends in
-// an s_barrier. In the in-phase kernels both waves of a SIMD issue DMA (60-185 cycles per piece, MI355X_MICROARCH.md) and
-// fragment reads at the same time and the matrix pipe idles meanwhile: 35 % MFMA-busy at 0.5 ms, independent of ring depth.
-//   slot 2k   : group 0 LOAD(k)     | group 1 COMPUTE(k-1)
-//   slot 2k+1 : group 0 COMPUTE(k)  | group 1 LOAD(k)
-// Slab j is complete (all 8 waves' pieces landed) after the barrier that ends slot 2j-1; group 0 reads it in slot 2j,
-// group 1 in slot 2j+1, and its ring buffer is rewritten (slab j+5) no earlier than slot 2j+2.
+// producer/consumer ring. s_memtime traces of the kernels above (COMET_SCAN_VARIANT=101) show where a K step's ~3900 cycles go
+// (the MFMAs need 2048): the CU accepts an LDS-DMA piece only every ~37 cycles, so the 64 pieces of a step take ~2400
+// cycles to ISSUE; the four waves that win arbitration are done after ~800 cycles and run their 32 MFMAs (~1550 cycles)
+// while the other four are still stuck on their pieces, which then run THEIR MFMAs while the first four wait at the
+// barrier — the two waves of a SIMD never overlap their MFMA phases. Ring depth, ping-pong phases, interleaved issue,
+// 16 waves and wave priorities leave that serialisation in place (0.51-0.56 ms each).
+// Here the eight MFMA waves never issue VMEM: TWO loader waves stream 32-wide K slabs into a four-slab ring, three slabs
+// ahead, and only ever wait for a slab that was requested two steps earlier. Two, because the per-CU piece rate is
+// sharply non-monotonic in the number of issuing waves (tools/dma_issue_probe.hip: 1 wave 29.5 cycles/piece, 2 waves 21.8,
+// 4 waves 75.6 (!), 8 waves 52, 16 waves 26): a slab's 32 pieces take ~700 cycles from two waves, under the 1024 of its MFMAs.
+//   barrier B(s+1):  consumers finished reading slab s | loaders guarantee slab s+1 has landed
 // ------------------------------------------------------------------------------------------------
-constexpr int PP_AHEAD = R5_STAGES - 1;     // slabs requested ahead of the one being read
-#define PP_WAIT_YOUNGER(y) do { if ((y) >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); \
-                                else if ((y) == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
-                                else if ((y) == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); \
+constexpr int PC_CONSUMERS = 8, PC_PRODUCERS = 2, PC_THREADS = (PC_CONSUMERS + PC_PRODUCERS) * 64, PC_RING = 4, PC_SLAB = 32768, PC_XBYTES = 16384, PC_K = 32;
+constexpr int PC_PIECES = 16 / PC_PRODUCERS;      // 1 KiB pieces of each operand per loader per slab
+__device__ __forceinline__ int swz32_off(int row, int kslot) { return row * 64 + ((kslot ^ ((row >> 2) & 3)) << 4); }
+static_assert(PC_PIECES == 8, "the vmcnt immediates below assume 16 loads per loader per slab");
+#define PC_WAIT_YOUNGER(y) do { if ((y) >= 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); \
+                                else if ((y) == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); \
                                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
 
-template <int MODE>
-__global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_pp_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
-                                                                      const _Float16* __restrict__ Qh /*256 x ldh*/,
-                                                                      const float* __restrict__ rn, const float* __restrict__ qn,
-                                                                      const unsigned char* __restrict__ elig,
-                                                                      float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 2, wn = wid & 3;      // wm = phase group
-    long tile;
-    {
-        const long L = blockIdx.x, nx = 8;
-        const long q = n_tiles / nx, r = n_tiles % nx, xcd = L % nx, idx = L / nx;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        if (idx >= (xcd < r ? q + 1 : q)) return;
-    }
-    const long row0 = tile * FB_M;
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
-
-    const int prow = lane >> 2, pslot = lane & 3;
-    const char* xsrc[2]; const char* qsrc[2]; int poff[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int r = (wid * 2 + i) * 16 + prow;
-        const int ks = pslot ^ ((r >> 2) & 3);
-        xsrc[i] = reinterpret_cast<const char*>(Xh) + (tile * (long)(ldh >> 5) * 256 + r) * 64 + ks * 16;
-        qsrc[i] = reinterpret_cast<const char*>(Qh + (long)r * ldh) + ks * 16;
-        poff[i] = (wid * 2 + i) * 1024;
-    }
-    auto stage = [&](int kt) {
-        unsigned char* sb = smem + (kt % R5_STAGES) * R5_STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + (long)kt * R5_XBYTES),
-                                             (__attribute__((address_space(3))) void*)(sb + poff[i]), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc[i] + (long)kt * 64),
-                                             (__attribute__((address_space(3))) void*)(sb + R5_XBYTES + poff[i]), 16, 0, 0);
-        }
-    };
-    const int nk = ldh / R5_K;
-    const int arow = wm * 128 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = lane >> 5;
-    half8 fa[2][4], fb[2][2];
-    auto read_frags = [&](int kt) {
-        const unsigned char* xb = smem + (kt % R5_STAGES) * R5_STAGE_BYTES;
-        const unsigned char* qb = xb + R5_XBYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-#pragma unroll
-            for (int mb = 0; mb < 4; mb++) fa[ks][mb] = *reinterpret_cast<const half8*>(xb + swz32_off(arow + mb * 32, ks * 2 + khalf));
-#pragma unroll
-            for (int nb = 0; nb < 2; nb++) fb[ks][nb] = *reinterpret_cast<const half8*>(qb + swz32_off(brow + nb * 32, ks * 2 + khalf));
-        }
-    };
-    auto compute = [&]() {
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-            for (int mb = 0; mb < 4; mb++)
-#pragma unroll
-                for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][mb], fb[ks][nb], acc[mb][nb], 0, 0, 0);
-    };
-    // end of an odd slot 2k+1: slab k+1 must have landed (this wave's pieces); younger slabs stay in flight
-    auto end_odd_slot = [&](int k) {
-        if (k + 1 < nk) { const int younger = min(nk - 1, k + PP_AHEAD) - (k + 1); PP_WAIT_YOUNGER(younger); }
-        __builtin_amdgcn_s_barrier();
-    };
-
-#pragma unroll
-    for (int s = 0; s < PP_AHEAD; s++) if (s < nk) stage(s);
-    { const int younger = min(nk - 1, PP_AHEAD - 1); PP_WAIT_YOUNGER(younger); }
-    __builtin_amdgcn_s_barrier();                      // slab 0 landed
-    if (wm == 0) {
-        for (int k = 0; k < nk; k++) {
-            // slot 2k: LOAD(k)
-            if (k + PP_AHEAD < nk) stage(k + PP_AHEAD);
-            read_frags(k);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            // slot 2k+1: COMPUTE(k)
-            __builtin_amdgcn_sched_barrier(0);
-            compute();
-            __builtin_amdgcn_sched_barrier(0);
-            end_odd_slot(k);
-        }
-        __builtin_amdgcn_s_barrier();                  // slot 2nk (group 1's last compute)
-    } else {
-        __builtin_amdgcn_s_barrier();                  // slot 0: nothing to do yet
-        for (int k = 0; k < nk; k++) {
-            // slot 2k+1: LOAD(k)
-            if (k + PP_AHEAD < nk) stage(k + PP_AHEAD);
-            read_frags(k);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            end_odd_slot(k);
-            // slot 2k+2: COMPUTE(k)
-            __builtin_amdgcn_sched_barrier(0);
-            compute();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-        }
-    }
-    __syncthreads();   // all LDS reads done before the epilogue reuses the ring
-    scan_epilogue<MODE>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
-}
-
-// ------------------------------------------------------------------------------------------------
-// persistent variant: one workgroup per CU walks its share of the row tiles; the LDS ring (4 x 32 KiB) never drains —
-// the slabs of the NEXT tile are already in flight while the current tile's epilogue runs, and the per-tile workgroup
-// launch (the 128-160 KiB of LDS make consecutive one-shot workgroups of a CU strictly serial: ~6 us of dispatch +
-// pipeline fill per tile, a quarter of the one-shot kernel's time with memory traffic removed) is paid once.
-// Timing breakdown of the one-shot kernel at 1M x 768, B = 256 (compile-time knock-outs, COMET_SCAN_DEBUG_SKIP):
-//   all of it 0.53 ms | no DMA 0.35 | no DMA, no epilogue 0.26 | + no fragment reads, no barriers 0.257 (MFMA only;
-//   0.157 at the 2.5 PF/s peak).
-// ------------------------------------------------------------------------------------------------
-constexpr int P7_STAGES = 4, P7_AHEAD = P7_STAGES - 1, P7_EPI_OFF = P7_STAGES * R5_STAGE_BYTES;
-
-template <int MODE, int DBG>
-__global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_persist_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
-                                                                           const _Float16* __restrict__ Qh /*256 x ldh*/,
-                                                                           const float* __restrict__ rn, const float* __restrict__ qn,
-                                                                           const unsigned char* __restrict__ elig,
-                                                                           float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 2, wn = wid & 3;
-    // XCD x = blockIdx % 8 owns a contiguous chunk of tiles; its workgroups (slots) take the chunk's tiles round-robin,
-    // so that the CUs of an XCD stream neighbouring rows at the same time
-    const int nx = 8, xcd = blockIdx.x % nx, slot = blockIdx.x / nx, slots = gridDim.x / nx;
-    const long tq = n_tiles / nx, tr = n_tiles % nx;
-    const long chunk0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
-    const long chunk_n = xcd < tr ? tq + 1 : tq;
-    const long my_tiles = slot < chunk_n ? (chunk_n - slot + slots - 1) / slots : 0;
-    if (my_tiles == 0) return;
-    const int nk = ldh / R5_K;
-    const long G = my_tiles * nk;                          // slabs this workgroup streams
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
-
-    const int prow = lane >> 2, pslot = lane & 3;
-    long xoff[2]; const char* qsrc[2]; int poff[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int r = (wid * 2 + i) * 16 + prow;
-        const int ks = pslot ^ ((r >> 2) & 3);
-        xoff[i] = (long)r * 64 + ks * 16;
-        qsrc[i] = reinterpret_cast<const char*>(Qh + (long)r * ldh) + ks * 16;
-        poff[i] = (wid * 2 + i) * 1024;
-    }
-    const char* Xb = reinterpret_cast<const char*>(Xh);
-    const long tile_bytes = (long)(ldh >> 5) * R5_XBYTES;
-    // issue state: slab counter gi -> (tile ordinal, kt) kept incrementally (no divisions in the loop)
-    long gi = 0; long gi_tile = chunk0 + slot; int gi_kt = 0;
-    auto stage_next = [&]() {
-        unsigned char* sb = smem + (int)(gi % P7_STAGES) * R5_STAGE_BYTES;
-        const char* xs = Xb + gi_tile * tile_bytes + (long)gi_kt * R5_XBYTES;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            if constexpr (!(DBG & 1))
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + xoff[i]),
-                                             (__attribute__((address_space(3))) void*)(sb + poff[i]), 16, 0, 0);
-            if constexpr (!(DBG & 2))
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc[i] + (long)gi_kt * 64),
-                                             (__attribute__((address_space(3))) void*)(sb + R5_XBYTES + poff[i]), 16, 0, 0);
-        }
-        gi++; gi_kt++;
-        if (gi_kt == nk) { gi_kt = 0; gi_tile += slots; }
-    };
-#pragma unroll
-    for (int s = 0; s < P7_AHEAD; s++) if (gi < G) stage_next();
-    const int arow = wm * 128 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = lane >> 5;
-    long tile = chunk0 + slot; int kt = 0;
-    for (long g = 0; g < G; g++) {
-        const long younger = min(G - 1 - g, (long)(P7_AHEAD - 1));
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // slab g landed for every wave; the buffer of slab g-1 is free
-        if (gi < G) stage_next();
-        const unsigned char* xb = smem + (int)(g % P7_STAGES) * R5_STAGE_BYTES;
-        const unsigned char* qb = xb + R5_XBYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            half8 a[4], b[2];
-#pragma unroll
-            for (int mb = 0; mb < 4; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz32_off(arow + mb * 32, ks * 2 + khalf));
-#pragma unroll
-            for (int nb = 0; nb < 2; nb++) b[nb] = *reinterpret_cast<const half8*>(qb + swz32_off(brow + nb * 32, ks * 2 + khalf));
-#pragma unroll
-            for (int mb = 0; mb < 4; mb++)
-#pragma unroll
-                for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
-        }
-        if (++kt == nk) {
-            // tile finished: epilogue from registers + a private LDS scratch beyond the ring (the ring keeps filling)
-            if constexpr ((DBG & 4) != 0) {
-                float s = 0.0f;
-#pragma unroll
-                for (int mb = 0; mb < 4; mb++)
-#pragma unroll
-                    for (int nb = 0; nb < 2; nb++)
-#pragma unroll
-                        for (int e = 0; e < 16; e++) s += acc[mb][nb][e];
-                if (s == 12345.678f) S0[tid] = s;
-            } else
-            scan_epilogue<MODE>(acc, smem + P7_EPI_OFF, tile, tile * FB_M, n, rn, qn, elig, S0, ldS, bound, ldB);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores + the slabs requested before the epilogue (long landed)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
-            kt = 0; tile += slots;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// producer/consumer variant. Knock-out timings of the kernel above (1M x 768, B = 256): 0.57 ms complete, 0.54 with the
-// DMA issued but never waited for, 0.35 with no DMA at all — the cost of the LDS-DMA is its ISSUE, not its latency or
-// bandwidth: 64 one-KiB pieces per K step queue on the CU's single texture-address path, a wave whose next instruction is
-// a piece stalls until the path accepts it, and with every wave of the workgroup both loader and MFMA issuer the matrix
-// pipe idles meanwhile (deeper rings, ping-pong phases and interleaved issue all leave this unchanged: 0.51-0.56 ms).
-// Here four extra waves (one per SIMD) do nothing but issue the pieces (16 each per step; a wave issues a piece every
-// ~100 cycles, so two loader waves could not keep up: 0.63 ms) and the eight MFMA waves never touch VMEM:
-//   consumers:  [fragment reads + 32 MFMAs on buffer k&1] -> s_barrier
-//   producers:  [64 pieces of step k+1 into buffer (k+1)&1] -> s_waitcnt vmcnt(0) -> s_barrier
-// 768 threads = 12 waves, three per SIMD: 168 VGPRs at most (the staging pointers are gone
-// from the MFMA waves, the accumulators stay at 128).
-// ------------------------------------------------------------------------------------------------
-constexpr int PC_THREADS = 768, PC_CONSUMERS = 8, PC_PRODUCERS = 4, PC_PIECES = 32 / PC_PRODUCERS;   // pieces of each operand per producer per step
-
-template <int MODE>
+template <int MODE, bool TRACE = false>
 __global__ __launch_bounds__(PC_THREADS) void flat_scan_f16_pc_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
                                                                       const _Float16* __restrict__ Qh /*256 x ldh*/,
                                                                       const float* __restrict__ rn, const float* __restrict__ qn,
                                                                       const unsigned char* __restrict__ elig,
-                                                                      float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles) {
+                                                                      float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles,
+                                                                      unsigned long long* __restrict__ trace = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [buf][X 32 KiB | Q 32 KiB], rows of 128 B with the same XOR swizzle as the kernel above
+    // ring slab = [rows 16 KiB | queries 16 KiB], 64-byte rows, 16-byte slots XOR-swizzled by (row >> 2) & 3
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     long tile;
     {
@@ -751,47 +400,48 @@ __global__ __launch_bounds__(PC_THREADS) void flat_scan_f16_pc_kernel(const _Flo
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         if (idx >= (xcd < r ? q + 1 : q)) return;
     }
-    const int nk = ldh / FB_K;
+    const int nk = ldh / PC_K;
     if (wid >= PC_CONSUMERS) {
-        // ---------------- producer wave p: PC_PIECES pieces of the row tile and as many of the query tile per step ----------------
+        // ---------------- loader wave p: PC_PIECES pieces (16 rows x 64 B each) of the row slab and as many of the query slab ----------------
         const int p = wid - PC_CONSUMERS;
-        const int prow = lane >> 3, pslot = lane & 7;
-        // piece i covers rows i*8 + prow; the swizzle term ((r >> 1) & 7) = (4*(i & 1) + (prow >> 1)) & 7 depends on i's parity only
-        int xlo[2], qlo[2];
-#pragma unroll
-        for (int par = 0; par < 2; par++) {
-            const int ks = pslot ^ ((4 * par + (prow >> 1)) & 7);
-            xlo[par] = (ks >> 2) * 16384 + prow * 64 + (ks & 3) * 16;          // two 16 KiB slabs per 64-wide K step
-            qlo[par] = prow * ldh * 2 + ks * 16;
-        }
-        const char* xbase = reinterpret_cast<const char*>(Xh) + tile * (long)(ldh >> 5) * 16384;
-        const char* qbase = reinterpret_cast<const char*>(Qh);
-        auto stage = [&](int buf, int kt) {
-            unsigned char* xb = smem + buf * 65536;
-            unsigned char* qb = xb + 32768;
-            const char* xs = xbase + (long)kt * 32768;
-            const char* qs = qbase + (long)kt * 128;
+        const int prow = lane >> 2, pslot = lane & 3;
+        const int ks = pslot ^ ((prow >> 2) & 3);          // piece bases are multiples of 16 rows: the swizzle term depends on prow only
+        const char* xl = reinterpret_cast<const char*>(Xh) + tile * (long)(ldh >> 5) * PC_XBYTES + (p * PC_PIECES) * 1024 + prow * 64 + ks * 16;
+        const char* ql = reinterpret_cast<const char*>(Qh) + ((long)(p * PC_PIECES * 16 + prow) * ldh) * 2 + ks * 16;
+        const long qstep = (long)16 * ldh * 2;
+        auto stage = [&](int kt) {
+            unsigned char* sb = smem + (kt % PC_RING) * PC_SLAB + (p * PC_PIECES) * 1024;
+            const char* xs = xl + (long)kt * PC_XBYTES;
+            const char* qs = ql + (long)kt * 64;
 #pragma unroll
             for (int j = 0; j < PC_PIECES; j++) {
-                const int i = p * PC_PIECES + j;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + i * 512 + xlo[j & 1]),
-                                                 (__attribute__((address_space(3))) void*)(xb + i * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qs + (long)i * 8 * ldh * 2 + qlo[j & 1]),
-                                                 (__attribute__((address_space(3))) void*)(qb + i * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + j * 1024),
+                                                 (__attribute__((address_space(3))) void*)(sb + j * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qs + j * qstep),
+                                                 (__attribute__((address_space(3))) void*)(sb + PC_XBYTES + j * 1024), 16, 0, 0);
             }
         };
-        stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        for (int kt = 0; kt < nk; kt++) {
-            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int s = 0; s < PC_RING - 1; s++) if (s < nk) stage(s);
+        { const int y = min(nk - 1, PC_RING - 2); PC_WAIT_YOUNGER(y); }
+        __builtin_amdgcn_s_barrier();                      // B(0): slab 0 landed
+        unsigned long long tp = TRACE ? __builtin_amdgcn_s_memtime() : 0;
+        for (int s = 0; s < nk; s++) {
+            if (s + PC_RING - 1 < nk) stage(s + PC_RING - 1);      // into the buffer of slab s-1, released by B(s)
+            unsigned long long t1 = TRACE ? __builtin_amdgcn_s_memtime() : 0;
+            if (s + 1 < nk) { const int y = min(nk - 1, s + PC_RING - 1) - (s + 1); PC_WAIT_YOUNGER(y); }
+            unsigned long long t2 = TRACE ? __builtin_amdgcn_s_memtime() : 0;
+            __builtin_amdgcn_s_barrier();                  // B(s+1)
+            if (TRACE) {
+                const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+                if (blockIdx.x == 64 && lane == 0 && s >= 4 && s < 12) { unsigned long long* o = trace + ((long)wid * 8 + (s - 4)) * 4; o[0] = tp; o[1] = t1; o[2] = t2; o[3] = t3; }
+                tp = t3;
+            }
         }
-        __builtin_amdgcn_s_barrier();              // the epilogue's barrier
+        __builtin_amdgcn_s_barrier();                      // the epilogue's barrier
         return;
     }
-    // ---------------- consumer waves: 2 (rows) x 4 (queries), wave tile 128 x 64 ----------------
+    // ---------------- MFMA waves: 2 (rows) x 4 (queries), wave tile 128 x 64 ----------------
     const int wm = wid >> 2, wn = wid & 3;
     const long row0 = tile * FB_M;
     f32x16 acc[4][2];
@@ -802,97 +452,153 @@ __global__ __launch_bounds__(PC_THREADS) void flat_scan_f16_pc_kernel(const _Flo
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
     const int arow = wm * 128 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = lane >> 5;
-    __builtin_amdgcn_s_barrier();                  // step 0 landed
-    for (int kt = 0; kt < nk; kt++) {
-        const unsigned char* xb = smem + (kt & 1) * 65536;
-        const unsigned char* qb = xb + 32768;
+    __builtin_amdgcn_s_barrier();                          // B(0)
+    unsigned long long tp = TRACE ? __builtin_amdgcn_s_memtime() : 0;
+    for (int s = 0; s < nk; s++) {
+        const unsigned char* xb = smem + (s % PC_RING) * PC_SLAB;
+        const unsigned char* qb = xb + PC_XBYTES;
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
+        for (int ks = 0; ks < 2; ks++) {
             half8 a[4], b[2];
 #pragma unroll
-            for (int mb = 0; mb < 4; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, ks * 2 + khalf));
+            for (int mb = 0; mb < 4; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz32_off(arow + mb * 32, ks * 2 + khalf));
 #pragma unroll
-            for (int nb = 0; nb < 2; nb++) b[nb] = *reinterpret_cast<const half8*>(qb + swz_off(brow + nb * 32, ks * 2 + khalf));
+            for (int nb = 0; nb < 2; nb++) b[nb] = *reinterpret_cast<const half8*>(qb + swz32_off(brow + nb * 32, ks * 2 + khalf));
 #pragma unroll
             for (int mb = 0; mb < 4; mb++)
 #pragma unroll
                 for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads done before the buffer is handed back
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads done before the slab is handed back
+        unsigned long long t2 = 0;
+        if (TRACE) { __builtin_amdgcn_sched_barrier(0); t2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        __builtin_amdgcn_s_barrier();                      // B(s+1)
+        if (TRACE) {
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            if (blockIdx.x == 64 && lane == 0 && s >= 4 && s < 12) { unsigned long long* o = trace + ((long)wid * 8 + (s - 4)) * 4; o[0] = tp; o[1] = tp; o[2] = t2; o[3] = t3; }
+            tp = t3;
+        }
     }
-    scan_epilogue_pc<MODE>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
+    scan_epilogue<MODE, 4>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
 }
 
 void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, int /*nq_used*/, const float* rn, const float* qn,
                           const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB) {
     const long n_tiles = ceil_div(n, FB_M);
     ProfScope ps(c, "flat_scan_f16");
-    const long grid = round_up(n_tiles, 8);
-    static const int variant = [] { const char* e = getenv("COMET_SCAN_VARIANT"); return e ? atoi(e) : 7; }();
-    if (variant == 9) {
-        const size_t lds = 2 * 65536;
-        if (mode == 0) {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_pc_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            flat_scan_f16_pc_kernel<0><<<dim3((unsigned)grid), dim3(PC_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
-        } else {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_pc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            flat_scan_f16_pc_kernel<1><<<dim3((unsigned)grid), dim3(PC_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
-        }
-        LAUNCH_CHECK();
-        return;
-    }
-    if (variant == 7) {
-        const size_t lds = (size_t)P7_EPI_OFF + 8192;
-        const long g7 = std::min<long>(round_up(n_tiles, 8), (long)c->prop.multiProcessorCount / 8 * 8);
-        static const int dbg7 = [] { const char* e = getenv("COMET_SCAN_DEBUG_SKIP"); return e ? atoi(e) : 0; }();   // timing experiments only
-#define SCAN7(M, D) do { HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_persist_kernel<M, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        flat_scan_f16_persist_kernel<M, D><<<dim3((unsigned)g7), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles); } while (0)
-        if (mode != 0) SCAN7(1, 0);
-        else switch (dbg7) { case 3: SCAN7(0, 3); break; case 7: SCAN7(0, 7); break; case 4: SCAN7(0, 4); break; case 1: SCAN7(0, 1); break; case 2: SCAN7(0, 2); break; default: SCAN7(0, 0); break; }
-#undef SCAN7
-        LAUNCH_CHECK();
-        return;
-    }
-    if (variant == 6) {
-        const size_t lds = (size_t)R5_STAGES * R5_STAGE_BYTES;
-        if (mode == 0) {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            flat_scan_f16_pp_kernel<0><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
-        } else {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_pp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            flat_scan_f16_pp_kernel<1><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
-        }
-        LAUNCH_CHECK();
-        return;
-    }
-    if (variant == 5) {
-        const size_t lds = (size_t)R5_STAGES * R5_STAGE_BYTES;
-        if (mode == 0) {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_ring_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            flat_scan_f16_ring_kernel<0><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
-        } else {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_ring_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            flat_scan_f16_ring_kernel<1><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
-        }
-        LAUNCH_CHECK();
-        return;
-    }
     const size_t lds = 2 * 65536;
-    static const int dbg = [] { const char* e = getenv("COMET_SCAN_DEBUG_SKIP"); return e ? atoi(e) : 0; }();   // timing experiments only (results invalid)
-#define SCAN8(M) do { HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<M, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        flat_scan_f16_kernel<M, 0, true><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles); } while (0)
-    if (variant == 8) { if (mode != 0) SCAN8(1); else SCAN8(0); LAUNCH_CHECK(); return; }
-#undef SCAN8
-#define SCAN1(M, D) do { HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<M, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        flat_scan_f16_kernel<M, D><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles); } while (0)
-    if (mode != 0) SCAN1(1, 0);
-    else switch (dbg) {
-        case 3: SCAN1(0, 3); break; case 7: SCAN1(0, 7); break; case 15: SCAN1(0, 15); break; case 31: SCAN1(0, 31); break;
-        case 4: SCAN1(0, 4); break; case 1: SCAN1(0, 1); break; case 2: SCAN1(0, 2); break; case 32: SCAN1(0, 32); break; case 36: SCAN1(0, 36); break;
-        default: SCAN1(0, 0); break;
+    const long grid = round_up(n_tiles, 8);
+    static const int variant = [] { const char* e = getenv("COMET_SCAN_VARIANT"); return e ? atoi(e) : 16; }();
+    if (variant == 111 && mode == 0) {
+        const size_t lds11 = (size_t)PC_RING * PC_SLAB;
+        unsigned long long* tr = c->salloc<unsigned long long>(12 * 8 * 4);
+        c->zero(tr, sizeof(unsigned long long) * 384);
+        HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_pc_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds11));
+        flat_scan_f16_pc_kernel<0, true><<<dim3((unsigned)grid), dim3(PC_THREADS), lds11, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles, tr);
+        LAUNCH_CHECK();
+        static int printed = 0;
+        if (printed++ == 2) {
+            unsigned long long h[384];
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            HIP_CHECK(hipMemcpy(h, tr, sizeof(h), hipMemcpyDeviceToHost));
+            for (int w = 0; w < 12; w++) for (int s = 2; s < 5; s++) {
+                const unsigned long long* o = h + (w * 8 + s) * 4;
+                fprintf(stderr, "TRACE %s %d slab %d: issue %llu  work/wait %llu  barrier %llu  total %llu\n", w < 8 ? "mfma" : "load", w, s + 4,
+                        o[1] - o[0], o[2] - o[1], o[3] - o[2], o[3] - o[0]);
+            }
+        }
+        return;
     }
-#undef SCAN1
+    if (variant == 11) {
+        const size_t lds11 = (size_t)PC_RING * PC_SLAB;
+        if (mode == 0) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_pc_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds11));
+            flat_scan_f16_pc_kernel<0><<<dim3((unsigned)grid), dim3(PC_THREADS), lds11, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        } else {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_pc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds11));
+            flat_scan_f16_pc_kernel<1><<<dim3((unsigned)grid), dim3(PC_THREADS), lds11, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        }
+        LAUNCH_CHECK();
+        return;
+    }
+    if (variant == 3) {     // one row group issues all pieces of a step, alternating
+        if (mode == 0) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            flat_scan_f16_kernel<0, false, false, true><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        } else {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<1, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            flat_scan_f16_kernel<1, false, false, true><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        }
+        LAUNCH_CHECK();
+        return;
+    }
+    if (variant == 2) {     // DMA issue at raised wave priority
+        if (mode == 0) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            flat_scan_f16_kernel<0, false, true><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        } else {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            flat_scan_f16_kernel<1, false, true><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        }
+        LAUNCH_CHECK();
+        return;
+    }
+    if (variant == 102 && mode == 0) {
+        unsigned long long* tr = c->salloc<unsigned long long>(8 * 8 * 5);
+        c->zero(tr, sizeof(unsigned long long) * 320);
+        HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        flat_scan_f16_kernel<0, true, true><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles, tr);
+        LAUNCH_CHECK();
+        static int printed = 0;
+        if (printed++ == 2) {
+            unsigned long long h[320];
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            HIP_CHECK(hipMemcpy(h, tr, sizeof(h), hipMemcpyDeviceToHost));
+            for (int w = 0; w < 8; w++) for (int s = 2; s < 4; s++) {
+                const unsigned long long* o = h + (w * 8 + s) * 5;
+                fprintf(stderr, "TRACE wave %d step %d: dma_issue %llu  mfma_issue %llu  vm_wait %llu  barrier %llu  total %llu\n", w, s + 2,
+                        o[1] - o[0], o[2] - o[1], o[3] - o[2], o[4] - o[3], o[4] - o[0]);
+            }
+        }
+        return;
+    }
+    if (variant == 101 && mode == 0) {     // instrumented run: prints the per-step stamps of one workgroup (results still valid)
+        unsigned long long* tr = c->salloc<unsigned long long>(8 * 8 * 5);
+        c->zero(tr, sizeof(unsigned long long) * 320);
+        HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        flat_scan_f16_kernel<0, true><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles, tr);
+        LAUNCH_CHECK();
+        static int printed = 0;
+        if (printed++ == 2) {
+            unsigned long long h[320];
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            HIP_CHECK(hipMemcpy(h, tr, sizeof(h), hipMemcpyDeviceToHost));
+            for (int w = 0; w < 8; w++) for (int s = 0; s < 8; s++) {
+                const unsigned long long* o = h + (w * 8 + s) * 5;
+                fprintf(stderr, "TRACE wave %d step %d: dma_issue %llu  mfma_issue %llu  vm_wait %llu  barrier %llu  total %llu\n", w, s + 2,
+                        o[1] - o[0], o[2] - o[1], o[3] - o[2], o[4] - o[3], o[4] - o[0]);
+            }
+        }
+        return;
+    }
+    if (variant == 16) {
+        if (mode == 0) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_w16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            flat_scan_f16_w16_kernel<0><<<dim3((unsigned)grid), dim3(W16_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        } else {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_w16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            flat_scan_f16_w16_kernel<1><<<dim3((unsigned)grid), dim3(W16_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        }
+        LAUNCH_CHECK();
+        return;
+    }
+    if (mode == 0) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        flat_scan_f16_kernel<0><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+    } else {
+        HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        flat_scan_f16_kernel<1><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+    }
     LAUNCH_CHECK();
 }
 int flat_fast_tile_rows() { return FB_M; }
@@ -1101,7 +807,7 @@ __device__ __forceinline__ void post_append(bool want, unsigned v, unsigned* lis
     if (want) { const int s = base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull)); if (s < cap) list[s] = v; }
 }
 
-template <int METRIC, int STOP = 0>
+template <int METRIC>
 __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __restrict__ S0, long ldS, const float* __restrict__ bound, long ldB,
                                                                  long n_tiles, long n, const unsigned char* __restrict__ elig,
                                                                  const float* __restrict__ err_abs, int K /*requested, sanitised against n*/, int kappa_rank /*0: tau = inf*/,
@@ -1190,7 +896,6 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
         }
     }
     __syncthreads();
-    if constexpr (STOP == 1) { if (tau == 12345.0f) out_counts[q] = 1; return; }
     // ---- 2. candidates ----
     const float* bd = bound + (long)q * ldB;
     for (long t0 = 0; t0 < n_tiles; t0 += POST_THREADS) {
@@ -1224,9 +929,7 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
     int n2 = 64; while (n2 < cnt) n2 <<= 1;
     for (int i = cnt + t; i < n2; i += POST_THREADS) lst[i] = 0xFFFFFFFFu;
     __syncthreads();
-    if constexpr (STOP == 2) { if (cnt == 123456) out_counts[q] = 1; return; }
     post_sort(lst, cnt, n2, hist);                     // ascending row = canonical tie order of the strict path (hist: 16 KiB scratch)
-    if constexpr (STOP == 3) { if (lst[0] == 123456) out_counts[q] = 1; return; }
     // ---- 3. exact distances ----
     float* terms = reinterpret_cast<float*>(psm) + wid * (POST_CPW * POST_CHUNK);   // 4 KiB per wave over the key area
     const float* __restrict__ qv = Qp + (long)q * ld;
@@ -1288,7 +991,6 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
         }
     }
     __syncthreads();
-    if constexpr (STOP == 4) { if (sc[0] == 123456.0f) out_counts[q] = 1; return; }
     // ---- 4. final order: (score, row position) ----
     unsigned long long* comp = reinterpret_cast<unsigned long long*>(psm);   // POST_CAP composites (32 KiB) over the slices
     int mine = 0;
@@ -1333,13 +1035,7 @@ void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const fl
 #define POST(M) do { HIP_CHECK(hipFuncSetAttribute((const void*)flat_post_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POST_LDS)); \
         flat_post_kernel<M><<<dim3(B), dim3(POST_THREADS), POST_LDS, c->stream>>>(S0, ldS, bound, ldB, n_tiles, n, elig, err_abs, K, kappa_rank, thr, X, ld, Qp, \
                                                                                  out_rows, out_scores, out_counts, k_cap, overflow, stats); } while (0)
-    static const int stop = [] { const char* e = getenv("COMET_POST_DEBUG_STOP"); return e ? atoi(e) : 0; }();   // timing experiments only
-#define POSTS(S) do { HIP_CHECK(hipFuncSetAttribute((const void*)flat_post_kernel<COMET_COSINE, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POST_LDS)); \
-        flat_post_kernel<COMET_COSINE, S><<<dim3(B), dim3(POST_THREADS), POST_LDS, c->stream>>>(S0, ldS, bound, ldB, n_tiles, n, elig, err_abs, K, kappa_rank, thr, X, ld, Qp, \
-                                                                                 out_rows, out_scores, out_counts, k_cap, overflow, stats); } while (0)
-    if (stop == 1) POSTS(1); else if (stop == 2) POSTS(2); else if (stop == 3) POSTS(3); else if (stop == 4) POSTS(4); else
     switch (metric) { case COMET_L2: POST(COMET_L2); break; case COMET_L2SQ: POST(COMET_L2SQ); break; default: POST(COMET_COSINE); break; }
-#undef POSTS
 #undef POST
     LAUNCH_CHECK();
 }
