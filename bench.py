@@ -126,6 +126,9 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        if world == 1:      # forced single-rank run outside a launcher: supply the rendezvous ourselves
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import comet_amd as ca
     ctx = ca.Context(local_rank)
@@ -243,9 +246,17 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args, ids, sc, cn)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio: flush that first so that the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -85,7 +85,7 @@ __device__ __forceinline__ void ins3(float& t0, float& t1, float& t2, float a) {
 }
 
 // ---- epilogue shared by the scan kernels: waves as WM (rows) x 4 (queries), wave tile MB*32 rows x 64 queries, acc[mb][nb] ----
-template <int MODE, int MB>
+template <int MODE, int MB = 4>
 __device__ __forceinline__ void scan_epilogue(f32x16 (&acc)[MB][2], unsigned char* smem, long tile, long row0, long n,
                                               const float* __restrict__ rn, const float* __restrict__ qn, const unsigned char* __restrict__ elig,
                                               float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB) {
@@ -163,14 +163,13 @@ __device__ __forceinline__ void scan_epilogue(f32x16 (&acc)[MB][2], unsigned cha
 
 // MODE 0: cosine   key = max(0, 1 - s)
 // MODE 1: L2 family key = max(0, qn[q] + rn[row] - 2 s)
-template <int MODE, bool TRACE = false, bool PRIO = false, bool ALT = false>
+template <int MODE>
 __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
                                                                    const _Float16* __restrict__ Qh /*256 x ldh*/,
                                                                    const float* __restrict__ rn, const float* __restrict__ qn,
                                                                    const unsigned char* __restrict__ elig,
                                                                    float* __restrict__ S0 /*[256][ldS]: 2 keys per tile*/, long ldS,
-                                                                   float* __restrict__ bound /*[256][ldB]*/, long ldB, long n_tiles,
-                                                                   unsigned long long* __restrict__ trace = nullptr) {
+                                                                   float* __restrict__ bound /*[256][ldB]*/, long ldB, long n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // [buf][X 32 KiB | Q 32 KiB]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -217,46 +216,13 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_kernel(const _Float1
         }
     };
 
-    // ALT: the row group that is NOT computing first issues all 64 pieces of the step (16 per wave), alternating every step
-    const int aprow = lane >> 3, apslot = lane & 7;
-    int axlo[2], aqlo[2];
-#pragma unroll
-    for (int par = 0; par < 2; par++) {
-        const int ks = apslot ^ ((4 * par + (aprow >> 1)) & 7);
-        axlo[par] = (ks >> 2) * 16384 + aprow * 64 + (ks & 3) * 16;
-        aqlo[par] = aprow * ldh * 2 + ks * 16;
-    }
-    auto stage_alt = [&](int buf, int kt) {
-        unsigned char* xb = smem + buf * 65536;
-        unsigned char* qb = xb + 32768;
-        const char* xs = reinterpret_cast<const char*>(Xh) + tile * (long)(ldh >> 5) * 16384 + (long)kt * 32768;
-        const char* qs = reinterpret_cast<const char*>(Qh) + (long)kt * 128;
-        const int p = wid & 3;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int i = p * 8 + j;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + i * 512 + axlo[j & 1]),
-                                             (__attribute__((address_space(3))) void*)(xb + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qs + (long)i * 8 * ldh * 2 + aqlo[j & 1]),
-                                             (__attribute__((address_space(3))) void*)(qb + i * 1024), 16, 0, 0);
-        }
-    };
     const int nk = ldh / FB_K;
     stage(0, 0);
     __syncthreads();   // compiler drains vmcnt before the barrier (LDS-DMA counts on vmcnt)
     const int arow = wm * 128 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = lane >> 5;
-    // TRACE: s_memtime stamps of every wave of ONE workgroup (blockIdx 64), steps 2..9
-    const bool tr = TRACE && blockIdx.x == 64 && lane == 0;
-    unsigned long long t_prev = 0;
-    if (TRACE) t_prev = __builtin_amdgcn_s_memtime();
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
-        if (PRIO) __builtin_amdgcn_s_setprio(3);
-        if (ALT) { if (kt + 1 < nk && (wid >> 2) == (kt & 1)) stage_alt(buf ^ 1, kt + 1); }
-        else if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        unsigned long long t1 = 0, t2 = 0, t3 = 0;
-        if (TRACE) { __builtin_amdgcn_sched_barrier(0); t1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
         const unsigned char* xb = smem + buf * 65536;
         const unsigned char* qb = xb + 32768;
 #pragma unroll
@@ -271,327 +237,23 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_kernel(const _Float1
 #pragma unroll
                 for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
         }
-        if (TRACE) { __builtin_amdgcn_sched_barrier(0); t2 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t3 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-        __syncthreads();
-        if (TRACE) {
-            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
-            if (tr && kt >= 2 && kt < 10) {
-                unsigned long long* o = trace + ((long)wid * 8 + (kt - 2)) * 5;
-                o[0] = t_prev; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4;
-            }
-            t_prev = t4;
-        }
-    }
-    scan_epilogue<MODE, 4>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
-}
-// ------------------------------------------------------------------------------------------------
-// 16-wave variant of the same tile: 4 (rows) x 4 (queries) waves, wave tile 64 x 64 (64 accumulators, <= 128 VGPRs), four
-// waves per SIMD. The cost of the LDS-DMA is its per-wave ISSUE (~100 cycles per 1 KiB piece, during which the wave issues
-// no MFMA): with 16 waves each wave issues 4 pieces per K step instead of 8, and three other waves on its SIMD can keep the
-// matrix pipe busy meanwhile. Fragment reads per MFMA rise from 0.75 to 1 KiB (the LDS array is ~15 % busy, so they fit).
-// ------------------------------------------------------------------------------------------------
-constexpr int W16_THREADS = 1024;
-template <int MODE>
-__global__ __launch_bounds__(W16_THREADS) void flat_scan_f16_w16_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
-                                                                        const _Float16* __restrict__ Qh /*256 x ldh*/,
-                                                                        const float* __restrict__ rn, const float* __restrict__ qn,
-                                                                        const unsigned char* __restrict__ elig,
-                                                                        float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 2, wn = wid & 3;
-    long tile;
-    {
-        const long L = blockIdx.x, nx = 8;
-        const long q = n_tiles / nx, r = n_tiles % nx, xcd = L % nx, idx = L / nx;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        if (idx >= (xcd < r ? q + 1 : q)) return;
-    }
-    const long row0 = tile * FB_M;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
-    // staging: each wave moves 2 X pieces + 2 Q pieces (8 rows x 128 B each) per K step
-    const int prow = lane >> 3, pslot = lane & 7;
-    const char* xsrc[2]; const char* qsrc[2]; int ldsoff[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int r = (wid * 2 + i) * 8 + prow;
-        const int ks = pslot ^ ((r >> 1) & 7);
-        xsrc[i] = reinterpret_cast<const char*>(Xh) + ((tile * (long)(ldh >> 5) + (ks >> 2)) * 256 + r) * 64 + (ks & 3) * 16;
-        qsrc[i] = reinterpret_cast<const char*>(Qh + (long)r * ldh) + ks * 16;
-        ldsoff[i] = (wid * 2 + i) * 8 * 128;
-    }
-    auto stage = [&](int buf, int kt) {
-        unsigned char* xb = smem + buf * 65536;
-        unsigned char* qb = xb + 32768;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + (long)kt * (256 * 128)),
-                                             (__attribute__((address_space(3))) void*)(xb + ldsoff[i]), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc[i] + (long)kt * 128),
-                                             (__attribute__((address_space(3))) void*)(qb + ldsoff[i]), 16, 0, 0);
-        }
-    };
-    const int nk = ldh / FB_K;
-    stage(0, 0);
-    __syncthreads();
-    const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = lane >> 5;
-    for (int kt = 0; kt < nk; kt++) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
-        const unsigned char* xb = smem + buf * 65536;
-        const unsigned char* qb = xb + 32768;
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            half8 a[2], b[2];
-#pragma unroll
-            for (int mb = 0; mb < 2; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, ks * 2 + khalf));
-#pragma unroll
-            for (int nb = 0; nb < 2; nb++) b[nb] = *reinterpret_cast<const half8*>(qb + swz_off(brow + nb * 32, ks * 2 + khalf));
-#pragma unroll
-            for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-                for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
-        }
         __syncthreads();
     }
-    scan_epilogue<MODE, 2>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
+    scan_epilogue<MODE>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
 }
-// ------------------------------------------------------------------------------------------------
-// producer/consumer ring. s_memtime traces of the kernels above (COMET_SCAN_VARIANT=101) show where a K step's ~3900 cycles go
-// (the MFMAs need 2048): the CU accepts an LDS-DMA piece only every ~37 cycles, so the 64 pieces of a step take ~2400
-// cycles to ISSUE; the four waves that win arbitration are done after ~800 cycles and run their 32 MFMAs (~1550 cycles)
-// while the other four are still stuck on their pieces, which then run THEIR MFMAs while the first four wait at the
-// barrier — the two waves of a SIMD never overlap their MFMA phases. Ring depth, ping-pong phases, interleaved issue,
-// 16 waves and wave priorities leave that serialisation in place (0.51-0.56 ms each).
-// Here the eight MFMA waves never issue VMEM: TWO loader waves stream 32-wide K slabs into a four-slab ring, three slabs
-// ahead, and only ever wait for a slab that was requested two steps earlier. Two, because the per-CU piece rate is
-// sharply non-monotonic in the number of issuing waves (tools/dma_issue_probe.hip: 1 wave 29.5 cycles/piece, 2 waves 21.8,
-// 4 waves 75.6 (!), 8 waves 52, 16 waves 26): a slab's 32 pieces take ~700 cycles from two waves, under the 1024 of its MFMAs.
-//   barrier B(s+1):  consumers finished reading slab s | loaders guarantee slab s+1 has landed
-// ------------------------------------------------------------------------------------------------
-constexpr int PC_CONSUMERS = 8, PC_PRODUCERS = 2, PC_THREADS = (PC_CONSUMERS + PC_PRODUCERS) * 64, PC_RING = 4, PC_SLAB = 32768, PC_XBYTES = 16384, PC_K = 32;
-constexpr int PC_PIECES = 16 / PC_PRODUCERS;      // 1 KiB pieces of each operand per loader per slab
-__device__ __forceinline__ int swz32_off(int row, int kslot) { return row * 64 + ((kslot ^ ((row >> 2) & 3)) << 4); }
-static_assert(PC_PIECES == 8, "the vmcnt immediates below assume 16 loads per loader per slab");
-#define PC_WAIT_YOUNGER(y) do { if ((y) >= 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); \
-                                else if ((y) == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); \
-                                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
-
-template <int MODE, bool TRACE = false>
-__global__ __launch_bounds__(PC_THREADS) void flat_scan_f16_pc_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
-                                                                      const _Float16* __restrict__ Qh /*256 x ldh*/,
-                                                                      const float* __restrict__ rn, const float* __restrict__ qn,
-                                                                      const unsigned char* __restrict__ elig,
-                                                                      float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles,
-                                                                      unsigned long long* __restrict__ trace = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // ring slab = [rows 16 KiB | queries 16 KiB], 64-byte rows, 16-byte slots XOR-swizzled by (row >> 2) & 3
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    long tile;
-    {
-        const long L = blockIdx.x, nx = 8;
-        const long q = n_tiles / nx, r = n_tiles % nx, xcd = L % nx, idx = L / nx;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        if (idx >= (xcd < r ? q + 1 : q)) return;
-    }
-    const int nk = ldh / PC_K;
-    if (wid >= PC_CONSUMERS) {
-        // ---------------- loader wave p: PC_PIECES pieces (16 rows x 64 B each) of the row slab and as many of the query slab ----------------
-        const int p = wid - PC_CONSUMERS;
-        const int prow = lane >> 2, pslot = lane & 3;
-        const int ks = pslot ^ ((prow >> 2) & 3);          // piece bases are multiples of 16 rows: the swizzle term depends on prow only
-        const char* xl = reinterpret_cast<const char*>(Xh) + tile * (long)(ldh >> 5) * PC_XBYTES + (p * PC_PIECES) * 1024 + prow * 64 + ks * 16;
-        const char* ql = reinterpret_cast<const char*>(Qh) + ((long)(p * PC_PIECES * 16 + prow) * ldh) * 2 + ks * 16;
-        const long qstep = (long)16 * ldh * 2;
-        auto stage = [&](int kt) {
-            unsigned char* sb = smem + (kt % PC_RING) * PC_SLAB + (p * PC_PIECES) * 1024;
-            const char* xs = xl + (long)kt * PC_XBYTES;
-            const char* qs = ql + (long)kt * 64;
-#pragma unroll
-            for (int j = 0; j < PC_PIECES; j++) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + j * 1024),
-                                                 (__attribute__((address_space(3))) void*)(sb + j * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qs + j * qstep),
-                                                 (__attribute__((address_space(3))) void*)(sb + PC_XBYTES + j * 1024), 16, 0, 0);
-            }
-        };
-#pragma unroll
-        for (int s = 0; s < PC_RING - 1; s++) if (s < nk) stage(s);
-        { const int y = min(nk - 1, PC_RING - 2); PC_WAIT_YOUNGER(y); }
-        __builtin_amdgcn_s_barrier();                      // B(0): slab 0 landed
-        unsigned long long tp = TRACE ? __builtin_amdgcn_s_memtime() : 0;
-        for (int s = 0; s < nk; s++) {
-            if (s + PC_RING - 1 < nk) stage(s + PC_RING - 1);      // into the buffer of slab s-1, released by B(s)
-            unsigned long long t1 = TRACE ? __builtin_amdgcn_s_memtime() : 0;
-            if (s + 1 < nk) { const int y = min(nk - 1, s + PC_RING - 1) - (s + 1); PC_WAIT_YOUNGER(y); }
-            unsigned long long t2 = TRACE ? __builtin_amdgcn_s_memtime() : 0;
-            __builtin_amdgcn_s_barrier();                  // B(s+1)
-            if (TRACE) {
-                const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-                if (blockIdx.x == 64 && lane == 0 && s >= 4 && s < 12) { unsigned long long* o = trace + ((long)wid * 8 + (s - 4)) * 4; o[0] = tp; o[1] = t1; o[2] = t2; o[3] = t3; }
-                tp = t3;
-            }
-        }
-        __builtin_amdgcn_s_barrier();                      // the epilogue's barrier
-        return;
-    }
-    // ---------------- MFMA waves: 2 (rows) x 4 (queries), wave tile 128 x 64 ----------------
-    const int wm = wid >> 2, wn = wid & 3;
-    const long row0 = tile * FB_M;
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
-    const int arow = wm * 128 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = lane >> 5;
-    __builtin_amdgcn_s_barrier();                          // B(0)
-    unsigned long long tp = TRACE ? __builtin_amdgcn_s_memtime() : 0;
-    for (int s = 0; s < nk; s++) {
-        const unsigned char* xb = smem + (s % PC_RING) * PC_SLAB;
-        const unsigned char* qb = xb + PC_XBYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            half8 a[4], b[2];
-#pragma unroll
-            for (int mb = 0; mb < 4; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz32_off(arow + mb * 32, ks * 2 + khalf));
-#pragma unroll
-            for (int nb = 0; nb < 2; nb++) b[nb] = *reinterpret_cast<const half8*>(qb + swz32_off(brow + nb * 32, ks * 2 + khalf));
-#pragma unroll
-            for (int mb = 0; mb < 4; mb++)
-#pragma unroll
-                for (int nb = 0; nb < 2; nb++) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads done before the slab is handed back
-        unsigned long long t2 = 0;
-        if (TRACE) { __builtin_amdgcn_sched_barrier(0); t2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-        __builtin_amdgcn_s_barrier();                      // B(s+1)
-        if (TRACE) {
-            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-            if (blockIdx.x == 64 && lane == 0 && s >= 4 && s < 12) { unsigned long long* o = trace + ((long)wid * 8 + (s - 4)) * 4; o[0] = tp; o[1] = tp; o[2] = t2; o[3] = t3; }
-            tp = t3;
-        }
-    }
-    scan_epilogue<MODE, 4>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
-}
-
+// What limits this kernel (profiles/r01_flat_scan_investigation.txt): of a K step's ~3900 cycles the 2 x 32 MFMAs of a SIMD
+// need 2048. The CU accepts the step's 64 LDS-DMA pieces only over ~2400 cycles while fragment reads are in flight; the four
+// waves that win arbitration finish their pieces after ~800 cycles and run their MFMAs while the other four are still issuing,
+// which then compute while the first four wait at the barrier: the MFMA phases of the two waves of a SIMD never overlap.
+// Deeper rings, ping-pong phases, interleaved issue, dedicated loader waves (1 KiB pieces cost 22-75 cycles CU-wide
+// depending on how many waves issue, tools/dma_issue_probe.hip, and 3-5x that next to ds_read traffic), 16-wave workgroups,
+// persistent tiles and wave priorities were all built and measured in round 1: 0.51-0.63 ms against 0.51-0.55 for this one.
 void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, int /*nq_used*/, const float* rn, const float* qn,
                           const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB) {
     const long n_tiles = ceil_div(n, FB_M);
     ProfScope ps(c, "flat_scan_f16");
     const size_t lds = 2 * 65536;
     const long grid = round_up(n_tiles, 8);
-    static const int variant = [] { const char* e = getenv("COMET_SCAN_VARIANT"); return e ? atoi(e) : 16; }();
-    if (variant == 111 && mode == 0) {
-        const size_t lds11 = (size_t)PC_RING * PC_SLAB;
-        unsigned long long* tr = c->salloc<unsigned long long>(12 * 8 * 4);
-        c->zero(tr, sizeof(unsigned long long) * 384);
-        HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_pc_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds11));
-        flat_scan_f16_pc_kernel<0, true><<<dim3((unsigned)grid), dim3(PC_THREADS), lds11, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles, tr);
-        LAUNCH_CHECK();
-        static int printed = 0;
-        if (printed++ == 2) {
-            unsigned long long h[384];
-            HIP_CHECK(hipStreamSynchronize(c->stream));
-            HIP_CHECK(hipMemcpy(h, tr, sizeof(h), hipMemcpyDeviceToHost));
-            for (int w = 0; w < 12; w++) for (int s = 2; s < 5; s++) {
-                const unsigned long long* o = h + (w * 8 + s) * 4;
-                fprintf(stderr, "TRACE %s %d slab %d: issue %llu  work/wait %llu  barrier %llu  total %llu\n", w < 8 ? "mfma" : "load", w, s + 4,
-                        o[1] - o[0], o[2] - o[1], o[3] - o[2], o[3] - o[0]);
-            }
-        }
-        return;
-    }
-    if (variant == 11) {
-        const size_t lds11 = (size_t)PC_RING * PC_SLAB;
-        if (mode == 0) {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_pc_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds11));
-            flat_scan_f16_pc_kernel<0><<<dim3((unsigned)grid), dim3(PC_THREADS), lds11, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
-        } else {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_pc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds11));
-            flat_scan_f16_pc_kernel<1><<<dim3((unsigned)grid), dim3(PC_THREADS), lds11, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
-        }
-        LAUNCH_CHECK();
-        return;
-    }
-    if (variant == 3) {     // one row group issues all pieces of a step, alternating
-        if (mode == 0) {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            flat_scan_f16_kernel<0, false, false, true><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
-        } else {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<1, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            flat_scan_f16_kernel<1, false, false, true><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
-        }
-        LAUNCH_CHECK();
-        return;
-    }
-    if (variant == 2) {     // DMA issue at raised wave priority
-        if (mode == 0) {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            flat_scan_f16_kernel<0, false, true><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
-        } else {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            flat_scan_f16_kernel<1, false, true><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
-        }
-        LAUNCH_CHECK();
-        return;
-    }
-    if (variant == 102 && mode == 0) {
-        unsigned long long* tr = c->salloc<unsigned long long>(8 * 8 * 5);
-        c->zero(tr, sizeof(unsigned long long) * 320);
-        HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        flat_scan_f16_kernel<0, true, true><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles, tr);
-        LAUNCH_CHECK();
-        static int printed = 0;
-        if (printed++ == 2) {
-            unsigned long long h[320];
-            HIP_CHECK(hipStreamSynchronize(c->stream));
-            HIP_CHECK(hipMemcpy(h, tr, sizeof(h), hipMemcpyDeviceToHost));
-            for (int w = 0; w < 8; w++) for (int s = 2; s < 4; s++) {
-                const unsigned long long* o = h + (w * 8 + s) * 5;
-                fprintf(stderr, "TRACE wave %d step %d: dma_issue %llu  mfma_issue %llu  vm_wait %llu  barrier %llu  total %llu\n", w, s + 2,
-                        o[1] - o[0], o[2] - o[1], o[3] - o[2], o[4] - o[3], o[4] - o[0]);
-            }
-        }
-        return;
-    }
-    if (variant == 101 && mode == 0) {     // instrumented run: prints the per-step stamps of one workgroup (results still valid)
-        unsigned long long* tr = c->salloc<unsigned long long>(8 * 8 * 5);
-        c->zero(tr, sizeof(unsigned long long) * 320);
-        HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        flat_scan_f16_kernel<0, true><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles, tr);
-        LAUNCH_CHECK();
-        static int printed = 0;
-        if (printed++ == 2) {
-            unsigned long long h[320];
-            HIP_CHECK(hipStreamSynchronize(c->stream));
-            HIP_CHECK(hipMemcpy(h, tr, sizeof(h), hipMemcpyDeviceToHost));
-            for (int w = 0; w < 8; w++) for (int s = 0; s < 8; s++) {
-                const unsigned long long* o = h + (w * 8 + s) * 5;
-                fprintf(stderr, "TRACE wave %d step %d: dma_issue %llu  mfma_issue %llu  vm_wait %llu  barrier %llu  total %llu\n", w, s + 2,
-                        o[1] - o[0], o[2] - o[1], o[3] - o[2], o[4] - o[3], o[4] - o[0]);
-            }
-        }
-        return;
-    }
-    if (variant == 16) {
-        if (mode == 0) {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_w16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            flat_scan_f16_w16_kernel<0><<<dim3((unsigned)grid), dim3(W16_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
-        } else {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_w16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            flat_scan_f16_w16_kernel<1><<<dim3((unsigned)grid), dim3(W16_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
-        }
-        LAUNCH_CHECK();
-        return;
-    }
     if (mode == 0) {
         HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         flat_scan_f16_kernel<0><<<dim3((unsigned)grid), dim3(FB_THREADS), lds, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
