@@ -247,7 +247,8 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_kernel(const _Float1
 // which then compute while the first four wait at the barrier: the MFMA phases of the two waves of a SIMD never overlap.
 // Deeper rings, ping-pong phases, interleaved issue, dedicated loader waves (1 KiB pieces cost 22-75 cycles CU-wide
 // depending on how many waves issue, tools/dma_issue_probe.hip, and 3-5x that next to ds_read traffic), 16-wave workgroups,
-// persistent tiles and wave priorities were all built and measured in round 1: 0.51-0.63 ms against 0.51-0.55 for this one.
+// persistent tiles, wave priorities and classic register staging (global_load -> ds_write_b128, no LDS-DMA: 0.59 ms) were all
+// built and measured in round 1: 0.51-0.63 ms against 0.51-0.55 for this one.
 void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, int /*nq_used*/, const float* rn, const float* qn,
                           const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB) {
     const long n_tiles = ceil_div(n, FB_M);
