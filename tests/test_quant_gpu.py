@@ -278,3 +278,47 @@ def test_merge_topk(ctx):
         assert mc[b] == cnt and np.array_equal(mi[b, :cnt], oi) and np.array_equal(bits(ms[b, :cnt]), bits(os_))
     for p in bufs + [o_ids, o_sc, o_cn]:
         ctx.free(p)
+
+
+@pytest.mark.parametrize("kind", ["ivf", "ivfpq"])
+def test_sharded_lists_merge_equals_unsharded(ctx, kind):
+    """SURVEY §8(e) for the inverted-list indexes: every rank trains on the same vectors (the GPU k-means is deterministic,
+    so centroids / codebooks are replicated bit for bit), holds a round-robin share of the members, probes the same lists,
+    and the per-shard top-K merged by comet_merge_topk_dev equal the unsharded search (scores bit for bit; ids wherever the
+    score is unique — inside runs of equal scores the merged order is (shard, position) instead of scan position)."""
+    import ctypes as C
+    from comet_amd._lib import check
+    n, d, B, k, R, nlist = 6000, 32, 8, 15, 3, 16
+    X = clustered(81, n, d, 24); Q = clustered(82, B, d, 24)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    train = X[:2000]
+
+    def make():
+        g = IVFIndex(ctx, d, L2_SQUARED, nlist) if kind == "ivf" else IVFPQIndex(ctx, d, L2_SQUARED, nlist, 8, 6)
+        g.train(train)
+        return g
+    full = make(); full.add_batch(ids, X)
+    f_ids, f_sc, f_cn = full.search_batch(Q, k, nprobes=5)
+    all_ids = np.zeros((R, B, k), np.uint32); all_sc = np.zeros((R, B, k), np.float32); all_cn = np.zeros((R, B), np.int32)
+    for r in range(R):
+        sh = make()
+        assert np.array_equal(sh.centroids(nlist), full.centroids(nlist))          # replicated quantiser
+        sh.add_batch(ids[r::R], X[r::R])
+        all_ids[r], all_sc[r], all_cn[r] = sh.search_batch(Q, k, nprobes=5)
+    bufs = [ctx.alloc(a.nbytes) for a in (all_ids, all_sc, all_cn)]
+    for p, a in zip(bufs, (all_ids, all_sc, all_cn)):
+        ctx.upload(p, a)
+    o_ids, o_sc, o_cn = ctx.alloc(B * k * 4), ctx.alloc(B * k * 4), ctx.alloc(B * 4)
+    check(ctx.lib.comet_merge_topk_dev(ctx.h, C.c_void_p(bufs[0]), C.c_void_p(bufs[1]), C.c_void_p(bufs[2]), R, B, k, k,
+                                       C.c_void_p(o_ids), C.c_void_p(o_sc), C.c_void_p(o_cn)))
+    ctx.sync()
+    mi, ms, mc = ctx.download(o_ids, (B, k), np.uint32), ctx.download(o_sc, (B, k), np.float32), ctx.download(o_cn, (B,), np.int32)
+    for b in range(B):
+        c = int(f_cn[b])
+        assert mc[b] == c
+        assert np.array_equal(bits(ms[b, :c]), bits(f_sc[b, :c]))
+        uniq = np.array([np.sum(f_sc[b, :c] == s) == 1 for s in f_sc[b, :c]])
+        assert np.array_equal(mi[b, :c][uniq], f_ids[b, :c][uniq])
+        assert sorted(mi[b, :c].tolist()) == sorted(f_ids[b, :c].tolist()) or not uniq.all()
+    for p in bufs + [o_ids, o_sc, o_cn]:
+        ctx.free(p)
