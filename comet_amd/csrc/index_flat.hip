@@ -175,16 +175,18 @@ struct FlatIndex : comet_index {
         const int64_t keff = (p.k <= 0 || p.k > n) ? n : p.k;
         const bool ok = std::isfinite(xmax_abs) && xmax_abs <= 60000.0f && std::isfinite(xmax_norm2) && keff <= 1024 && n >= 1;
         if (p.mode == 2) return ok;
-        // auto: small batches are HBM-bound on the exact kernel anyway; the tile-top-2 proposal needs many more
-        // 256-row tiles than requested results to be selective
-        return ok && B >= 32 && n >= (int64_t)flat_fast_tile_rows() * 24 * keff;
+        // auto: small batches are HBM-bound on the exact kernel anyway; the tile-top-2 proposal needs several times more
+        // 256-row tiles than requested results to stay selective (measured at K = 100, B = 256: 125k rows 0.34 ms fast vs
+        // 1.19 ms strict, 500k rows 0.45 vs 4.7 — the row shards of a multi-GPU run live in this regime)
+        return ok && B >= 32 && n >= (int64_t)flat_fast_unit_rows() * 4 * keff;
     }
 
     // MFMA fast path for up to 256 prepared queries; writes candidate positions `pos` as ROW indices
     void search_fast(const float* Qp, int bn, const comet_search_params& p, const uint8_t* elig, uint32_t* pos, float* out_scores,
                      int32_t* out_counts, int k_cap, Pending* pend) {
         ScratchMark sm(c);
-        const int64_t n_tiles = ceil_div(n, flat_fast_tile_rows());
+        // key units: the scan emits, per query, 2 keys + 1 bound for every 128-row unit (two per 256-row tile)
+        const int64_t n_tiles = ceil_div(n, flat_fast_tile_rows()) * (flat_fast_tile_rows() / flat_fast_unit_rows());
         const int64_t ldS = round_up(2 * n_tiles, 16), ldB = round_up(n_tiles, 16);
         const int NB = flat_fast_batch();
         void* Qh = c->scratch_alloc((size_t)NB * ldh * 2);

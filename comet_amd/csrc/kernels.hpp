@@ -85,6 +85,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
 
 // ---- kernels_fast.hip (MFMA fast path of the Flat scan) ------------------------------------------
 int flat_fast_tile_rows();
+int flat_fast_unit_rows();
 int flat_fast_batch();
 // fp32 padded rows -> fp16 shadow in the TILED layout [256-row tile][64-half K step][row][64] (each (tile, K step)
 // slab is 32 KiB contiguous). X / rn point at the first new row whose global row index is row_base; the shadow

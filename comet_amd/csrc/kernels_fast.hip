@@ -69,6 +69,7 @@ void launch_to_half_rows(Ctx* c, const float* X, int64_t n, int ld, void* Xh, in
 // the scan kernel
 // ------------------------------------------------------------------------------------------------
 constexpr int FB_M = 256;     // corpus rows per workgroup tile
+constexpr int FB_UNIT = 128;  // rows per key unit (a wave row group): 2 emitted keys + 1 bound per (query, unit)
 constexpr int FB_N = 256;     // queries per tile (the whole batch)
 constexpr int FB_K = 64;      // halves per K step (128 bytes per row)
 constexpr int FB_THREADS = 512;
@@ -92,10 +93,9 @@ __device__ __forceinline__ void scan_epilogue(f32x16 (&acc)[MB][2], unsigned cha
     constexpr int WM = FB_M / (MB * 32);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 2, wn = wid & 3, khalf = lane >> 5;
-    // per (query, tile): the two smallest packed keys + the third smallest (bound).
+    // per (query, key unit = row group of the tile): the two smallest packed keys + the third smallest (bound).
     // C layout of the 32x32 MFMA: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     const float INF = __builtin_inff();
-    float* trip = reinterpret_cast<float*>(smem);     // [wm][query 256][3]  (3 KiB per row group), LDS is free now
     const int lane_rowbits = 4 * khalf + MB * 32 * wm;   // the row-in-tile bits that depend on the lane / wave (disjoint from rconst's)
     const long nvalid = n - row0;
     const bool check = (nvalid < FB_M) || (elig != nullptr);   // workgroup-uniform
@@ -147,17 +147,13 @@ __device__ __forceinline__ void scan_epilogue(f32x16 (&acc)[MB][2], unsigned cha
         // merge with the other half-wave (rows +4): exchange triples across lane ^ 32
         const float o0 = __shfl_xor(t0, 32, 64), o1 = __shfl_xor(t1, 32, 64), o2 = __shfl_xor(t2, 32, 64);
         ins3(t0, t1, t2, o0); ins3(t0, t1, t2, o1); ins3(t0, t1, t2, o2);
-        if (lane < 32) { float* p = trip + ((wm * 256 + q) * 3); p[0] = t0; p[1] = t1; p[2] = t2; }
-    }
-    __syncthreads();
-    if (tid < 256) {
-        const float* pa = trip + tid * 3;
-        float t0 = pa[0], t1 = pa[1], t2 = pa[2];
-#pragma unroll
-        for (int w = 1; w < WM; w++) { const float* pb = trip + (w * 256 + tid) * 3; ins3(t0, t1, t2, pb[0]); ins3(t0, t1, t2, pb[1]); ins3(t0, t1, t2, pb[2]); }
-        S0[(long)tid * ldS + 2 * tile] = t0;
-        S0[(long)tid * ldS + 2 * tile + 1] = t1;
-        bound[(long)tid * ldB + tile] = t2;
+        // one key unit = the MB*32 rows of this wave's row group: two smallest keys + the third as the unit's bound
+        if (lane < 32) {
+            const long u = tile * WM + wm;
+            S0[(long)q * ldS + 2 * u] = t0;
+            S0[(long)q * ldS + 2 * u + 1] = t1;
+            bound[(long)q * ldB + u] = t2;
+        }
     }
 }
 
@@ -265,6 +261,7 @@ void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, 
     LAUNCH_CHECK();
 }
 int flat_fast_tile_rows() { return FB_M; }
+int flat_fast_unit_rows() { return FB_UNIT; }
 int flat_fast_batch() { return FB_N; }
 
 // ------------------------------------------------------------------------------------------------
@@ -301,8 +298,8 @@ __global__ __launch_bounds__(COLLECT_THREADS) void flat_collect_kernel(const flo
         if (bd[t] <= tau) {
             // some non-emitted row of this tile may qualify: take the whole tile
             atomicAdd(&s_exp, 1);
-            const long r0 = t * FB_M;
-            for (int j = 0; j < FB_M; j++) {
+            const long r0 = t * FB_UNIT;
+            for (int j = 0; j < FB_UNIT; j++) {
                 const long r = r0 + j;
                 if (r < n && (!elig || elig[r])) { int s = atomicAdd(&s_cnt, 1); if (s < cap) lst[s] = (unsigned)r; }
             }
@@ -312,7 +309,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void flat_collect_kernel(const flo
                 const float key = s0[2 * t + e];
                 if (key <= tau) {   // inf keys (masked rows) only pass when tau is inf; they carry no row -> skip
                     if (key == __builtin_inff()) continue;
-                    const long r = t * FB_M + (__float_as_uint(key) & 0xFFu);
+                    const long r = t * FB_UNIT + (__float_as_uint(key) & (unsigned)(FB_UNIT - 1));
                     int s = atomicAdd(&s_cnt, 1); if (s < cap) lst[s] = (unsigned)r;
                 }
             }
@@ -571,15 +568,15 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
             const int src = __builtin_ctzll(em); em &= em - 1ull;
             const long te = t0 + (t & ~63) + src;      // tile of lane `src`
             if (lane == src) atomicAdd(&s_exp, 1);
-            for (int j = lane; j < FB_M; j += 64) {
-                const long r = te * FB_M + j;
+            for (int j = lane; j < FB_UNIT; j += 64) {
+                const long r = te * FB_UNIT + j;
                 post_append(r < n && (!elig || elig[r]), (unsigned)r, lst, &s_cnt, POST_CAP);
             }
         }
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const float key = (live && !expand) ? s0[2 * tl + e] : INF;
-            post_append(key <= tau && key != INF, (unsigned)(tl * FB_M + (__float_as_uint(key) & 0xFFu)), lst, &s_cnt, POST_CAP);
+            post_append(key <= tau && key != INF, (unsigned)(tl * FB_UNIT + (__float_as_uint(key) & (unsigned)(FB_UNIT - 1))), lst, &s_cnt, POST_CAP);
         }
     }
     __syncthreads();

@@ -107,7 +107,9 @@ def test_auto_mode_picks_fast_for_big_batches(ctx):
     assert g.stat("fast_queries") > 0
     g.search_batch(synth(15, 4, d), 10)          # small batches stay on the exact kernel (HBM-bound there)
     assert g.stat("fast_queries") == 0
-    g.search_batch(synth(15, 64, d), 100)        # too few tiles per requested result: exact kernel
+    g.search_batch(synth(15, 64, d), 100)        # 100000 >= 128 * 4 * 100 rows: still selective enough
+    assert g.stat("fast_queries") > 0
+    g.search_batch(synth(15, 64, d), 500)        # too few key units per requested result: exact kernel
     assert g.stat("fast_queries") == 0
 
 
