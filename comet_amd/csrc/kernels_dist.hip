@@ -92,6 +92,9 @@ __global__ __launch_bounds__(256) void ingest_rows_wave_kernel(int metric, const
         __builtin_amdgcn_wave_barrier();
         float sum = 0.0f;
         if (lane == 0) {
+            // the serial float32 sum of the reference (distance.go Norm); eight 16-byte reads in flight so that the chain
+            // of adds, not the LDS latency, paces the loop
+#pragma unroll 8
             for (int i = 0; i < dpad; i += 4) {
                 const f32x4 p = *reinterpret_cast<const f32x4*>(&my[i]);
                 sum = sum + p[0]; sum = sum + p[1]; sum = sum + p[2]; sum = sum + p[3];   // trailing pad terms are +0

@@ -135,3 +135,23 @@ def test_async_pipeline_equals_sync(ctx):
     g.search_wait(tickets[0])          # waiting twice is a no-op
     for p in qd + [x for o in outs for x in o]:
         ctx.free(p)
+
+
+def test_fast_path_beyond_the_fused_post_stage(ctx):
+    """More than 8192 key units (> 1,048,576 rows): the fused post-scan kernel does not apply and the five-launch pipeline
+    (tile-key selection, collection, rescoring, selection, gather) runs; results must still equal the strict path and the
+    oracle."""
+    n, d, B, k = 1_100_000, 16, 32, 10
+    X = synth(31, n, d)
+    Q = synth(32, B, d)
+    g = FlatIndex(ctx, d, L2_SQUARED)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    for lo in range(0, n, 200_000):
+        g.add_batch(ids[lo:lo + 200_000], X[lo:lo + 200_000])
+    fast = g.search_batch(Q, k, mode=2)
+    assert g.stat("fast_queries") == B
+    same(fast, g.search_batch(Q, k, mode=1))
+    o = orc.Flat(d, L2_SQUARED); assert o.add_batch(ids, X) == 0
+    for b in range(4):
+        c, oi, os_ = o.search(Q[b], k)
+        assert fast[2][b] == c and np.array_equal(fast[0][b, :c], oi) and np.array_equal(fast[1][b, :c].view(np.uint32), os_.view(np.uint32))
