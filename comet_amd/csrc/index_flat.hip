@@ -203,26 +203,9 @@ struct FlatIndex : comet_index {
         int32_t* ovf = c->salloc<int32_t>(bn);
         int32_t* st = c->salloc<int32_t>(4);
         c->zero(st, 16);
-        static const bool no_fused = getenv("COMET_FLAT_NO_FUSED_POST") != nullptr;
-        if (flat_post_usable(n_tiles) && !no_fused) {
-            // if the tile keys cannot even supply K values (tiny index / huge K) tau = +inf: every tile is expanded
-            launch_flat_post(c, metric, S0, ldS, bound, ldB, n_tiles, n, elig, err, p.k, (Kq == keff) ? Kq : 0, p.threshold, X.as<float>(), ld, Qp, bn,
-                             pos, out_scores, out_counts, k_cap, ovf, st);
-        } else {
-            uint32_t* kpos = c->salloc<uint32_t>((size_t)bn * Kq);
-            float* kkeys = c->salloc<float>((size_t)bn * Kq);
-            int32_t* kcnt = c->salloc<int32_t>(bn);
-            launch_select_topk(c, S0, ldS, bn, 2 * n_tiles, nullptr, 0.0f, Kq, kpos, kkeys, kcnt, Kq);
-            const int cap = 4096;
-            uint32_t* cand = c->salloc<uint32_t>((size_t)bn * cap);
-            int32_t* ccnt = c->salloc<int32_t>(bn);
-            launch_flat_collect(c, S0, ldS, bound, ldB, n_tiles, n, elig, kkeys, Kq, kcnt, (Kq == keff) ? Kq : 0x7fffffff, err, bn, cand, cap, ccnt, ovf, st);
-            float* D2 = c->salloc<float>((size_t)bn * cap);
-            launch_rescore_exact(c, metric, X.as<float>(), ld, Qp, bn, cand, cap, ccnt, cap, D2, cap);
-            uint32_t* pos2 = c->salloc<uint32_t>((size_t)bn * k_cap);
-            launch_select_topk(c, D2, cap, bn, cap, ccnt, p.threshold, p.k, pos2, out_scores, out_counts, k_cap);
-            launch_gather_indirect(c, cand, cap, pos2, bn, k_cap, pos);
-        }
+        // if the unit keys cannot even supply K values (tiny index / huge K) tau = +inf: every unit is expanded
+        launch_flat_post(c, metric, S0, ldS, bound, ldB, n_tiles, n, elig, err, p.k, (Kq == keff) ? Kq : 0, p.threshold, X.as<float>(), ld, Qp, bn,
+                         pos, out_scores, out_counts, k_cap, ovf, st);
         // overflow flags + statistics go to pinned host memory asynchronously; search_finish() acts on them
         int32_t* hf = pend->flags + (size_t)pend->nfast_slices * kSliceInts;
         c->d2h(hf, ovf, bn * sizeof(int32_t));

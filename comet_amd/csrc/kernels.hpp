@@ -28,8 +28,6 @@ void launch_dist_gather(Ctx* c, int metric, const float* X, int ld, const float*
                         const int32_t* cnts, int64_t Cmax, float* D, int64_t ldD);
 // Same contract as launch_dist_gather but for a FEW valid candidates per query (no EXCLUDED entries
 // below cnts[q]); wave-per-4-candidates mapping that hides HBM latency (fast path re-scoring).
-void launch_rescore_exact(Ctx* c, int metric, const float* X, int ld, const float* Q, int B, const uint32_t* cand, int64_t ldc,
-                          const int32_t* cnts, int64_t Cmax, float* D, int64_t ldD);
 // Bit pattern written into a distance matrix for candidates that must not be returned (soft-deleted,
 // filtered out). A negative quiet NaN with all payload bits set — never produced by the arithmetic here.
 constexpr uint32_t EXCLUDED_BITS = 0xFFFFFFFFu;
@@ -95,13 +93,9 @@ void launch_to_half_rows(Ctx* c, const float* X, int64_t n, int ld, void* Xh, in
 // mode 0 cosine / 1 L2 family. Qh: 256 x ldh fp16. S0: 256 x ldS (2 packed keys per 256-row tile), bound: 256 x ldB.
 void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, int nq_used, const float* rn, const float* qn,
                           const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB);
-bool flat_post_usable(int64_t n_tiles);
 void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const float* bound, int64_t ldB, int64_t n_tiles, int64_t n, const uint8_t* elig,
                       const float* err_abs, int K, int kappa_rank, float thr, const float* X, int ld, const float* Qp, int B,
                       uint32_t* out_rows, float* out_scores, int32_t* out_counts, int k_cap, int32_t* overflow, int32_t* stats);
-void launch_flat_collect(Ctx* c, const float* S0, int64_t ldS, const float* bound, int64_t ldB, int64_t n_tiles, int64_t n, const uint8_t* elig,
-                         const float* kth_keys, int kcap, const int32_t* kth_cnt, int K, const float* err_abs, int B, uint32_t* cand, int cap,
-                         int32_t* cand_cnt, int32_t* overflow, int32_t* stats);
 void launch_prep_queries_fast(Ctx* c, const float* Qp, int B, int ld, int dim, void* Qh, int ldh, float* qn, float* err_abs, int mode, float xmax_norm2);
 
 }  // namespace comet

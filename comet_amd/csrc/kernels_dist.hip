@@ -336,80 +336,6 @@ void launch_dist_gather(Ctx* c, int metric, const float* X, int ld, const float*
 }
 
 // ------------------------------------------------------------------------------------------------
-// exact re-scoring of a FEW candidates per query (the fast path's step 3): latency- not throughput-bound,
-// so the mapping is different from the scan kernels. A wave takes 16 candidates: all 64 lanes fetch each
-// candidate row coalesced and compute the per-element terms (diff^2 or product: independent, exactly
-// rounded), park them in LDS, then lanes 0..15 each run one candidate's serial float32 sum in index order.
-// ------------------------------------------------------------------------------------------------
-constexpr int RS_CPW = 16;       // candidates per wave (lanes 0..15 run the serial sums)
-constexpr int RS_CHUNK = 256;    // max floats of a row staged per pass
-template <int METRIC>
-__global__ __launch_bounds__(256) void rescore_exact_kernel(const float* __restrict__ X, int ld, const float* __restrict__ Q,
-                                                            const unsigned* __restrict__ cand, long ldc, const int* __restrict__ cnts,
-                                                            float* __restrict__ D, long ldD, int chunk) {
-    extern __shared__ __attribute__((aligned(16))) float terms_all[];   // [4 waves][RS_CPW][chunk]
-    const int q = blockIdx.y;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int cnt = cnts[q];
-    float* terms = terms_all + (long)w * RS_CPW * chunk;
-    const float* __restrict__ qv = Q + (long)q * ld;
-    // the grid covers a fixed number of candidate groups per query; longer lists loop
-    for (int c0 = (blockIdx.x * 4 + w) * RS_CPW; c0 < cnt; c0 += gridDim.x * 4 * RS_CPW) {
-        unsigned rows[RS_CPW];
-#pragma unroll
-        for (int j = 0; j < RS_CPW; j++) rows[j] = (c0 + j < cnt) ? cand[(long)q * ldc + c0 + j] : 0u;
-        float acc = 0.0f;   // lanes 0..RS_CPW-1: running sum of candidate `lane`
-        for (int k0 = 0; k0 < ld; k0 += chunk) {
-            const int kn = min(chunk, ld - k0);   // multiple of 32
-#pragma unroll
-            for (int j = 0; j < RS_CPW; j++) {
-                const float* __restrict__ x = X + (long)rows[j] * ld + k0;
-                for (int i = lane * 4; i < kn; i += 256) {
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
-                    const f32x4 qq = *reinterpret_cast<const f32x4*>(qv + k0 + i);
-                    f32x4 t;
-                    if constexpr (METRIC == COMET_COSINE) { t[0] = qq[0] * xv[0]; t[1] = qq[1] * xv[1]; t[2] = qq[2] * xv[2]; t[3] = qq[3] * xv[3]; }
-                    else {
-                        const float d0 = qq[0] - xv[0], d1 = qq[1] - xv[1], d2 = qq[2] - xv[2], d3 = qq[3] - xv[3];
-                        t[0] = d0 * d0; t[1] = d1 * d1; t[2] = d2 * d2; t[3] = d3 * d3;
-                    }
-                    *reinterpret_cast<f32x4*>(&terms[j * chunk + i]) = t;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < RS_CPW) {
-                const float* tp = terms + lane * chunk;
-#pragma unroll 8
-                for (int i = 0; i < kn; i += 4) {
-                    const f32x4 p = *reinterpret_cast<const f32x4*>(tp + i);
-                    acc = acc + p[0]; acc = acc + p[1]; acc = acc + p[2]; acc = acc + p[3];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (lane < RS_CPW && c0 + lane < cnt) D[(long)q * ldD + c0 + lane] = acc_finish<METRIC>(acc);
-    }
-}
-void launch_rescore_exact(Ctx* c, int metric, const float* X, int ld, const float* Q, int B, const uint32_t* cand, int64_t ldc,
-                          const int32_t* cnts, int64_t Cmax, float* D, int64_t ldD) {
-    if (B <= 0 || Cmax <= 0) return;
-    ProfScope ps(c, "rescore_exact");
-    const int chunk = std::min(ld, RS_CHUNK);
-    const size_t lds = (size_t)4 * RS_CPW * chunk * sizeof(float);
-    const int groups = (int)std::min<int64_t>(ceil_div(Cmax, 4 * RS_CPW), 4);    // 256 candidates per sweep; longer lists loop
-    dim3 grid(groups, B), blk(256);
-#define RS(M) do { if (lds > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)rescore_exact_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                   rescore_exact_kernel<M><<<grid, blk, lds, c->stream>>>(X, ld, Q, cand, ldc, cnts, D, ldD, chunk); } while (0)
-    switch (metric) {
-        case COMET_L2: RS(COMET_L2); break;
-        case COMET_L2SQ: RS(COMET_L2SQ); break;
-        default: RS(COMET_COSINE); break;
-    }
-#undef RS
-    LAUNCH_CHECK();
-}
-
-// ------------------------------------------------------------------------------------------------
 // a handful of pairs, one thread each (comet.Distance singletons; not a throughput path)
 // ------------------------------------------------------------------------------------------------
 __global__ void dist_pairs_kernel(int metric, const float* __restrict__ A, const float* __restrict__ Bv, int npairs, int d,

@@ -9,17 +9,17 @@
 //               256-query tile per workgroup, K streamed through LDS with global_load_lds (16 B/lane,
 //               XOR-swizzled source so ds_read_b128 is conflict-free). The epilogue never writes S: it
 //               turns each accumulator into a non-negative approximate distance, packs the row-in-tile
-//               into the low 8 mantissa bits, and keeps per (query, tile) the two smallest keys plus the
-//               third smallest (a lower bound for every row of the tile that was NOT emitted) with a
+//               into the low 8 mantissa bits, and keeps per (query, 128-row key unit) the two smallest keys
+//               plus the third smallest (a lower bound for every row of the unit that was NOT emitted) with a
 //               branch-free min/med3 network.
-//   2. collect: kappa = exact K-th smallest emitted key; tau = kappa + 2E, E a rigorous bound on
-//               |approx - exact| (fp16 rounding of both operands, fp32 accumulation, key packing).
-//               Candidates = emitted keys <= tau, plus ALL rows of any tile whose bound <= tau.
-//               Every row with approx <= tau is in that set, and the exact top-K all have
-//               approx <= a_K + 2E <= tau, so the set contains the exact answer.
-//   3. rescore: the exact gather kernel (kernels_dist.hip) + the exact selection give ids and scores
-//               bit-identical to the strict path; a query whose candidate list overflows falls back to
-//               the strict path.
+//   2. post   : one workgroup per query (flat_post_kernel): kappa = exact K-th smallest emitted key;
+//               tau = kappa + 2E, E a rigorous bound on |approx - exact| (fp16 rounding of both operands, fp32
+//               accumulation, key packing). Candidates = emitted keys <= tau, plus ALL rows of any unit whose
+//               bound <= tau. Every row with approx <= tau is in that set, and the exact top-K all have
+//               approx <= a_K + 2E <= tau, so the set contains the exact answer. The candidates are then
+//               re-scored in the reference's float32 order and selected exactly: ids and scores are
+//               bit-identical to the strict path; a query whose candidate list overflows is flagged and
+//               re-run on the strict path.
 #include "kernels.hpp"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -265,94 +265,6 @@ int flat_fast_unit_rows() { return FB_UNIT; }
 int flat_fast_batch() { return FB_N; }
 
 // ------------------------------------------------------------------------------------------------
-// collect: candidates of one query (one workgroup per query)
-// ------------------------------------------------------------------------------------------------
-constexpr int COLLECT_THREADS = 256;
-
-// kth_keys: [B][kcap] sorted emitted keys (select_topk output), kth_cnt[B]; K = requested k (after sanitising
-// against the eligible count is not known here: if fewer than K keys were found tau = +inf).
-// err_abs[q]: E (absolute) for this query; candidates: cand[q][cap] ascending row indices, cand_cnt[q];
-// overflow[q] = 1 if more than cap candidates (the host re-runs those queries on the strict path).
-__global__ __launch_bounds__(COLLECT_THREADS) void flat_collect_kernel(const float* __restrict__ S0, long ldS, const float* __restrict__ bound, long ldB,
-                                                                       long n_tiles, long n, const unsigned char* __restrict__ elig,
-                                                                       const float* __restrict__ kth_keys, int kcap, const int* __restrict__ kth_cnt, int K,
-                                                                       const float* __restrict__ err_abs, unsigned* __restrict__ cand, int cap,
-                                                                       int* __restrict__ cand_cnt, int* __restrict__ overflow, int* __restrict__ stats) {
-    extern __shared__ unsigned lst[];   // cap2 entries (power of two >= cap)
-    __shared__ int s_cnt; __shared__ int s_exp;
-    const int q = blockIdx.x;
-    int cap2 = 1; while (cap2 < cap) cap2 <<= 1;
-    if (threadIdx.x == 0) { s_cnt = 0; s_exp = 0; }
-    for (int i = threadIdx.x; i < cap2; i += COLLECT_THREADS) lst[i] = 0xFFFFFFFFu;
-    __syncthreads();
-    const int found = kth_cnt[q];
-    float tau = __builtin_inff();
-    if (K > 0 && found >= K) {
-        const float kappa = kth_keys[(long)q * kcap + (K - 1)];
-        // tau = kappa + 2E, plus the relative slack of the 8 truncated mantissa bits of both sides
-        tau = kappa + 2.0f * err_abs[q] + 1.0e-4f * fabsf(kappa) + 1e-30f;   // 1e-4 ~ 3 * 2^-15: key packing slack, both sides
-    }
-    const float* s0 = S0 + (long)q * ldS;
-    const float* bd = bound + (long)q * ldB;
-    for (long t = threadIdx.x; t < n_tiles; t += COLLECT_THREADS) {
-        if (bd[t] <= tau) {
-            // some non-emitted row of this tile may qualify: take the whole tile
-            atomicAdd(&s_exp, 1);
-            const long r0 = t * FB_UNIT;
-            for (int j = 0; j < FB_UNIT; j++) {
-                const long r = r0 + j;
-                if (r < n && (!elig || elig[r])) { int s = atomicAdd(&s_cnt, 1); if (s < cap) lst[s] = (unsigned)r; }
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const float key = s0[2 * t + e];
-                if (key <= tau) {   // inf keys (masked rows) only pass when tau is inf; they carry no row -> skip
-                    if (key == __builtin_inff()) continue;
-                    const long r = t * FB_UNIT + (__float_as_uint(key) & (unsigned)(FB_UNIT - 1));
-                    int s = atomicAdd(&s_cnt, 1); if (s < cap) lst[s] = (unsigned)r;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const int cnt = s_cnt;
-    if (cnt > cap) {
-        if (threadIdx.x == 0) { overflow[q] = 1; cand_cnt[q] = 0; if (stats) { atomicAdd(&stats[1], 1); } }
-        return;
-    }
-    // ascending row order = the canonical tie order of the strict path (sort only the used prefix)
-    int n2 = 64; while (n2 < cnt) n2 <<= 1;
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n2; i += COLLECT_THREADS) {
-                int ixj = i ^ j;
-                if (ixj > i) {
-                    unsigned a = lst[i], b = lst[ixj];
-                    bool up = ((i & k) == 0);
-                    if ((a > b) == up) { lst[i] = b; lst[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (int i = threadIdx.x; i < cap; i += COLLECT_THREADS) cand[(long)q * cap + i] = lst[i];
-    if (threadIdx.x == 0) {
-        cand_cnt[q] = cnt; overflow[q] = 0;
-        if (stats) { atomicAdd(&stats[0], cnt); atomicAdd(&stats[2], s_exp); }
-    }
-}
-void launch_flat_collect(Ctx* c, const float* S0, int64_t ldS, const float* bound, int64_t ldB, int64_t n_tiles, int64_t n, const uint8_t* elig,
-                         const float* kth_keys, int kcap, const int32_t* kth_cnt, int K, const float* err_abs, int B, uint32_t* cand, int cap,
-                         int32_t* cand_cnt, int32_t* overflow, int32_t* stats) {
-    int cap2 = 1; while (cap2 < cap) cap2 <<= 1;
-    ProfScope ps(c, "flat_collect");
-    flat_collect_kernel<<<dim3(B), dim3(COLLECT_THREADS), sizeof(unsigned) * cap2, c->stream>>>(S0, ldS, bound, ldB, n_tiles, n, elig, kth_keys, kcap, kth_cnt, K,
-                                                                                            err_abs, cand, cap, cand_cnt, overflow, stats);
-    LAUNCH_CHECK();
-}
-
-// ------------------------------------------------------------------------------------------------
 // query side: fp16 copy (zero-padded to 256 rows), squared norms, rigorous error bound per query
 // ------------------------------------------------------------------------------------------------
 // mode 0 cosine: |approx - exact| <= E; mode 1 L2 family (squared space).
@@ -475,8 +387,7 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
                                                                  unsigned* __restrict__ out_rows, float* __restrict__ out_scores, int* __restrict__ out_counts,
                                                                  int k_cap, int* __restrict__ overflow, int* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
-    unsigned* keys = reinterpret_cast<unsigned*>(psm);                       // [POST_MAXKEYS]; later the rescoring slices / sort buffer
-    unsigned* hist = keys + POST_MAXKEYS;                                    // [4096]
+    unsigned* hist = reinterpret_cast<unsigned*>(psm) + POST_MAXKEYS;       // [4096]; the 64 KiB in front: rescoring slices, then the sort buffer
     unsigned* lst = hist + 4096;                                             // [POST_CAP] candidate rows
     float* sc = reinterpret_cast<float*>(lst + POST_CAP);                    // [POST_CAP] exact scores
     __shared__ unsigned wsum[16];
@@ -489,8 +400,10 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
     // ---- 1. kappa ----
     float tau = INF;
     if (kappa_rank > 0) {
+        // the unit keys are streamed from global memory in every pass (a query's row is 31 KiB at 1M rows and L2-resident;
+        // no size limit), keys >= 0 so bit order = value order
         int mine = 0;
-        for (int i = t; i < nkeys; i += POST_THREADS) { const float v = s0[i]; keys[i] = __float_as_uint(v); if (v != INF) mine++; }   // keys >= 0: bit order = value order
+        for (int i = t; i < nkeys; i += POST_THREADS) { if (s0[i] != INF) mine++; }
         __syncthreads();
         if (mine) atomicAdd(&s_valid, mine);
         __syncthreads();
@@ -499,7 +412,7 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
             // LINEARLY over [min, max] instead (monotone: float subtract, multiply and floor are), locate the bin of the
             // K-th smallest, and rank the handful of keys inside it directly.
             float lo = INF, hi = 0.0f;
-            for (int i = t; i < nkeys; i += POST_THREADS) { const float v = __uint_as_float(keys[i]); if (v != INF) { lo = fminf(lo, v); hi = fmaxf(hi, v); } }
+            for (int i = t; i < nkeys; i += POST_THREADS) { const float v = s0[i]; if (v != INF) { lo = fminf(lo, v); hi = fmaxf(hi, v); } }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
             float* wlo = reinterpret_cast<float*>(hist); float* whi = wlo + 16;
@@ -511,7 +424,7 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
             auto bin_of = [&](unsigned k) { const int bq = (int)((__uint_as_float(k) - lo) * scale); return bq < 0 ? 0 : (bq > 4095 ? 4095 : bq); };
             for (int i = t; i < 4096; i += POST_THREADS) hist[i] = 0;
             __syncthreads();
-            for (int i = t; i < nkeys; i += POST_THREADS) { const unsigned k = keys[i]; if (k != 0x7F800000u) atomicAdd(&hist[bin_of(k)], 1u); }
+            for (int i = t; i < nkeys; i += POST_THREADS) { const unsigned k = __float_as_uint(s0[i]); if (k != 0x7F800000u) atomicAdd(&hist[bin_of(k)], 1u); }
             __syncthreads();
             post_find_bin(hist, kappa_rank, wsum, &s_bin, &s_before);
             const int kbin = s_bin, rank_in = kappa_rank - s_before, members = (int)hist[kbin];
@@ -521,7 +434,7 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
                 unsigned* mem = lst;                      // the candidate list is not in use yet
                 if (t == 0) s_cnt = 0;
                 __syncthreads();
-                for (int i = t; i < nkeys; i += POST_THREADS) { const unsigned k = keys[i]; if (k != 0x7F800000u && bin_of(k) == kbin) mem[atomicAdd(&s_cnt, 1)] = k; }
+                for (int i = t; i < nkeys; i += POST_THREADS) { const unsigned k = __float_as_uint(s0[i]); if (k != 0x7F800000u && bin_of(k) == kbin) mem[atomicAdd(&s_cnt, 1)] = k; }
                 __syncthreads();
                 if (t < members) {
                     const unsigned me = mem[t]; int less = 0;
@@ -541,7 +454,7 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
                     __syncthreads();
                     const unsigned bm = (1u << nbits[p]) - 1u;
                     for (int i = t; i < nkeys; i += POST_THREADS) {
-                        const unsigned k = keys[i];
+                        const unsigned k = __float_as_uint(s0[i]);
                         if (k != 0x7F800000u && bin_of(k) == kbin && (k & mask) == prefix) atomicAdd(&hist[(k >> shifts[p]) & bm], 1u);
                     }
                     __syncthreads();
@@ -686,7 +599,6 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
         if (stats) { atomicAdd(&stats[0], cnt); atomicAdd(&stats[2], s_exp); }
     }
 }
-bool flat_post_usable(int64_t n_tiles) { return 2 * n_tiles <= POST_MAXKEYS; }
 void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const float* bound, int64_t ldB, int64_t n_tiles, int64_t n, const uint8_t* elig,
                       const float* err_abs, int K, int kappa_rank, float thr, const float* X, int ld, const float* Qp, int B,
                       uint32_t* out_rows, float* out_scores, int32_t* out_counts, int k_cap, int32_t* overflow, int32_t* stats) {
