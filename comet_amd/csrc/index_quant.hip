@@ -574,4 +574,19 @@ int comet_merge_topk_dev(comet_ctx* c, const uint32_t* ids_dev, const float* sco
     });
 }
 
+/* one packed block per shard: [B*k_cap ids | B*k_cap scores | B counts] (32-bit words), blocks `block_words` apart —
+ * the layout a single all-gather of per-rank result blocks produces */
+int comet_merge_topk_packed_dev(comet_ctx* c, const uint32_t* packed_dev, int64_t block_words, int32_t R, int32_t B, int32_t k_cap, int32_t k,
+                                uint32_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev) {
+    return guarded([&] {
+        if (R <= 0 || B < 0 || k_cap <= 0 || block_words < (int64_t)2 * B * k_cap + B) COMET_FAIL(COMET_ERR_INVALID_ARG, "bad packed merge shape");
+        std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind();
+        const uint32_t* ids = packed_dev;
+        const float* scores = reinterpret_cast<const float*>(packed_dev + (size_t)B * k_cap);
+        const int32_t* counts = reinterpret_cast<const int32_t*>(packed_dev + (size_t)2 * B * k_cap);
+        launch_merge_topk(c, ids, scores, counts, R, B, k_cap, k, out_ids_dev, out_scores_dev, out_counts_dev, block_words, block_words);
+        return (int)COMET_OK;
+    });
+}
+
 }  // extern "C"

@@ -53,7 +53,7 @@ void launch_gather_indirect(Ctx* c, const uint32_t* table, int64_t ldt, const ui
 int select_max_k();
 // merge R per-shard sorted top-k lists per query (ties: lower shard, then lower position). R*k_cap <= select_max_k().
 void launch_merge_topk(Ctx* c, const uint32_t* ids, const float* scores, const int32_t* counts, int R, int B, int k_cap, int k,
-                       uint32_t* out_ids, float* out_scores, int32_t* out_counts);
+                       uint32_t* out_ids, float* out_scores, int32_t* out_counts, int64_t rank_stride = 0, int64_t rank_stride_counts = 0);
 void launch_select_topk(Ctx* c, const float* D, int64_t ldD, int B, int64_t C, const int32_t* cnts, float thr, int K,
                         uint32_t* out_pos, float* out_scores, int32_t* out_counts, int k_cap);
 

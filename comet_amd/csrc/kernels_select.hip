@@ -740,7 +740,7 @@ void launch_select_topk(Ctx* c, const float* D, int64_t ldD, int B, int64_t C, c
 __global__ __launch_bounds__(1024) void merge_topk_kernel(const unsigned* __restrict__ ids, const float* __restrict__ scores,
                                                           const int* __restrict__ counts, int R, int B, int k_cap, int k,
                                                           unsigned* __restrict__ out_ids, float* __restrict__ out_scores,
-                                                          int* __restrict__ out_counts, int n2) {
+                                                          int* __restrict__ out_counts, int n2, long rs /*elements between two shards' blocks*/, long rsc) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
     const int q = blockIdx.x;
     int total = 0;
@@ -748,12 +748,12 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const unsigned* __rest
         unsigned long long v = ~0ull;
         if (i < R * k_cap) {
             const int r = i / k_cap, j = i - r * k_cap;
-            int cnt = counts[(long)r * B + q]; if (cnt > k_cap) cnt = k_cap;
-            if (j < cnt) v = ((unsigned long long)f2key(__float_as_uint(scores[((long)r * B + q) * k_cap + j])) << 32) | (unsigned)i;
+            int cnt = counts[r * rsc + q]; if (cnt > k_cap) cnt = k_cap;
+            if (j < cnt) v = ((unsigned long long)f2key(__float_as_uint(scores[r * rs + (long)q * k_cap + j])) << 32) | (unsigned)i;
         }
         sm[i] = v;
     }
-    for (int r = 0; r < R; r++) { int cnt = counts[(long)r * B + q]; if (cnt < 0) { total = cnt; break; } total += cnt < k_cap ? cnt : k_cap; }
+    for (int r = 0; r < R; r++) { int cnt = counts[r * rsc + q]; if (cnt < 0) { total = cnt; break; } total += cnt < k_cap ? cnt : k_cap; }
     __syncthreads();
     for (int kk = 2; kk <= n2; kk <<= 1) {
         for (int j = kk >> 1; j > 0; j >>= 1) {
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const unsigned* __rest
             unsigned long long cmp = sm[i];
             unsigned src = (unsigned)(cmp & 0xFFFFFFFFull);
             const int r = src / k_cap, j = src - r * k_cap;
-            id = ids[((long)r * B + q) * k_cap + j];
+            id = ids[r * rs + (long)q * k_cap + j];
             sc = __uint_as_float(key2f((unsigned)(cmp >> 32)));
         }
         out_ids[(long)q * k_cap + i] = id; out_scores[(long)q * k_cap + i] = sc;
@@ -784,13 +784,14 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const unsigned* __rest
     if (threadIdx.x == 0) out_counts[q] = total < 0 ? total : kq;
 }
 void launch_merge_topk(Ctx* c, const uint32_t* ids, const float* scores, const int32_t* counts, int R, int B, int k_cap, int k,
-                       uint32_t* out_ids, float* out_scores, int32_t* out_counts) {
+                       uint32_t* out_ids, float* out_scores, int32_t* out_counts, int64_t rank_stride, int64_t rank_stride_counts) {
     if (B <= 0) return;
+    const long rs = rank_stride > 0 ? rank_stride : (long)B * k_cap, rsc = rank_stride_counts > 0 ? rank_stride_counts : B;
     int n2 = 1; while (n2 < R * k_cap) n2 <<= 1;
     if (n2 > 2 * SORT_MAX) COMET_FAIL(COMET_ERR_UNSUPPORTED, "merge of %d x %d candidates exceeds the on-device limit", R, k_cap);
     ProfScope ps(c, "merge_topk");
     int threads = n2 >= 2048 ? 1024 : (n2 >= 512 ? 256 : 64);
-    merge_topk_kernel<<<dim3(B), dim3(threads), sizeof(unsigned long long) * n2, c->stream>>>(ids, scores, counts, R, B, k_cap, k, out_ids, out_scores, out_counts, n2);
+    merge_topk_kernel<<<dim3(B), dim3(threads), sizeof(unsigned long long) * n2, c->stream>>>(ids, scores, counts, R, B, k_cap, k, out_ids, out_scores, out_counts, n2, rs, rsc);
     LAUNCH_CHECK();
 }
 

@@ -47,8 +47,10 @@ def merge_topk_host(ids: np.ndarray, scores: np.ndarray, counts: np.ndarray, k: 
 
 
 class TopKExchange:
-    """Pre-allocated buffers + one all-gather per array per batch. `ctx` is a comet_amd.Context for CUDA tensors,
-    None for the CPU/gloo path."""
+    """Pre-allocated buffers + ONE all-gather per batch. A rank's result block is one packed int32 buffer
+    [B*k_cap ids | B*k_cap scores | B counts]; the search writes its three outputs straight into it (local_ptrs), the
+    all-gather stacks the W blocks, and comet_merge_topk_packed_dev merges them. `ctx` is a comet_amd.Context for CUDA
+    tensors, None for the CPU/gloo path."""
 
     def __init__(self, B: int, k_cap: int, device, ctx=None, group=None):
         import torch
@@ -56,30 +58,39 @@ class TopKExchange:
         self.torch, self.dist, self.group, self.ctx = torch, dist, group, ctx
         self.world = dist.get_world_size(group)
         self.B, self.k_cap = B, k_cap
+        self.block = 2 * B * k_cap + B                      # 32-bit words per rank
         mk = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
-        self.ids, self.scores, self.counts = mk((B, k_cap), torch.int32), mk((B, k_cap), torch.float32), mk((B,), torch.int32)
-        self.g_ids, self.g_scores, self.g_counts = mk((self.world, B, k_cap), torch.int32), mk((self.world, B, k_cap), torch.float32), mk((self.world, B), torch.int32)
+        self.pack = mk((self.block,), torch.int32)
+        self.g_pack = mk((self.world, self.block), torch.int32)
+        n = B * k_cap
+        # typed views into this rank's block (what a search fills) and into the gathered blocks
+        self.ids, self.scores, self.counts = self.pack[:n].view(B, k_cap), self.pack[n:2 * n].view(torch.float32).view(B, k_cap), self.pack[2 * n:]
+        self.g_ids = self.g_pack[:, :n].view(torch.int32)
         self.m_ids, self.m_scores, self.m_counts = mk((B, k_cap), torch.int32), mk((B, k_cap), torch.float32), mk((B,), torch.int32)
 
     def local_ptrs(self):
-        return self.ids.data_ptr(), self.scores.data_ptr(), self.counts.data_ptr()
+        base = self.pack.data_ptr()
+        n = self.B * self.k_cap
+        return base, base + 4 * n, base + 8 * n
 
     def exchange_and_merge(self, k: int):
         """self.ids/scores/counts hold this rank's rows; returns the merged (ids, scores, counts) tensors."""
         d = self.dist
-        W, B, K = self.world, self.B, self.k_cap     # flattened [W*B, K] views: both RCCL and gloo accept them
-        d.all_gather_into_tensor(self.g_ids.view(W * B, K), self.ids, group=self.group)
-        d.all_gather_into_tensor(self.g_scores.view(W * B, K), self.scores, group=self.group)
-        d.all_gather_into_tensor(self.g_counts.view(W * B), self.counts, group=self.group)
-        if self.ids.is_cuda:
+        W, B, K = self.world, self.B, self.k_cap
+        d.all_gather_into_tensor(self.g_pack.view(W * self.block), self.pack, group=self.group)
+        if self.pack.is_cuda:
             from ._lib import check
             self.torch.cuda.current_stream().synchronize()      # the merge runs on the library's own stream
-            check(self.ctx.lib.comet_merge_topk_dev(self.ctx.h, C.c_void_p(self.g_ids.data_ptr()), C.c_void_p(self.g_scores.data_ptr()),
-                                                    C.c_void_p(self.g_counts.data_ptr()), self.world, self.B, self.k_cap, int(k),
-                                                    C.c_void_p(self.m_ids.data_ptr()), C.c_void_p(self.m_scores.data_ptr()),
-                                                    C.c_void_p(self.m_counts.data_ptr())))
+            check(self.ctx.lib.comet_merge_topk_packed_dev(self.ctx.h, C.c_void_p(self.g_pack.data_ptr()), self.block, W, B, K, int(k),
+                                                           C.c_void_p(self.m_ids.data_ptr()), C.c_void_p(self.m_scores.data_ptr()),
+                                                           C.c_void_p(self.m_counts.data_ptr())))
         else:
-            i, s, c = merge_topk_host(self.g_ids.numpy().view(np.uint32), self.g_scores.numpy(), self.g_counts.numpy(), k)
+            g = self.g_pack.numpy()
+            n = B * K
+            gi = np.ascontiguousarray(g[:, :n]).view(np.uint32).reshape(W, B, K)
+            gs = np.ascontiguousarray(g[:, n:2 * n]).view(np.float32).reshape(W, B, K)
+            gc = np.ascontiguousarray(g[:, 2 * n:]).reshape(W, B)
+            i, s, c = merge_topk_host(gi, gs, gc, k)
             self.m_ids.copy_(self.torch.from_numpy(i.view(np.int32)))
             self.m_scores.copy_(self.torch.from_numpy(s))
             self.m_counts.copy_(self.torch.from_numpy(c))

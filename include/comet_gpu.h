@@ -174,6 +174,12 @@ COMET_API int comet_index_search_wait(comet_index* idx, uint64_t ticket);
 COMET_API int comet_merge_topk_dev(comet_ctx* ctx, const uint32_t* ids_dev, const float* scores_dev,
                                    const int32_t* counts_dev, int32_t R, int32_t B, int32_t k_cap, int32_t k,
                                    uint32_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev);
+/* Same merge over R packed per-shard blocks, `block_words` 32-bit words apart, each laid out as
+ * [B*k_cap ids | B*k_cap scores | B counts] — what ONE all-gather of per-rank result blocks produces (a search writes its
+ * three outputs straight into such a block). */
+COMET_API int comet_merge_topk_packed_dev(comet_ctx* ctx, const uint32_t* packed_dev, int64_t block_words, int32_t R, int32_t B,
+                                          int32_t k_cap, int32_t k, uint32_t* out_ids_dev, float* out_scores_dev,
+                                          int32_t* out_counts_dev);
 
 /* ---- introspection --------------------------------------------------------------------------- */
 /* Read back trained state (host copies). centroids: nlist x dim, codebooks: M x Ksub x dsub. */

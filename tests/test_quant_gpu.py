@@ -322,3 +322,30 @@ def test_sharded_lists_merge_equals_unsharded(ctx, kind):
         assert sorted(mi[b, :c].tolist()) == sorted(f_ids[b, :c].tolist()) or not uniq.all()
     for p in bufs + [o_ids, o_sc, o_cn]:
         ctx.free(p)
+
+
+def test_merge_topk_packed_blocks(ctx):
+    """comet_merge_topk_packed_dev: the same merge over per-shard blocks [ids | scores | counts] as one all-gather stacks them."""
+    import ctypes as C
+    from comet_amd._lib import check
+    R, B, k = 3, 5, 8
+    rng = np.random.default_rng(9)
+    sc = np.sort(rng.random((R, B, k)).astype(np.float32), axis=2)
+    ids = rng.integers(1, 1 << 30, (R, B, k)).astype(np.uint32)
+    cn = rng.integers(0, k + 1, (R, B)).astype(np.int32)
+    block = 2 * B * k + B + 7                                  # blocks may be padded
+    packed = np.zeros((R, block), np.uint32)
+    for r in range(R):
+        packed[r, :B * k] = ids[r].ravel(); packed[r, B * k:2 * B * k] = sc[r].ravel().view(np.uint32); packed[r, 2 * B * k:2 * B * k + B] = cn[r].view(np.uint32)
+    pk = ctx.alloc(packed.nbytes); ctx.upload(pk, packed)
+    o_ids, o_sc, o_cn = ctx.alloc(B * k * 4), ctx.alloc(B * k * 4), ctx.alloc(B * 4)
+    check(ctx.lib.comet_merge_topk_packed_dev(ctx.h, C.c_void_p(pk), block, R, B, k, k, C.c_void_p(o_ids), C.c_void_p(o_sc), C.c_void_p(o_cn)))
+    ctx.sync()
+    from comet_amd.dist import merge_topk_host
+    ei, es, ec = merge_topk_host(ids, sc, cn, k)
+    mi, ms, mc = ctx.download(o_ids, (B, k), np.uint32), ctx.download(o_sc, (B, k), np.float32), ctx.download(o_cn, (B,), np.int32)
+    assert np.array_equal(mc, ec)
+    for b in range(B):
+        assert np.array_equal(mi[b, :ec[b]], ei[b, :ec[b]]) and np.array_equal(bits(ms[b, :ec[b]]), bits(es[b, :ec[b]]))
+    for p in (pk, o_ids, o_sc, o_cn):
+        ctx.free(p)
