@@ -181,9 +181,9 @@ struct FlatIndex : comet_index {
         return ok && B >= 32 && n >= (int64_t)flat_fast_unit_rows() * 4 * keff;
     }
 
-    // MFMA fast path for up to 256 prepared queries; writes candidate positions `pos` as ROW indices
-    void search_fast(const float* Qp, int bn, const comet_search_params& p, const uint8_t* elig, uint32_t* pos, float* out_scores,
-                     int32_t* out_counts, int k_cap, Pending* pend) {
+    // MFMA fast path for up to 256 prepared queries; writes the final ids / scores / counts of the slice
+    void search_fast(const float* Qp, const int32_t* zflag, int bn, const comet_search_params& p, const uint8_t* elig, uint32_t* out_ids,
+                     float* out_scores, int32_t* out_counts, int k_cap, Pending* pend) {
         ScratchMark sm(c);
         // key units: the scan emits, per query, 2 keys + 1 bound for every 128-row unit (two per 256-row tile)
         const int64_t n_tiles = ceil_div(n, flat_fast_tile_rows()) * (flat_fast_tile_rows() / flat_fast_unit_rows());
@@ -192,24 +192,22 @@ struct FlatIndex : comet_index {
         void* Qh = c->scratch_alloc((size_t)NB * ldh * 2);
         float* qn = c->salloc<float>(NB);
         float* err = c->salloc<float>(NB);
+        int32_t* flags = c->salloc<int32_t>(kSliceInts);     // [256 overflow flags | 4 stats], copied to the host in one piece
+        int32_t* ovf = flags; int32_t* st = flags + 256;
         const int fmode = metric == COMET_COSINE ? 0 : 1;
-        launch_prep_queries_fast(c, Qp, bn, ld, dim, Qh, ldh, qn, err, fmode, metric == COMET_COSINE ? 1.0002f : xmax_norm2);
+        launch_prep_queries_fast(c, Qp, bn, ld, dim, Qh, ldh, qn, err, fmode, metric == COMET_COSINE ? 1.0002f : xmax_norm2, st);
         float* S0 = c->salloc<float>((size_t)NB * ldS);
         float* bound = c->salloc<float>((size_t)NB * ldB);
         launch_flat_scan_f16(c, fmode, Xh.p, n, ldh, Qh, bn, rn.as<float>(), qn, elig, S0, ldS, bound, ldB);
         // kappa: exact K-th smallest emitted key per query
         const int64_t keff = (p.k <= 0 || p.k > n) ? n : p.k;
         const int Kq = (int)std::min<int64_t>(keff, 2 * n_tiles);
-        int32_t* ovf = c->salloc<int32_t>(bn);
-        int32_t* st = c->salloc<int32_t>(4);
-        c->zero(st, 16);
         // if the unit keys cannot even supply K values (tiny index / huge K) tau = +inf: every unit is expanded
         launch_flat_post(c, metric, S0, ldS, bound, ldB, n_tiles, n, elig, err, p.k, (Kq == keff) ? Kq : 0, p.threshold, X.as<float>(), ld, Qp, bn,
-                         pos, out_scores, out_counts, k_cap, ovf, st);
+                         ids_dev.as<uint32_t>(), zflag, out_ids, out_scores, out_counts, k_cap, ovf, st);
         // overflow flags + statistics go to pinned host memory asynchronously; search_finish() acts on them
         int32_t* hf = pend->flags + (size_t)pend->nfast_slices * kSliceInts;
-        c->d2h(hf, ovf, bn * sizeof(int32_t));
-        c->d2h(hf + 256, st, 16);
+        c->d2h(hf, flags, kSliceInts * sizeof(int32_t));
         pend->nfast_slices++;
     }
 
@@ -218,8 +216,8 @@ struct FlatIndex : comet_index {
                      int32_t* out_counts, int k_cap, Pending* pend) {
         float* Qp; int32_t* zflag;
         prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag);
-        uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
         if (n == 0) {   // empty index: zero results (sanitizeK(k, 0) == 0)
+            uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
             launch_select_topk(c, nullptr, 0, B, 0, nullptr, 0.0f, p.k, pos, out_scores, out_counts, k_cap);
             launch_finalize(c, nullptr, pos, B, k_cap, zflag, out_ids, out_counts);
             return;
@@ -240,11 +238,12 @@ struct FlatIndex : comet_index {
         if (pend && fast_usable(B, p) && ceil_div(B, NB) <= kMaxSlices) {
             for (int b0 = 0; b0 < B; b0 += NB) {
                 const int bn = std::min(NB, B - b0);
-                search_fast(Qp + (size_t)b0 * ld, bn, p, elig, pos + (size_t)b0 * k_cap, out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap, pend);
+                search_fast(Qp + (size_t)b0 * ld, zflag + b0, bn, p, elig, out_ids + (size_t)b0 * k_cap, out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap, pend);
             }
-        } else {
-            search_strict(Qp, B, p, elig, pos, out_scores, out_counts, k_cap);
+            return;                                  // the post stage wrote ids and statuses itself
         }
+        uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
+        search_strict(Qp, B, p, elig, pos, out_scores, out_counts, k_cap);
         launch_finalize(c, ids_dev.as<uint32_t>(), pos, B, k_cap, zflag, out_ids, out_counts);
     }
 

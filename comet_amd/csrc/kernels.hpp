@@ -95,7 +95,9 @@ void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, 
                           const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB);
 void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const float* bound, int64_t ldB, int64_t n_tiles, int64_t n, const uint8_t* elig,
                       const float* err_abs, int K, int kappa_rank, float thr, const float* X, int ld, const float* Qp, int B,
-                      uint32_t* out_rows, float* out_scores, int32_t* out_counts, int k_cap, int32_t* overflow, int32_t* stats);
-void launch_prep_queries_fast(Ctx* c, const float* Qp, int B, int ld, int dim, void* Qh, int ldh, float* qn, float* err_abs, int mode, float xmax_norm2);
+                      const uint32_t* ids_table, const int32_t* zflag, uint32_t* out_ids, float* out_scores, int32_t* out_counts, int k_cap,
+                      int32_t* overflow, int32_t* stats);
+void launch_prep_queries_fast(Ctx* c, const float* Qp, int B, int ld, int dim, void* Qh, int ldh, float* qn, float* err_abs, int mode, float xmax_norm2,
+                              int32_t* stats4);
 
 }  // namespace comet

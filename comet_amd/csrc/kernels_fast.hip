@@ -269,9 +269,10 @@ int flat_fast_batch() { return FB_N; }
 // ------------------------------------------------------------------------------------------------
 // mode 0 cosine: |approx - exact| <= E; mode 1 L2 family (squared space).
 __global__ __launch_bounds__(256) void prep_queries_fast_kernel(const float* __restrict__ Qp, int B, int ld, int dim, _Float16* __restrict__ Qh, int ldh,
-                                                                float* __restrict__ qn, float* __restrict__ err_abs, int mode, float xmax_norm2) {
+                                                                float* __restrict__ qn, float* __restrict__ err_abs, int mode, float xmax_norm2, int* __restrict__ stats4) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (stats4 && blockIdx.x == 0 && threadIdx.x < 4) stats4[threadIdx.x] = 0;   // the post stage accumulates into these
     if (q >= FB_N) return;
     _Float16* o = Qh + (long)q * ldh;
     float s = 0.0f;
@@ -291,8 +292,9 @@ __global__ __launch_bounds__(256) void prep_queries_fast_kernel(const float* __r
         err_abs[q] = 1.25f * e;
     }
 }
-void launch_prep_queries_fast(Ctx* c, const float* Qp, int B, int ld, int dim, void* Qh, int ldh, float* qn, float* err_abs, int mode, float xmax_norm2) {
-    prep_queries_fast_kernel<<<dim3(FB_N / 4), dim3(256), 0, c->stream>>>(Qp, B, ld, dim, (_Float16*)Qh, ldh, qn, err_abs, mode, xmax_norm2);
+void launch_prep_queries_fast(Ctx* c, const float* Qp, int B, int ld, int dim, void* Qh, int ldh, float* qn, float* err_abs, int mode, float xmax_norm2,
+                              int32_t* stats4) {
+    prep_queries_fast_kernel<<<dim3(FB_N / 4), dim3(256), 0, c->stream>>>(Qp, B, ld, dim, (_Float16*)Qh, ldh, qn, err_abs, mode, xmax_norm2, stats4);
     LAUNCH_CHECK();
 }
 
@@ -306,7 +308,7 @@ void launch_prep_queries_fast(Ctx* c, const float* Qp, int B, int ld, int dim, v
 //      third-smallest key (bound) is <= tau; more than POST_CAP -> overflow flag (the host re-runs that query strictly)
 //   3. candidates sorted by row (canonical tie order), exact distances in the reference's float32 order: a wave takes
 //      32 candidates, stages 32-float slices of their products in LDS, lanes 0..31 run the serial sums
-//   4. (score, row) sort, threshold + sanitizeK, rows / scores / count written
+//   4. (score, row) sort, threshold + sanitizeK, ids / scores / count written (count = -ErrZeroVector for a zero cosine query)
 // ------------------------------------------------------------------------------------------------
 constexpr int POST_THREADS = 1024, POST_WAVES = 16, POST_MAXKEYS = 16384, POST_CAP = 4096, POST_CPW = 32, POST_CHUNK = 32;
 constexpr int POST_LPC = POST_CHUNK / 4, POST_CPI = 64 / POST_LPC, POST_NJ = POST_CPW / POST_CPI;   // lanes per candidate slice, candidates per load instruction, instructions per slice
@@ -384,7 +386,8 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
                                                                  long n_tiles, long n, const unsigned char* __restrict__ elig,
                                                                  const float* __restrict__ err_abs, int K /*requested, sanitised against n*/, int kappa_rank /*0: tau = inf*/,
                                                                  float thr, const float* __restrict__ X, int ld, const float* __restrict__ Qp,
-                                                                 unsigned* __restrict__ out_rows, float* __restrict__ out_scores, int* __restrict__ out_counts,
+                                                                 const unsigned* __restrict__ ids_table, const int* __restrict__ zflag,
+                                                                 unsigned* __restrict__ out_ids, float* __restrict__ out_scores, int* __restrict__ out_counts,
                                                                  int k_cap, int* __restrict__ overflow, int* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
     unsigned* hist = reinterpret_cast<unsigned*>(psm) + POST_MAXKEYS;       // [4096]; the 64 KiB in front: rescoring slices, then the sort buffer
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
     __syncthreads();
     const int cnt = s_cnt;
     if (cnt > POST_CAP) {                              // empty row; the host re-runs this query on the strict path
-        for (int i = t; i < k_cap; i += POST_THREADS) { out_rows[(long)q * k_cap + i] = 0xFFFFFFFFu; out_scores[(long)q * k_cap + i] = 0.0f; }
+        for (int i = t; i < k_cap; i += POST_THREADS) { out_ids[(long)q * k_cap + i] = 0u; out_scores[(long)q * k_cap + i] = 0.0f; }
         if (t == 0) { out_counts[q] = 0; overflow[q] = 1; if (stats) atomicAdd(&stats[1], 1); }
         return;
     }
@@ -587,26 +590,28 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
     for (int i = t; i < k_cap; i += POST_THREADS) {
         if (i < nw) {
             const unsigned long long cc = comp[i];
-            out_rows[(long)q * k_cap + i] = lst[(unsigned)(cc & 0xFFFFFFFFull)];
+            out_ids[(long)q * k_cap + i] = ids_table[lst[(unsigned)(cc & 0xFFFFFFFFull)]];     // VectorResult.Node.ID()
             out_scores[(long)q * k_cap + i] = __uint_as_float(pkey2f((unsigned)(cc >> 32)));
         } else {
-            out_rows[(long)q * k_cap + i] = 0xFFFFFFFFu;
+            out_ids[(long)q * k_cap + i] = 0u;
             out_scores[(long)q * k_cap + i] = 0.0f;
         }
     }
     if (t == 0) {
-        out_counts[q] = kq; overflow[q] = 0;
+        out_counts[q] = (zflag && zflag[q]) ? -(int)COMET_ERR_ZERO_VECTOR : kq;      // a zero cosine query fails as a whole (ErrZeroVector)
+        overflow[q] = 0;
         if (stats) { atomicAdd(&stats[0], cnt); atomicAdd(&stats[2], s_exp); }
     }
 }
 void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const float* bound, int64_t ldB, int64_t n_tiles, int64_t n, const uint8_t* elig,
                       const float* err_abs, int K, int kappa_rank, float thr, const float* X, int ld, const float* Qp, int B,
-                      uint32_t* out_rows, float* out_scores, int32_t* out_counts, int k_cap, int32_t* overflow, int32_t* stats) {
+                      const uint32_t* ids_table, const int32_t* zflag, uint32_t* out_ids, float* out_scores, int32_t* out_counts, int k_cap,
+                      int32_t* overflow, int32_t* stats) {
     if (B <= 0) return;
     ProfScope ps(c, "flat_post");
 #define POST(M) do { HIP_CHECK(hipFuncSetAttribute((const void*)flat_post_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POST_LDS)); \
         flat_post_kernel<M><<<dim3(B), dim3(POST_THREADS), POST_LDS, c->stream>>>(S0, ldS, bound, ldB, n_tiles, n, elig, err_abs, K, kappa_rank, thr, X, ld, Qp, \
-                                                                                 out_rows, out_scores, out_counts, k_cap, overflow, stats); } while (0)
+                                                                                 ids_table, zflag, out_ids, out_scores, out_counts, k_cap, overflow, stats); } while (0)
     switch (metric) { case COMET_L2: POST(COMET_L2); break; case COMET_L2SQ: POST(COMET_L2SQ); break; default: POST(COMET_COSINE); break; }
 #undef POST
     LAUNCH_CHECK();
