@@ -155,3 +155,24 @@ def test_fast_path_beyond_the_fused_post_stage(ctx):
     for b in range(4):
         c, oi, os_ = o.search(Q[b], k)
         assert fast[2][b] == c and np.array_equal(fast[0][b, :c], oi) and np.array_equal(fast[1][b, :c].view(np.uint32), os_.view(np.uint32))
+
+
+def test_wide_rows_and_large_k(ctx):
+    """Rows wider than the wave-ingest limit (2048 floats) take the lane-per-row ingest; K = 512 on the fast path keeps
+    thousands of candidates per query. Both must equal the strict path / the oracle."""
+    n, d = 700, 2500
+    X = synth(41, n, d); Q = synth(42, 5, d)
+    for metric in (COSINE, L2_SQUARED):
+        g = FlatIndex(ctx, d, metric); ids = np.arange(1, n + 1, dtype=np.uint32); g.add_batch(ids, X)
+        o = orc.Flat(d, metric); assert o.add_batch(ids, X) == 0
+        r = g.search_batch(Q, 7)
+        for b in range(len(Q)):
+            c, oi, os_ = o.search(Q[b], 7)
+            assert r[2][b] == c and np.array_equal(r[0][b, :c], oi) and np.array_equal(r[1][b, :c].view(np.uint32), os_.view(np.uint32))
+    n, d, B, k = 300_000, 16, 40, 512
+    X = synth(43, n, d); Q = synth(44, B, d)
+    g = FlatIndex(ctx, d, L2_SQUARED)
+    g.add_batch(np.arange(1, n + 1, dtype=np.uint32), X)
+    fast = g.search_batch(Q, k, mode=2)
+    assert g.stat("fast_queries") + g.stat("fast_overflows") >= B
+    same(fast, g.search_batch(Q, k, mode=1))
