@@ -336,6 +336,82 @@ void launch_dist_gather(Ctx* c, int metric, const float* X, int ld, const float*
 }
 
 // ------------------------------------------------------------------------------------------------
+// IVF list scan, list-ordered (ivf_index_search.go:277-301). Same per-candidate arithmetic as dist_gather_kernel, but the
+// work is laid out by (query, probed list) PAIR in list order: blockIdx.y walks the pairs sorted by list, so the workgroups
+// that scan one inverted list for its different queries run back to back and the list's rows are served by L2 for all but
+// the first (the per-query layout re-read every probed row from HBM once per query: 46 GB per 256-query batch at
+// nprobe = 32 on 1M x 768). Rows are addressed straight from the slot layout (no candidate-row matrix).
+// ------------------------------------------------------------------------------------------------
+template <int METRIC>
+__global__ __launch_bounds__(256) void dist_list_kernel(const float* __restrict__ X, int ld, const float* __restrict__ Q,
+                                                        const unsigned* __restrict__ order, int np, const unsigned* __restrict__ probe_list, int ldp,
+                                                        const int* __restrict__ seg_off, const long* __restrict__ list_base, const int* __restrict__ list_len,
+                                                        const unsigned* __restrict__ row_of_slot, const unsigned char* __restrict__ elig,
+                                                        float* __restrict__ D, long ldD) {
+    __shared__ __attribute__((aligned(16))) float xs[TILE_ROWS * XS_LD];
+    __shared__ unsigned rows[TILE_ROWS];
+    const int pair = (int)order[blockIdx.y];
+    const int q = pair / np, pi = pair - q * np;
+    const int so = seg_off[(long)q * (np + 1) + pi];
+    if (seg_off[(long)q * (np + 1) + pi + 1] == so) return;          // empty list / unused probe slot
+    const unsigned L = probe_list[(long)q * ldp + pi];
+    const int len = list_len[L];
+    const long base = list_base[L];
+    const int t = threadIdx.x;
+    const float* __restrict__ qv = Q + (long)q * ld;
+    const int nchunks = ld / DC;
+    for (int pos0 = blockIdx.x * TILE_ROWS; pos0 < len; pos0 += gridDim.x * TILE_ROWS) {
+        const int pos = pos0 + t;
+        unsigned myrow = 0xFFFFFFFFu;
+        if (pos < len && (!elig || elig[base + pos])) myrow = row_of_slot[base + pos];
+        __syncthreads();                                   // previous tile's rows[] / xs[] no longer in use
+        rows[t] = myrow;
+        __syncthreads();
+        const int lrow = t >> 3, lc4 = (t & 7) * 4;
+        f32x4 pre[8];
+        const float* xrow[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            unsigned r = rows[j * 32 + lrow];
+            if (r == 0xFFFFFFFFu) r = 0;                   // excluded / past the end: read row 0, result discarded
+            xrow[j] = X + (long)r * ld + lc4;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) pre[j] = *reinterpret_cast<const f32x4*>(xrow[j]);
+        float acc = 0.0f;
+        for (int c = 0; c < nchunks; c++) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; j++) *reinterpret_cast<f32x4*>(&xs[(j * 32 + lrow) * XS_LD + lc4]) = pre[j];
+            __syncthreads();
+            {
+                const int cn = (c + 1 < nchunks) ? c + 1 : c;
+#pragma unroll
+                for (int j = 0; j < 8; j++) pre[j] = *reinterpret_cast<const f32x4*>(xrow[j] + cn * DC);
+            }
+#pragma unroll
+            for (int i4 = 0; i4 < DC / 4; i4++) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[t * XS_LD + i4 * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc = acc_step<METRIC>(acc, qv[c * DC + i4 * 4 + e], x[e]);
+            }
+        }
+        if (pos < len) D[(long)q * ldD + so + pos] = (myrow == 0xFFFFFFFFu) ? __uint_as_float(EXCLUDED_BITS) : acc_finish<METRIC>(acc);
+    }
+}
+void launch_dist_list(Ctx* c, int metric, const float* X, int ld, const float* Q, const uint32_t* order, int n_pairs, int np, const uint32_t* probe_list,
+                      int ldp, const int32_t* seg_off, const int64_t* list_base, const int32_t* list_len, const uint32_t* row_of_slot,
+                      const uint8_t* elig, int max_list_len, float* D, int64_t ldD) {
+    if (n_pairs <= 0 || max_list_len <= 0) return;
+    ProfScope ps(c, "dist_list");
+    dim3 grid((unsigned)std::min<int64_t>(8, ceil_div(max_list_len, TILE_ROWS)), (unsigned)n_pairs), blk(256);
+#define DL(M) dist_list_kernel<M><<<grid, blk, 0, c->stream>>>(X, ld, Q, order, np, probe_list, ldp, seg_off, (const long*)list_base, list_len, row_of_slot, elig, D, ldD)
+    switch (metric) { case COMET_L2: DL(COMET_L2); break; case COMET_L2SQ: DL(COMET_L2SQ); break; default: DL(COMET_COSINE); break; }
+#undef DL
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
 // a handful of pairs, one thread each (comet.Distance singletons; not a throughput path)
 // ------------------------------------------------------------------------------------------------
 __global__ void dist_pairs_kernel(int metric, const float* __restrict__ A, const float* __restrict__ Bv, int npairs, int d,

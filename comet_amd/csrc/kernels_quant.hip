@@ -588,6 +588,18 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const float* __re
         }
     }
 }
+// pairs of a (sub-)batch grouped by probed list; falls back to the identity order when the list count does not fit in LDS
+void launch_order_pairs(Ctx* c, const uint32_t* probe_list, int ldp, int np, const int32_t* seg_off, int n_pairs, int nlist, uint32_t* order) {
+    if (n_pairs <= 0) return;
+    static bool attr_done = false;
+    if (!attr_done) { HIP_CHECK(hipFuncSetAttribute((const void*)order_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (ORDER_MAX_LISTS + 1) * 4)); attr_done = true; }
+    ProfScope ps(c, "order_pairs");
+    if (nlist <= ORDER_MAX_LISTS && n_pairs > 1)
+        order_pairs_kernel<<<dim3(1), dim3(1024), (size_t)(nlist + 1) * 4, c->stream>>>(probe_list, ldp, np, seg_off, n_pairs, nlist, order);
+    else
+        iota_kernel<<<dim3((unsigned)ceil_div(n_pairs, 256)), dim3(256), 0, c->stream>>>(order, n_pairs);
+    LAUNCH_CHECK();
+}
 size_t adc_lds_bytes(int M, int Ksub, int dim) { (void)dim; int KL = Ksub < 256 ? Ksub : 256; return (size_t)M * KL * sizeof(float); }
 static size_t adc_lut_budget() {
     static size_t b = [] { const char* e = getenv("COMET_ADC_LUT_MB"); long mb = e ? atol(e) : 1024; if (mb < 1) mb = 1; return (size_t)mb << 20; }();
