@@ -22,14 +22,7 @@ void launch_unpad_rows(Ctx* c, const float* src, int64_t n, int ld, float* dst, 
 // elig (nullable): per-row eligibility bytes; ineligible rows get the EXCLUDED sentinel in D.
 void launch_dist_exact(Ctx* c, int metric, const float* X, int64_t n, int ld, const float* Q, int B, float* D, int64_t ldD,
                        const uint8_t* elig);
-// Per-query candidate rows: D[q][pos] = Calculate(Q[q], X[rowidx[q][pos]]) for pos < cnts[q]
-// (rowidx == 0xFFFFFFFF -> EXCLUDED). rowidx: B x ldR, D: B x ldD, Cmax >= max cnts.
-void launch_dist_gather(Ctx* c, int metric, const float* X, int ld, const float* Q, int B, const uint32_t* rowidx, int64_t ldR,
-                        const int32_t* cnts, int64_t Cmax, float* D, int64_t ldD);
-// Same contract as launch_dist_gather but for a FEW valid candidates per query (no EXCLUDED entries
-// below cnts[q]); wave-per-4-candidates mapping that hides HBM latency (fast path re-scoring).
-// Bit pattern written into a distance matrix for candidates that must not be returned (soft-deleted,
-// filtered out). A negative quiet NaN with all payload bits set — never produced by the arithmetic here.
+// ineligible / excluded candidates carry this bit pattern (a NaN the arithmetic cannot produce) in distance matrices
 constexpr uint32_t EXCLUDED_BITS = 0xFFFFFFFFu;
 // one pair / a few pairs, single thread (comet.Distance singletons)
 void launch_dist_pairs(Ctx* c, int metric, const float* A, const float* Bv, int npairs, int d, int a_stride, int b_stride, float* out);
@@ -76,8 +69,6 @@ void launch_order_pairs(Ctx* c, const uint32_t* probe_list, int ldp, int np, con
 void launch_dist_list(Ctx* c, int metric, const float* X, int ld, const float* Q, const uint32_t* order, int n_pairs, int np, const uint32_t* probe_list,
                       int ldp, const int32_t* seg_off, const int64_t* list_base, const int32_t* list_len, const uint32_t* row_of_slot,
                       const uint8_t* elig, int max_list_len, float* D, int64_t ldD);
-void launch_cand_rows(Ctx* c, const uint32_t* probe_list, int ldp, const int32_t* seg_off, int np, const int64_t* list_base,
-                      const uint32_t* row_of_slot, const uint8_t* elig, const int32_t* cnts, int B, uint32_t* rowidx, int64_t ldR);
 void launch_finalize_probe(Ctx* c, const uint32_t* pos, int B, int k_cap, const uint32_t* probe_list, int ldp, const int32_t* seg_off, int np,
                            const int64_t* list_base, const uint32_t* ids_of_slot, const int32_t* zflag, uint32_t* out_ids, int32_t* counts);
 size_t adc_lds_bytes(int M, int Ksub, int dim);

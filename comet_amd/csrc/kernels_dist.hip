@@ -269,75 +269,9 @@ void launch_dist_exact(Ctx* c, int metric, const float* X, int64_t n, int ld, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// gathered exact distances: every query has its own candidate rows (IVF list scan,
-// ivf_index_search.go:277-301). D[q][pos] = Calculate(Q[q], X[rowidx[q][pos]]); rowidx == 0xFFFFFFFF
-// marks an excluded candidate. One lane per candidate, same LDS-transposed 128-byte-chunk pipeline as
-// dist_exact_kernel — row indirection is free because each row chunk is fetched independently anyway.
-// ------------------------------------------------------------------------------------------------
-template <int METRIC>
-__global__ __launch_bounds__(256) void dist_gather_kernel(const float* __restrict__ X, int ld, const float* __restrict__ Q,
-                                                          const unsigned* __restrict__ rowidx, long ldR,
-                                                          const int* __restrict__ cnts, float* __restrict__ D, long ldD) {
-    __shared__ __attribute__((aligned(16))) float xs[TILE_ROWS * XS_LD];
-    __shared__ unsigned rows[TILE_ROWS];
-    const int q = blockIdx.y;
-    const long pos0 = (long)blockIdx.x * TILE_ROWS;
-    const long cnt = cnts[q];
-    if (pos0 >= cnt) return;
-    const int t = threadIdx.x;
-    const long pos = pos0 + t;
-    const unsigned myrow = pos < cnt ? rowidx[(long)q * ldR + pos] : 0xFFFFFFFFu;
-    rows[t] = myrow;
-    __syncthreads();
-    const int lrow = t >> 3, lc4 = (t & 7) * 4;
-    f32x4 pre[8];
-    const float* xrow[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        unsigned r = rows[j * 32 + lrow];
-        if (r == 0xFFFFFFFFu) r = 0;           // excluded: read row 0, result discarded
-        xrow[j] = X + (long)r * ld + lc4;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; j++) pre[j] = *reinterpret_cast<const f32x4*>(xrow[j]);
-    float acc = 0.0f;
-    const float* __restrict__ qv = Q + (long)q * ld;
-    const int nchunks = ld / DC;
-    for (int c = 0; c < nchunks; c++) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 8; j++) *reinterpret_cast<f32x4*>(&xs[(j * 32 + lrow) * XS_LD + lc4]) = pre[j];
-        __syncthreads();
-        {
-            const int cn = (c + 1 < nchunks) ? c + 1 : c;
-#pragma unroll
-            for (int j = 0; j < 8; j++) pre[j] = *reinterpret_cast<const f32x4*>(xrow[j] + cn * DC);
-        }
-#pragma unroll
-        for (int i4 = 0; i4 < DC / 4; i4++) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[t * XS_LD + i4 * 4]);
-#pragma unroll
-            for (int e = 0; e < 4; e++) acc = acc_step<METRIC>(acc, qv[c * DC + i4 * 4 + e], x[e]);
-        }
-    }
-    if (pos < cnt) D[(long)q * ldD + pos] = (myrow == 0xFFFFFFFFu) ? __uint_as_float(EXCLUDED_BITS) : acc_finish<METRIC>(acc);
-}
-void launch_dist_gather(Ctx* c, int metric, const float* X, int ld, const float* Q, int B, const uint32_t* rowidx, int64_t ldR,
-                        const int32_t* cnts, int64_t Cmax, float* D, int64_t ldD) {
-    if (B <= 0 || Cmax <= 0) return;
-    ProfScope ps(c, "dist_gather");
-    dim3 grid((unsigned)ceil_div(Cmax, TILE_ROWS), B), blk(256);
-    switch (metric) {
-        case COMET_L2: dist_gather_kernel<COMET_L2><<<grid, blk, 0, c->stream>>>(X, ld, Q, rowidx, ldR, cnts, D, ldD); break;
-        case COMET_L2SQ: dist_gather_kernel<COMET_L2SQ><<<grid, blk, 0, c->stream>>>(X, ld, Q, rowidx, ldR, cnts, D, ldD); break;
-        default: dist_gather_kernel<COMET_COSINE><<<grid, blk, 0, c->stream>>>(X, ld, Q, rowidx, ldR, cnts, D, ldD); break;
-    }
-    LAUNCH_CHECK();
-}
-
-// ------------------------------------------------------------------------------------------------
-// IVF list scan, list-ordered (ivf_index_search.go:277-301). Same per-candidate arithmetic as dist_gather_kernel, but the
-// work is laid out by (query, probed list) PAIR in list order: blockIdx.y walks the pairs sorted by list, so the workgroups
+// IVF list scan, list-ordered (ivf_index_search.go:277-301). One lane per candidate, the same LDS-transposed 128-byte-chunk
+// pipeline as dist_exact_kernel (row indirection is free because each row chunk is fetched independently anyway); the work
+// is laid out by (query, probed list) PAIR in list order: blockIdx.y walks the pairs sorted by list, so the workgroups
 // that scan one inverted list for its different queries run back to back and the list's rows are served by L2 for all but
 // the first (the per-query layout re-read every probed row from HBM once per query: 46 GB per 256-query batch at
 // nprobe = 32 on 1M x 768). Rows are addressed straight from the slot layout (no candidate-row matrix).

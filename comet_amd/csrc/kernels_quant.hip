@@ -267,30 +267,6 @@ __device__ __forceinline__ int find_probe(const int* __restrict__ so, int np, in
     while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (so[mid] <= pos) lo = mid; else hi = mid; }
     return lo;
 }
-// rowidx[q][pos] = row_of_slot[list_base[L] + j] (or EXCLUDED when the slot is ineligible / pos >= cnt)
-__global__ __launch_bounds__(256) void cand_rows_kernel(const unsigned* __restrict__ probe_list, int ldp, const int* __restrict__ seg_off, int np,
-                                                        const long* __restrict__ list_base, const unsigned* __restrict__ row_of_slot,
-                                                        const unsigned char* __restrict__ elig, const int* __restrict__ cnts,
-                                                        unsigned* __restrict__ rowidx, long ldR) {
-    const int q = blockIdx.y;
-    const long pos = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= ldR) return;
-    unsigned out = 0xFFFFFFFFu;
-    if (pos < cnts[q]) {
-        const int* so = seg_off + (long)q * (np + 1);
-        int p = find_probe(so, np, (int)pos);
-        long slot = list_base[probe_list[(long)q * ldp + p]] + (pos - so[p]);
-        if (!elig || elig[slot]) out = row_of_slot ? row_of_slot[slot] : (unsigned)slot;
-    }
-    rowidx[(long)q * ldR + pos] = out;
-}
-void launch_cand_rows(Ctx* c, const uint32_t* probe_list, int ldp, const int32_t* seg_off, int np, const int64_t* list_base,
-                      const uint32_t* row_of_slot, const uint8_t* elig, const int32_t* cnts, int B, uint32_t* rowidx, int64_t ldR) {
-    if (B <= 0 || ldR <= 0) return;
-    ProfScope ps(c, "cand_rows");
-    cand_rows_kernel<<<dim3((unsigned)ceil_div(ldR, 256), B), dim3(256), 0, c->stream>>>(probe_list, ldp, seg_off, np, (const long*)list_base, row_of_slot, elig, cnts, rowidx, ldR);
-    LAUNCH_CHECK();
-}
 // out_ids[q][i] = ids_of_slot[ list_base[L] + j ] for the selected candidate positions
 __global__ __launch_bounds__(256) void finalize_probe_kernel(const unsigned* __restrict__ pos, int B, int k_cap, const unsigned* __restrict__ probe_list,
                                                              int ldp, const int* __restrict__ seg_off, int np, const long* __restrict__ list_base,
