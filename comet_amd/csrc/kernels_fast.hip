@@ -303,7 +303,8 @@ void launch_prep_queries_fast(Ctx* c, const float* Qp, int B, int ld, int dim, v
 // fused post-scan stage: ONE workgroup per query does what used to be five launches (K-th tile key, candidate
 // collection, exact rescoring, final selection, row gather). Each of those is a short, latency-bound, one-workgroup-
 // per-query kernel; chained through HBM they cost ~0.2 ms per 256-query batch, a quarter of the whole search step.
-//   1. tile keys of the query -> LDS; kappa = exact K-th smallest (three radix passes, 12+12+8 bits)
+//   1. kappa = exact K-th smallest unit key of the query (keys streamed from L2; linear binning over [min, max], then the
+//      few keys of the K-th's bin are ranked directly)
 //   2. tau = kappa + 2E (+ key-packing slack); candidates = emitted rows with key <= tau, plus every row of a tile whose
 //      third-smallest key (bound) is <= tau; more than POST_CAP -> overflow flag (the host re-runs that query strictly)
 //   3. candidates sorted by row (canonical tie order), exact distances in the reference's float32 order: a wave takes

@@ -1,4 +1,4 @@
-// kernels_quant.hip — k-means, coarse assignment, PQ encode and the fused PQ lookup-table + ADC scan
+// kernels_quant.hip — k-means, coarse assignment, PQ encode, PQ lookup tables and the ADC scan
 // for gfx950. Everything here reproduces the reference's float32 evaluation order exactly
 // (clustering.go:119-272, pq_index.go:439-471, ivfpq_index_search.go:350-390) — see each kernel.
 #include "kernels.hpp"

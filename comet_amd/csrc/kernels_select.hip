@@ -289,7 +289,7 @@ __global__ __launch_bounds__(1024) void sel_sort_kernel(const unsigned long long
 
 // ---- small candidate rows (C <= 8192): one workgroup per query, everything in LDS ---------------------
 // Same result as the multi-pass path (composite = order-preserving key << 32 | position, ascending), one
-// launch instead of nine: used for IVF / IVFPQ candidate lists, the fast path's tile keys and rescoring.
+// launch instead of nine: used for the coarse top-nprobe, short IVF / IVFPQ candidate lists and HNSW result lists.
 //   * up to 1024 candidates: bitonic sort of the composites;
 //   * more: two 12-bit radix histogram passes in LDS locate the 24-bit prefix of the K-th key, the
 //     candidates at or below that prefix are compacted (typically K + a handful) and only those are sorted;
