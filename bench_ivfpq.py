@@ -49,10 +49,23 @@ def main():
     ap.add_argument("--no-recall", action="store_true")
     args = ap.parse_args()
 
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = world > 1 or os.environ.get("COMET_BENCH_FORCE_DIST") == "1"
+    dist = None
+    if use_dist:
+        # SURVEY §8(e) for IVFPQ: every rank trains on the same vectors (deterministic GPU k-means -> replicated centroids and
+        # codebooks), holds a round-robin share of the rows, probes the same lists; per-shard top-K are all-gathered and merged
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        if world == 1:
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29578")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import comet_amd as ca
     from comet_amd._lib import check
     import oracle_lib as orc
-    ctx = ca.Context(0)
+    ctx = ca.Context(local_rank)
     d, n = args.dim, args.rows
     ntrain = min(n, args.train or args.nlist * 100)
 
@@ -78,6 +91,8 @@ def main():
         hi = min(n, lo + chunk)
         X = rows(lo, hi)
         ids = np.arange(lo + 1, hi + 1, dtype=np.uint32)
+        if world > 1:                                  # this rank's round-robin share of the chunk
+            X, ids = X[rank::world], ids[rank::world]
         idx.add_batch(ids, X)
         if flat is not None:
             flat.add_batch(ids, X)
@@ -87,18 +102,53 @@ def main():
     Q = np.vstack([rows(int(r), int(r) + 1) for r in qrows]) + orc.synth(0xBEEF + 4, 0, B * d).reshape(B, d) * np.float32(0.05)
 
     q_dev = ctx.alloc(B * d * 4); ctx.upload(q_dev, Q)
-    oi, os_, oc = ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)
-    for _ in range(args.warmup):
+    ex = None
+    if use_dist:
+        from comet_amd.dist import TopKExchange
+        ex = TopKExchange(B, K, torch.device("cuda", local_rank), ctx=ctx)
+        oi, os_, oc = ex.local_ptrs()
+    else:
+        oi, os_, oc = ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)
+
+    def step():
         idx.search_batch_dev(q_dev, B, K, oi, os_, oc, K, nprobes=args.nprobe)
-    ctx.sync()
+        if ex is not None:
+            ctx.sync()
+            ex.exchange_and_merge(K)
+
+    def barrier():
+        ctx.sync()
+        if use_dist:
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
     ctx.profile(True); ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        idx.search_batch_dev(q_dev, B, K, oi, os_, oc, K, nprobes=args.nprobe)
-    ctx.sync()
+        step()
+    barrier()
     el = time.perf_counter() - t0
     prof = ctx.profile_dump(); ctx.profile(False)
-    g_ids = ctx.download(oi, (B, K), np.uint32); g_sc = ctx.download(os_, (B, K), np.float32); g_cn = ctx.download(oc, (B,), np.int32)
+    if use_dist:
+        t = torch.tensor([el], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if ex is not None:
+        ctx.sync()
+        g_ids = ex.m_ids.cpu().numpy().view(np.uint32); g_sc = ex.m_scores.cpu().numpy(); g_cn = ex.m_counts.cpu().numpy()
+    else:
+        g_ids = ctx.download(oi, (B, K), np.uint32); g_sc = ctx.download(os_, (B, K), np.float32); g_cn = ctx.download(oc, (B,), np.int32)
+    if world > 1:
+        # multi-GPU line: throughput only (the exported single-rank index needed for the roofline / oracle sections lives on one rank)
+        if rank == 0:
+            print(json.dumps({"metric": "queries/sec, IVFPQ search, rows sharded round-robin over the ranks (RCCL all-gather of per-shard top-K)",
+                              "value": B * args.steps / el, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+                              "config": {"workload": f"IVFPQ L2^2 {n}x{d}, nlist={args.nlist} nprobe={args.nprobe} M={args.M} nbits={args.nbits}, batch={B}, K={K}"},
+                              "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())}}), flush=True)
+        dist.destroy_process_group()
+        return
 
     # ---- algorithmic bytes of the ADC scan: recompute the probed lists on the host from the exported state ----
     e_ids, e_lists, e_codes = idx.export(codes_width=args.M)
@@ -117,7 +167,7 @@ def main():
 
     line = {
         "metric": "queries/sec, IVFPQ search (BASELINE configs[3] shape) on 1 MI355X",
-        "value": B * args.steps / el, "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "value": B * args.steps / el, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "dtype": "f32 tables / u8 codes", "data": "synthetic (clustered)",
         "config": {"workload": f"IVFPQ L2^2 {n}x{d}, nlist={args.nlist} nprobe={args.nprobe} M={args.M} nbits={args.nbits}, batch={B}, K={K}",
                    "train_vectors": ntrain, "train_s": round(train_s, 2), "add_s": round(add_s, 2), "max_list_len": int(list_len.max()),
@@ -159,6 +209,12 @@ def main():
         line["cpu_baseline"] = {"value": nq / cel, "unit": "queries/s", "cores": T, "kind": "port",
                                 "sample": f"{nq} of the batch's queries on the GPU-built index (quantizers + codes exported), {T} threads, {cel:.2f}s",
                                 "parity_checked_queries": nq, "parity_mismatches": len(bad)}
+    if use_dist:
+        dist.destroy_process_group()
+        try:                                   # RCCL's version banner goes through C stdio: keep the JSON line last
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
     print(json.dumps(line), flush=True)
 
 
