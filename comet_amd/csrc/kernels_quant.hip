@@ -316,7 +316,9 @@ void launch_finalize_probe(Ctx* c, const uint32_t* pos, int B, int k_cap, const 
 constexpr int ADC_THREADS = 1024;
 constexpr int ADC_WAVES = ADC_THREADS / 64;
 constexpr int ADC_CHAINS = 4;
-constexpr int ADC_SEG_CODES = ADC_WAVES * ADC_CHAINS * 64;     // codes one workgroup takes per item
+constexpr int ADC_PASS_CODES = ADC_WAVES * ADC_CHAINS * 64;    // codes one workgroup scans per pass (one block per chain per wave)
+constexpr int ADC_SEG_PASSES = 4;
+constexpr int ADC_SEG_CODES = ADC_PASS_CODES * ADC_SEG_PASSES;  // codes per item: long lists re-use the table for up to four passes
 constexpr int ADC_XCD_CHUNK = 4;                               // adjacent sorted pairs kept on one XCD
 constexpr int LUT_PAIRS_PER_WG = 32;
 constexpr int ORDER_MAX_LISTS = 36 * 1024;                     // counting-sort bins that fit in LDS
@@ -508,18 +510,17 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const float* __re
             if (seg_off[(long)q * (np + 1) + p + 1] == so) live = false;
             else { L = probe_list[(long)q * ldp + p]; len = list_len[L]; live = start < len; }
         }
-        // code words of the first group are requested before the table so that both are in flight together
+        // code words of the first group (of the first pass) are requested before the table so that both are in flight together
         unsigned cur[ADC_CHAINS][ADC_G];
-        int end = 0, nact = 0, blk0 = 0;
+        int seg_end = 0, nact = 0, blk0 = 0;
         long base_slot = 0;
         const unsigned* __restrict__ cw = codes;
         const long stride16 = (long)ADC_WAVES * M4 * 64;
-        if (live) {
-            end = min(len, start + ADC_SEG_CODES);
-            const int nblk = (end - start + 63) >> 6;   // blocks of this segment, 1..64
+        auto pass_setup = [&](int pstart) {              // blocks wid, wid+16, ... of the pass that starts at code pstart
+            const int pend = min(seg_end, pstart + ADC_PASS_CODES);
+            const int nblk = (pend - pstart + 63) >> 6;  // 1..64
             nact = wid < nblk ? (nblk - wid + ADC_WAVES - 1) / ADC_WAVES : 0;
-            base_slot = list_base[L];                   // multiple of 64
-            blk0 = (start >> 6) + wid;
+            blk0 = (pstart >> 6) + wid;
             cw = codes + ((base_slot >> 6) + blk0) * (long)M4 * 64 + lane;
             if ((M >> 2) >= ADC_G) {
 #pragma unroll
@@ -529,6 +530,11 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const float* __re
                         for (int i = 0; i < ADC_G; i++) cur[c][i] = cw[c * stride16 + (long)i * 64];
                     }
             }
+        };
+        if (live) {
+            seg_end = min(len, start + ADC_SEG_CODES);
+            base_slot = list_base[L];                   // multiple of 64
+            pass_setup(start);
         }
         if (live) {                                 // workgroup-uniform
             const float* __restrict__ src = lutg + (long)pair * n_ent;
@@ -546,20 +552,23 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const float* __re
         if (threadIdx.x == 0) { const int t = take(my_q, tried); s_ticket[0] = my_q; s_ticket[1] = t; }   // overlaps the table load
         __syncthreads();                            // table in LDS (the compiler drains vmcnt before the barrier), next ticket published
         if (!live) continue;
-        float acc[ADC_CHAINS];
-        switch (nact) {
-            case 1: adc_chains<1>(lut, M, M4, KL, cw, stride16, cur, acc); break;
-            case 2: adc_chains<2>(lut, M, M4, KL, cw, stride16, cur, acc); break;
-            case 3: adc_chains<3>(lut, M, M4, KL, cw, stride16, cur, acc); break;
-            case 4: adc_chains<4>(lut, M, M4, KL, cw, stride16, cur, acc); break;
-            default: break;
-        }
+        for (int pstart = start; pstart < seg_end; pstart += ADC_PASS_CODES) {
+            if (pstart != start) pass_setup(pstart);
+            float acc[ADC_CHAINS];
+            switch (nact) {
+                case 1: adc_chains<1>(lut, M, M4, KL, cw, stride16, cur, acc); break;
+                case 2: adc_chains<2>(lut, M, M4, KL, cw, stride16, cur, acc); break;
+                case 3: adc_chains<3>(lut, M, M4, KL, cw, stride16, cur, acc); break;
+                case 4: adc_chains<4>(lut, M, M4, KL, cw, stride16, cur, acc); break;
+                default: break;
+            }
 #pragma unroll
-        for (int c = 0; c < ADC_CHAINS; c++) {
-            const int j = (blk0 + c * ADC_WAVES) * 64 + lane;
-            if (c < nact && j < end) {
-                const bool ok = elig ? (elig[base_slot + j] != 0) : true;
-                D[(long)q * ldD + so + j] = ok ? go_sqrt32q(acc[c]) : __uint_as_float(EXCLUDED_BITS);
+            for (int c = 0; c < ADC_CHAINS; c++) {
+                const int j = (blk0 + c * ADC_WAVES) * 64 + lane;
+                if (c < nact && j < seg_end) {
+                    const bool ok = elig ? (elig[base_slot + j] != 0) : true;
+                    D[(long)q * ldD + so + j] = ok ? go_sqrt32q(acc[c]) : __uint_as_float(EXCLUDED_BITS);
+                }
             }
         }
     }
