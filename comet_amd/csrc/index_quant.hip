@@ -263,13 +263,15 @@ struct IVFIndex : comet_index {
             int qb = (int)std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(budget / ((size_t)ldR * 4))));
             float* D = c->salloc<float>((size_t)qb * ldR);
             uint32_t* order = c->salloc<uint32_t>((size_t)qb * np);
+            uint32_t* olist = c->salloc<uint32_t>((size_t)qb * np);
             for (int b0 = 0; b0 < B; b0 += qb) {
                 const int bn = std::min(qb, B - b0);
                 const uint32_t* pl = probe_list + (size_t)b0 * np;
                 const int32_t* so = seg_off + (size_t)b0 * (np + 1);
                 // (query, list) pairs in list order: the scans of one inverted list run back to back and share its rows through L2
-                launch_order_pairs(c, pl, np, np, so, bn * np, nlist, order);
-                launch_dist_list(c, metric, V.as<float>(), ld, Qp + (size_t)b0 * ld, order, bn * np, np, pl, np, so, lay.list_base.as<int64_t>(),
+                // groups pay off once lists are shared: on average at least two (query, list) pairs per list
+                const bool grouped = launch_order_pairs(c, pl, np, np, so, bn * np, nlist, order, olist) && (int64_t)bn * np >= 2 * (int64_t)nlist;
+                launch_dist_list(c, metric, V.as<float>(), ld, Qp + (size_t)b0 * ld, order, grouped ? olist : nullptr, bn * np, nlist, np, pl, np, so, lay.list_base.as<int64_t>(),
                                  lay.list_len.as<int32_t>(), lay.row_of_slot.as<uint32_t>(), elig, lay.max_len, D, ldR);
                 launch_select_topk(c, D, ldR, bn, Cmax, cnts + b0, p.threshold, p.k, pos + (size_t)b0 * k_cap,
                                    out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);

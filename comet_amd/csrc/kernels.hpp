@@ -65,10 +65,11 @@ void launch_pq_encode(Ctx* c, const float* R, int ld, int64_t n, const float* co
 void launch_interleave_codes(Ctx* c, const uint32_t* src_words, int M4, const uint32_t* row_of_slot, int64_t nslots, uint32_t* dst);
 void launch_probe_segments(Ctx* c, const uint32_t* probe_list, int ldp, const int32_t* probe_cnt, const int32_t* list_len, int B, int np,
                            int32_t* seg_off, int32_t* cnts);
-void launch_order_pairs(Ctx* c, const uint32_t* probe_list, int ldp, int np, const int32_t* seg_off, int n_pairs, int nlist, uint32_t* order);
-void launch_dist_list(Ctx* c, int metric, const float* X, int ld, const float* Q, const uint32_t* order, int n_pairs, int np, const uint32_t* probe_list,
-                      int ldp, const int32_t* seg_off, const int64_t* list_base, const int32_t* list_len, const uint32_t* row_of_slot,
-                      const uint8_t* elig, int max_list_len, float* D, int64_t ldD);
+bool launch_order_pairs(Ctx* c, const uint32_t* probe_list, int ldp, int np, const int32_t* seg_off, int n_pairs, int nlist, uint32_t* order,
+                        uint32_t* olist = nullptr);
+void launch_dist_list(Ctx* c, int metric, const float* X, int ld, const float* Q, const uint32_t* order, const uint32_t* olist, int n_pairs, int nlist, int np,
+                      const uint32_t* probe_list, int ldp, const int32_t* seg_off, const int64_t* list_base, const int32_t* list_len,
+                      const uint32_t* row_of_slot, const uint8_t* elig, int max_list_len, float* D, int64_t ldD);
 void launch_finalize_probe(Ctx* c, const uint32_t* pos, int B, int k_cap, const uint32_t* probe_list, int ldp, const int32_t* seg_off, int np,
                            const int64_t* list_base, const uint32_t* ids_of_slot, const int32_t* zflag, uint32_t* out_ids, int32_t* counts);
 size_t adc_lds_bytes(int M, int Ksub, int dim);

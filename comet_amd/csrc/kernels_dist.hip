@@ -276,32 +276,30 @@ void launch_dist_exact(Ctx* c, int metric, const float* X, int64_t n, int ld, co
 // the first (the per-query layout re-read every probed row from HBM once per query: 46 GB per 256-query batch at
 // nprobe = 32 on 1M x 768). Rows are addressed straight from the slot layout (no candidate-row matrix).
 // ------------------------------------------------------------------------------------------------
-template <int METRIC>
-__global__ __launch_bounds__(256) void dist_list_kernel(const float* __restrict__ X, int ld, const float* __restrict__ Q,
-                                                        const unsigned* __restrict__ order, int np, const unsigned* __restrict__ probe_list, int ldp,
-                                                        const int* __restrict__ seg_off, const long* __restrict__ list_base, const int* __restrict__ list_len,
-                                                        const unsigned* __restrict__ row_of_slot, const unsigned char* __restrict__ elig,
-                                                        float* __restrict__ D, long ldD) {
-    __shared__ __attribute__((aligned(16))) float xs[TILE_ROWS * XS_LD];
-    __shared__ unsigned rows[TILE_ROWS];
-    const int pair = (int)order[blockIdx.y];
-    const int q = pair / np, pi = pair - q * np;
-    const int so = seg_off[(long)q * (np + 1) + pi];
-    if (seg_off[(long)q * (np + 1) + pi + 1] == so) return;          // empty list / unused probe slot
-    const unsigned L = probe_list[(long)q * ldp + pi];
-    const int len = list_len[L];
-    const long base = list_base[L];
+constexpr int LG_WINDOW = 16;     // sorted positions per grouping window = the largest query group
+template <int METRIC, int QT>
+__device__ __forceinline__ void list_group_scan(const float* __restrict__ X, int ld, const float* __restrict__ Q, const int* mq, const int* mso, int cnt,
+                                                long base, int len, const unsigned* __restrict__ row_of_slot, const unsigned char* __restrict__ elig,
+                                                float* __restrict__ D, long ldD, float* xs, float* qs, unsigned* rows) {
     const int t = threadIdx.x;
-    const float* __restrict__ qv = Q + (long)q * ld;
     const int nchunks = ld / DC;
+    // loader roles: thread t fetches float4 #(j*256+t) of the 256 x 32 row tile, and floats t, t+256 of the QT x 32 query tile
+    const int lrow = t >> 3, lc4 = (t & 7) * 4;
+    const float* qsrc[2]; int qdst[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int e = t + h * 256, j = e >> 5, col = e & 31;           // member j (clamped: pad with the last one), column col
+        qsrc[h] = Q + (long)mq[j < cnt ? j : cnt - 1] * ld + col;
+        qdst[h] = col * QT + (j < QT ? j : 0);
+    }
+    constexpr bool QH1 = QT * 32 > 256;                                 // the second half-load exists only for QT = 16
     for (int pos0 = blockIdx.x * TILE_ROWS; pos0 < len; pos0 += gridDim.x * TILE_ROWS) {
         const int pos = pos0 + t;
         unsigned myrow = 0xFFFFFFFFu;
         if (pos < len && (!elig || elig[base + pos])) myrow = row_of_slot[base + pos];
-        __syncthreads();                                   // previous tile's rows[] / xs[] no longer in use
+        __syncthreads();                                   // previous tile's rows[] / xs[] / qs[] no longer in use
         rows[t] = myrow;
         __syncthreads();
-        const int lrow = t >> 3, lc4 = (t & 7) * 4;
         f32x4 pre[8];
         const float* xrow[8];
 #pragma unroll
@@ -312,34 +310,103 @@ __global__ __launch_bounds__(256) void dist_list_kernel(const float* __restrict_
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) pre[j] = *reinterpret_cast<const f32x4*>(xrow[j]);
-        float acc = 0.0f;
+        float qpre0 = (QT > 1 && t < QT * 32) ? qsrc[0][0] : 0.0f, qpre1 = 0.0f;
+        if constexpr (QH1) qpre1 = qsrc[1][0];
+        float acc[QT];
+#pragma unroll
+        for (int j = 0; j < QT; j++) acc[j] = 0.0f;
         for (int c = 0; c < nchunks; c++) {
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < 8; j++) *reinterpret_cast<f32x4*>(&xs[(j * 32 + lrow) * XS_LD + lc4]) = pre[j];
+            if (QT > 1 && t < QT * 32) qs[qdst[0]] = qpre0;
+            if constexpr (QH1) qs[qdst[1]] = qpre1;
             __syncthreads();
             {
                 const int cn = (c + 1 < nchunks) ? c + 1 : c;
 #pragma unroll
                 for (int j = 0; j < 8; j++) pre[j] = *reinterpret_cast<const f32x4*>(xrow[j] + cn * DC);
+                if (QT > 1 && t < QT * 32) qpre0 = qsrc[0][cn * DC];
+                if constexpr (QH1) qpre1 = qsrc[1][cn * DC];
             }
+            if constexpr (QT == 1) {
+                // a lone query: its values are wave-uniform, read them with scalar loads straight from the query row
+                const float* __restrict__ qv = Q + (long)mq[0] * ld + c * DC;
 #pragma unroll
-            for (int i4 = 0; i4 < DC / 4; i4++) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[t * XS_LD + i4 * 4]);
+                for (int i4 = 0; i4 < DC / 4; i4++) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[t * XS_LD + i4 * 4]);
 #pragma unroll
-                for (int e = 0; e < 4; e++) acc = acc_step<METRIC>(acc, qv[c * DC + i4 * 4 + e], x[e]);
+                    for (int e = 0; e < 4; e++) acc[0] = acc_step<METRIC>(acc[0], qv[i4 * 4 + e], x[e]);
+                }
+            } else {
+#pragma unroll 2
+                for (int i4 = 0; i4 < DC / 4; i4++) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[t * XS_LD + i4 * 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float xe = x[e];
+                        const float* qrow = qs + (i4 * 4 + e) * QT;          // QT consecutive floats: broadcast LDS reads
+#pragma unroll
+                        for (int j = 0; j < QT; j++) acc[j] = acc_step<METRIC>(acc[j], qrow[j], xe);
+                    }
+                }
             }
         }
-        if (pos < len) D[(long)q * ldD + so + pos] = (myrow == 0xFFFFFFFFu) ? __uint_as_float(EXCLUDED_BITS) : acc_finish<METRIC>(acc);
+        if (pos < len) {
+#pragma unroll
+            for (int j = 0; j < QT; j++)
+                if (j < cnt) D[(long)mq[j] * ldD + mso[j] + pos] = (myrow == 0xFFFFFFFFu) ? __uint_as_float(EXCLUDED_BITS) : acc_finish<METRIC>(acc[j]);
+        }
     }
 }
-void launch_dist_list(Ctx* c, int metric, const float* X, int ld, const float* Q, const uint32_t* order, int n_pairs, int np, const uint32_t* probe_list,
-                      int ldp, const int32_t* seg_off, const int64_t* list_base, const int32_t* list_len, const uint32_t* row_of_slot,
-                      const uint8_t* elig, int max_list_len, float* D, int64_t ldD) {
+
+template <int METRIC, bool GROUPED>
+__global__ __launch_bounds__(256) void dist_list_kernel(const float* __restrict__ X, int ld, const float* __restrict__ Q,
+                                                        const unsigned* __restrict__ order, const unsigned* __restrict__ olist /*nullable*/, int n_pairs, int nlist,
+                                                        int np, const unsigned* __restrict__ probe_list, int ldp,
+                                                        const int* __restrict__ seg_off, const long* __restrict__ list_base, const int* __restrict__ list_len,
+                                                        const unsigned* __restrict__ row_of_slot, const unsigned char* __restrict__ elig,
+                                                        float* __restrict__ D, long ldD) {
+    __shared__ __attribute__((aligned(16))) float xs[TILE_ROWS * XS_LD];
+    __shared__ __attribute__((aligned(16))) float qs[32 * LG_WINDOW];
+    __shared__ unsigned rows[TILE_ROWS];
+    __shared__ int mq[LG_WINDOW], mso[LG_WINDOW];
+    const int y = blockIdx.y;
+    // groups: inside every window of 16 sorted positions, a maximal run of pairs that probe the same list is ONE workgroup's
+    // job (its leader = the run's first position); the row tile is fetched and transposed once for the whole group
+    int cnt = 1;
+    if (GROUPED) {
+        const unsigned L0 = olist[y];
+        if (L0 >= (unsigned)nlist) return;                              // pairs with nothing to scan sort last
+        if ((y % LG_WINDOW) != 0 && olist[y - 1] == L0) return;         // not a leader
+        while (y + cnt < n_pairs && ((y + cnt) % LG_WINDOW) != 0 && olist[y + cnt] == L0) cnt++;
+    }
+    const int t = threadIdx.x;
+    if (t < cnt) {
+        const int pair = (int)order[y + t];
+        const int q = pair / np, pi = pair - q * np;
+        mq[t] = q; mso[t] = seg_off[(long)q * (np + 1) + pi];
+    }
+    const int pair0 = (int)order[y];
+    const int q0 = pair0 / np, pi0 = pair0 - q0 * np;
+    if (seg_off[(long)q0 * (np + 1) + pi0 + 1] == seg_off[(long)q0 * (np + 1) + pi0]) return;   // (identity order) empty list / unused probe slot
+    const unsigned L = probe_list[(long)q0 * ldp + pi0];
+    const int len = list_len[L];
+    const long base = list_base[L];
+    __syncthreads();
+#define LG(QTV) list_group_scan<METRIC, QTV>(X, ld, Q, mq, mso, cnt, base, len, row_of_slot, elig, D, ldD, xs, qs, rows)
+    if constexpr (!GROUPED) LG(1);      // a kernel of its own: the 16-accumulator path would set the register count (and occupancy) for everyone
+    else { if (cnt == 1) LG(1); else if (cnt == 2) LG(2); else if (cnt <= 4) LG(4); else if (cnt <= 8) LG(8); else LG(16); }
+#undef LG
+}
+void launch_dist_list(Ctx* c, int metric, const float* X, int ld, const float* Q, const uint32_t* order, const uint32_t* olist, int n_pairs, int nlist, int np,
+                      const uint32_t* probe_list, int ldp, const int32_t* seg_off, const int64_t* list_base, const int32_t* list_len,
+                      const uint32_t* row_of_slot, const uint8_t* elig, int max_list_len, float* D, int64_t ldD) {
     if (n_pairs <= 0 || max_list_len <= 0) return;
     ProfScope ps(c, "dist_list");
     dim3 grid((unsigned)std::min<int64_t>(8, ceil_div(max_list_len, TILE_ROWS)), (unsigned)n_pairs), blk(256);
-#define DL(M) dist_list_kernel<M><<<grid, blk, 0, c->stream>>>(X, ld, Q, order, np, probe_list, ldp, seg_off, (const long*)list_base, list_len, row_of_slot, elig, D, ldD)
+#define DL(M) do { if (olist) dist_list_kernel<M, true><<<grid, blk, 0, c->stream>>>(X, ld, Q, order, olist, n_pairs, nlist, np, probe_list, ldp, seg_off, (const long*)list_base, list_len, row_of_slot, elig, D, ldD); \
+                    else dist_list_kernel<M, false><<<grid, blk, 0, c->stream>>>(X, ld, Q, order, olist, n_pairs, nlist, np, probe_list, ldp, seg_off, (const long*)list_base, list_len, row_of_slot, elig, D, ldD); } while (0)
     switch (metric) { case COMET_L2: DL(COMET_L2); break; case COMET_L2SQ: DL(COMET_L2SQ); break; default: DL(COMET_COSINE); break; }
 #undef DL
     LAUNCH_CHECK();

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ Q
 // order[] = the pair indices grouped by probed list (counting sort in LDS; pairs with nothing to scan go last; the
 // order inside a list is whatever the atomics give — results do not depend on it). One workgroup, nlist + 1 bins in LDS.
 __global__ __launch_bounds__(1024) void order_pairs_kernel(const unsigned* __restrict__ probe_list, int ldp, int np, const int* __restrict__ seg_off,
-                                                           int n_pairs, int nlist, unsigned* __restrict__ order) {
+                                                           int n_pairs, int nlist, unsigned* __restrict__ order, unsigned* __restrict__ olist /*nullable: list of every sorted position*/) {
     extern __shared__ __attribute__((aligned(16))) int obin[];   // nlist + 1 counters
     __shared__ int part[1024];
     const int nb = nlist + 1, t = threadIdx.x;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(1024) void order_pairs_kernel(const unsigned* __res
     int run = part[t] - s;                                      // exclusive prefix of this thread's bins
     for (int i = lo; i < hi; i++) { const int cnt = obin[i]; obin[i] = run; run += cnt; }
     __syncthreads();
-    for (int i = t; i < n_pairs; i += 1024) order[atomicAdd(&obin[key_of(i)], 1)] = (unsigned)i;
+    for (int i = t; i < n_pairs; i += 1024) { const int k = key_of(i); const int pos = atomicAdd(&obin[k], 1); order[pos] = (unsigned)i; if (olist) olist[pos] = (unsigned)k; }
 }
 __global__ __launch_bounds__(256) void iota_kernel(unsigned* __restrict__ p, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -574,16 +574,18 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const float* __re
     }
 }
 // pairs of a (sub-)batch grouped by probed list; falls back to the identity order when the list count does not fit in LDS
-void launch_order_pairs(Ctx* c, const uint32_t* probe_list, int ldp, int np, const int32_t* seg_off, int n_pairs, int nlist, uint32_t* order) {
-    if (n_pairs <= 0) return;
+bool launch_order_pairs(Ctx* c, const uint32_t* probe_list, int ldp, int np, const int32_t* seg_off, int n_pairs, int nlist, uint32_t* order, uint32_t* olist) {
+    if (n_pairs <= 0) return false;
     static bool attr_done = false;
     if (!attr_done) { HIP_CHECK(hipFuncSetAttribute((const void*)order_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (ORDER_MAX_LISTS + 1) * 4)); attr_done = true; }
     ProfScope ps(c, "order_pairs");
-    if (nlist <= ORDER_MAX_LISTS && n_pairs > 1)
-        order_pairs_kernel<<<dim3(1), dim3(1024), (size_t)(nlist + 1) * 4, c->stream>>>(probe_list, ldp, np, seg_off, n_pairs, nlist, order);
+    const bool sorted = nlist <= ORDER_MAX_LISTS;
+    if (sorted)
+        order_pairs_kernel<<<dim3(1), dim3(1024), (size_t)(nlist + 1) * 4, c->stream>>>(probe_list, ldp, np, seg_off, n_pairs, nlist, order, olist);
     else
         iota_kernel<<<dim3((unsigned)ceil_div(n_pairs, 256)), dim3(256), 0, c->stream>>>(order, n_pairs);
     LAUNCH_CHECK();
+    return sorted;     // false: identity order, olist not written (the caller must not group by list)
 }
 size_t adc_lds_bytes(int M, int Ksub, int dim) { (void)dim; int KL = Ksub < 256 ? Ksub : 256; return (size_t)M * KL * sizeof(float); }
 static size_t adc_lut_budget() {
@@ -639,7 +641,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
         {
             ProfScope ps(c, "adc_order");
             if (nlist <= ORDER_MAX_LISTS && n_pairs > 1) {
-                order_pairs_kernel<<<dim3(1), dim3(1024), (size_t)(nlist + 1) * 4, c->stream>>>(pl, ldp, np, so, n_pairs, nlist, order);
+                order_pairs_kernel<<<dim3(1), dim3(1024), (size_t)(nlist + 1) * 4, c->stream>>>(pl, ldp, np, so, n_pairs, nlist, order, nullptr);
             } else {
                 iota_kernel<<<dim3((unsigned)ceil_div(n_pairs, 256)), dim3(256), 0, c->stream>>>(order, n_pairs);
             }
