@@ -178,7 +178,7 @@ struct FlatIndex : comet_index {
         // auto: small batches are HBM-bound on the exact kernel anyway; the tile-top-2 proposal needs several times more
         // 256-row tiles than requested results to stay selective (measured at K = 100, B = 256: 125k rows 0.34 ms fast vs
         // 1.19 ms strict, 500k rows 0.45 vs 4.7 — the row shards of a multi-GPU run live in this regime)
-        return ok && B >= 32 && n >= (int64_t)flat_fast_unit_rows() * 4 * keff;
+        return ok && B >= 16 && n >= (int64_t)flat_fast_unit_rows() * 4 * keff;      // 1M x 768: B = 16 strict 0.97 ms, fast 0.61; B <= 4 strict 0.72 (HBM-bound)
     }
 
     // MFMA fast path for up to 256 prepared queries; writes the final ids / scores / counts of the slice
