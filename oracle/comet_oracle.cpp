@@ -913,6 +913,14 @@ ORC_API int orc_bm25_remove(void* p, uint32_t id) {  // soft delete bm25_index.g
     if (!h->doc_tokens.count(id)) return ORC_OK;
     h->deleted.insert(id); return ORC_OK;
 }
+// BM25SearchIndex.Flush bm25_index.go:374-400: hard-delete every soft-deleted document (roaring iterates ascending), which
+// changes N, df and avgDocLen — scores after a flush differ from the soft-deleted state
+ORC_API void orc_bm25_flush(void* p) {
+    auto* h = (OBM25*)p;
+    std::vector<uint32_t> d(h->deleted.begin(), h->deleted.end()); std::sort(d.begin(), d.end());
+    for (uint32_t id : d) bm25_remove_internal(h, id);
+    h->deleted.clear();
+}
 ORC_API uint32_t orc_bm25_num_docs(void* p) { return ((OBM25*)p)->num_docs; }
 ORC_API double orc_bm25_avg_doc_len(void* p) { return ((OBM25*)p)->avg_doc_len; }
 // bm25TextSearch.searchSingleQuery bm25_index_search.go:278-397. Scores accumulate in float64 in

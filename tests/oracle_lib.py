@@ -57,7 +57,7 @@ def lib() -> C.CDLL:
             "orc_hnsw_search": (i32, [vp, vp, i32, i32, f32, vp, i32, vp, vp, i32]),
             "orc_go_log": (dbl, [dbl]),
             "orc_bm25_new": (vp, []), "orc_bm25_free": (None, [vp]), "orc_bm25_add": (i32, [vp, u32, vp, i32]),
-            "orc_bm25_remove": (i32, [vp, u32]), "orc_bm25_num_docs": (u32, [vp]), "orc_bm25_avg_doc_len": (dbl, [vp]),
+            "orc_bm25_remove": (i32, [vp, u32]), "orc_bm25_flush": (None, [vp]), "orc_bm25_num_docs": (u32, [vp]), "orc_bm25_avg_doc_len": (dbl, [vp]),
             "orc_bm25_search": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, vp, i32]),
             "orc_aggregate": (i32, [i32, vp, vp, i32, vp, vp]),
             "orc_rrf": (i32, [dbl, vp, vp, i32, vp, vp, i32, vp, vp]),
@@ -384,6 +384,9 @@ class BM25:
 
     def remove(self, doc_id):
         return lib().orc_bm25_remove(self.h, int(doc_id))
+
+    def flush(self):
+        lib().orc_bm25_flush(self.h)
 
     def num_docs(self):
         return lib().orc_bm25_num_docs(self.h)

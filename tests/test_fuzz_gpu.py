@@ -93,3 +93,74 @@ def test_ivfpq_random_operation_sequence(ctx):
             for b, q in enumerate(Q):
                 n, oi, os_ = o.search(q, k, npb)
                 assert cnt[b] == n and np.array_equal(ids[b, :n], oi) and np.array_equal(bits(sc[b, :n]), bits(os_)), (step, b)
+
+
+def test_bm25_random_operation_sequence(ctx):
+    """Adds, removes, flushes and searches (with document filters) on one BM25 index vs the oracle: float64 scores bit for bit."""
+    from comet_amd import BM25SearchIndex
+    rng = np.random.default_rng(21)
+    g = BM25SearchIndex(ctx); o = orc.BM25()
+    vocab = 300
+    next_id, live = 1, []
+    for step in range(60):
+        op = rng.random()
+        if op < 0.45 or len(live) < 20:
+            for _ in range(int(rng.integers(1, 60))):
+                toks = np.minimum(vocab - 1, (rng.pareto(1.2, int(rng.integers(1, 40))) * 8).astype(np.int64)).astype(np.uint32)
+                g.add(next_id, toks); assert o.add(next_id, toks) == 0
+                live.append(next_id); next_id += 1
+        elif op < 0.6 and live:
+            for _ in range(int(rng.integers(1, 10))):
+                if not live:
+                    break
+                i = live.pop(int(rng.integers(0, len(live))))
+                g.remove(i); assert o.remove(i) == 0
+        elif op < 0.65:
+            g.flush(); o.flush()      # hard delete: N, df and avgDocLen change (bm25_index.go:374-400)
+        else:
+            B = int(rng.choice([1, 4, 33]))
+            queries = [np.minimum(vocab - 1, (rng.pareto(1.2, int(rng.integers(1, 7))) * 8).astype(np.int64)).astype(np.uint32).tolist() for _ in range(B)]
+            k = int(rng.choice([1, 5, 20]))
+            flt = [int(x) for x in rng.choice(live, size=min(len(live), 30), replace=False)] if rng.random() < 0.3 else []
+            ids, sc, sc64, cnt = g.search_batch(queries, k, document_ids=flt)
+            for b in range(B):
+                n, oi, _, os64 = o.search(queries[b], k, filter_ids=flt)
+                assert cnt[b] == n, (step, b, cnt[b], n)
+                assert np.array_equal(ids[b, :n], oi[:n]), (step, b)
+                assert np.array_equal(sc64[b, :n].view(np.uint64), np.asarray(os64[:n], np.float64).view(np.uint64)), (step, b)
+
+
+@pytest.mark.parametrize("metric,m,efc", [(L2_SQUARED, 4, 30), (COSINE, 12, 60), (EUCLIDEAN, 24, 40)])
+def test_hnsw_random_parameters_and_deletes(ctx, metric, m, efc):
+    """Graphs of random shape built by the oracle (random levels from its seeded generator), loaded into the GPU index; searches with
+    random ef / k / thresholds / filters and a growing set of soft-deleted nodes must match the oracle's traversal exactly."""
+    from comet_amd import HNSWIndex
+    rng = np.random.default_rng(m * 100 + efc)
+    n, d = int(rng.integers(800, 2500)), int(rng.choice([16, 48, 100]))
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    o = orc.HNSW(d, metric, m, efc, 50, seed=int(rng.integers(1, 1 << 30)))
+    assert o.add_batch(np.arange(1, n + 1), X) == 0
+    ids, levels, vecs, eoff, edges = o.export()
+    g = HNSWIndex(ctx, d, metric, m, efc, 50)
+    g.load_graph(ids, levels, vecs, eoff, edges, o.entry(), o.max_level())
+    alive = list(range(1, n + 1))
+    for rnd in range(8):
+        B = int(rng.choice([1, 5, 30])); k = int(rng.choice([1, 10, 0])); ef = int(rng.choice([0, 8, 64, 200]))
+        Q = rng.standard_normal((B, d)).astype(np.float32)
+        kw = {}
+        if rng.random() < 0.4:
+            kw["filter_ids"] = [int(x) for x in rng.choice(alive, size=min(len(alive), 200), replace=False)]
+        if rng.random() < 0.4:
+            probe = o.search(Q[0], 10, 64)[2]
+            if len(probe) > 2:
+                kw["threshold"] = float(probe[len(probe) // 2])
+        kcap = max(1, k if k > 0 else (ef if ef > 0 else 50))
+        res = g.search_batch(Q, k, ef_search=ef, threshold=kw.get("threshold", 0.0), document_ids=kw.get("filter_ids", ()), k_cap=kcap)
+        for b, q in enumerate(Q):
+            cn, oi, os_ = o.search(q, k, ef, threshold=kw.get("threshold", 0.0), filter_ids=kw.get("filter_ids", ()))
+            assert res[2][b] == cn, (rnd, b, res[2][b], cn)
+            mm = min(cn, kcap)
+            assert np.array_equal(res[0][b, :mm], oi[:mm]) and np.array_equal(bits(res[1][b, :mm]), bits(os_[:mm])), (rnd, b)
+        for _ in range(int(rng.integers(0, 25))):
+            i = alive.pop(int(rng.integers(0, len(alive))))
+            g.remove(i); assert o.remove(i) == 0
