@@ -58,20 +58,35 @@ template <bool MAXHEAP> __device__ HC heap_pop(HC* h, int& n) {
     return h[m];
 }
 
-// exact distances from the query to up to 64 rows (rows[j] == HN_NONE -> skipped); lane j gets row j's distance
+// exact distances from the query to up to 64 rows (rows[j] == HN_NONE -> skipped); lane j gets row j's distance.
+// The 256-byte row pieces of slice k+1 are requested (into registers) before slice k is summed: the traversal is a chain of
+// dependent random reads, so every exposed load latency is paid once per expansion.
 template <int METRIC>
 __device__ __forceinline__ float wave_dists(const float* __restrict__ V, int ld, const float* __restrict__ qv, const unsigned* rows, int cnt, float* tile) {
     const int lane = threadIdx.x;
     float acc = 0.0f;
-    const int lrow = lane >> 4, lc = (lane & 15) * 4;      // loader: 4 rows x 16 float4 per instruction
+    const int lrow = lane >> 4, lc = (lane & 15) * 4;      // loader: 4 rows x 16 float4 per instruction, up to 16 instructions per slice
+    constexpr int NI = 16;
+    const float* src[NI];
+#pragma unroll
+    for (int j = 0; j < NI; j++) {
+        const int r = j * 4 + lrow;
+        unsigned row = r < cnt ? rows[r] : HN_NONE; if (row == HN_NONE) row = 0;
+        src[j] = V + (long)row * ld + lc;
+    }
+    const int ni = (cnt + 3) >> 2;                          // instructions actually needed (wave-uniform)
+    f32x4 pre[NI];
+#pragma unroll
+    for (int j = 0; j < NI; j++) if (j < ni) pre[j] = (lc < min(HN_TD, ld)) ? *reinterpret_cast<const f32x4*>(src[j]) : f32x4{0, 0, 0, 0};
     for (int k0 = 0; k0 < ld; k0 += HN_TD) {
         const int kn = min(HN_TD, ld - k0);                // multiple of 32
-        for (int r0 = 0; r0 < cnt; r0 += 4) {
-            const int r = r0 + lrow;
-            if (r < cnt && lc < kn) {
-                unsigned row = rows[r]; if (row == HN_NONE) row = 0;
-                *reinterpret_cast<f32x4*>(&tile[r * HN_LD + lc]) = *reinterpret_cast<const f32x4*>(V + (long)row * ld + k0 + lc);
-            }
+#pragma unroll
+        for (int j = 0; j < NI; j++) if (j < ni && lc < kn) *reinterpret_cast<f32x4*>(&tile[(j * 4 + lrow) * HN_LD + lc]) = pre[j];
+        const int k1 = k0 + HN_TD;
+        if (k1 < ld) {
+            const int kn1 = min(HN_TD, ld - k1);
+#pragma unroll
+            for (int j = 0; j < NI; j++) if (j < ni && lc < kn1) pre[j] = *reinterpret_cast<const f32x4*>(src[j] + k1);
         }
         __builtin_amdgcn_wave_barrier();
         if (lane < cnt) {
