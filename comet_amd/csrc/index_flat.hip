@@ -175,10 +175,12 @@ struct FlatIndex : comet_index {
         const int64_t keff = (p.k <= 0 || p.k > n) ? n : p.k;
         const bool ok = std::isfinite(xmax_abs) && xmax_abs <= 60000.0f && std::isfinite(xmax_norm2) && keff <= 1024 && n >= 1;
         if (p.mode == 2) return ok;
-        // auto: small batches are HBM-bound on the exact kernel anyway; the tile-top-2 proposal needs several times more
-        // 256-row tiles than requested results to stay selective (measured at K = 100, B = 256: 125k rows 0.34 ms fast vs
-        // 1.19 ms strict, 500k rows 0.45 vs 4.7 — the row shards of a multi-GPU run live in this regime)
-        return ok && B >= 16 && n >= (int64_t)flat_fast_unit_rows() * 4 * keff;      // 1M x 768: B = 16 strict 0.97 ms, fast 0.61; B <= 4 strict 0.72 (HBM-bound)
+        // auto: the unit-top-2 proposal needs several times more 128-row units than requested results to stay selective
+        // (measured at K = 100, B = 256: 125k rows 0.20 ms fast vs 1.19 ms strict, 500k rows 0.38 vs 4.7 — the row shards of a
+        // multi-GPU run live in this regime). The batch size does not matter: even ONE query is faster through the half-
+        // precision shadow (1.5 GB streamed instead of 3 GB; 1M x 768: 0.61 ms vs 0.72; 100k rows: 0.14 vs 0.22).
+        (void)B;
+        return ok && n >= (int64_t)flat_fast_unit_rows() * 4 * keff;
     }
 
     // MFMA fast path for up to 256 prepared queries; writes the final ids / scores / counts of the slice

@@ -105,8 +105,8 @@ def test_auto_mode_picks_fast_for_big_batches(ctx):
     g.add_batch(np.arange(1, n + 1, dtype=np.uint32), X)
     g.search_batch(synth(15, 64, d), 10)
     assert g.stat("fast_queries") > 0
-    g.search_batch(synth(15, 4, d), 10)          # small batches stay on the exact kernel (HBM-bound there)
-    assert g.stat("fast_queries") == 0
+    g.search_batch(synth(15, 4, d), 10)          # small batches too: the fp16 shadow is half the bytes of the exact scan
+    assert g.stat("fast_queries") == 4
     g.search_batch(synth(15, 64, d), 100)        # 100000 >= 128 * 4 * 100 rows: still selective enough
     assert g.stat("fast_queries") > 0
     g.search_batch(synth(15, 64, d), 500)        # too few key units per requested result: exact kernel
