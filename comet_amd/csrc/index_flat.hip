@@ -180,15 +180,16 @@ struct FlatIndex : comet_index {
         // multi-GPU run live in this regime). The batch size does not matter: even ONE query is faster through the half-
         // precision shadow (1.5 GB streamed instead of 3 GB; 1M x 768: 0.61 ms vs 0.72; 100k rows: 0.14 vs 0.22).
         (void)B;
-        return ok && n >= (int64_t)flat_fast_unit_rows() * 4 * keff;
+        return ok && n >= (int64_t)flat_fast_unit_rows(256) * 4 * keff;
     }
 
     // MFMA fast path for up to 256 prepared queries; writes the final ids / scores / counts of the slice
     void search_fast(const float* Qp, const int32_t* zflag, int bn, const comet_search_params& p, const uint8_t* elig, uint32_t* out_ids,
                      float* out_scores, int32_t* out_counts, int k_cap, Pending* pend) {
         ScratchMark sm(c);
-        // key units: the scan emits, per query, 2 keys + 1 bound for every 128-row unit (two per 256-row tile)
-        const int64_t n_tiles = ceil_div(n, flat_fast_tile_rows()) * (flat_fast_tile_rows() / flat_fast_unit_rows());
+        // key units: the scan emits, per query, 2 keys + 1 bound for every 128-row unit (64-row unit on the narrow tile for <= 64 queries)
+        const int unit_rows = flat_fast_unit_rows(bn);
+        const int64_t n_tiles = ceil_div(n, flat_fast_tile_rows()) * (flat_fast_tile_rows() / unit_rows);
         const int64_t ldS = round_up(2 * n_tiles, 16), ldB = round_up(n_tiles, 16);
         const int NB = flat_fast_batch();
         void* Qh = c->scratch_alloc((size_t)NB * ldh * 2);
@@ -205,7 +206,7 @@ struct FlatIndex : comet_index {
         const int64_t keff = (p.k <= 0 || p.k > n) ? n : p.k;
         const int Kq = (int)std::min<int64_t>(keff, 2 * n_tiles);
         // if the unit keys cannot even supply K values (tiny index / huge K) tau = +inf: every unit is expanded
-        launch_flat_post(c, metric, S0, ldS, bound, ldB, n_tiles, n, elig, err, p.k, (Kq == keff) ? Kq : 0, p.threshold, X.as<float>(), ld, Qp, bn,
+        launch_flat_post(c, metric, S0, ldS, bound, ldB, n_tiles, unit_rows, n, elig, err, p.k, (Kq == keff) ? Kq : 0, p.threshold, X.as<float>(), ld, Qp, bn,
                          ids_dev.as<uint32_t>(), zflag, out_ids, out_scores, out_counts, k_cap, ovf, st);
         // overflow flags + statistics go to pinned host memory asynchronously; search_finish() acts on them
         int32_t* hf = pend->flags + (size_t)pend->nfast_slices * kSliceInts;

@@ -85,14 +85,14 @@ __device__ __forceinline__ void ins3(float& t0, float& t1, float& t2, float a) {
     t0 = fminf(t0, a); t1 = n1; t2 = n2;
 }
 
-// ---- epilogue shared by the scan kernels: waves as WM (rows) x 4 (queries), wave tile MB*32 rows x 64 queries, acc[mb][nb] ----
-template <int MODE, int MB = 4>
-__device__ __forceinline__ void scan_epilogue(f32x16 (&acc)[MB][2], unsigned char* smem, long tile, long row0, long n,
+// ---- epilogue shared by the scan kernels: waves as WM (rows) x NWN (queries), wave tile MB*32 rows x NB*32 queries, acc[mb][nb] ----
+template <int MODE, int MB = 4, int NB = 2, int NWN = 4>
+__device__ __forceinline__ void scan_epilogue(f32x16 (&acc)[MB][NB], unsigned char* smem, long tile, long row0, long n,
                                               const float* __restrict__ rn, const float* __restrict__ qn, const unsigned char* __restrict__ elig,
                                               float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB) {
     constexpr int WM = FB_M / (MB * 32);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 2, wn = wid & 3, khalf = lane >> 5;
+    const int wm = wid / NWN, wn = wid % NWN, khalf = lane >> 5;
     // per (query, key unit = row group of the tile): the two smallest packed keys + the third smallest (bound).
     // C layout of the 32x32 MFMA: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     const float INF = __builtin_inff();
@@ -122,8 +122,8 @@ __device__ __forceinline__ void scan_epilogue(f32x16 (&acc)[MB][2], unsigned cha
             }
     }
 #pragma unroll
-    for (int nb = 0; nb < 2; nb++) {
-        const int q = wn * 64 + nb * 32 + (lane & 31);
+    for (int nb = 0; nb < NB; nb++) {
+        const int q = wn * (NB * 32) + nb * 32 + (lane & 31);
         float qnv = 0.0f;
         if constexpr (MODE == 1) qnv = qn[q];
         float t0 = INF, t1 = INF, t2 = INF;
@@ -237,6 +237,78 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_kernel(const _Float1
     }
     scan_epilogue<MODE>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
 }
+// ------------------------------------------------------------------------------------------------
+// narrow variant for batches of at most 64 queries (the reference's API runs ONE query per Execute()): 256 rows x 64 queries per
+// workgroup, 8 waves as 4 (rows) x 2 (queries), wave tile 64 x 32 (32 accumulators), 2 x 40 KiB of LDS — two workgroups share a
+// CU. A quarter of the MFMA work and of the query staging of the 256-query tile; key units are the 64-row wave groups.
+// ------------------------------------------------------------------------------------------------
+constexpr int FN_N = 64, FN_UNIT = 64, FN_STAGE = 32768 + 8192;
+template <int MODE>
+__global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_n64_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
+                                                                       const _Float16* __restrict__ Qh /*>= 64 x ldh*/,
+                                                                       const float* __restrict__ rn, const float* __restrict__ qn,
+                                                                       const unsigned char* __restrict__ elig,
+                                                                       float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [buf][X 32 KiB | Q 8 KiB]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    long tile;
+    {
+        const long L = blockIdx.x, nx = 8;
+        const long q = n_tiles / nx, r = n_tiles % nx, xcd = L % nx, idx = L / nx;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        if (idx >= (xcd < r ? q + 1 : q)) return;
+    }
+    const long row0 = tile * FB_M;
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[i][0][e] = 0.0f;
+    // staging: 32 row pieces (4 per wave) + 8 query pieces (1 per wave), 8 rows x 128 B each
+    const int prow = lane >> 3, pslot = lane & 7;
+    const char* xsrc[4]; int xdst[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = (wid * 4 + i) * 8 + prow;
+        const int ks = pslot ^ ((r >> 1) & 7);
+        xsrc[i] = reinterpret_cast<const char*>(Xh) + ((tile * (long)(ldh >> 5) + (ks >> 2)) * 256 + r) * 64 + (ks & 3) * 16;
+        xdst[i] = (wid * 4 + i) * 8 * 128;
+    }
+    const int qr = wid * 8 + prow;
+    const char* qsrc = reinterpret_cast<const char*>(Qh + (long)qr * ldh) + (pslot ^ ((qr >> 1) & 7)) * 16;
+    const int qdst = 32768 + wid * 8 * 128;
+    auto stage = [&](int buf, int kt) {
+        unsigned char* sb = smem + buf * FN_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + (long)kt * (256 * 128)),
+                                             (__attribute__((address_space(3))) void*)(sb + xdst[i]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc + (long)kt * 128),
+                                         (__attribute__((address_space(3))) void*)(sb + qdst), 16, 0, 0);
+    };
+    const int nk = ldh / FB_K;
+    stage(0, 0);
+    __syncthreads();
+    const int arow = wm * 64 + (lane & 31), brow = wn * 32 + (lane & 31), khalf = lane >> 5;
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+        const unsigned char* xb = smem + buf * FN_STAGE;
+        const unsigned char* qb = xb + 32768;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            half8 a[2], b;
+#pragma unroll
+            for (int mb = 0; mb < 2; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, ks * 2 + khalf));
+            b = *reinterpret_cast<const half8*>(qb + swz_off(brow, ks * 2 + khalf));
+#pragma unroll
+            for (int mb = 0; mb < 2; mb++) acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b, acc[mb][0], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    scan_epilogue<MODE, 2, 1, 2>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
+}
 // What limits this kernel (profiles/r01_flat_scan_investigation.txt): of a K step's ~3900 cycles the 2 x 32 MFMAs of a SIMD
 // need 2048. The CU accepts the step's 64 LDS-DMA pieces only over ~2400 cycles while fragment reads are in flight; the four
 // waves that win arbitration finish their pieces after ~800 cycles and run their MFMAs while the other four are still issuing,
@@ -245,10 +317,23 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_kernel(const _Float1
 // depending on how many waves issue, tools/dma_issue_probe.hip, and 3-5x that next to ds_read traffic), 16-wave workgroups,
 // persistent tiles, wave priorities and classic register staging (global_load -> ds_write_b128, no LDS-DMA: 0.59 ms) were all
 // built and measured in round 1: 0.51-0.63 ms against 0.51-0.55 for this one.
-void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, int /*nq_used*/, const float* rn, const float* qn,
+void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, int nq_used, const float* rn, const float* qn,
                           const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB) {
     const long n_tiles = ceil_div(n, FB_M);
     ProfScope ps(c, "flat_scan_f16");
+    if (nq_used <= FN_N) {      // S0 / bound are laid out for 64-row units in this case (flat_fast_unit_rows(nq))
+        const size_t ldsn = 2 * FN_STAGE;
+        const long gridn = round_up(n_tiles, 8);
+        if (mode == 0) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_n64_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
+            flat_scan_f16_n64_kernel<0><<<dim3((unsigned)gridn), dim3(FB_THREADS), ldsn, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        } else {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_n64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
+            flat_scan_f16_n64_kernel<1><<<dim3((unsigned)gridn), dim3(FB_THREADS), ldsn, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        }
+        LAUNCH_CHECK();
+        return;
+    }
     const size_t lds = 2 * 65536;
     const long grid = round_up(n_tiles, 8);
     if (mode == 0) {
@@ -261,7 +346,7 @@ void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, 
     LAUNCH_CHECK();
 }
 int flat_fast_tile_rows() { return FB_M; }
-int flat_fast_unit_rows() { return FB_UNIT; }
+int flat_fast_unit_rows(int nq) { return nq <= FN_N ? FN_UNIT : FB_UNIT; }
 int flat_fast_batch() { return FB_N; }
 
 // ------------------------------------------------------------------------------------------------
@@ -384,7 +469,7 @@ __device__ __forceinline__ void post_append(bool want, unsigned v, unsigned* lis
 
 template <int METRIC>
 __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __restrict__ S0, long ldS, const float* __restrict__ bound, long ldB,
-                                                                 long n_tiles, long n, const unsigned char* __restrict__ elig,
+                                                                 long n_tiles, int unit_rows, long n, const unsigned char* __restrict__ elig,
                                                                  const float* __restrict__ err_abs, int K /*requested, sanitised against n*/, int kappa_rank /*0: tau = inf*/,
                                                                  float thr, const float* __restrict__ X, int ld, const float* __restrict__ Qp,
                                                                  const unsigned* __restrict__ ids_table, const int* __restrict__ zflag,
@@ -485,15 +570,15 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
             const int src = __builtin_ctzll(em); em &= em - 1ull;
             const long te = t0 + (t & ~63) + src;      // tile of lane `src`
             if (lane == src) atomicAdd(&s_exp, 1);
-            for (int j = lane; j < FB_UNIT; j += 64) {
-                const long r = te * FB_UNIT + j;
+            for (int j = lane; j < unit_rows; j += 64) {
+                const long r = te * unit_rows + j;
                 post_append(r < n && (!elig || elig[r]), (unsigned)r, lst, &s_cnt, POST_CAP);
             }
         }
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const float key = (live && !expand) ? s0[2 * tl + e] : INF;
-            post_append(key <= tau && key != INF, (unsigned)(tl * FB_UNIT + (__float_as_uint(key) & (unsigned)(FB_UNIT - 1))), lst, &s_cnt, POST_CAP);
+            post_append(key <= tau && key != INF, (unsigned)(tl * unit_rows + (__float_as_uint(key) & (unsigned)(unit_rows - 1))), lst, &s_cnt, POST_CAP);
         }
     }
     __syncthreads();
@@ -604,14 +689,14 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
         if (stats) { atomicAdd(&stats[0], cnt); atomicAdd(&stats[2], s_exp); }
     }
 }
-void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const float* bound, int64_t ldB, int64_t n_tiles, int64_t n, const uint8_t* elig,
+void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const float* bound, int64_t ldB, int64_t n_tiles, int unit_rows, int64_t n, const uint8_t* elig,
                       const float* err_abs, int K, int kappa_rank, float thr, const float* X, int ld, const float* Qp, int B,
                       const uint32_t* ids_table, const int32_t* zflag, uint32_t* out_ids, float* out_scores, int32_t* out_counts, int k_cap,
                       int32_t* overflow, int32_t* stats) {
     if (B <= 0) return;
     ProfScope ps(c, "flat_post");
 #define POST(M) do { HIP_CHECK(hipFuncSetAttribute((const void*)flat_post_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POST_LDS)); \
-        flat_post_kernel<M><<<dim3(B), dim3(POST_THREADS), POST_LDS, c->stream>>>(S0, ldS, bound, ldB, n_tiles, n, elig, err_abs, K, kappa_rank, thr, X, ld, Qp, \
+        flat_post_kernel<M><<<dim3(B), dim3(POST_THREADS), POST_LDS, c->stream>>>(S0, ldS, bound, ldB, n_tiles, unit_rows, n, elig, err_abs, K, kappa_rank, thr, X, ld, Qp, \
                                                                                  ids_table, zflag, out_ids, out_scores, out_counts, k_cap, overflow, stats); } while (0)
     switch (metric) { case COMET_L2: POST(COMET_L2); break; case COMET_L2SQ: POST(COMET_L2SQ); break; default: POST(COMET_COSINE); break; }
 #undef POST
