@@ -89,7 +89,7 @@ def main():
             noise = orc.synth(0xC0FFEE + 4, lo * d, (hi - lo) * d).reshape(hi - lo, d)
             blob = ((np.arange(lo, hi, dtype=np.uint64) * np.uint64(2654435761)) >> np.uint64(7)) % np.uint64(2048)
             return (centers[blob.astype(np.int64)] + noise * np.float32(0.15)).astype(np.float32)
-        ivf = ca.IVFIndex(ctx, d, ca.COSINE, nlist)
+        ivf = ca.IVFIndex(ctx, d, nlist, ca.COSINE)
         t0 = time.time(); ivf.train(rows(0, nlist * 100)); train_s = time.time() - t0
         t0 = time.time()
         for lo in range(0, n, 131072):

@@ -18,6 +18,7 @@ HEADER_PATH = _HERE.parent / "include" / "comet_gpu.h"
 # status codes (include/comet_gpu.h: comet_status)
 OK, ERR_INVALID_ARG, ERR_DIM_MISMATCH, ERR_ZERO_VECTOR, ERR_NOT_TRAINED, ERR_NOT_FOUND = 0, 1, 2, 3, 4, 5
 ERR_ALREADY_DELETED, ERR_TRAIN_DATA, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_UNKNOWN_METRIC = 6, 7, 8, 9, 10, 11
+ERR_FORMAT, ERR_IO = 12, 13
 
 L2, L2SQ, COSINE = 0, 1, 2
 KIND_FLAT, KIND_IVF, KIND_PQ, KIND_IVFPQ, KIND_HNSW, KIND_BM25 = range(6)
@@ -37,6 +38,9 @@ class SearchParams(C.Structure):
     _fields_ = [("k", C.c_int32), ("threshold", C.c_float), ("nprobes", C.c_int32), ("ef_search", C.c_int32),
                 ("filter_ids", C.POINTER(C.c_uint32)), ("n_filter", C.c_int32), ("mode", C.c_int32)]
 
+
+WRITE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)   # comet_write_cb
+READ_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)    # comet_read_cb
 
 _lib = None
 
@@ -123,6 +127,10 @@ def load() -> C.CDLL:
         "comet_bm25_avg_doc_len": (C.c_double, [p]),
         "comet_bm25_search": (i32, [p, p, p, i32, i32, p, i32, p, p, p, p, i32]),
         "comet_index_export": (i32, [p, p, p, p]),
+        "comet_index_write_to": (i32, [p, WRITE_CB, p, C.POINTER(i64)]),
+        "comet_index_read_from": (i32, [p, READ_CB, p, C.POINTER(i64)]),
+        "comet_index_serialize": (i32, [p, p, sz, C.POINTER(sz)]),
+        "comet_index_deserialize": (i32, [p, p, sz, C.POINTER(sz)]),
         "comet_index_get_stat": (i32, [p, C.c_char_p, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():

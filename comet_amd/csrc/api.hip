@@ -304,6 +304,53 @@ int comet_index_search_wait(comet_index* idx, uint64_t ticket) {
     });
 }
 
+// ---- persistence (io.WriterTo / io.ReaderFrom, index.go:58-60) -----------------------------------------
+int comet_index_write_to(comet_index* idx, comet_write_cb cb, void* user, int64_t* out_bytes) {
+    return guarded([&] {
+        if (out_bytes) *out_bytes = 0;
+        if (!cb) COMET_FAIL(COMET_ERR_INVALID_ARG, "null write callback");
+        CallGuard g(idx->c);
+        Sink s(cb, user);
+        try { idx->write_to(s); } catch (...) { if (out_bytes) *out_bytes = s.total; throw; }
+        idx->c->sync();
+        if (out_bytes) *out_bytes = s.total;
+        return (int)COMET_OK;
+    });
+}
+int comet_index_read_from(comet_index* idx, comet_read_cb cb, void* user, int64_t* out_bytes) {
+    return guarded([&] {
+        if (out_bytes) *out_bytes = 0;
+        if (!cb) COMET_FAIL(COMET_ERR_INVALID_ARG, "null read callback");
+        CallGuard g(idx->c);
+        Source s(cb, user);
+        try { idx->read_from(s); } catch (...) { if (out_bytes) *out_bytes = s.total; throw; }
+        idx->c->sync();
+        if (out_bytes) *out_bytes = s.total;
+        return (int)COMET_OK;
+    });
+}
+namespace {
+struct BufW { uint8_t* p; size_t cap, len; };
+struct BufR { const uint8_t* p; size_t len, off; };
+int buf_write(void* u, const void* d, size_t n) { auto* b = (BufW*)u; if (b->p) { if (b->len + n > b->cap) return 1; std::memcpy(b->p + b->len, d, n); } b->len += n; return 0; }
+int buf_read(void* u, void* d, size_t n) { auto* b = (BufR*)u; if (b->off + n > b->len) return 1; std::memcpy(d, b->p + b->off, n); b->off += n; return 0; }
+}  // namespace
+int comet_index_serialize(comet_index* idx, uint8_t* buf, size_t cap, size_t* out_len) {
+    BufW w{buf, cap, 0};
+    int64_t bytes = 0;
+    const int rc = comet_index_write_to(idx, buf_write, &w, &bytes);
+    if (out_len) *out_len = w.len;
+    if (rc == COMET_ERR_IO) return set_error(COMET_ERR_INVALID_ARG, "buffer too small: %zu bytes given", cap);
+    return rc;
+}
+int comet_index_deserialize(comet_index* idx, const uint8_t* buf, size_t len, size_t* out_consumed) {
+    BufR r{buf, len, 0};
+    int64_t bytes = 0;
+    const int rc = comet_index_read_from(idx, buf_read, &r, &bytes);
+    if (out_consumed) *out_consumed = (size_t)bytes;
+    return rc;
+}
+
 // ---- introspection -----------------------------------------------------------------------------
 int comet_index_get_centroids(const comet_index* idx, float* out) { return guarded([&] { CallGuard g(idx->c); idx->get_centroids(out); return (int)COMET_OK; }); }
 int comet_index_get_codebooks(const comet_index* idx, float* out) { return guarded([&] { CallGuard g(idx->c); idx->get_codebooks(out); return (int)COMET_OK; }); }

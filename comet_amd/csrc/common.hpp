@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -160,6 +161,26 @@ struct ProfScope {
     ProfScope(Ctx* c_, const char* name) : c(c_) { c->prof_begin(name); }
     ~ProfScope() { c->prof_end(); }
 };
+
+// math.Log as Go's portable implementation computes it (FreeBSD e_log.c; src/math/log.go) — restated so
+// idf matches the reference bit for bit instead of depending on the host libm.
+inline double go_log(double x) {
+    const double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10;
+    const double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01,
+                 L4 = 2.222219843214978396e-01, L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+                 L7 = 1.479819860511658591e-01;
+    if (std::isnan(x) || (std::isinf(x) && x > 0)) return x;
+    if (x < 0) return std::nan("");
+    if (x == 0) return -INFINITY;
+    int ki; double f1 = std::frexp(x, &ki);
+    if (f1 < 0.70710678118654752440) { f1 *= 2; ki--; }
+    const double f = f1 - 1, k = (double)ki;
+    const double s = f / (2 + f), s2 = s * s, s4 = s2 * s2;
+    const double t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7)));
+    const double t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
+    const double R = t1 + t2, hfsq = 0.5 * f * f;
+    return k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
+}
 
 #define LAUNCH_CHECK() HIP_CHECK(hipGetLastError())
 

@@ -9,6 +9,7 @@
 #include <unordered_set>
 
 #include "kernels.hpp"
+#include "io.hpp"
 
 struct comet_ctx : comet::Ctx {};
 
@@ -40,6 +41,9 @@ struct comet_index {
     virtual int64_t list_size(int /*list*/) const { return size(); }
     virtual void list_read(int /*list*/, uint32_t* /*ids*/, uint8_t* /*codes*/, float* /*vecs*/) const {}
     virtual void export_all(uint32_t* /*ids*/, int32_t* /*lists*/, uint8_t* /*codes*/) const { COMET_FAIL(COMET_ERR_UNSUPPORTED, "export not supported for this index kind"); }
+    // io.WriterTo / io.ReaderFrom in the reference's byte layout (io.hpp); write_to flushes first like the reference
+    virtual void write_to(comet::Sink& /*s*/) { COMET_FAIL(COMET_ERR_UNSUPPORTED, "serialisation not supported for this index kind"); }
+    virtual void read_from(comet::Source& /*s*/) { COMET_FAIL(COMET_ERR_UNSUPPORTED, "deserialisation not supported for this index kind"); }
     virtual bool get_stat(const char* /*name*/, double* /*out*/) const { return false; }
     virtual void get_centroids(float*) const { COMET_FAIL(COMET_ERR_UNSUPPORTED, "index has no centroids"); }
     virtual void get_codebooks(float*) const { COMET_FAIL(COMET_ERR_UNSUPPORTED, "index has no codebooks"); }

@@ -68,6 +68,7 @@ struct FlatIndex : comet_index {
 
     int64_t size() const override { return n; }
     bool contains_id(uint32_t id) const override { return id_count.count(id) != 0; }
+    bool raw_ingest = false;   // ReadFrom: stored vectors are already preprocessed (flat_index.go:592 keeps them as read)
 
     // FlatIndex.Add flat_index.go:170-186, batched.
     int64_t add_dev(const uint32_t* ids_d, const uint32_t* ids_h, const float* vecs_dev, int64_t m, int64_t* zero_at,
@@ -78,9 +79,10 @@ struct FlatIndex : comet_index {
         ids_dev.reserve((size_t)(n + m) * 4, c->stream, (size_t)n * 4);
         float* dst = X.as<float>() + (size_t)n * ld;
         int32_t* zf = c->salloc<int32_t>(m);
-        launch_ingest_rows(c, metric, vecs_dev, m, dim, dst, ld, zf);
+        const int im = raw_ingest ? (int)COMET_L2SQ : metric;
+        launch_ingest_rows(c, im, vecs_dev, m, dim, dst, ld, zf);
         int64_t added = m;
-        if (metric == COMET_COSINE) {   // ErrZeroVector stops the batch at the first offending vector
+        if (im == COMET_COSINE) {   // ErrZeroVector stops the batch at the first offending vector
             std::vector<int32_t> h(m);
             c->d2h(h.data(), zf, m * sizeof(int32_t));
             HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -317,6 +319,64 @@ struct FlatIndex : comet_index {
         else return false;
         return true;
     }
+    void export_all(uint32_t* oids, int32_t* olists, uint8_t*) const override {
+        if (oids) std::copy(ids.begin(), ids.end(), oids);
+        if (olists) std::fill(olists, olists + n, 0);
+    }
+
+    // FlatIndex.WriteTo flat_index.go:366-470: Flush, then magic "FLAT", version, dim, distance kind, count,
+    // per vector {id, dim, dim float32}, empty roaring bitmap.
+    void write_to(Sink& s) override {
+        flush();
+        write_header(s, "FLAT", dim, metric);
+        s.u32((uint32_t)n);
+        const int64_t chunk = 16384;
+        ScratchMark sm(c);
+        float* tmp = c->salloc<float>((size_t)std::min<int64_t>(chunk, std::max<int64_t>(n, 1)) * dim);
+        std::vector<float> host((size_t)std::min<int64_t>(chunk, std::max<int64_t>(n, 1)) * dim);
+        for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+            const int64_t m = std::min(chunk, n - r0);
+            launch_unpad_rows(c, X.as<float>() + (size_t)r0 * ld, m, ld, tmp, dim);
+            c->d2h(host.data(), tmp, (size_t)m * dim * 4);
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            for (int64_t i = 0; i < m; i++) { s.u32(ids[r0 + i]); s.u32((uint32_t)dim); s.put(&host[(size_t)i * dim], (size_t)dim * 4); }
+        }
+        write_empty_bitmap(s);
+        s.flush();
+    }
+    // FlatIndex.ReadFrom flat_index.go:488-614. The stream is parsed into a scratch index; this index is replaced
+    // only if everything parsed (the reference assigns idx.vectors / idx.deletedNodes last, :609-611).
+    void read_from(Source& s) override {
+        read_header(s, "FLAT", dim, metric);
+        const uint32_t count = s.u32("vector count");
+        FlatIndex t; t.c = c; t.kind = kind; t.dim = dim; t.ld = ld; t.ldh = ldh; t.metric = metric; t.trained = true; t.raw_ingest = true;
+        const int64_t chunk = 16384;
+        std::vector<float> host((size_t)std::min<int64_t>(chunk, std::max<int64_t>(count, 1)) * dim);
+        std::vector<uint32_t> hid(std::min<int64_t>(chunk, std::max<int64_t>(count, 1)));
+        for (int64_t r0 = 0; r0 < (int64_t)count; r0 += chunk) {
+            const int64_t m = std::min<int64_t>(chunk, count - r0);
+            for (int64_t i = 0; i < m; i++) {
+                hid[i] = s.u32("vector ID");
+                const uint32_t vd = s.u32("vector dimension");
+                if ((int)vd != dim) COMET_FAIL(COMET_ERR_FORMAT, "vector %lld has dimension %u, expected %d", (long long)(r0 + i), vd, dim);   // :573
+                s.get(&host[(size_t)i * dim], (size_t)dim * 4, "vector component");
+            }
+            ScratchMark sm(c);
+            float* dv = c->salloc<float>((size_t)m * dim);
+            c->h2d(dv, host.data(), (size_t)m * dim * 4);
+            int64_t zero_at = -1;
+            t.add_dev(nullptr, hid.data(), dv, m, &zero_at, nullptr);
+        }
+        const std::vector<uint32_t> del = read_bitmap(s);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        // commit
+        for (auto& r : ring) if (r.active) search_finish(r.ticket);
+        std::swap(X.p, t.X.p); std::swap(X.cap, t.X.cap); std::swap(ids_dev.p, t.ids_dev.p); std::swap(ids_dev.cap, t.ids_dev.cap);
+        std::swap(Xh.p, t.Xh.p); std::swap(Xh.cap, t.Xh.cap); std::swap(rn.p, t.rn.p); std::swap(rn.cap, t.rn.cap);
+        ids.swap(t.ids); id_count.swap(t.id_count); n = t.n; xmax_abs = t.xmax_abs; xmax_norm2 = t.xmax_norm2;
+        deleted.clear(); deleted.insert(del.begin(), del.end()); deleted_dirty = true;
+    }
+
     void list_read(int, uint32_t* oids, uint8_t*, float* ovecs) const override {
         if (oids) std::copy(ids.begin(), ids.end(), oids);
         if (ovecs && n > 0) {

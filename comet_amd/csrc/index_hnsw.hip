@@ -253,9 +253,12 @@ __global__ __launch_bounds__(256) void hnsw_mask_kernel(const unsigned* __restri
 
 struct HNSWIndex : comet_index {
     int M = 16, efC = 200, efS = 200;
-    int64_t n = 0; int max_level = -1; uint32_t entry = 0;
+    int64_t n = 0; int max_level = -1; uint32_t entry = 0;   // entry: dense node index
     DevBuf V, ids_dev, level, slot_base, edge_off, edges, del_bm;
     std::vector<uint32_t> ids; std::unordered_map<uint32_t, uint32_t> id2idx;
+    // host mirror of the graph as loaded (hnswNode{Level, Edges} hnsw_index.go:50-61): Flush and WriteTo work on it
+    std::vector<int32_t> h_levels; std::vector<int64_t> h_eoff; std::vector<uint32_t> h_edges;   // h_edges: neighbour NODE IDS, per (node, layer)
+    uint32_t entry_id = 0;
     bool del_dirty = true;
     uint64_t st_evals = 0, st_exp = 0;
 
@@ -264,35 +267,166 @@ struct HNSWIndex : comet_index {
     int64_t add_dev(const uint32_t*, const uint32_t*, const float*, int64_t, int64_t*, float*) override {
         COMET_FAIL(COMET_ERR_UNSUPPORTED, "HNSW graph construction on the GPU is not built yet: load a graph with comet_hnsw_load_graph");
     }
-    void flush() override { if (!deleted.empty()) COMET_FAIL(COMET_ERR_UNSUPPORTED, "HNSW Flush (graph repair) is not built yet"); }
+
+    // stored (preprocessed) vectors, dense n x dim, host
+    std::vector<float> download_vectors() {
+        std::vector<float> out((size_t)std::max<int64_t>(n, 1) * dim);
+        if (n == 0) return out;
+        const int64_t chunk = 65536;
+        ScratchMark sm(c);
+        float* tmp = c->salloc<float>((size_t)std::min(chunk, n) * dim);
+        for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+            const int64_t m = std::min(chunk, n - r0);
+            launch_unpad_rows(c, V.as<float>() + (size_t)r0 * ld, m, ld, tmp, dim);
+            c->d2h(&out[(size_t)r0 * dim], tmp, (size_t)m * dim * 4);
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
+        return out;
+    }
+
+    // HNSWIndex.Flush hnsw_index.go:348-431: drop edges to deleted nodes, re-seat the entry point, delete the nodes.
+    // The reference picks the replacement entry point by iterating a Go map (undefined order); here nodes are
+    // visited in ascending id order (first node at maxLevel, else the first node of the highest remaining level).
+    void flush() override {
+        if (deleted.empty()) return;
+        std::vector<float> vecs = download_vectors();
+        std::vector<int64_t> order(n);
+        for (int64_t i = 0; i < n; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return ids[a] < ids[b]; });
+        std::vector<int64_t> sb(n + 1, 0);
+        for (int64_t i = 0; i < n; i++) sb[i + 1] = sb[i] + h_levels[i] + 1;
+        uint32_t new_entry = entry_id; int new_max = max_level;
+        if (deleted.count(entry_id)) {                                        // PHASE 2 (:383-412)
+            bool found = false;
+            for (int64_t oi : order) if (!deleted.count(ids[oi]) && h_levels[oi] == max_level) { new_entry = ids[oi]; found = true; break; }
+            if (!found) {
+                int best = -1;
+                for (int64_t oi : order) if (!deleted.count(ids[oi]) && h_levels[oi] > best) { best = h_levels[oi]; new_entry = ids[oi]; }
+                if (best >= 0) new_max = best; else { new_entry = 0; new_max = -1; }
+            }
+        }
+        std::vector<uint32_t> nids; std::vector<int32_t> nlev; std::vector<float> nvec; std::vector<int64_t> neoff; std::vector<uint32_t> nedges;
+        neoff.push_back(0);
+        for (int64_t i = 0; i < n; i++) {
+            if (deleted.count(ids[i])) continue;                              // PHASE 3
+            nids.push_back(ids[i]); nlev.push_back(h_levels[i]);
+            nvec.insert(nvec.end(), vecs.begin() + (size_t)i * dim, vecs.begin() + (size_t)(i + 1) * dim);
+            for (int l = 0; l <= h_levels[i]; l++) {                          // PHASE 1: keep an edge only if its target is not deleted
+                for (int64_t e = h_eoff[sb[i] + l]; e < h_eoff[sb[i] + l + 1]; e++) if (!deleted.count(h_edges[e])) nedges.push_back(h_edges[e]);
+                neoff.push_back((int64_t)nedges.size());
+            }
+        }
+        if (nedges.empty()) nedges.push_back(0);
+        load((int64_t)nids.size(), nids.data(), nlev.data(), nvec.data(), neoff.data(), nedges.data(), new_entry, new_max);
+        deleted.clear(); deleted_dirty = true; del_dirty = true;               // PHASE 4
+    }
 
     void load(int64_t nn, const uint32_t* ids_h, const int32_t* levels, const float* vecs, const int64_t* eoff, const uint32_t* edge_ids,
-              uint32_t entry_id, int maxl) {
-        n = nn; max_level = maxl;
-        ids.assign(ids_h, ids_h + nn); id2idx.clear();
-        for (int64_t i = 0; i < nn; i++) id2idx[ids[i]] = (uint32_t)i;
+              uint32_t entry_id_in, int maxl) {
+        std::vector<uint32_t> nid(ids_h, ids_h + nn); std::unordered_map<uint32_t, uint32_t> nmap;
+        for (int64_t i = 0; i < nn; i++) nmap[nid[i]] = (uint32_t)i;
         std::vector<int64_t> sb(nn + 1); int64_t slots = 0;
-        for (int64_t i = 0; i < nn; i++) { sb[i] = slots; slots += levels[i] + 1; }
+        for (int64_t i = 0; i < nn; i++) { if (levels[i] < 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "node %u has negative level", nid[i]); sb[i] = slots; slots += levels[i] + 1; }
         sb[nn] = slots;
         const int64_t ne = eoff[slots];
-        std::vector<uint32_t> eidx(std::max<int64_t>(ne, 1));
-        for (int64_t e = 0; e < ne; e++) {
-            auto it = id2idx.find(edge_ids[e]);
-            if (it == id2idx.end()) COMET_FAIL(COMET_ERR_INVALID_ARG, "edge references unknown node id %u", edge_ids[e]);
-            eidx[e] = it->second;
+        // device copy: dense indices, duplicate neighbours inside one edge list removed (first occurrence kept). A duplicate
+        // never changes the reference's result — the second occurrence is already in `visited` (hnsw_index.go:604), and in the
+        // greedy descent it recomputes an equal distance — but it would make the kernel's parallel claim of `visited` unordered.
+        std::vector<uint32_t> eidx; eidx.reserve(std::max<int64_t>(ne, 1));
+        std::vector<int64_t> deoff(slots + 1, 0);
+        uint32_t new_entry = 0;
+        for (int64_t sl = 0; sl < slots; sl++) {
+            const size_t s0 = eidx.size();
+            for (int64_t e = eoff[sl]; e < eoff[sl + 1]; e++) {
+                auto it = nmap.find(edge_ids[e]);
+                if (it == nmap.end()) COMET_FAIL(COMET_ERR_INVALID_ARG, "edge references unknown node id %u", edge_ids[e]);
+                bool dup = false;
+                for (size_t j = s0; j < eidx.size(); j++) if (eidx[j] == it->second) { dup = true; break; }
+                if (!dup) eidx.push_back(it->second);
+            }
+            deoff[sl + 1] = (int64_t)eidx.size();
         }
-        if (nn > 0) { auto it = id2idx.find(entry_id); if (it == id2idx.end()) COMET_FAIL(COMET_ERR_INVALID_ARG, "entry point %u is not a node", entry_id); entry = it->second; }
+        if (eidx.empty()) eidx.push_back(0);
+        if (nn > 0 && maxl >= 0) { auto it = nmap.find(entry_id_in); if (it == nmap.end()) COMET_FAIL(COMET_ERR_INVALID_ARG, "entry point %u is not a node", entry_id_in); new_entry = it->second; }
+        n = nn; max_level = nn > 0 ? maxl : -1; entry = new_entry; entry_id = entry_id_in;
+        ids.swap(nid); id2idx.swap(nmap);
+        h_levels.assign(levels, levels + nn); h_eoff.assign(eoff, eoff + slots + 1); h_edges.assign(edge_ids, edge_ids + ne);
         V.reserve(std::max<size_t>(4, (size_t)nn * ld * 4), c->stream, 0);
-        float* raw = c->salloc<float>(std::max<size_t>(1, (size_t)nn * dim));
-        c->h2d(raw, vecs, (size_t)nn * dim * 4);
-        launch_ingest_rows(c, COMET_L2SQ, raw, nn, dim, V.as<float>(), ld, nullptr);   // stored vectors are already preprocessed
+        {
+            ScratchMark sm(c);
+            float* raw = c->salloc<float>(std::max<size_t>(1, (size_t)nn * dim));
+            c->h2d(raw, vecs, (size_t)nn * dim * 4);
+            launch_ingest_rows(c, COMET_L2SQ, raw, nn, dim, V.as<float>(), ld, nullptr);   // stored vectors are already preprocessed
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
         ids_dev.reserve(std::max<size_t>(4, nn * 4), c->stream, 0); level.reserve(std::max<size_t>(4, nn * 4), c->stream, 0);
         slot_base.reserve((nn + 1) * 8, c->stream, 0); edge_off.reserve((slots + 1) * 8, c->stream, 0); edges.reserve(eidx.size() * 4, c->stream, 0);
         c->h2d(ids_dev.p, ids.data(), nn * 4); c->h2d(level.p, levels, nn * 4);
-        c->h2d(slot_base.p, sb.data(), (nn + 1) * 8); c->h2d(edge_off.p, eoff, (slots + 1) * 8); c->h2d(edges.p, eidx.data(), eidx.size() * 4);
+        c->h2d(slot_base.p, sb.data(), (nn + 1) * 8); c->h2d(edge_off.p, deoff.data(), (slots + 1) * 8); c->h2d(edges.p, eidx.data(), eidx.size() * 4);
         HIP_CHECK(hipStreamSynchronize(c->stream));
         trained = true; del_dirty = true;
     }
+
+    // HNSWIndex.WriteTo hnsw_index.go:734-880: Flush; "HNSW", version, dim, kind, M, efConstruction, efSearch, levelMult (f64),
+    // maxLevel (i32), entryPoint, node count, per node {id, level, dim, floats, layer count, per layer {count, edge ids}},
+    // empty bitmap. Nodes in ascending id order (the reference ranges over a Go map).
+    void write_to(Sink& s) override {
+        flush();
+        write_header(s, "HNSW", dim, metric);
+        s.u32((uint32_t)M); s.u32((uint32_t)efC); s.u32((uint32_t)efS);
+        s.f64(1.0 / go_log((double)M));                     // levelMult = 1/ln(M) hnsw_index.go:206
+        s.i32(max_level); s.u32(n > 0 ? entry_id : 0u); s.u32((uint32_t)n);
+        std::vector<float> vecs = download_vectors();
+        std::vector<int64_t> order(n);
+        for (int64_t i = 0; i < n; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return ids[a] < ids[b]; });
+        std::vector<int64_t> sb(n + 1, 0);
+        for (int64_t i = 0; i < n; i++) sb[i + 1] = sb[i] + h_levels[i] + 1;
+        for (int64_t i : order) {
+            s.u32(ids[i]); s.i32(h_levels[i]); s.u32((uint32_t)dim); s.put(&vecs[(size_t)i * dim], (size_t)dim * 4);
+            s.u32((uint32_t)(h_levels[i] + 1));
+            for (int l = 0; l <= h_levels[i]; l++) {
+                const int64_t e0 = h_eoff[sb[i] + l], e1 = h_eoff[sb[i] + l + 1];
+                s.u32((uint32_t)(e1 - e0));
+                if (e1 > e0) s.put(&h_edges[e0], (size_t)(e1 - e0) * 4);
+            }
+        }
+        write_empty_bitmap(s);
+        s.flush();
+    }
+    // HNSWIndex.ReadFrom hnsw_index.go:898-1096
+    void read_from(Source& s) override {
+        read_header(s, "HNSW", dim, metric);
+        const uint32_t fM = s.u32("M"), fC = s.u32("efConstruction"), fS = s.u32("efSearch");
+        check_param("M", M, fM); check_param("efConstruction", efC, fC); check_param("efSearch", efS, fS);   // :975-986
+        (void)s.f64("levelMult");
+        const int32_t maxl = s.i32("maxLevel");
+        const uint32_t ep = s.u32("entryPoint");
+        const uint32_t count = s.u32("node count");
+        std::vector<uint32_t> nids(count); std::vector<int32_t> nlev(count); std::vector<float> nvec((size_t)std::max<uint32_t>(count, 1) * dim);
+        std::vector<int64_t> neoff; std::vector<uint32_t> nedges;
+        neoff.push_back(0);
+        for (uint32_t i = 0; i < count; i++) {
+            nids[i] = s.u32("node ID"); nlev[i] = s.i32("node level");
+            const uint32_t vd = s.u32("vector dimension");
+            if ((int)vd != dim) COMET_FAIL(COMET_ERR_FORMAT, "node %u has dimension %u, expected %d", nids[i], vd, dim);
+            s.get(&nvec[(size_t)i * dim], (size_t)dim * 4, "vector data");
+            const uint32_t layers = s.u32("edge layer count");
+            if (nlev[i] < 0 || nlev[i] > 64 || (int64_t)layers != (int64_t)nlev[i] + 1) COMET_FAIL(COMET_ERR_FORMAT, "node %u: %u edge layers for level %d", nids[i], layers, nlev[i]);
+            for (uint32_t l = 0; l < layers; l++) {
+                const uint32_t ec = s.u32("edge count");
+                if (ec > (1u << 24)) COMET_FAIL(COMET_ERR_FORMAT, "node %u layer %u: edge count %u is not plausible", nids[i], l, ec);
+                const size_t o = nedges.size(); nedges.resize(o + ec);
+                s.get(nedges.data() + o, (size_t)ec * 4, "edge ids");
+                neoff.push_back((int64_t)nedges.size());
+            }
+        }
+        const std::vector<uint32_t> del = read_bitmap(s);
+        if (nedges.empty()) nedges.push_back(0);
+        load(count, nids.data(), nlev.data(), nvec.data(), neoff.data(), nedges.data(), ep, maxl);
+        deleted.clear(); deleted.insert(del.begin(), del.end()); deleted_dirty = true; del_dirty = true;
+    }
+
     const uint32_t* deleted_bitmap() {
         if (deleted.empty()) return nullptr;
         if (del_dirty || deleted_dirty) {
@@ -301,7 +435,7 @@ struct HNSWIndex : comet_index {
             del_bm.reserve(bm.size() * 4, c->stream, 0);
             c->h2d(del_bm.p, bm.data(), bm.size() * 4);
             HIP_CHECK(hipStreamSynchronize(c->stream));
-            del_dirty = false;
+            del_dirty = false; deleted_dirty = false;       // HNSW consumes the soft-delete set only through this bitmap
         }
         return del_bm.as<uint32_t>();
     }

@@ -188,6 +188,103 @@ struct IVFIndex : comet_index {
     int64_t size() const override { return lay.n; }
     int default_nprobes() const override { return (int)std::sqrt((double)nlist); }   // ivf_index.go:406-413
     bool contains_id(uint32_t id) const override { return lay.id_count.count(id) != 0; }
+    void export_all(uint32_t* oids, int32_t* olists, uint8_t*) const override {
+        if (oids) std::copy(lay.ids.begin(), lay.ids.end(), oids);
+        if (olists) std::copy(lay.list_of.begin(), lay.list_of.end(), olists);
+    }
+
+    // IVFIndex.WriteTo ivf_index.go:468-588: Flush; "IVFX", version, dim, kind, nlist, trained byte, centroids
+    // {size, floats} when trained, list count, per list {size, per vector {id, dim floats}}, empty bitmap.
+    void write_to(Sink& s) override {
+        flush();
+        lay.compile(c);
+        write_header(s, "IVFX", dim, metric);
+        s.u32((uint32_t)nlist);
+        s.u8(trained ? 1 : 0);
+        if (trained) {
+            std::vector<float> cen((size_t)nlist * dim);
+            get_centroids(cen.data());
+            for (int l = 0; l < nlist; l++) { s.u32((uint32_t)dim); s.put(&cen[(size_t)l * dim], (size_t)dim * 4); }
+        }
+        s.u32((uint32_t)nlist);
+        const int64_t chunk = 16384;
+        ScratchMark sm(c);
+        const size_t cap = (size_t)std::min<int64_t>(chunk, std::max<int64_t>(lay.n, 1));
+        int32_t* didx = c->salloc<int32_t>(cap);
+        float* padded = c->salloc<float>(cap * ld);
+        float* dense = c->salloc<float>(cap * dim);
+        std::vector<float> host(cap * dim); std::vector<int32_t> hidx(cap);
+        for (int l = 0; l < nlist; l++) {
+            const int len = lay.len_h[l];
+            s.u32((uint32_t)len);
+            for (int j0 = 0; j0 < len; j0 += (int)chunk) {
+                const int m = (int)std::min<int64_t>(chunk, len - j0);
+                for (int j = 0; j < m; j++) hidx[j] = (int32_t)lay.row_of_slot_h[lay.base_h[l] + j0 + j];
+                c->h2d(didx, hidx.data(), (size_t)m * 4);
+                launch_gather_rows(c, V.as<float>(), ld, didx, m, padded);
+                launch_unpad_rows(c, padded, m, ld, dense, dim);
+                c->d2h(host.data(), dense, (size_t)m * dim * 4);
+                HIP_CHECK(hipStreamSynchronize(c->stream));
+                for (int j = 0; j < m; j++) { s.u32(lay.ids[hidx[j]]); s.put(&host[(size_t)j * dim], (size_t)dim * 4); }
+            }
+        }
+        write_empty_bitmap(s);
+        s.flush();
+    }
+    // IVFIndex.ReadFrom ivf_index.go:620-785 (parsed into scratch state, committed at the end like :778-782)
+    void read_from(Source& s) override {
+        read_header(s, "IVFX", dim, metric);
+        const uint32_t nl = s.u32("nlist");
+        if ((int)nl != nlist) COMET_FAIL(COMET_ERR_FORMAT, "nlist mismatch: index has nlist=%d, serialized data has nlist=%u", nlist, nl);   // :676
+        const bool tr = s.u8("trained flag") == 1;
+        DevBuf ncent, nV; ListLayout nlay; nlay.nlist = nlist; nlay.align = 1;
+        if (tr) {
+            std::vector<float> cen((size_t)nlist * dim);
+            for (int l = 0; l < nlist; l++) {
+                const uint32_t cs = s.u32("centroid size");
+                if ((int)cs != dim) COMET_FAIL(COMET_ERR_FORMAT, "centroid %d has %u components, expected %d", l, cs, dim);
+                s.get(&cen[(size_t)l * dim], (size_t)dim * 4, "centroid data");
+            }
+            ScratchMark sm(c);
+            float* raw = c->salloc<float>((size_t)nlist * dim);
+            c->h2d(raw, cen.data(), cen.size() * 4);
+            ncent.reserve((size_t)nlist * ld * 4, c->stream, 0);
+            launch_ingest_rows(c, COMET_L2SQ, raw, nlist, dim, ncent.as<float>(), ld, nullptr);
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
+        const uint32_t lc = s.u32("list count");
+        if ((int)lc != nlist) COMET_FAIL(COMET_ERR_FORMAT, "list count %u does not match nlist %d", lc, nlist);
+        const int64_t chunk = 16384;
+        std::vector<float> host((size_t)chunk * dim); std::vector<uint32_t> hid(chunk); std::vector<int32_t> hl(chunk);
+        int64_t fill = 0;
+        auto spill = [&]() {
+            if (!fill) return;
+            ScratchMark sm(c);
+            float* dv = c->salloc<float>((size_t)fill * dim);
+            c->h2d(dv, host.data(), (size_t)fill * dim * 4);
+            nV.reserve((size_t)(nlay.n + fill) * ld * 4, c->stream, (size_t)nlay.n * ld * 4);
+            launch_ingest_rows(c, COMET_L2SQ, dv, fill, dim, nV.as<float>() + (size_t)nlay.n * ld, ld, nullptr);   // stored vectors are already preprocessed
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            nlay.append(hid.data(), hl.data(), fill);
+            fill = 0;
+        };
+        for (uint32_t l = 0; l < lc; l++) {
+            const uint32_t len = s.u32("list size");
+            for (uint32_t j = 0; j < len; j++) {
+                hid[fill] = s.u32("vector ID"); hl[fill] = (int32_t)l;
+                s.get(&host[(size_t)fill * dim], (size_t)dim * 4, "vector data");
+                if (++fill == chunk) spill();
+            }
+        }
+        spill();
+        const std::vector<uint32_t> del = read_bitmap(s);
+        // commit
+        trained = tr;
+        std::swap(centroids.p, ncent.p); std::swap(centroids.cap, ncent.cap);
+        std::swap(V.p, nV.p); std::swap(V.cap, nV.cap);
+        lay.ids.swap(nlay.ids); lay.list_of.swap(nlay.list_of); lay.id_count.swap(nlay.id_count); lay.n = nlay.n; lay.dirty = true;
+        deleted.clear(); deleted.insert(del.begin(), del.end()); deleted_dirty = true;
+    }
 
     // IVFIndex.Train ivf_index.go:206-235
     void train_dev(const float* vecs_dev, int64_t n) override {
@@ -480,6 +577,103 @@ struct PQFamilyIndex : comet_index {
         if (!trained) COMET_FAIL(COMET_ERR_NOT_TRAINED, "index must be trained");
         c->d2h(out, codebooks.p, (size_t)M * Ksub * dsub * sizeof(float));
         HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+
+    // PQIndex.WriteTo pq_index.go:509-640 ("PQIX": dim, kind, M, Nbits, Ksub, dsub, trained, codebooks {size, floats},
+    // count, per vector {id, M code bytes}) and IVFPQIndex.WriteTo ivfpq_index.go:544-700 ("IVPQ": dim, kind, nlist, M,
+    // Nbits, Ksub, dsub, trained, centroids, codebooks, list count, per list {size, per vector {id, M code bytes}});
+    // both Flush first and end with the empty roaring bitmap.
+    void write_to(Sink& s) override {
+        flush();
+        lay.compile(c);
+        write_header(s, ivf ? "IVPQ" : "PQIX", dim, metric);
+        if (ivf) s.u32((uint32_t)nlist);
+        s.u32((uint32_t)M); s.u32((uint32_t)nbits); s.u32((uint32_t)Ksub); s.u32((uint32_t)dsub);
+        s.u8(trained ? 1 : 0);
+        if (trained) {
+            if (ivf) {
+                std::vector<float> cen((size_t)nlist * dim);
+                get_centroids(cen.data());
+                for (int l = 0; l < nlist; l++) { s.u32((uint32_t)dim); s.put(&cen[(size_t)l * dim], (size_t)dim * 4); }
+            }
+            std::vector<float> cb((size_t)M * Ksub * dsub);
+            get_codebooks(cb.data());
+            for (int m = 0; m < M; m++) { s.u32((uint32_t)(Ksub * dsub)); s.put(&cb[(size_t)m * Ksub * dsub], (size_t)Ksub * dsub * 4); }
+        }
+        std::vector<uint8_t> all((size_t)std::max<int64_t>(lay.n, 1) * M4 * 4);
+        if (lay.n > 0) { c->d2h(all.data(), codes_arr.p, (size_t)lay.n * M4 * 4); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+        if (ivf) s.u32((uint32_t)nlist); else s.u32((uint32_t)lay.n);
+        for (int l = 0; l < nlist; l++) {
+            const int len = lay.len_h[l];
+            if (ivf) s.u32((uint32_t)len);
+            for (int j = 0; j < len; j++) {
+                const uint32_t r = lay.row_of_slot_h[lay.base_h[l] + j];
+                s.u32(lay.ids[r]); s.put(&all[(size_t)r * M4 * 4], (size_t)M);
+            }
+        }
+        write_empty_bitmap(s);
+        s.flush();
+    }
+    // PQIndex.ReadFrom pq_index.go:672-846 / IVFPQIndex.ReadFrom ivfpq_index.go:745-936
+    void read_from(Source& s) override {
+        read_header(s, ivf ? "IVPQ" : "PQIX", dim, metric);
+        if (ivf) { const uint32_t nl = s.u32("nlist"); if ((int)nl != nlist) COMET_FAIL(COMET_ERR_FORMAT, "nlist mismatch: index has nlist=%d, serialized data has nlist=%u", nlist, nl); }
+        const uint32_t fM = s.u32("M"), fN = s.u32("Nbits"), fK = s.u32("Ksub"), fd = s.u32("dsub");
+        check_param("M", M, fM); check_param("Nbits", nbits, fN); check_param("Ksub", Ksub, fK); check_param("dsub", dsub, fd);   // pq_index.go:737-748
+        const bool tr = s.u8("trained flag") == 1;
+        DevBuf ncent, ncb, ncodes; ListLayout nlay; nlay.nlist = nlist; nlay.align = 64;
+        if (tr) {
+            if (ivf) {
+                std::vector<float> cen((size_t)nlist * dim);
+                for (int l = 0; l < nlist; l++) {
+                    const uint32_t cs = s.u32("centroid size");
+                    if ((int)cs != dim) COMET_FAIL(COMET_ERR_FORMAT, "centroid %d has %u components, expected %d", l, cs, dim);
+                    s.get(&cen[(size_t)l * dim], (size_t)dim * 4, "centroid data");
+                }
+                ScratchMark sm(c);
+                float* raw = c->salloc<float>((size_t)nlist * dim);
+                c->h2d(raw, cen.data(), cen.size() * 4);
+                ncent.reserve((size_t)nlist * ld * 4, c->stream, 0);
+                launch_ingest_rows(c, COMET_L2SQ, raw, nlist, dim, ncent.as<float>(), ld, nullptr);
+                HIP_CHECK(hipStreamSynchronize(c->stream));
+            }
+            std::vector<float> cb((size_t)M * Ksub * dsub);
+            for (int m = 0; m < M; m++) {
+                const uint32_t sz = s.u32("codebook size");
+                if ((int64_t)sz != (int64_t)Ksub * dsub) COMET_FAIL(COMET_ERR_FORMAT, "codebook %d has %u values, expected %d", m, sz, Ksub * dsub);
+                s.get(&cb[(size_t)m * Ksub * dsub], (size_t)Ksub * dsub * 4, "codebook data");
+            }
+            ncb.reserve(cb.size() * 4, c->stream, 0);
+            c->h2d(ncb.p, cb.data(), cb.size() * 4);
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
+        std::vector<uint8_t> codes; std::vector<uint32_t> rid; std::vector<int32_t> rl;
+        const uint32_t outer = s.u32(ivf ? "list count" : "vector count");
+        if (ivf && (int)outer != nlist) COMET_FAIL(COMET_ERR_FORMAT, "list count %u does not match nlist %d", outer, nlist);
+        const uint32_t nl_iter = ivf ? outer : 1;
+        for (uint32_t l = 0; l < nl_iter; l++) {
+            const uint32_t len = ivf ? s.u32("list size") : outer;
+            for (uint32_t j = 0; j < len; j++) {
+                rid.push_back(s.u32("vector ID")); rl.push_back((int32_t)l);
+                const size_t o = codes.size(); codes.resize(o + (size_t)M4 * 4, 0);
+                s.get(&codes[o], (size_t)M, "vector code");
+            }
+        }
+        const std::vector<uint32_t> del = read_bitmap(s);
+        if (!rid.empty()) {
+            ncodes.reserve(codes.size(), c->stream, 0);
+            c->h2d(ncodes.p, codes.data(), codes.size());
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            nlay.append(rid.data(), rl.data(), (int64_t)rid.size());
+        }
+        // commit
+        trained = tr;
+        std::swap(centroids.p, ncent.p); std::swap(centroids.cap, ncent.cap);
+        std::swap(codebooks.p, ncb.p); std::swap(codebooks.cap, ncb.cap);
+        std::swap(codes_arr.p, ncodes.p); std::swap(codes_arr.cap, ncodes.cap);
+        lay.ids.swap(nlay.ids); lay.list_of.swap(nlay.list_of); lay.id_count.swap(nlay.id_count); lay.n = nlay.n; lay.dirty = true;
+        il_dirty = true;
+        deleted.clear(); deleted.insert(del.begin(), del.end()); deleted_dirty = true;
     }
     bool get_stat(const char* name, double* out) const override {
         std::string k(name);

@@ -105,10 +105,10 @@ class HybridSearch:
                 comb = reciprocal_rank_fusion(vres, tres, self.rrf_k)
             elif self.fusion_kind == WEIGHTED_SUM_FUSION:
                 comb = weighted_sum_fusion(vres, tres)
-            elif self.fusion_kind == MAX_FUSION:
+            elif self.fusion_kind == MAX_FUSION:      # maxFusion.Combine fusion.go:252-271: union, larger score where both
                 comb = {d: max(vres.get(d, float("-inf")), tres.get(d, float("-inf"))) for d in {**vres, **tres}}
-            elif self.fusion_kind == MIN_FUSION:
-                comb = {d: min(vres.get(d, float("inf")), tres.get(d, float("inf"))) for d in {**vres, **tres}}
+            elif self.fusion_kind == MIN_FUSION:      # minFusion.Combine fusion.go:291-306: only documents present in BOTH maps
+                comb = {d: min(vres[d], tres[d]) for d in vres if d in tres}
             else:
                 raise ValueError(f"unknown fusion kind: {self.fusion_kind}")
         else:

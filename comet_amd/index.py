@@ -392,6 +392,60 @@ class VectorIndex:
     def new_search(self) -> VectorSearch:
         return VectorSearch(self)
 
+    # -- io.WriterTo / io.ReaderFrom (index.go:58-60): the reference's own byte layout --
+    def write_to(self, w) -> int:
+        """VectorIndex.WriteTo(w): flushes, then streams the reference's on-disk format into `w.write`. Returns bytes written."""
+        err: list[BaseException] = []
+
+        def cb(_user, data, n):
+            try:
+                w.write(C.string_at(data, n))
+                return 0
+            except BaseException as e:   # surfaced below
+                err.append(e)
+                return 1
+        n = C.c_int64()
+        rc = self.lib.comet_index_write_to(self.h, _lib.WRITE_CB(cb), None, C.byref(n))
+        if err:
+            raise err[0]
+        check(rc)
+        return n.value
+
+    def read_from(self, r) -> int:
+        """VectorIndex.ReadFrom(r): parses the reference's on-disk format from `r.read` (io.ReadFull semantics) and
+        replaces this index's contents; the constructor parameters must match the stream. Returns bytes consumed."""
+        err: list[BaseException] = []
+
+        def cb(_user, dst, n):
+            try:
+                got = 0
+                while got < n:
+                    chunk = r.read(n - got)
+                    if not chunk:
+                        return 1          # io.ErrUnexpectedEOF
+                    C.memmove(dst + got, chunk, len(chunk))
+                    got += len(chunk)
+                return 0
+            except BaseException as e:
+                err.append(e)
+                return 1
+        n = C.c_int64()
+        rc = self.lib.comet_index_read_from(self.h, _lib.READ_CB(cb), None, C.byref(n))
+        if err:
+            raise err[0]
+        check(rc)
+        return n.value
+
+    def to_bytes(self) -> bytes:
+        import io
+        b = io.BytesIO()
+        self.write_to(b)
+        return b.getvalue()
+
+    def from_bytes(self, data: bytes) -> int:
+        import io
+        return self.read_from(io.BytesIO(data))
+
     # -- batched entry (one call = B independent queries) --
     def search_batch(self, queries, k: int, threshold: float = 0.0, nprobes: int = 0, ef_search: int = 0,
                      document_ids: Iterable[int] = (), k_cap: int | None = None, mode: int = 0):
@@ -493,6 +547,16 @@ class FlatIndex(VectorIndex):
         super().flush()
         self._deleted.clear()
 
+    def write_to(self, w) -> int:
+        n = super().write_to(w)       # WriteTo flushes (flat_index.go:368)
+        self._deleted.clear()
+        return n
+
+    def read_from(self, r) -> int:
+        n = super().read_from(r)
+        self._deleted.clear()
+        return n
+
     def _lookup_node_vectors(self, node_ids):
         ids, _, vecs = self.list_read(0, want_vectors=True)
         out = []
@@ -525,10 +589,10 @@ class _TrainedIndex(VectorIndex):
 
 
 class IVFIndex(_TrainedIndex):
-    """comet.NewIVFIndex(dim, distanceKind, nlist) — ivf_index.go:140."""
+    """comet.NewIVFIndex(dim, nlist, distanceKind) — ivf_index.go:147 (nlist comes BEFORE the distance kind there)."""
     kind_name = "ivf"
 
-    def __init__(self, ctx: Context, dim: int, distance_kind: str, nlist: int):
+    def __init__(self, ctx: Context, dim: int, nlist: int, distance_kind: str):
         if dim <= 0:
             raise ValueError("dimension must be positive")
         if nlist <= 0:

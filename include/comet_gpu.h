@@ -52,7 +52,9 @@ typedef enum {
     COMET_ERR_HIP = 8,             /* HIP runtime failure */
     COMET_ERR_NO_DEVICE = 9,       /* no usable gfx950 device */
     COMET_ERR_UNSUPPORTED = 10,
-    COMET_ERR_UNKNOWN_METRIC = 11  /* ErrUnknownDistanceKind distance.go:9 */
+    COMET_ERR_UNKNOWN_METRIC = 11, /* ErrUnknownDistanceKind distance.go:9 */
+    COMET_ERR_FORMAT = 12,         /* ReadFrom: "invalid magic number: expected 'FLAT', got '%s'" flat_index.go:516, "unsupported version", "dimension mismatch", ... */
+    COMET_ERR_IO = 13              /* ReadFrom / WriteTo: the caller's reader ran dry ("failed to read ...") or its writer failed */
 } comet_status;
 
 COMET_API const char* comet_last_error(void);
@@ -137,6 +139,25 @@ COMET_API int comet_index_add_dev(comet_index* idx, const uint32_t* ids_dev, con
 COMET_API int comet_index_remove(comet_index* idx, uint32_t id);
 /* Flush (hard-delete soft-deleted rows) — flat_index.go:268-296 */
 COMET_API int comet_index_flush(comet_index* idx);
+
+/* ---- persistence: VectorIndex embeds io.WriterTo / io.ReaderFrom (index.go:58-60) --------------------
+ * comet_index_write_to emits, and comet_index_read_from parses, the reference's own on-disk layouts byte for byte:
+ *   Flat  "FLAT" flat_index.go:348-360 (WriteTo :366, ReadFrom :488)     IVF   "IVFX" ivf_index.go:441-462 (:468, :620)
+ *   PQ    "PQIX" pq_index.go:480-505 (:509, :672)                        IVFPQ "IVPQ" ivfpq_index.go:507-535 (:544, :745)
+ *   HNSW  "HNSW" hnsw_index.go:701-727 (:734, :898)
+ * so an index written by the Go reference loads into the GPU backend and vice versa. Like the reference, write_to
+ * calls Flush() first (soft-deleted vectors are never serialised; the roaring tail is the empty bitmap), and
+ * read_from validates magic / version / every constructor parameter against the receiving index and replaces its
+ * contents only when the whole stream parsed. HNSW nodes are written in ascending id order (the reference iterates
+ * a Go map: any order is valid). The callbacks are what a cgo shim forwards to io.Writer.Write / io.ReadFull;
+ * they return 0 on success. *out_bytes = bytes written / consumed (the int64 the Go methods return). */
+typedef int (*comet_write_cb)(void* user, const void* data, size_t len);
+typedef int (*comet_read_cb)(void* user, void* dst, size_t len);   /* must fill exactly len bytes */
+COMET_API int comet_index_write_to(comet_index* idx, comet_write_cb cb, void* user, int64_t* out_bytes);
+COMET_API int comet_index_read_from(comet_index* idx, comet_read_cb cb, void* user, int64_t* out_bytes);
+/* Buffer forms: serialize with buf == NULL only reports the size (after the flush); deserialize consumes a prefix of buf. */
+COMET_API int comet_index_serialize(comet_index* idx, uint8_t* buf, size_t cap, size_t* out_len);
+COMET_API int comet_index_deserialize(comet_index* idx, const uint8_t* buf, size_t len, size_t* out_consumed);
 
 /* ---- search --------------------------------------------------------------------------------- */
 typedef struct {

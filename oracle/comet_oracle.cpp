@@ -1029,3 +1029,268 @@ ORC_API void orc_synth_fill(uint64_t seed, uint64_t offset, uint64_t n, float* o
         out[i] = 2.0f * u - 1.0f;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// On-disk formats: WriteTo / ReadFrom of the five vector indexes, restated from
+//   flat_index.go:366-470 / :488-614      ("FLAT")     ivf_index.go:468-588 / :620-785     ("IVFX")
+//   pq_index.go:509-640 / :672-846        ("PQIX")     ivfpq_index.go:544-700 / :745-936   ("IVPQ")
+//   hnsw_index.go:734-880 / :898-1096     ("HNSW")
+// binary.Write(w, binary.LittleEndian, x) of uint32/int32/float32/float64/uint8 = the value's little-endian bytes.
+// Every WriteTo calls Flush() first, so deletedNodes is empty when serialised: roaring v1.9.4 (go.mod:6, not vendored)
+// writes an empty bitmap in its portable format as the 8 bytes {uint32 12346 (serialCookieNoRunContainer),
+// uint32 0 containers} (roaringArray.writeTo) — the only roaring bytes the reference can emit on this path.
+// ReadFrom here accepts exactly that empty tail (anything else: ORC_ERR_ARG).
+// HNSW iterates a Go map in WriteTo and Flush (undefined order): nodes are visited in ascending id order here.
+// API: orc_*_write(h, buf, cap) -> bytes needed (writes only if cap suffices); orc_*_read(h, buf, len) ->
+// bytes consumed, or a negative ORC_ERR_* (ORC_ERR_ARG for magic / version / parameter mismatch, ORC_ERR_DIM
+// for a dimension mismatch, -8 for a short read).
+// ---------------------------------------------------------------------------------------------
+static const int ORC_ERR_EOF = -8;
+struct OW {
+    std::vector<uint8_t> b;
+    void raw(const void* p, size_t n) { b.insert(b.end(), (const uint8_t*)p, (const uint8_t*)p + n); }
+    void u8(uint8_t v) { raw(&v, 1); } void u32(uint32_t v) { raw(&v, 4); } void i32(int32_t v) { raw(&v, 4); }
+    void f32(float v) { raw(&v, 4); } void f64(double v) { raw(&v, 8); }
+    void kind(int metric) { const char* s = metric == ORC_L2 ? "l2" : metric == ORC_L2SQ ? "l2_squared" : "cosine"; u32((uint32_t)std::strlen(s)); raw(s, std::strlen(s)); }
+    void empty_bitmap() { u32(8); u32(12346u); u32(0u); }
+    int64_t finish(uint8_t* out, int64_t cap) const { if (out && (int64_t)b.size() <= cap) std::memcpy(out, b.data(), b.size()); return (int64_t)b.size(); }
+};
+struct OR {
+    const uint8_t* p; int64_t len, off = 0; bool eof = false;
+    OR(const uint8_t* p_, int64_t l) : p(p_), len(l) {}
+    bool raw(void* d, size_t n) { if (off + (int64_t)n > len) { eof = true; std::memset(d, 0, n); return false; } std::memcpy(d, p + off, n); off += (int64_t)n; return true; }
+    uint8_t u8() { uint8_t v = 0; raw(&v, 1); return v; } uint32_t u32() { uint32_t v = 0; raw(&v, 4); return v; }
+    int32_t i32() { int32_t v = 0; raw(&v, 4); return v; } double f64() { double v = 0; raw(&v, 8); return v; }
+    // magic + version + dim + distance kind; 0 or a negative error
+    int header(const char* magic, int dim, int metric) {
+        char m[4]; if (!raw(m, 4)) return ORC_ERR_EOF;
+        if (std::memcmp(m, magic, 4) != 0) return ORC_ERR_ARG;
+        if (u32() != 1u) return eof ? ORC_ERR_EOF : ORC_ERR_ARG;
+        if ((int)u32() != dim) return eof ? ORC_ERR_EOF : ORC_ERR_DIM;
+        uint32_t kl = u32(); if (eof) return ORC_ERR_EOF; if (kl > 64) return ORC_ERR_ARG;
+        char k[65] = {0}; if (!raw(k, kl)) return ORC_ERR_EOF;
+        const char* want = metric == ORC_L2 ? "l2" : metric == ORC_L2SQ ? "l2_squared" : "cosine";
+        return std::strcmp(k, want) == 0 ? 0 : ORC_ERR_ARG;
+    }
+    int empty_bitmap() { uint32_t sz = u32(); if (eof) return ORC_ERR_EOF; if (sz != 8) return ORC_ERR_ARG; uint32_t a = u32(), b = u32(); if (eof) return ORC_ERR_EOF; return (a == 12346u && b == 0u) ? 0 : ORC_ERR_ARG; }
+};
+
+ORC_API int64_t orc_flat_write(void* p, uint8_t* out, int64_t cap) {
+    auto* h = (OFlat*)p; orc_flat_flush(p);                       // flat_index.go:368
+    OW w; w.raw("FLAT", 4); w.u32(1); w.u32((uint32_t)h->dim); w.kind(h->metric);
+    w.u32((uint32_t)h->ids.size());
+    for (size_t i = 0; i < h->ids.size(); i++) { w.u32(h->ids[i]); w.u32((uint32_t)h->dim); w.raw(&h->vecs[i * h->dim], (size_t)h->dim * 4); }
+    w.empty_bitmap();
+    return w.finish(out, cap);
+}
+ORC_API int64_t orc_flat_read(void* p, const uint8_t* in, int64_t len) {
+    auto* h = (OFlat*)p; OR r(in, len);
+    if (int rc = r.header("FLAT", h->dim, h->metric)) return rc;
+    uint32_t n = r.u32(); if (r.eof) return ORC_ERR_EOF;
+    std::vector<uint32_t> ids(n); std::vector<float> vecs((size_t)n * h->dim);
+    for (uint32_t i = 0; i < n; i++) {
+        ids[i] = r.u32(); uint32_t vd = r.u32(); if (r.eof) return ORC_ERR_EOF;
+        if ((int)vd != h->dim) return ORC_ERR_DIM;                 // :573
+        if (!r.raw(&vecs[(size_t)i * h->dim], (size_t)h->dim * 4)) return ORC_ERR_EOF;
+    }
+    if (int rc = r.empty_bitmap()) return rc;
+    h->ids.swap(ids); h->vecs.swap(vecs); h->deleted.clear();
+    return r.off;
+}
+
+// IVFIndex.Flush ivf_index.go:362-400
+ORC_API void orc_ivf_flush(void* p) {
+    auto* h = (OIVF*)p; if (h->deleted.empty()) return;
+    for (int l = 0; l < h->nlist; l++) {
+        std::vector<uint32_t> ids; std::vector<float> vecs;
+        for (size_t j = 0; j < h->list_ids[l].size(); j++) if (!h->deleted.count(h->list_ids[l][j])) {
+            ids.push_back(h->list_ids[l][j]); vecs.insert(vecs.end(), h->list_vecs[l].begin() + j * h->dim, h->list_vecs[l].begin() + (j + 1) * h->dim);
+        }
+        h->list_ids[l].swap(ids); h->list_vecs[l].swap(vecs);
+    }
+    h->deleted.clear();
+}
+ORC_API int64_t orc_ivf_write(void* p, uint8_t* out, int64_t cap) {
+    auto* h = (OIVF*)p; orc_ivf_flush(p);
+    OW w; w.raw("IVFX", 4); w.u32(1); w.u32((uint32_t)h->dim); w.kind(h->metric); w.u32((uint32_t)h->nlist); w.u8(h->trained ? 1 : 0);
+    if (h->trained) for (int l = 0; l < h->nlist; l++) { w.u32((uint32_t)h->dim); w.raw(&h->centroids[(size_t)l * h->dim], (size_t)h->dim * 4); }
+    w.u32((uint32_t)h->nlist);
+    for (int l = 0; l < h->nlist; l++) {
+        w.u32((uint32_t)h->list_ids[l].size());
+        for (size_t j = 0; j < h->list_ids[l].size(); j++) { w.u32(h->list_ids[l][j]); w.raw(&h->list_vecs[l][j * h->dim], (size_t)h->dim * 4); }
+    }
+    w.empty_bitmap();
+    return w.finish(out, cap);
+}
+ORC_API int64_t orc_ivf_read(void* p, const uint8_t* in, int64_t len) {
+    auto* h = (OIVF*)p; OR r(in, len);
+    if (int rc = r.header("IVFX", h->dim, h->metric)) return rc;
+    if ((int)r.u32() != h->nlist) return r.eof ? ORC_ERR_EOF : ORC_ERR_ARG;
+    bool tr = r.u8() == 1; if (r.eof) return ORC_ERR_EOF;
+    std::vector<float> cen;
+    if (tr) { cen.resize((size_t)h->nlist * h->dim); for (int l = 0; l < h->nlist; l++) { uint32_t cs = r.u32(); if (r.eof) return ORC_ERR_EOF; if ((int)cs != h->dim) return ORC_ERR_DIM; if (!r.raw(&cen[(size_t)l * h->dim], (size_t)h->dim * 4)) return ORC_ERR_EOF; } }
+    uint32_t lc = r.u32(); if (r.eof) return ORC_ERR_EOF; if ((int)lc != h->nlist) return ORC_ERR_ARG;
+    std::vector<std::vector<uint32_t>> li(lc); std::vector<std::vector<float>> lv(lc);
+    for (uint32_t l = 0; l < lc; l++) {
+        uint32_t n = r.u32(); if (r.eof) return ORC_ERR_EOF;
+        li[l].resize(n); lv[l].resize((size_t)n * h->dim);
+        for (uint32_t j = 0; j < n; j++) { li[l][j] = r.u32(); if (!r.raw(&lv[l][(size_t)j * h->dim], (size_t)h->dim * 4)) return ORC_ERR_EOF; }
+    }
+    if (int rc = r.empty_bitmap()) return rc;
+    h->trained = tr; if (tr) h->centroids.swap(cen); h->list_ids.swap(li); h->list_vecs.swap(lv); h->deleted.clear();
+    return r.off;
+}
+
+// PQIndex.Flush pq_index.go:340-380
+ORC_API void orc_pq_flush(void* p) {
+    auto* h = (OPQ*)p; if (h->deleted.empty()) return;
+    std::vector<uint32_t> ids; std::vector<uint8_t> codes;
+    for (size_t i = 0; i < h->ids.size(); i++) if (!h->deleted.count(h->ids[i])) { ids.push_back(h->ids[i]); codes.insert(codes.end(), h->codes.begin() + i * h->M, h->codes.begin() + (i + 1) * h->M); }
+    h->ids.swap(ids); h->codes.swap(codes); h->deleted.clear();
+}
+ORC_API int64_t orc_pq_write(void* p, uint8_t* out, int64_t cap) {
+    auto* h = (OPQ*)p; orc_pq_flush(p);
+    OW w; w.raw("PQIX", 4); w.u32(1); w.u32((uint32_t)h->dim); w.kind(h->metric);
+    w.u32((uint32_t)h->M); w.u32((uint32_t)h->nbits); w.u32((uint32_t)h->Ksub); w.u32((uint32_t)h->dsub); w.u8(h->trained ? 1 : 0);
+    const size_t cbs = (size_t)h->Ksub * h->dsub;
+    if (h->trained) for (int m = 0; m < h->M; m++) { w.u32((uint32_t)cbs); w.raw(&h->codebooks[m * cbs], cbs * 4); }
+    w.u32((uint32_t)h->ids.size());
+    for (size_t i = 0; i < h->ids.size(); i++) { w.u32(h->ids[i]); w.raw(&h->codes[i * h->M], (size_t)h->M); }
+    w.empty_bitmap();
+    return w.finish(out, cap);
+}
+ORC_API int64_t orc_pq_read(void* p, const uint8_t* in, int64_t len) {
+    auto* h = (OPQ*)p; OR r(in, len);
+    if (int rc = r.header("PQIX", h->dim, h->metric)) return rc;
+    uint32_t M = r.u32(), nb = r.u32(), K = r.u32(), ds = r.u32(); if (r.eof) return ORC_ERR_EOF;
+    if ((int)M != h->M || (int)nb != h->nbits || (int)K != h->Ksub || (int)ds != h->dsub) return ORC_ERR_ARG;   // pq_index.go:737-748
+    bool tr = r.u8() == 1; if (r.eof) return ORC_ERR_EOF;
+    const size_t cbs = (size_t)h->Ksub * h->dsub;
+    std::vector<float> cb;
+    if (tr) { cb.resize((size_t)h->M * cbs); for (int m = 0; m < h->M; m++) { uint32_t sz = r.u32(); if (r.eof) return ORC_ERR_EOF; if (sz != cbs) return ORC_ERR_ARG; if (!r.raw(&cb[m * cbs], cbs * 4)) return ORC_ERR_EOF; } }
+    uint32_t n = r.u32(); if (r.eof) return ORC_ERR_EOF;
+    std::vector<uint32_t> ids(n); std::vector<uint8_t> codes((size_t)n * h->M);
+    for (uint32_t i = 0; i < n; i++) { ids[i] = r.u32(); if (!r.raw(&codes[(size_t)i * h->M], (size_t)h->M)) return ORC_ERR_EOF; }
+    if (int rc = r.empty_bitmap()) return rc;
+    h->trained = tr; if (tr) h->codebooks.swap(cb); h->ids.swap(ids); h->codes.swap(codes); h->deleted.clear();
+    return r.off;
+}
+
+// IVFPQIndex.Flush ivfpq_index.go:401-439
+ORC_API void orc_ivfpq_flush(void* p) {
+    auto* h = (OIVFPQ*)p; if (h->deleted.empty()) return;
+    for (int l = 0; l < h->nlist; l++) {
+        std::vector<uint32_t> ids; std::vector<uint8_t> codes;
+        for (size_t j = 0; j < h->list_ids[l].size(); j++) if (!h->deleted.count(h->list_ids[l][j])) {
+            ids.push_back(h->list_ids[l][j]); codes.insert(codes.end(), h->list_codes[l].begin() + j * h->M, h->list_codes[l].begin() + (j + 1) * h->M);
+        }
+        h->list_ids[l].swap(ids); h->list_codes[l].swap(codes);
+    }
+    h->deleted.clear();
+}
+ORC_API int64_t orc_ivfpq_write(void* p, uint8_t* out, int64_t cap) {
+    auto* h = (OIVFPQ*)p; orc_ivfpq_flush(p);
+    OW w; w.raw("IVPQ", 4); w.u32(1); w.u32((uint32_t)h->dim); w.kind(h->metric); w.u32((uint32_t)h->nlist);
+    w.u32((uint32_t)h->M); w.u32((uint32_t)h->nbits); w.u32((uint32_t)h->Ksub); w.u32((uint32_t)h->dsub); w.u8(h->trained ? 1 : 0);
+    const size_t cbs = (size_t)h->Ksub * h->dsub;
+    if (h->trained) {
+        for (int l = 0; l < h->nlist; l++) { w.u32((uint32_t)h->dim); w.raw(&h->centroids[(size_t)l * h->dim], (size_t)h->dim * 4); }
+        for (int m = 0; m < h->M; m++) { w.u32((uint32_t)cbs); w.raw(&h->codebooks[m * cbs], cbs * 4); }
+    }
+    w.u32((uint32_t)h->nlist);
+    for (int l = 0; l < h->nlist; l++) {
+        w.u32((uint32_t)h->list_ids[l].size());
+        for (size_t j = 0; j < h->list_ids[l].size(); j++) { w.u32(h->list_ids[l][j]); w.raw(&h->list_codes[l][j * h->M], (size_t)h->M); }
+    }
+    w.empty_bitmap();
+    return w.finish(out, cap);
+}
+ORC_API int64_t orc_ivfpq_read(void* p, const uint8_t* in, int64_t len) {
+    auto* h = (OIVFPQ*)p; OR r(in, len);
+    if (int rc = r.header("IVPQ", h->dim, h->metric)) return rc;
+    uint32_t nl = r.u32(), M = r.u32(), nb = r.u32(), K = r.u32(), ds = r.u32(); if (r.eof) return ORC_ERR_EOF;
+    if ((int)nl != h->nlist || (int)M != h->M || (int)nb != h->nbits || (int)K != h->Ksub || (int)ds != h->dsub) return ORC_ERR_ARG;
+    bool tr = r.u8() == 1; if (r.eof) return ORC_ERR_EOF;
+    const size_t cbs = (size_t)h->Ksub * h->dsub;
+    std::vector<float> cen, cb;
+    if (tr) {
+        cen.resize((size_t)h->nlist * h->dim);
+        for (int l = 0; l < h->nlist; l++) { uint32_t cs = r.u32(); if (r.eof) return ORC_ERR_EOF; if ((int)cs != h->dim) return ORC_ERR_DIM; if (!r.raw(&cen[(size_t)l * h->dim], (size_t)h->dim * 4)) return ORC_ERR_EOF; }
+        cb.resize((size_t)h->M * cbs);
+        for (int m = 0; m < h->M; m++) { uint32_t sz = r.u32(); if (r.eof) return ORC_ERR_EOF; if (sz != cbs) return ORC_ERR_ARG; if (!r.raw(&cb[m * cbs], cbs * 4)) return ORC_ERR_EOF; }
+    }
+    uint32_t lc = r.u32(); if (r.eof) return ORC_ERR_EOF; if ((int)lc != h->nlist) return ORC_ERR_ARG;
+    std::vector<std::vector<uint32_t>> li(lc); std::vector<std::vector<uint8_t>> lcodes(lc);
+    for (uint32_t l = 0; l < lc; l++) {
+        uint32_t n = r.u32(); if (r.eof) return ORC_ERR_EOF;
+        li[l].resize(n); lcodes[l].resize((size_t)n * h->M);
+        for (uint32_t j = 0; j < n; j++) { li[l][j] = r.u32(); if (!r.raw(&lcodes[l][(size_t)j * h->M], (size_t)h->M)) return ORC_ERR_EOF; }
+    }
+    if (int rc = r.empty_bitmap()) return rc;
+    h->trained = tr; if (tr) { h->centroids.swap(cen); h->codebooks.swap(cb); } h->list_ids.swap(li); h->list_codes.swap(lcodes); h->deleted.clear();
+    return r.off;
+}
+
+static std::vector<uint32_t> hnsw_sorted_ids(OHNSW* h) { std::vector<uint32_t> v; for (auto& kv : h->nodes) v.push_back(kv.first); std::sort(v.begin(), v.end()); return v; }
+// HNSWIndex.Flush hnsw_index.go:348-431 (map iteration replaced by ascending id order)
+ORC_API void orc_hnsw_flush(void* p) {
+    auto* h = (OHNSW*)p; if (h->deleted.empty()) return;
+    const auto order = hnsw_sorted_ids(h);
+    for (uint32_t id : order) {                                                  // PHASE 1
+        if (h->deleted.count(id)) continue;
+        ONode* n = h->nodes[id];
+        for (auto& e : n->edges) { std::vector<uint32_t> f; for (uint32_t x : e) if (!h->deleted.count(x)) f.push_back(x); e.swap(f); }
+    }
+    if (h->deleted.count(h->entry)) {                                            // PHASE 2
+        bool found = false;
+        for (uint32_t id : order) { ONode* n = h->nodes[id]; if (!h->deleted.count(id) && n->level == h->max_level) { h->entry = id; found = true; break; } }
+        if (!found) {
+            int best = -1;
+            for (uint32_t id : order) { ONode* n = h->nodes[id]; if (!h->deleted.count(id) && n->level > best) { best = n->level; h->entry = id; } }
+            if (best >= 0) h->max_level = best; else { h->entry = 0; h->max_level = -1; }
+        }
+    }
+    for (uint32_t id : h->deleted) { auto it = h->nodes.find(id); if (it != h->nodes.end()) { delete it->second; h->nodes.erase(it); } }   // PHASE 3
+    std::vector<uint32_t> io; for (uint32_t id : h->insertion_order) if (h->nodes.count(id)) io.push_back(id);
+    h->insertion_order.swap(io);
+    h->deleted.clear();                                                          // PHASE 4
+}
+ORC_API int64_t orc_hnsw_write(void* p, uint8_t* out, int64_t cap) {
+    auto* h = (OHNSW*)p; orc_hnsw_flush(p);
+    OW w; w.raw("HNSW", 4); w.u32(1); w.u32((uint32_t)h->dim); w.kind(h->metric);
+    w.u32((uint32_t)h->M); w.u32((uint32_t)h->efC); w.u32((uint32_t)h->efS);
+    w.f64(1.0 / go_log((double)h->M));                                           // levelMult hnsw_index.go:206
+    w.i32(h->max_level); w.u32(h->entry); w.u32((uint32_t)h->nodes.size());
+    for (uint32_t id : hnsw_sorted_ids(h)) {
+        ONode* n = h->nodes[id];
+        w.u32(id); w.i32(n->level); w.u32((uint32_t)n->vec.size()); w.raw(n->vec.data(), n->vec.size() * 4);
+        w.u32((uint32_t)n->edges.size());
+        for (auto& e : n->edges) { w.u32((uint32_t)e.size()); if (!e.empty()) w.raw(e.data(), e.size() * 4); }
+    }
+    w.empty_bitmap();
+    return w.finish(out, cap);
+}
+ORC_API int64_t orc_hnsw_read(void* p, const uint8_t* in, int64_t len) {
+    auto* h = (OHNSW*)p; OR r(in, len);
+    if (int rc = r.header("HNSW", h->dim, h->metric)) return rc;
+    uint32_t M = r.u32(), efc = r.u32(), efs = r.u32(); if (r.eof) return ORC_ERR_EOF;
+    if ((int)M != h->M || (int)efc != h->efC || (int)efs != h->efS) return ORC_ERR_ARG;   // :975-986
+    (void)r.f64(); int32_t maxl = r.i32(); uint32_t ep = r.u32(); uint32_t n = r.u32(); if (r.eof) return ORC_ERR_EOF;
+    std::unordered_map<uint32_t, ONode*> nodes; std::vector<uint32_t> order;
+    auto fail = [&](int rc) { for (auto& kv : nodes) delete kv.second; return (int64_t)rc; };
+    for (uint32_t i = 0; i < n; i++) {
+        ONode* nd = new ONode(); nd->id = r.u32(); nd->level = r.i32(); uint32_t vd = r.u32();
+        if (r.eof || vd > (1u << 20)) { delete nd; return fail(r.eof ? ORC_ERR_EOF : ORC_ERR_ARG); }
+        nd->vec.resize(vd); r.raw(nd->vec.data(), (size_t)vd * 4);
+        uint32_t layers = r.u32(); if (r.eof || layers > 64) { delete nd; return fail(r.eof ? ORC_ERR_EOF : ORC_ERR_ARG); }
+        nd->edges.resize(layers);
+        for (uint32_t l = 0; l < layers; l++) { uint32_t ec = r.u32(); if (r.eof || ec > (1u << 24)) { delete nd; return fail(r.eof ? ORC_ERR_EOF : ORC_ERR_ARG); } nd->edges[l].resize(ec); r.raw(nd->edges[l].data(), (size_t)ec * 4); }
+        if (r.eof) { delete nd; return fail(ORC_ERR_EOF); }
+        auto it = nodes.find(nd->id); if (it != nodes.end()) delete it->second;
+        nodes[nd->id] = nd; order.push_back(nd->id);
+    }
+    if (int rc = r.empty_bitmap()) return fail(rc);
+    for (auto& kv : h->nodes) delete kv.second;
+    h->nodes.swap(nodes); h->insertion_order.swap(order); h->max_level = maxl; h->entry = ep; h->deleted.clear();
+    return r.off;
+}

@@ -62,6 +62,12 @@ def lib() -> C.CDLL:
             "orc_aggregate": (i32, [i32, vp, vp, i32, vp, vp]),
             "orc_rrf": (i32, [dbl, vp, vp, i32, vp, vp, i32, vp, vp]),
             "orc_synth_fill": (None, [u64, u64, u64, vp]),
+            "orc_ivf_flush": (None, [vp]), "orc_pq_flush": (None, [vp]), "orc_ivfpq_flush": (None, [vp]), "orc_hnsw_flush": (None, [vp]),
+            "orc_flat_write": (i64, [vp, vp, i64]), "orc_flat_read": (i64, [vp, vp, i64]),
+            "orc_ivf_write": (i64, [vp, vp, i64]), "orc_ivf_read": (i64, [vp, vp, i64]),
+            "orc_pq_write": (i64, [vp, vp, i64]), "orc_pq_read": (i64, [vp, vp, i64]),
+            "orc_ivfpq_write": (i64, [vp, vp, i64]), "orc_ivfpq_read": (i64, [vp, vp, i64]),
+            "orc_hnsw_write": (i64, [vp, vp, i64]), "orc_hnsw_read": (i64, [vp, vp, i64]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -158,6 +164,26 @@ def synth(seed, offset, n):
 class _Index:
     _free = None
     _search = None
+    _io = None     # "flat" / "ivf" / "pq" / "ivfpq" / "hnsw"
+
+    def to_bytes(self) -> bytes:
+        """WriteTo: flushes, then the reference's on-disk layout."""
+        fn = getattr(lib(), f"orc_{self._io}_write")
+        n = fn(self.h, None, 0)
+        buf = (C.c_uint8 * max(1, n))()
+        assert fn(self.h, buf, n) == n
+        return bytes(buf[:n])
+
+    def from_bytes(self, data: bytes) -> int:
+        """ReadFrom: bytes consumed, or a negative error."""
+        buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data or b"\0")
+        n = getattr(lib(), f"orc_{self._io}_read")(self.h, buf, len(data))
+        if n >= 0 and hasattr(self, "n"):
+            self.n = self._count()
+        return n
+
+    def flush(self):
+        getattr(lib(), f"orc_{self._io}_flush")(self.h)
 
     def __del__(self):
         try:
@@ -183,6 +209,7 @@ class _Index:
 
 class Flat(_Index):
     _free = "orc_flat_free"
+    _io = "flat"
 
     def __init__(self, dim, metric):
         self.dim, self.metric = dim, metric
@@ -215,6 +242,10 @@ class Flat(_Index):
 
 class IVF(_Index):
     _free = "orc_ivf_free"
+    _io = "ivf"
+
+    def _count(self):
+        return sum(self.list_sizes())
 
     def __init__(self, dim, metric, nlist):
         self.dim, self.metric, self.nlist, self.n = dim, metric, nlist, 0
@@ -256,6 +287,7 @@ class IVF(_Index):
 
 class PQ(_Index):
     _free = "orc_pq_free"
+    _io = "pq"
 
     def __init__(self, dim, metric, M, nbits):
         self.dim, self.metric, self.M, self.nbits = dim, metric, M, nbits
@@ -298,6 +330,10 @@ class PQ(_Index):
 
 class IVFPQ(_Index):
     _free = "orc_ivfpq_free"
+    _io = "ivfpq"
+
+    def _count(self):
+        return sum(self.list_size(l) for l in range(self.nlist))
 
     def __init__(self, dim, metric, nlist, M, nbits):
         self.dim, self.metric, self.nlist, self.M, self.nbits, self.n = dim, metric, nlist, M, nbits, 0
@@ -405,6 +441,7 @@ class BM25:
 
 class HNSW(_Index):
     _free = "orc_hnsw_free"
+    _io = "hnsw"
 
     def __init__(self, dim, metric, m=0, efc=0, efs=0, seed=12345):
         self.dim, self.metric = dim, metric

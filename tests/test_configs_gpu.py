@@ -1,0 +1,138 @@
+"""Every BASELINE.json config at its OWN parameters (all of them together), at a corpus size the CPU oracle covers in
+seconds; every query of the batch compared bit for bit (ids, float32 score bits, counts, order).
+
+  configs[1]  Flat cosine d=768, batch=256, K=100                                   (n = 48k rows here, 1M in bench.py)
+  configs[2]  HNSW M=16 efConstruction=200 efSearch=128, d=384, L2, K=10            (n = 30k nodes, graph built by the oracle)
+  configs[3]  IVFPQ nlist=4096 nprobe=32 M=96 nbits=8, d=768, K=10                  (n = 60k; GPU train + add, index handed
+              to the oracle through the reference's own IVPQ on-disk format)
+  configs[4]  Hybrid: IVF d=768 nlist=1024 nprobe=32 + BM25 100k docs + RRF, k=10   (IVF n = 40k; GPU-trained index handed
+              to the oracle through the IVFX format)
+  configs[0]  Flat L2^2 10k x 128, K=10 — the reference's CPU plumbing case — runs through the GPU path too.
+Full-size runs of the same configurations (with the same parity checks on a query sample) live in bench.py."""
+import ctypes as C
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from comet_amd import (BM25SearchIndex, COSINE, EUCLIDEAN, FlatIndex, HNSWIndex, IVFIndex, IVFPQIndex, L2_SQUARED)
+from comet_amd.hybrid import RECIPROCAL_RANK_FUSION, HybridSearch
+
+pytestmark = pytest.mark.gpu
+POOL = ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 4))      # the oracle releases the GIL (ctypes)
+
+
+def synth(seed, n, d, off=0):
+    return orc.synth(seed, off, n * d).reshape(n, d)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def compare_all(gpu_rows, oracle_search, Q):
+    gi, gs, gc = gpu_rows
+    res = list(POOL.map(oracle_search, list(Q)))
+    bad = [b for b, (n, oi, os_) in enumerate(res)
+           if not (gc[b] == n and np.array_equal(gi[b, :n], oi) and np.array_equal(bits(gs[b, :n]), bits(os_)))]
+    assert not bad, f"{len(bad)} of {len(Q)} queries differ from the oracle, first: {bad[:5]}"
+
+
+def test_config0_flat_l2sq_10k_x_128_k10(ctx):
+    n, d = 10_000, 128
+    X = synth(0xC0FFEE + 1, n, d); Q = synth(0xBEEF + 1, 32, d)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    g = FlatIndex(ctx, d, L2_SQUARED); g.add_batch(ids, X)
+    o = orc.Flat(d, "l2_squared"); assert o.add_batch(ids, X) == 0
+    compare_all(g.search_batch(Q, 10), lambda q: o.search(q, 10), Q)
+    r = g.new_search().with_query(Q[0]).with_k(10).execute()               # NewSearch().WithQuery().WithK().Execute()
+    assert [x.id for x in r] == o.search(Q[0], 10)[1].tolist()
+
+
+def test_config1_flat_cosine_768_batch256_k100(ctx):
+    n, d, B, K = 48_000, 768, 256, 100
+    X = synth(0xC0FFEE + 2, n, d); Q = synth(0xBEEF + 2, B, d)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    g = FlatIndex(ctx, d, COSINE); g.add_batch(ids, X)
+    o = orc.Flat(d, "cosine"); assert o.add_batch(ids, X) == 0
+    for mode in (0, 1):                                                     # auto (MFMA fast path at this size) and strict kernels
+        rows = g.search_batch(Q, K, mode=mode)
+        if mode == 0:
+            assert g.stat("fast_queries") == B                              # the fast path really served the batch
+        compare_all(rows, lambda q: o.search(q, K), Q)
+
+
+def test_config2_hnsw_m16_efc200_ef128_d384_l2_k10(ctx):
+    n, d, B = 30_000, 384, 256
+    X = synth(0x48, n, d)
+    o = orc.HNSW(d, "l2", 16, 200, 128, seed=7)
+    assert o.add_batch(np.arange(1, n + 1), X) == 0
+    ids, levels, vecs, eoff, edges = o.export()
+    g = HNSWIndex(ctx, d, EUCLIDEAN, 16, 200, 128)
+    g.load_graph(ids, levels, vecs, eoff, edges, o.entry(), o.max_level())
+    Q = synth(0x49, B, d)
+    compare_all(g.search_batch(Q, 10), lambda q: o.search(q, 10), Q)        # index default efSearch = 128
+    compare_all(g.search_batch(Q, 10, ef_search=128), lambda q: o.search(q, 10, 128), Q)
+    assert g.stat("hnsw_distance_evals") > 0
+
+
+def test_config3_ivfpq_nlist4096_nprobe32_m96_nbits8_d768_k10(ctx):
+    n, d, nlist, M, nbits, B = 60_000, 768, 4096, 96, 8, 64
+    ntrain = nlist * 10                                                     # the reference's minimum (ivfpq_index.go:185)
+    g = IVFPQIndex(ctx, d, L2_SQUARED, nlist, M, nbits)
+    X = synth(0xC0FFEE + 3, n, d)
+    g.train(X[:ntrain])
+    g.add_batch(np.arange(1, n + 1, dtype=np.uint32), X)
+    blob = g.to_bytes()
+    o = orc.IVFPQ(d, "l2_squared", nlist, M, nbits)
+    assert o.from_bytes(blob) == len(blob)                                  # the oracle searches the index the GPU built
+    Q = synth(0xBEEF + 3, B, d)
+    compare_all(g.search_batch(Q, 10, nprobes=32), lambda q: o.search(q, 10, 32), Q)
+    # encode parity on a sample: the oracle re-encodes vectors with the GPU's quantisers and must land in the same list with the same code
+    o2 = orc.IVFPQ(d, "l2_squared", nlist, M, nbits)
+    assert o2.set_quantizers(o.centroids(), o.codebooks()) == 0
+    for i in range(0, 200):
+        assert o2.add(i + 1, X[i]) == 0
+    by_id = {}
+    for l in range(nlist):
+        for idv, code in zip(o.list_ids(l), o.list_codes(l)):
+            if idv <= 200:
+                by_id[int(idv)] = (l, bytes(code))
+    for l in range(nlist):
+        for idv, code in zip(o2.list_ids(l), o2.list_codes(l)):
+            assert by_id[int(idv)] == (l, bytes(code)), idv
+
+
+def test_config4_hybrid_ivf768_nlist1024_nprobe32_bm25_100k_rrf(ctx):
+    n, d, nlist, k, ndocs = 40_000, 768, 1024, 10, 100_000
+    X = synth(0xC0FFEE + 4, n, d)
+    g = IVFIndex(ctx, d, nlist, COSINE)
+    g.train(X[:4 * nlist]); g.add_batch(np.arange(1, n + 1, dtype=np.uint32), X)
+    blob = g.to_bytes()
+    o = orc.IVF(d, "cosine", nlist)
+    assert o.from_bytes(blob) == len(blob)
+    rng = np.random.default_rng(3)
+    vocab = 50_000
+    zipf = lambda size: np.minimum(vocab - 1, (rng.pareto(1.1, size) * 20).astype(np.int64)).astype(np.uint32)
+    tg, to = BM25SearchIndex(ctx), orc.BM25()
+    for i, ln in enumerate(rng.integers(64, 257, ndocs)):                   # doc length 64-256
+        t = zipf(int(ln))
+        tg.add(i + 1, t); to.add(i + 1, t)
+    Q = synth(0xBEEF + 4, 24, d)
+    compare_all(g.search_batch(Q, k, nprobes=32), lambda q: o.search(q, k, 32), Q)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for qi in range(24):
+        terms = zipf(3).tolist()
+        res = HybridSearch(g, tg).with_vector(Q[qi]).with_text(terms).with_k(k).with_n_probes(32).with_fusion_kind(RECIPROCAL_RANK_FUSION).execute()
+        nv, vi, vs = o.search(Q[qi], k, 32)
+        nt, ti, ts32, ts64 = to.search(terms, k)
+        gt = tg.search_batch([terms], k)
+        assert gt[3][0] == nt and np.array_equal(gt[0][0, :nt], ti) and np.array_equal(gt[2][0, :nt].view(np.uint64), np.asarray(ts64, np.float64).view(np.uint64))
+        vsd, tsd = vs.astype(np.float64), ts32.astype(np.float64)
+        oi, os_ = np.zeros(2 * k, np.uint32), np.zeros(2 * k, np.float64)
+        m = orc.lib().orc_rrf(C.c_double(60.0), p(vi), p(vsd), nv, p(ti), p(tsd), nt, p(oi), p(os_))
+        want = sorted(zip(os_[:m].tolist(), oi[:m].tolist()), key=lambda t: -t[0])[:k]
+        assert sorted(r.score for r in res) == sorted(s for s, _ in want)
+        assert {r.id for r in res if r.score > want[-1][0]} == {i for s, i in want if s > want[-1][0]}

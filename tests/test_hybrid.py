@@ -21,6 +21,28 @@ def test_rrf_reference_kat():
     assert score_map_to_ranks({1: 20.0, 2: 15.0, 4: 10.0}, False) == {1: 0, 2: 1, 4: 2}
 
 
+def test_min_max_fusion_follow_the_reference():
+    """minFusion keeps only documents in BOTH result maps (fusion.go:291-306); maxFusion the union (fusion.go:252-271)."""
+    from comet_amd.hybrid import MAX_FUSION, MIN_FUSION
+    from comet_amd.index import TextResult, VectorResult
+
+    class FakeSearch:
+        def __init__(self, res): self.res = res
+        def __getattr__(self, name): return lambda *a, **k: self
+        def execute(self): return self.res
+
+    class FakeIndex:
+        def __init__(self, res): self.res = res
+        def new_search(self): return FakeSearch(self.res)
+
+    vec = FakeIndex([VectorResult(1, 0.5), VectorResult(2, 0.25), VectorResult(3, 2.0)])
+    txt = FakeIndex([TextResult(2, 1.5), TextResult(3, 0.75), TextResult(4, 9.0)])
+    run = lambda kind: {r.id: r.score for r in HybridSearch(vec, txt).with_vector([0.0]).with_text([1]).with_k(10).with_fusion_kind(kind).execute()}
+    assert run(MIN_FUSION) == {2: 0.25, 3: 0.75}
+    assert run(MAX_FUSION) == {1: 0.5, 2: 1.5, 3: 2.0, 4: 9.0}
+    assert [r.id for r in HybridSearch(vec, txt).with_vector([0.0]).with_text([1]).with_k(10).with_fusion_kind(MAX_FUSION).execute()] == [4, 3, 2, 1]
+
+
 @pytest.mark.gpu
 def test_config5_hybrid_ivf_bm25_rrf(ctx):
     import ctypes as C
@@ -29,7 +51,7 @@ def test_config5_hybrid_ivf_bm25_rrf(ctx):
     n, d, nlist, k = 4000, 32, 16, 10
     X = orc.synth(3, 0, n * d).reshape(n, d)
     ids = np.arange(1, n + 1, dtype=np.uint32)
-    g = IVFIndex(ctx, d, L2_SQUARED, nlist); o = orc.IVF(d, "l2_squared", nlist)
+    g = IVFIndex(ctx, d, nlist, L2_SQUARED); o = orc.IVF(d, "l2_squared", nlist)
     g.train(X[:1000]); o.train(X[:1000]); g.add_batch(ids, X); o.add_batch(ids, X)
     rng = np.random.default_rng(4)
     tg, to = BM25SearchIndex(ctx), orc.BM25()

@@ -89,7 +89,7 @@ def test_nearest_centroid(ctx):
 def build_ivf(ctx, metric, X, train, nlist):
     n, d = X.shape
     ids = np.arange(1, n + 1, dtype=np.uint32)
-    g = IVFIndex(ctx, d, metric, nlist)
+    g = IVFIndex(ctx, d, nlist, metric)
     o = orc.IVF(d, metric, nlist)
     g.train(train); assert o.train(train) == 0
     assert g.trained()
@@ -124,7 +124,7 @@ def test_ivf_matches_oracle(ctx, metric):
 
 
 def test_ivf_untrained_and_training_errors(ctx):
-    g = IVFIndex(ctx, 8, L2_SQUARED, 10)
+    g = IVFIndex(ctx, 8, 10, L2_SQUARED)
     with pytest.raises(RuntimeError, match="index must be trained before searching"):
         g.new_search().with_query(np.zeros(8, np.float32)).execute()
     with pytest.raises(CometError, match="need at least 10 training vectors"):
@@ -132,7 +132,7 @@ def test_ivf_untrained_and_training_errors(ctx):
     with pytest.raises(CometError, match="must be trained"):
         g.add(1, np.ones(8, np.float32))
     with pytest.raises(ValueError):
-        IVFIndex(ctx, 8, L2_SQUARED, 0)
+        IVFIndex(ctx, 8, 0, L2_SQUARED)
 
 
 # ---------------------------------------------------------------------------------------------- PQ
@@ -294,7 +294,7 @@ def test_sharded_lists_merge_equals_unsharded(ctx, kind):
     train = X[:2000]
 
     def make():
-        g = IVFIndex(ctx, d, L2_SQUARED, nlist) if kind == "ivf" else IVFPQIndex(ctx, d, L2_SQUARED, nlist, 8, 6)
+        g = IVFIndex(ctx, d, nlist, L2_SQUARED) if kind == "ivf" else IVFPQIndex(ctx, d, L2_SQUARED, nlist, 8, 6)
         g.train(train)
         return g
     full = make(); full.add_batch(ids, X)
