@@ -80,6 +80,7 @@ def load() -> C.CDLL:
         "comet_memcpy_h2d": (i32, [p, p, p, sz]),
         "comet_memcpy_d2h": (i32, [p, p, p, sz]),
         "comet_synth_fill_dev": (i32, [p, u64, u64, u64, p]),
+        "comet_synth_mixture_dev": (i32, [p, u64, i32, f32, u64, u64, i32, p]),
         "comet_profile_enable": (i32, [p, i32]),
         "comet_profile_reset": (i32, [p]),
         "comet_profile_get": (i32, [p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),

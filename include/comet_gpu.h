@@ -74,6 +74,11 @@ COMET_API int comet_memcpy_d2h(comet_ctx* ctx, void* dst_host, const void* src_d
 /* SplitMix64 synthetic data, value = 2*((next>>40)*2^-24)-1 in [-1,1); element i of the stream uses
  * counter (offset+i) — bit-identical to the oracle's orc_synth_fill. */
 COMET_API int comet_synth_fill_dev(comet_ctx* ctx, uint64_t seed, uint64_t offset, uint64_t n, float* out_dev);
+/* Clustered variant (for meaningful ANN recall): rows [row_base, row_base+n_rows) x dim of
+ * centre[blob(r)][j] + sigma * u(seed, r*dim+j), centre[c][j] = u(seed ^ 0x5EED, c*dim+j), blob(r) = ((r*2654435761)>>7) % n_centers;
+ * bit-identical to the oracle's orc_synth_mixture. n_centers <= 0: the plain stream. */
+COMET_API int comet_synth_mixture_dev(comet_ctx* ctx, uint64_t seed, int32_t n_centers, float sigma, uint64_t row_base, uint64_t n_rows,
+                                      int32_t dim, float* out_dev);
 
 /* per-kernel timing (HIP events recorded on the context's stream around each launch) */
 COMET_API int comet_profile_enable(comet_ctx* ctx, int on);

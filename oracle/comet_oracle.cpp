@@ -1030,6 +1030,23 @@ ORC_API void orc_synth_fill(uint64_t seed, uint64_t offset, uint64_t n, float* o
     }
 }
 
+// clustered variant: centre[blob(r)][j] + sigma * u(seed, r*dim+j); see comet_synth_mixture_dev
+static inline float synth_u(uint64_t seed, uint64_t counter) {
+    uint64_t s = seed + counter * 0x9E3779B97F4A7C15ull; uint64_t z = splitmix64(s);
+    return 2.0f * ((float)(z >> 40) * (1.0f / 16777216.0f)) - 1.0f;
+}
+ORC_API void orc_synth_mixture(uint64_t seed, int n_centers, float sigma, uint64_t row_base, uint64_t n_rows, int dim, float* out) {
+    if (n_centers <= 0) { orc_synth_fill(seed, row_base * (uint64_t)dim, n_rows * (uint64_t)dim, out); return; }
+    for (uint64_t i = 0; i < n_rows; i++) {
+        const uint64_t r = row_base + i, blob = ((r * 2654435761ull) >> 7) % (uint64_t)n_centers;
+        for (int j = 0; j < dim; j++) {
+            const float ctr = synth_u(seed ^ 0x5EEDull, blob * (uint64_t)dim + j);
+            const float noise = synth_u(seed, r * (uint64_t)dim + j) * sigma;
+            out[i * dim + j] = ctr + noise;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // On-disk formats: WriteTo / ReadFrom of the five vector indexes, restated from
 //   flat_index.go:366-470 / :488-614      ("FLAT")     ivf_index.go:468-588 / :620-785     ("IVFX")

@@ -1,7 +1,7 @@
 """Every BASELINE.json config at its OWN parameters (all of them together), at a corpus size the CPU oracle covers in
 seconds; every query of the batch compared bit for bit (ids, float32 score bits, counts, order).
 
-  configs[1]  Flat cosine d=768, batch=256, K=100                                   (n = 48k rows here, 1M in bench.py)
+  configs[1]  Flat cosine d=768, batch=256, K=100                                   (n = 56k rows here, 1M in bench.py)
   configs[2]  HNSW M=16 efConstruction=200 efSearch=128, d=384, L2, K=10            (n = 30k nodes, graph built by the oracle)
   configs[3]  IVFPQ nlist=4096 nprobe=32 M=96 nbits=8, d=768, K=10                  (n = 60k; GPU train + add, index handed
               to the oracle through the reference's own IVPQ on-disk format)
@@ -52,7 +52,7 @@ def test_config0_flat_l2sq_10k_x_128_k10(ctx):
 
 
 def test_config1_flat_cosine_768_batch256_k100(ctx):
-    n, d, B, K = 48_000, 768, 256, 100
+    n, d, B, K = 56_000, 768, 256, 100
     X = synth(0xC0FFEE + 2, n, d); Q = synth(0xBEEF + 2, B, d)
     ids = np.arange(1, n + 1, dtype=np.uint32)
     g = FlatIndex(ctx, d, COSINE); g.add_batch(ids, X)

@@ -223,6 +223,17 @@ def test_synth_fill_matches_oracle_stream(ctx):
     assert np.array_equal(got.view(np.uint32), orc.synth(0xC0FFEE, 12345, n).view(np.uint32))
 
 
+def test_synth_mixture_matches_oracle(ctx):
+    rows, dim = 777, 96
+    p = ctx.alloc(rows * dim * 4)
+    for centers in (64, 0):
+        ctx.synth_mixture(p, 0xC0FFEE + 5, centers, 0.15, 123456, rows, dim)
+        ctx.sync()
+        got = ctx.download(p, (rows, dim), np.float32)
+        assert np.array_equal(got.view(np.uint32), orc.synth_mixture(0xC0FFEE + 5, centers, 0.15, 123456, rows, dim).view(np.uint32))
+    ctx.free(p)
+
+
 def test_long_rows_sample_bound_and_its_generic_fallback(ctx):
     """Rows longer than 2 x 8192 candidates take the sample-bound selection (bound from the row's prefix, one filtering
     pass); orders that defeat the bound — distances DESCENDING along the row, or every distance equal — must fall
