@@ -80,7 +80,7 @@ def load() -> C.CDLL:
         "comet_memcpy_h2d": (i32, [p, p, p, sz]),
         "comet_memcpy_d2h": (i32, [p, p, p, sz]),
         "comet_synth_fill_dev": (i32, [p, u64, u64, u64, p]),
-        "comet_synth_mixture_dev": (i32, [p, u64, i32, f32, u64, u64, i32, p]),
+        "comet_synth_mixture_dev": (i32, [p, u64, i32, f32, i32, f32, u64, u64, i32, p]),
         "comet_profile_enable": (i32, [p, i32]),
         "comet_profile_reset": (i32, [p]),
         "comet_profile_get": (i32, [p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
@@ -128,6 +128,16 @@ def load() -> C.CDLL:
         "comet_bm25_avg_doc_len": (C.c_double, [p]),
         "comet_bm25_search": (i32, [p, p, p, i32, i32, p, i32, p, p, p, p, i32]),
         "comet_index_export": (i32, [p, p, p, p]),
+        "comet_comm_unique_id": (i32, [p]),
+        "comet_comm_create": (i32, [p, p, i32, i32, pp]),
+        "comet_comm_destroy": (i32, [p]),
+        "comet_comm_rank": (i32, [p]),
+        "comet_comm_world": (i32, [p]),
+        "comet_comm_allreduce_f64": (i32, [p, C.POINTER(C.c_double), i32]),
+        "comet_comm_barrier": (i32, [p]),
+        "comet_comm_sync": (i32, [p]),
+        "comet_index_search_sharded_async": (i32, [p, p, p, i32, C.POINTER(SearchParams), p, p, p, i32, C.POINTER(u64)]),
+        "comet_index_search_sharded_wait": (i32, [p, p, u64, i32]),
         "comet_index_write_to": (i32, [p, WRITE_CB, p, C.POINTER(i64)]),
         "comet_index_read_from": (i32, [p, READ_CB, p, C.POINTER(i64)]),
         "comet_index_serialize": (i32, [p, p, sz, C.POINTER(sz)]),

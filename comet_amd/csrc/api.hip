@@ -74,8 +74,9 @@ int comet_synth_fill_dev(comet_ctx* c, uint64_t seed, uint64_t offset, uint64_t 
     return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); launch_synth_fill(c, seed, offset, n, out_dev); return COMET_OK; });
 }
 
-int comet_synth_mixture_dev(comet_ctx* c, uint64_t seed, int32_t n_centers, float sigma, uint64_t row_base, uint64_t n_rows, int32_t dim, float* out_dev) {
-    return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); launch_synth_mixture(c, seed, n_centers, sigma, row_base, n_rows, dim, out_dev); return COMET_OK; });
+int comet_synth_mixture_dev(comet_ctx* c, uint64_t seed, int32_t n_centers, float sigma, int32_t n_sub, float sigma_noise, uint64_t row_base,
+                            uint64_t n_rows, int32_t dim, float* out_dev) {
+    return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); launch_synth_mixture(c, seed, n_centers, sigma, n_sub, sigma_noise, row_base, n_rows, dim, out_dev); return COMET_OK; });
 }
 
 int comet_profile_enable(comet_ctx* c, int on) { return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->sync(); c->profile = on != 0; return COMET_OK; }); }

@@ -1,0 +1,196 @@
+// comm.hip — the multi-GPU exchange step behind the C ABI: RCCL over xGMI, one process per GPU.
+//
+// Reference analogue: the per-segment fan-out + mergeResults of the persistent layer (storage.go:546-626,
+// storage_merge.go:13-46), which also searches independent parts and merges their top-K lists. Here the parts are
+// index shards on different GPUs: every rank searches its shard for the SAME query batch, the per-shard
+// (ids | scores | counts) blocks are exchanged with ONE ncclAllGather per batch, and every rank merges the R
+// sorted lists per query (merge_topk_kernel) — exact, because the top-K of a union is the top-K of the parts'
+// top-Ks, and identical to the unsharded canonical order as long as lower ranks hold earlier scan positions.
+//
+// The exchange runs on a second HIP stream of the communicator: search(i+1) on the context's stream overlaps
+// all-gather(i) + merge(i); nothing on this path blocks the host except the explicit waits the caller asks for.
+// librccl.so.1 is bound at run time (dlopen) the first time a communicator is made, so single-GPU users of the
+// library never load it.
+#include <dlfcn.h>
+
+#include "index.hpp"
+
+namespace comet {
+
+// the few RCCL entry points used (signatures from rccl.h; ncclComm_t / ncclResult_t as opaque pointer / int)
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+struct UniqueId { char internal[128]; };   // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed BY VALUE to ncclCommInitRank
+constexpr int NCCL_INT32 = 2, NCCL_FLOAT64 = 8, NCCL_MAX = 2, NCCL_SUM = 0;
+
+static Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+        for (const char* n : names) { r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+        if (!r.h) return;
+        r.GetUniqueId = (int (*)(void*))dlsym(r.h, "ncclGetUniqueId");
+        r.CommDestroy = (int (*)(void*))dlsym(r.h, "ncclCommDestroy");
+        r.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(r.h, "ncclAllGather");
+        r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(r.h, "ncclAllReduce");
+        r.GetErrorString = (const char* (*)(int))dlsym(r.h, "ncclGetErrorString");
+    });
+    if (!r.h || !r.GetUniqueId || !r.AllGather || !r.AllReduce) COMET_FAIL(COMET_ERR_UNSUPPORTED, "RCCL (librccl.so.1) is not available: %s", dlerror() ? dlerror() : "missing symbols");
+    return r;
+}
+#define RCCL_CHECK(expr) do { int _r = (expr); if (_r != 0) COMET_FAIL(COMET_ERR_HIP, "RCCL error %d (%s) in %s", _r, rccl().GetErrorString ? rccl().GetErrorString(_r) : "?", #expr); } while (0)
+
+// run launches of a scope on another stream of the same context (calls are serialised by the context mutex)
+struct StreamSwap {
+    Ctx* c; hipStream_t saved;
+    StreamSwap(Ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
+    ~StreamSwap() { c->stream = saved; }
+};
+
+}  // namespace comet
+
+using namespace comet;
+
+struct comet_comm {
+    Ctx* c = nullptr; int rank = 0, world = 1;
+    void* comm = nullptr;
+    hipStream_t xstream = nullptr;       // exchange + merge
+    DevBuf scalar;                       // small device scratch for barrier / all-reduce
+    struct Slot {
+        bool active = false; uint64_t ticket = 0, search_ticket = 0;
+        comet_index* idx = nullptr; int B = 0, k_cap = 0, k = 0;
+        DevBuf pack, gathered;           // this rank's block [B*k_cap ids | B*k_cap scores | B counts], and the R gathered blocks
+        uint32_t* out_ids = nullptr; float* out_scores = nullptr; int32_t* out_counts = nullptr;
+        hipEvent_t searched = nullptr, merged = nullptr;
+    };
+    static constexpr int kSlots = 4;
+    Slot slots[kSlots];
+    uint64_t next_ticket = 1;
+};
+
+extern "C" {
+
+int comet_comm_unique_id(uint8_t* out_id128) {
+    return guarded([&] {
+        UniqueId id; std::memset(&id, 0, sizeof(id));
+        RCCL_CHECK(rccl().GetUniqueId(&id));
+        std::memcpy(out_id128, &id, sizeof(id));
+        return (int)COMET_OK;
+    });
+}
+
+int comet_comm_create(comet_ctx* c, const uint8_t* id128, int32_t rank, int32_t world, comet_comm** out) {
+    return guarded([&] {
+        *out = nullptr;
+        if (world <= 0 || rank < 0 || rank >= world || !id128) COMET_FAIL(COMET_ERR_INVALID_ARG, "bad communicator shape: rank %d of %d", rank, world);
+        std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind();
+        Rccl& r = rccl();
+        // ncclCommInitRank takes the 128-byte id by value: on the SysV x86-64 ABI a struct that large travels in memory, i.e.
+        // exactly like the dereferenced pointer the typed declaration below passes
+        using InitFn = int (*)(void**, int, UniqueId, int);
+        InitFn init = (InitFn)dlsym(r.h, "ncclCommInitRank");
+        if (!init) COMET_FAIL(COMET_ERR_UNSUPPORTED, "ncclCommInitRank not found in librccl");
+        UniqueId id; std::memcpy(&id, id128, sizeof(id));
+        auto* cm = new comet_comm();
+        cm->c = c; cm->rank = rank; cm->world = world;
+        int rc = init(&cm->comm, world, id, rank);
+        if (rc != 0) { delete cm; COMET_FAIL(COMET_ERR_HIP, "ncclCommInitRank failed: %d (%s)", rc, r.GetErrorString ? r.GetErrorString(rc) : "?"); }
+        HIP_CHECK(hipStreamCreateWithFlags(&cm->xstream, hipStreamNonBlocking));
+        cm->scalar.reserve(256, c->stream, 0);
+        *out = cm;
+        return (int)COMET_OK;
+    });
+}
+
+int comet_comm_destroy(comet_comm* cm) {
+    return guarded([&] {
+        if (!cm) return (int)COMET_OK;
+        Ctx* c = cm->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind();
+        (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(cm->xstream);
+        for (auto& s : cm->slots) { if (s.searched) (void)hipEventDestroy(s.searched); if (s.merged) (void)hipEventDestroy(s.merged); }
+        if (cm->comm && rccl().CommDestroy) (void)rccl().CommDestroy(cm->comm);
+        (void)hipStreamDestroy(cm->xstream);
+        delete cm;
+        return (int)COMET_OK;
+    });
+}
+int comet_comm_rank(const comet_comm* cm) { return cm->rank; }
+int comet_comm_world(const comet_comm* cm) { return cm->world; }
+
+// all ranks: *inout = max over ranks (op 0) or sum over ranks (op 1) of a host double; blocks until complete (a barrier).
+int comet_comm_allreduce_f64(comet_comm* cm, double* inout, int32_t op) {
+    return guarded([&] {
+        Ctx* c = cm->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind();
+        HIP_CHECK(hipStreamSynchronize(c->stream));                       // everything enqueued so far on the search stream is part of "before the barrier"
+        double* d = cm->scalar.as<double>();
+        HIP_CHECK(hipMemcpyAsync(d, inout, 8, hipMemcpyHostToDevice, cm->xstream));
+        RCCL_CHECK(rccl().AllReduce(d, d + 1, 1, NCCL_FLOAT64, op == 0 ? NCCL_MAX : NCCL_SUM, cm->comm, cm->xstream));
+        HIP_CHECK(hipMemcpyAsync(inout, d + 1, 8, hipMemcpyDeviceToHost, cm->xstream));
+        HIP_CHECK(hipStreamSynchronize(cm->xstream));
+        return (int)COMET_OK;
+    });
+}
+int comet_comm_barrier(comet_comm* cm) { double x = 0; return comet_comm_allreduce_f64(cm, &x, 1); }
+
+// Sharded search, enqueue only: this rank's shard is searched for the batch (results land in the slot's packed block).
+int comet_index_search_sharded_async(comet_index* idx, comet_comm* cm, const float* queries_dev, int32_t B, const comet_search_params* p,
+                                     uint32_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev, int32_t k_cap, uint64_t* out_ticket) {
+    return guarded([&] {
+        if (!p || B <= 0 || k_cap <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "bad batch size / k_cap");
+        if (idx->c != cm->c) COMET_FAIL(COMET_ERR_INVALID_ARG, "index and communicator live on different contexts");
+        Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->scratch_reset();
+        comet_comm::Slot* s = nullptr;
+        for (auto& sl : cm->slots) if (!sl.active) { s = &sl; break; }
+        if (!s) COMET_FAIL(COMET_ERR_INVALID_ARG, "more than %d sharded searches in flight: wait for one first", comet_comm::kSlots);
+        if (!s->searched) { HIP_CHECK(hipEventCreateWithFlags(&s->searched, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&s->merged, hipEventDisableTiming)); }
+        const size_t words = (size_t)2 * B * k_cap + B;
+        // the merge of the previous user of this slot must be done before its buffers are overwritten
+        HIP_CHECK(hipEventSynchronize(s->merged));
+        s->pack.reserve(words * 4, c->stream, 0); s->gathered.reserve(words * 4 * cm->world, c->stream, 0);
+        uint32_t* pids = s->pack.as<uint32_t>(); float* psc = reinterpret_cast<float*>(pids + (size_t)B * k_cap); int32_t* pcn = reinterpret_cast<int32_t*>(pids + (size_t)2 * B * k_cap);
+        s->search_ticket = idx->search_begin(queries_dev, B, *p, pids, psc, pcn, k_cap);
+        s->idx = idx; s->B = B; s->k_cap = k_cap; s->k = p->k; s->out_ids = out_ids_dev; s->out_scores = out_scores_dev; s->out_counts = out_counts_dev;
+        s->ticket = cm->next_ticket++; s->active = true;
+        if (out_ticket) *out_ticket = s->ticket;
+        return (int)COMET_OK;
+    });
+}
+
+// Finish a sharded search: make the local results final (the one host-side decision the Flat fast path defers), then enqueue
+// all-gather + merge on the communicator's stream. block != 0: return when the merged results are in the output buffers;
+// block == 0: return at once (the outputs are final after a later blocking wait, comet_comm_barrier or comet_comm_sync).
+int comet_index_search_sharded_wait(comet_index* idx, comet_comm* cm, uint64_t ticket, int32_t block) {
+    return guarded([&] {
+        Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind();
+        comet_comm::Slot* s = nullptr;
+        for (auto& sl : cm->slots) if (sl.active && sl.ticket == ticket) { s = &sl; break; }
+        if (!s) { if (block) HIP_CHECK(hipStreamSynchronize(cm->xstream)); return (int)COMET_OK; }
+        idx->search_finish(s->search_ticket);                      // waits for THIS search only (its event), not for later ones
+        HIP_CHECK(hipEventRecord(s->searched, c->stream));          // everything up to here (incl. a rare strict re-run) produced the block
+        HIP_CHECK(hipStreamWaitEvent(cm->xstream, s->searched, 0));
+        const size_t words = (size_t)2 * s->B * s->k_cap + s->B;
+        {
+            StreamSwap sw(c, cm->xstream);
+            { ProfScope ps(c, "shard_allgather"); RCCL_CHECK(rccl().AllGather(s->pack.p, s->gathered.p, words, NCCL_INT32, cm->comm, cm->xstream)); }
+            const uint32_t* g = s->gathered.as<uint32_t>();
+            launch_merge_topk(c, g, reinterpret_cast<const float*>(g + (size_t)s->B * s->k_cap), reinterpret_cast<const int32_t*>(g + (size_t)2 * s->B * s->k_cap),
+                              cm->world, s->B, s->k_cap, s->k, s->out_ids, s->out_scores, s->out_counts, (int64_t)words, (int64_t)words);
+        }
+        HIP_CHECK(hipEventRecord(s->merged, cm->xstream));
+        s->active = false;
+        if (block) HIP_CHECK(hipEventSynchronize(s->merged));
+        return (int)COMET_OK;
+    });
+}
+int comet_comm_sync(comet_comm* cm) {
+    return guarded([&] { Ctx* c = cm->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); HIP_CHECK(hipStreamSynchronize(c->stream)); HIP_CHECK(hipStreamSynchronize(cm->xstream)); c->collect_profile(); return (int)COMET_OK; });
+}
+
+}  // extern "C"

@@ -29,7 +29,7 @@ void launch_dist_pairs(Ctx* c, int metric, const float* A, const float* Bv, int 
 // SplitMix64 synthetic fill
 void launch_synth_fill(Ctx* c, uint64_t seed, uint64_t offset, uint64_t n, float* out);
 // clustered synthetic rows [row_base, row_base + n_rows) x dim (n_centers <= 0: the plain stream)
-void launch_synth_mixture(Ctx* c, uint64_t seed, int n_centers, float sigma, uint64_t row_base, uint64_t n_rows, int dim, float* out);
+void launch_synth_mixture(Ctx* c, uint64_t seed, int n_centers, float sigma, int n_sub, float sigma_noise, uint64_t row_base, uint64_t n_rows, int dim, float* out);
 // elig[row] = id not in deleted_sorted && (n_filter == 0 || id in filter_sorted)
 void launch_build_elig(Ctx* c, const uint32_t* ids, int64_t n, const uint32_t* deleted_sorted, int n_deleted,
                        const uint32_t* filter_sorted, int n_filter, uint8_t* elig);

@@ -456,9 +456,12 @@ void launch_synth_fill(Ctx* c, uint64_t seed, uint64_t offset, uint64_t n, float
     LAUNCH_CHECK();
 }
 
-// Clustered synthetic rows (SURVEY.md §8d "mixture-of-Gaussians variant" for meaningful ANN recall):
-//   row r, column j = centre[blob(r)][j] + sigma * u(seed, r*dim + j),   centre[c][j] = u(seed ^ 0x5EED, c*dim + j),
-//   blob(r) = ((r * 2654435761) >> 7) % n_centers   (64-bit), u = the SplitMix64 stream of synth_fill; product rounded, then added.
+// Clustered synthetic rows (SURVEY.md §8d "mixture-of-Gaussians variant" for meaningful ANN recall), two levels:
+//   row r, column j = C1[b1(r)][j] + sigma * C2[b2(r)][j] + sigma_noise * u(seed, r*dim + j)          (n_sub > 0)
+//                   = C1[b1(r)][j] + sigma * u(seed, r*dim + j)                                          (n_sub <= 0)
+//   C1[c][j] = u(seed ^ 0x5EED, c*dim + j), C2[c][j] = u(seed ^ 0x5EED2, c*dim + j), u = the SplitMix64 stream of synth_fill,
+//   b1(r) = ((r * 2654435761) >> 7) % n_centers, b2(r) = ((r * 0x9E3779B1) >> 5) % n_sub (64-bit arithmetic);
+//   every product is rounded before its add (no FMA), left to right.
 __device__ __forceinline__ float synth_u(unsigned long long seed, unsigned long long counter) {
     unsigned long long z = seed + (counter + 1ull) * 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -466,23 +469,33 @@ __device__ __forceinline__ float synth_u(unsigned long long seed, unsigned long 
     z = z ^ (z >> 31);
     return 2.0f * ((float)(z >> 40) * (1.0f / 16777216.0f)) - 1.0f;
 }
-__global__ __launch_bounds__(256) void synth_mixture_kernel(unsigned long long seed, int n_centers, float sigma, unsigned long long row_base,
-                                                            unsigned long long n_rows, int dim, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void synth_mixture_kernel(unsigned long long seed, int n_centers, float sigma, int n_sub, float sigma_noise,
+                                                            unsigned long long row_base, unsigned long long n_rows, int dim, float* __restrict__ out) {
     unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, total = n_rows * (unsigned long long)dim;
     for (; i < total; i += stride) {
         const unsigned long long r = row_base + i / (unsigned long long)dim; const unsigned j = (unsigned)(i % (unsigned long long)dim);
-        const unsigned long long blob = ((r * 2654435761ull) >> 7) % (unsigned long long)n_centers;
-        const float ctr = synth_u(seed ^ 0x5EEDull, blob * (unsigned long long)dim + j);
-        const float noise = synth_u(seed, r * (unsigned long long)dim + j) * sigma;
-        out[i] = ctr + noise;
+        const unsigned long long b1 = ((r * 2654435761ull) >> 7) % (unsigned long long)n_centers;
+        float v = synth_u(seed ^ 0x5EEDull, b1 * (unsigned long long)dim + j);
+        const float nz = synth_u(seed, r * (unsigned long long)dim + j);
+        if (n_sub > 0) {
+            const unsigned long long b2 = ((r * 0x9E3779B1ull) >> 5) % (unsigned long long)n_sub;
+            const float s2 = synth_u(seed ^ 0x5EED2ull, b2 * (unsigned long long)dim + j) * sigma;
+            v = v + s2;
+            const float t = nz * sigma_noise;
+            v = v + t;
+        } else {
+            const float t = nz * sigma;
+            v = v + t;
+        }
+        out[i] = v;
     }
 }
-void launch_synth_mixture(Ctx* c, uint64_t seed, int n_centers, float sigma, uint64_t row_base, uint64_t n_rows, int dim, float* out) {
+void launch_synth_mixture(Ctx* c, uint64_t seed, int n_centers, float sigma, int n_sub, float sigma_noise, uint64_t row_base, uint64_t n_rows, int dim, float* out) {
     if (!n_rows || dim <= 0) return;
     if (n_centers <= 0) { launch_synth_fill(c, seed, row_base * (uint64_t)dim, n_rows * (uint64_t)dim, out); return; }
     unsigned grid = (unsigned)std::min<uint64_t>(ceil_div((int64_t)(n_rows * (uint64_t)dim), 256), 256 * 32);
-    synth_mixture_kernel<<<dim3(grid), dim3(256), 0, c->stream>>>(seed, n_centers, sigma, row_base, n_rows, dim, out);
+    synth_mixture_kernel<<<dim3(grid), dim3(256), 0, c->stream>>>(seed, n_centers, sigma, n_sub, sigma_noise, row_base, n_rows, dim, out);
     LAUNCH_CHECK();
 }
 

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_n64_kernel(const _Fl
 void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, int nq_used, const float* rn, const float* qn,
                           const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB) {
     const long n_tiles = ceil_div(n, FB_M);
-    ProfScope ps(c, "flat_scan_f16");
+    ProfScope ps(c, nq_used <= FN_N ? "flat_scan_f16_n64" : "flat_scan_f16");
     if (nq_used <= FN_N) {      // S0 / bound are laid out for 64-row units in this case (flat_fast_unit_rows(nq))
         const size_t ldsn = 2 * FN_STAGE;
         const long gridn = round_up(n_tiles, 8);

@@ -1,6 +1,10 @@
-"""Multi-GPU exchange for row-sharded indexes: one process per GPU (torch.distributed; backend "nccl" is RCCL
-over xGMI on ROCm), every rank searches its own shard for the same query batch, the per-shard top-K rows are
-exchanged with ONE all-gather per array per batch, and every rank merges them.
+"""Multi-GPU exchange for sharded indexes: one process per GPU, every rank searches its own shard for the same query
+batch, the per-shard top-K blocks are exchanged with ONE RCCL all-gather per batch and every rank merges them.
+
+On GPUs the whole data path lives behind the C ABI (comet_comm_* / comet_index_search_sharded_*: RCCL over xGMI on the
+library's own exchange stream, merge_topk_kernel) — `Comm` / `ShardedSearch` below only carry the 128-byte RCCL id from
+rank 0 to the other processes over a plain TCP socket (the control plane a Go host would do with whatever it has) and
+forward calls. torch is not involved.
 
 The merge is exact (top-K of a union = top-K of the per-part top-Ks) and keeps the canonical tie order of the
 unsharded index as long as shards hold contiguous, ascending row blocks: ties go to the lower shard, then to the
@@ -46,11 +50,106 @@ def merge_topk_host(ids: np.ndarray, scores: np.ndarray, counts: np.ndarray, k: 
     return out_ids, out_sc, out_cnt
 
 
+def _rendezvous_id(lib, rank: int, world: int, addr: str, port: int, timeout_s: float = 120.0) -> bytes:
+    """Rank 0 makes the RCCL unique id and hands it to the other ranks over TCP (control plane only)."""
+    import socket
+    import time
+    if rank == 0:
+        buf = (C.c_uint8 * 128)()
+        from ._lib import check
+        check(lib.comet_comm_unique_id(buf))
+        ident = bytes(buf)
+        if world > 1:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port)); srv.listen(world)
+            srv.settimeout(timeout_s)
+            for _ in range(world - 1):
+                conn, _a = srv.accept()
+                conn.sendall(ident); conn.close()
+            srv.close()
+        return ident
+    deadline = time.time() + timeout_s
+    while True:
+        try:
+            s = socket.create_connection((addr, port), timeout=5.0)
+            break
+        except OSError:
+            if time.time() > deadline:
+                raise
+            time.sleep(0.05)
+    data = b""
+    while len(data) < 128:
+        chunk = s.recv(128 - len(data))
+        if not chunk:
+            raise ConnectionError("rendezvous socket closed early")
+        data += chunk
+    s.close()
+    return data
+
+
+class Comm:
+    """comet_comm: an RCCL communicator owned by the library, bound to a comet_amd.Context (one per process / GPU)."""
+
+    def __init__(self, ctx, rank: int, world: int, addr: str = "127.0.0.1", port: int = 29641):
+        from ._lib import check
+        self.ctx, self.lib, self.rank, self.world = ctx, ctx.lib, rank, world
+        ident = _rendezvous_id(self.lib, rank, world, addr, port)
+        buf = (C.c_uint8 * 128).from_buffer_copy(ident)
+        self.h = C.c_void_p()
+        check(self.lib.comet_comm_create(ctx.h, buf, rank, world, C.byref(self.h)))
+
+    @classmethod
+    def from_env(cls, ctx):
+        """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run exports them (the id socket uses MASTER_PORT + 101:
+        the launcher's own store owns MASTER_PORT)."""
+        import os
+        port = int(os.environ.get("COMET_RDZV_PORT", int(os.environ.get("MASTER_PORT", "29540")) + 101))
+        return cls(ctx, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), os.environ.get("MASTER_ADDR", "127.0.0.1"), port)
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.comet_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def barrier(self):
+        from ._lib import check
+        check(self.lib.comet_comm_barrier(self.h))
+
+    def sync(self):
+        from ._lib import check
+        check(self.lib.comet_comm_sync(self.h))
+
+    def allreduce_max(self, x: float) -> float:
+        from ._lib import check
+        v = C.c_double(x)
+        check(self.lib.comet_comm_allreduce_f64(self.h, C.byref(v), 0))
+        return v.value
+
+    def search_async(self, index, q_dev: int, B: int, k: int, out_ids_dev: int, out_scores_dev: int, out_counts_dev: int, k_cap: int,
+                     threshold: float = 0.0, nprobes: int = 0, mode: int = 0) -> int:
+        from ._lib import SearchParams, check
+        p = SearchParams(k=int(k), threshold=float(threshold), nprobes=int(nprobes), ef_search=0, filter_ids=None, n_filter=0, mode=int(mode))
+        t = C.c_uint64()
+        check(self.lib.comet_index_search_sharded_async(index.h, self.h, C.c_void_p(q_dev), int(B), C.byref(p), C.c_void_p(out_ids_dev),
+                                                        C.c_void_p(out_scores_dev), C.c_void_p(out_counts_dev), int(k_cap), C.byref(t)))
+        return t.value
+
+    def search_wait(self, index, ticket: int, block: bool = True) -> None:
+        from ._lib import check
+        check(self.lib.comet_index_search_sharded_wait(index.h, self.h, C.c_uint64(int(ticket)), 1 if block else 0))
+
+
 class TopKExchange:
-    """Pre-allocated buffers + ONE all-gather per batch. A rank's result block is one packed int32 buffer
-    [B*k_cap ids | B*k_cap scores | B counts]; the search writes its three outputs straight into it (local_ptrs), the
-    all-gather stacks the W blocks, and comet_merge_topk_packed_dev merges them. `ctx` is a comet_amd.Context for CUDA
-    tensors, None for the CPU/gloo path."""
+    """CPU (gloo) model of the exchange, used by the world-2 CPU test of the sharding bookkeeping: the same packed block
+    [B*k_cap ids | B*k_cap scores | B counts] per rank, ONE all-gather, the same (score, shard, position) merge order — in
+    numpy. The GPU data path does not come through here (Comm above)."""
 
     def __init__(self, B: int, k_cap: int, device, ctx=None, group=None):
         import torch
@@ -79,11 +178,7 @@ class TopKExchange:
         W, B, K = self.world, self.B, self.k_cap
         d.all_gather_into_tensor(self.g_pack.view(W * self.block), self.pack, group=self.group)
         if self.pack.is_cuda:
-            from ._lib import check
-            self.torch.cuda.current_stream().synchronize()      # the merge runs on the library's own stream
-            check(self.ctx.lib.comet_merge_topk_packed_dev(self.ctx.h, C.c_void_p(self.g_pack.data_ptr()), self.block, W, B, K, int(k),
-                                                           C.c_void_p(self.m_ids.data_ptr()), C.c_void_p(self.m_scores.data_ptr()),
-                                                           C.c_void_p(self.m_counts.data_ptr())))
+            raise RuntimeError("TopKExchange is the CPU model of the exchange; on GPUs use comet_amd.dist.Comm (RCCL inside libcomet_hip.so)")
         else:
             g = self.g_pack.numpy()
             n = B * K

@@ -92,9 +92,9 @@ class Context:
     def synth_fill(self, ptr: int, seed: int, offset: int, n: int):
         check(self.lib.comet_synth_fill_dev(self.h, C.c_uint64(seed), C.c_uint64(offset), C.c_uint64(n), C.c_void_p(ptr)))
 
-    def synth_mixture(self, ptr: int, seed: int, n_centers: int, sigma: float, row_base: int, n_rows: int, dim: int):
-        check(self.lib.comet_synth_mixture_dev(self.h, C.c_uint64(seed), int(n_centers), C.c_float(sigma), C.c_uint64(row_base),
-                                               C.c_uint64(n_rows), int(dim), C.c_void_p(ptr)))
+    def synth_mixture(self, ptr: int, seed: int, n_centers: int, sigma: float, n_sub: int, sigma_noise: float, row_base: int, n_rows: int, dim: int):
+        check(self.lib.comet_synth_mixture_dev(self.h, C.c_uint64(seed), int(n_centers), C.c_float(sigma), int(n_sub), C.c_float(sigma_noise),
+                                               C.c_uint64(row_base), C.c_uint64(n_rows), int(dim), C.c_void_p(ptr)))
 
     # profiling
     def profile(self, on: bool = True):

@@ -74,11 +74,12 @@ COMET_API int comet_memcpy_d2h(comet_ctx* ctx, void* dst_host, const void* src_d
 /* SplitMix64 synthetic data, value = 2*((next>>40)*2^-24)-1 in [-1,1); element i of the stream uses
  * counter (offset+i) — bit-identical to the oracle's orc_synth_fill. */
 COMET_API int comet_synth_fill_dev(comet_ctx* ctx, uint64_t seed, uint64_t offset, uint64_t n, float* out_dev);
-/* Clustered variant (for meaningful ANN recall): rows [row_base, row_base+n_rows) x dim of
- * centre[blob(r)][j] + sigma * u(seed, r*dim+j), centre[c][j] = u(seed ^ 0x5EED, c*dim+j), blob(r) = ((r*2654435761)>>7) % n_centers;
- * bit-identical to the oracle's orc_synth_mixture. n_centers <= 0: the plain stream. */
-COMET_API int comet_synth_mixture_dev(comet_ctx* ctx, uint64_t seed, int32_t n_centers, float sigma, uint64_t row_base, uint64_t n_rows,
-                                      int32_t dim, float* out_dev);
+/* Clustered variant (for meaningful ANN recall), two levels: rows [row_base, row_base+n_rows) x dim of
+ *   C1[b1(r)][j] + sigma * C2[b2(r)][j] + sigma_noise * u(seed, r*dim+j)    (n_sub > 0; n_sub <= 0: C1[b1(r)][j] + sigma * u(...))
+ * C1[c][j] = u(seed ^ 0x5EED, c*dim+j), C2[c][j] = u(seed ^ 0x5EED2, c*dim+j), b1(r) = ((r*2654435761)>>7) % n_centers,
+ * b2(r) = ((r*0x9E3779B1)>>5) % n_sub; bit-identical to the oracle's orc_synth_mixture. n_centers <= 0: the plain stream. */
+COMET_API int comet_synth_mixture_dev(comet_ctx* ctx, uint64_t seed, int32_t n_centers, float sigma, int32_t n_sub, float sigma_noise,
+                                      uint64_t row_base, uint64_t n_rows, int32_t dim, float* out_dev);
 
 /* per-kernel timing (HIP events recorded on the context's stream around each launch) */
 COMET_API int comet_profile_enable(comet_ctx* ctx, int on);
@@ -206,6 +207,33 @@ COMET_API int comet_merge_topk_dev(comet_ctx* ctx, const uint32_t* ids_dev, cons
 COMET_API int comet_merge_topk_packed_dev(comet_ctx* ctx, const uint32_t* packed_dev, int64_t block_words, int32_t R, int32_t B,
                                           int32_t k_cap, int32_t k, uint32_t* out_ids_dev, float* out_scores_dev,
                                           int32_t* out_counts_dev);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI inside the library --------------------------------
+ * Every rank holds one shard of an index (Flat: a contiguous row block; IVF / PQ / IVFPQ: see comet_index_set_shard)
+ * and searches it for the SAME query batch; the per-shard top-K blocks are exchanged with ONE ncclAllGather per batch on
+ * the communicator's own HIP stream and merged on every rank (ties: lower rank, then lower position — the unsharded
+ * canonical order when lower ranks hold earlier rows / lists). The reference's analogue is the per-segment fan-out +
+ * mergeResults of storage.go:546-626 / storage_merge.go:13-46. The host only has to carry the 128-byte RCCL id from rank 0
+ * to the other processes (any side channel: a socket, a file, MPI). */
+typedef struct comet_comm comet_comm;
+#define COMET_COMM_ID_BYTES 128
+COMET_API int comet_comm_unique_id(uint8_t* out_id128);                                   /* rank 0: ncclGetUniqueId */
+COMET_API int comet_comm_create(comet_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t world, comet_comm** out); /* collective */
+COMET_API int comet_comm_destroy(comet_comm* comm);
+COMET_API int comet_comm_rank(const comet_comm* comm);
+COMET_API int comet_comm_world(const comet_comm* comm);
+/* host-value all-reduce (op 0 = max, 1 = sum); returns when every rank's contribution is in: a barrier */
+COMET_API int comet_comm_allreduce_f64(comet_comm* comm, double* inout, int32_t op);
+COMET_API int comet_comm_barrier(comet_comm* comm);
+COMET_API int comet_comm_sync(comet_comm* comm);          /* wait for the context's stream and the exchange stream */
+/* Sharded search. `_async` enqueues this rank's shard search and returns a ticket (up to 4 in flight); `_wait` makes the
+ * local results final, enqueues all-gather + merge on the exchange stream and — if block != 0 — returns when the MERGED
+ * rows (same layout and meaning as comet_index_search_dev's outputs) are in the output buffers; with block == 0 they are
+ * final after the next blocking wait / comet_comm_sync. Every rank must issue the same sequence of calls. */
+COMET_API int comet_index_search_sharded_async(comet_index* idx, comet_comm* comm, const float* queries_dev, int32_t B,
+                                               const comet_search_params* p, uint32_t* out_ids_dev, float* out_scores_dev,
+                                               int32_t* out_counts_dev, int32_t k_cap, uint64_t* out_ticket);
+COMET_API int comet_index_search_sharded_wait(comet_index* idx, comet_comm* comm, uint64_t ticket, int32_t block);
 
 /* ---- introspection --------------------------------------------------------------------------- */
 /* Read back trained state (host copies). centroids: nlist x dim, codebooks: M x Ksub x dsub. */

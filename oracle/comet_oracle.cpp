@@ -1035,14 +1035,17 @@ static inline float synth_u(uint64_t seed, uint64_t counter) {
     uint64_t s = seed + counter * 0x9E3779B97F4A7C15ull; uint64_t z = splitmix64(s);
     return 2.0f * ((float)(z >> 40) * (1.0f / 16777216.0f)) - 1.0f;
 }
-ORC_API void orc_synth_mixture(uint64_t seed, int n_centers, float sigma, uint64_t row_base, uint64_t n_rows, int dim, float* out) {
+ORC_API void orc_synth_mixture(uint64_t seed, int n_centers, float sigma, int n_sub, float sigma_noise, uint64_t row_base, uint64_t n_rows, int dim, float* out) {
     if (n_centers <= 0) { orc_synth_fill(seed, row_base * (uint64_t)dim, n_rows * (uint64_t)dim, out); return; }
     for (uint64_t i = 0; i < n_rows; i++) {
-        const uint64_t r = row_base + i, blob = ((r * 2654435761ull) >> 7) % (uint64_t)n_centers;
+        const uint64_t r = row_base + i, b1 = ((r * 2654435761ull) >> 7) % (uint64_t)n_centers;
+        const uint64_t b2 = n_sub > 0 ? ((r * 0x9E3779B1ull) >> 5) % (uint64_t)n_sub : 0;
         for (int j = 0; j < dim; j++) {
-            const float ctr = synth_u(seed ^ 0x5EEDull, blob * (uint64_t)dim + j);
-            const float noise = synth_u(seed, r * (uint64_t)dim + j) * sigma;
-            out[i * dim + j] = ctr + noise;
+            float v = synth_u(seed ^ 0x5EEDull, b1 * (uint64_t)dim + j);
+            const float nz = synth_u(seed, r * (uint64_t)dim + j);
+            if (n_sub > 0) { const float s2 = synth_u(seed ^ 0x5EED2ull, b2 * (uint64_t)dim + j) * sigma; v = v + s2; const float t = nz * sigma_noise; v = v + t; }
+            else { const float t = nz * sigma; v = v + t; }
+            out[i * dim + j] = v;
         }
     }
 }

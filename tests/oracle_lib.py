@@ -61,7 +61,7 @@ def lib() -> C.CDLL:
             "orc_bm25_search": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, vp, i32]),
             "orc_aggregate": (i32, [i32, vp, vp, i32, vp, vp]),
             "orc_rrf": (i32, [dbl, vp, vp, i32, vp, vp, i32, vp, vp]),
-            "orc_synth_fill": (None, [u64, u64, u64, vp]), "orc_synth_mixture": (None, [u64, i32, f32, u64, u64, i32, vp]),
+            "orc_synth_fill": (None, [u64, u64, u64, vp]), "orc_synth_mixture": (None, [u64, i32, f32, i32, f32, u64, u64, i32, vp]),
             "orc_ivf_flush": (None, [vp]), "orc_pq_flush": (None, [vp]), "orc_ivfpq_flush": (None, [vp]), "orc_hnsw_flush": (None, [vp]),
             "orc_flat_write": (i64, [vp, vp, i64]), "orc_flat_read": (i64, [vp, vp, i64]),
             "orc_ivf_write": (i64, [vp, vp, i64]), "orc_ivf_read": (i64, [vp, vp, i64]),
@@ -161,9 +161,10 @@ def synth(seed, offset, n):
     return out
 
 
-def synth_mixture(seed, n_centers, sigma, row_base, n_rows, dim):
+def synth_mixture(seed, n_centers, sigma, n_sub, sigma_noise, row_base, n_rows, dim):
     out = np.empty((n_rows, dim), np.float32)
-    lib().orc_synth_mixture(C.c_uint64(seed), int(n_centers), C.c_float(sigma), C.c_uint64(row_base), C.c_uint64(n_rows), int(dim), _p(out))
+    lib().orc_synth_mixture(C.c_uint64(seed), int(n_centers), C.c_float(sigma), int(n_sub), C.c_float(sigma_noise), C.c_uint64(row_base),
+                            C.c_uint64(n_rows), int(dim), _p(out))
     return out
 
 

@@ -226,11 +226,11 @@ def test_synth_fill_matches_oracle_stream(ctx):
 def test_synth_mixture_matches_oracle(ctx):
     rows, dim = 777, 96
     p = ctx.alloc(rows * dim * 4)
-    for centers in (64, 0):
-        ctx.synth_mixture(p, 0xC0FFEE + 5, centers, 0.15, 123456, rows, dim)
+    for centers, sub in ((64, 0), (64, 4096), (0, 0)):
+        ctx.synth_mixture(p, 0xC0FFEE + 5, centers, 0.15, sub, 0.02, 123456, rows, dim)
         ctx.sync()
         got = ctx.download(p, (rows, dim), np.float32)
-        assert np.array_equal(got.view(np.uint32), orc.synth_mixture(0xC0FFEE + 5, centers, 0.15, 123456, rows, dim).view(np.uint32))
+        assert np.array_equal(got.view(np.uint32), orc.synth_mixture(0xC0FFEE + 5, centers, 0.15, sub, 0.02, 123456, rows, dim).view(np.uint32))
     ctx.free(p)
 
 

@@ -1,0 +1,14 @@
+#!/bin/bash
+# usage (on the GPU box): tools/pmc_bench.sh <outname>
+# Separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, LDS conflict counters) over a short bench.py run; the per-kernel
+# averages land in gpurun_out/<outname>.json in the format bench.py's roofline.traffic reads (profiles/r*_pmc*.json).
+# PMC passes carry no trace options besides the implicit kernel dispatch records (gpurun refuses --pmc with sys/hip traces).
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$1; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+RUN="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --regions 1 --steps 3 --warmup 1"
+i=0
+for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- $RUN > $OUT/p$i.log 2>&1
+done
+cd $GRAFT_REPO_ROOT
+python tools/pmc_collect.py $OUT gpurun_out/$1.json

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc counter_collection CSVs (one directory per pass) into per-kernel, per-launch averages.
+usage: pmc_collect.py <dir-with-p*/...csv> <out.json>
+HBM read bytes use the gfx950 correction of MI355X_MICROARCH.md §HBM: FETCH_SIZE (KB) reports half the bytes of a wide
+coalesced streaming read -> read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is uncalibrated (reported as is)."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+src, out = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))     # kernel -> counter -> per-dispatch values
+for f in sorted(glob.glob(f"{src}/p*/**/*counter_collection.csv", recursive=True)):
+    per_dispatch = collections.defaultdict(float)
+    names = {}
+    for r in csv.DictReader(open(f)):
+        key = (r.get("Dispatch_Id") or r.get("Correlation_Id"), r["Counter_Name"])
+        per_dispatch[key] += float(r["Counter_Value"])
+        names[key[0]] = r["Kernel_Name"]
+    for (did, cname), v in per_dispatch.items():
+        acc[names[did]][cname].append(v)
+
+
+def short(name):
+    m = re.search(r"comet::(\w+)", name) or re.search(r"_ZN5comet\d+(\w+?_kernel)", name)
+    return m.group(1) if m else name.split("(")[0]
+
+
+kern = {}
+for name, ctrs in acc.items():
+    if "comet" not in name:
+        continue
+    e = {"launches": max(len(v) for v in ctrs.values())}
+    for cname, vals in ctrs.items():
+        e[f"{cname}_per_launch"] = sum(vals) / len(vals)
+    if "FETCH_SIZE" in ctrs:
+        e["hbm_read_bytes_per_launch_corrected"] = 2.0 * e["FETCH_SIZE_per_launch"] * 1024.0
+    if "WRITE_SIZE" in ctrs:
+        e["hbm_write_bytes_per_launch_uncalibrated"] = e["WRITE_SIZE_per_launch"] * 1024.0
+    if "SQ_LDS_BANK_CONFLICT" in ctrs and e.get("SQ_LDS_IDX_ACTIVE_per_launch"):
+        e["lds_conflict_fraction"] = e["SQ_LDS_BANK_CONFLICT_per_launch"] / e["SQ_LDS_IDX_ACTIVE_per_launch"]
+    key = name if name not in kern else name + "#2"
+    kern[key] = e
+    e["short"] = short(name)
+json.dump({"what": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | LDS | TCC, one pass each) over `bench.py --no-cpu-baseline --regions 1 --steps 3 --warmup 1`",
+           "correction": "gfx950: read bytes = 2 * FETCH_SIZE(KB) * 1024 (MI355X_MICROARCH.md §HBM); WRITE_SIZE uncalibrated",
+           "rows": 1000000, "kernels": kern}, open(out, "w"), indent=1)
+print(f"wrote {out}: {len(kern)} kernels")
