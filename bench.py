@@ -328,32 +328,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     legs = set(args.legs.split(","))
-    dist = torch = None
     use_dist = world > 1 or os.environ.get("COMET_BENCH_FORCE_DIST") == "1"   # the env knob exercises the RCCL path at world size 1
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if world == 1:      # forced single-rank run outside a launcher: supply the rendezvous ourselves
-            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import comet_amd as ca
     ctx = ca.Context(local_rank)
+    comm = None
+    if use_dist:
+        # RCCL lives inside libcomet_hip.so (comet_comm_*): the host only carries the 128-byte id from rank 0 to the others
+        from comet_amd.dist import Comm
+        comm = Comm.from_env(ctx)
 
     def barrier():
         ctx.sync()
-        if use_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
 
     def reduce_max(x):
-        if not use_dist:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=torch.device("cuda", local_rank))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        return comm.allreduce_max(x) if comm is not None else x
     timer = Timer(barrier, reduce_max)
 
     # ---------------------------------------------------------------- headline: Flat (configs[1])
@@ -367,31 +357,22 @@ def main():
     B, K = args.batch, args.k
     q_dev = ctx.alloc(B * args.dim * 4)
     ctx.synth_fill(q_dev, QUERY_SEED, 0, B * args.dim)
-    # two result-buffer sets: batch i+1 is enqueued before batch i is finalised / exchanged (software pipeline)
-    if use_dist:
-        from comet_amd.dist import TopKExchange
-        dev = torch.device("cuda", local_rank)
-        sets = [TopKExchange(B, K, dev, ctx=ctx) for _ in range(2)]
-        ptrs = [e.local_ptrs() for e in sets]
-    else:
-        sets = [None, None]
-        ptrs = [(ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)) for _ in range(2)]
-
-    def finish(ticket, which):
-        idx.search_wait(ticket)                 # results of that batch final (device side complete)
-        if use_dist:
-            sets[which].exchange_and_merge(K)   # one RCCL all-gather of the packed per-rank blocks + merge kernel on every rank
+    # result-buffer sets: batch i+1 is enqueued before batch i is finalised / exchanged (software pipeline)
+    ptrs = [(ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)) for _ in range(3)]
 
     def run(nsteps):
         prev = None
         for i in range(nsteps):
-            w = i & 1
-            t = idx.search_batch_dev_async(q_dev, B, K, ptrs[w][0], ptrs[w][1], ptrs[w][2], K, mode=args.mode)
+            w = i % 3
+            if comm is not None:    # shard search now; all-gather + merge of the previous batch follow it on the exchange stream
+                t = comm.search_async(idx, q_dev, B, K, ptrs[w][0], ptrs[w][1], ptrs[w][2], K, mode=args.mode)
+            else:
+                t = idx.search_batch_dev_async(q_dev, B, K, ptrs[w][0], ptrs[w][1], ptrs[w][2], K, mode=args.mode)
             if prev is not None:
-                finish(*prev)
-            prev = (t, w)
+                comm.search_wait(idx, prev, block=False) if comm is not None else idx.search_wait(prev)
+            prev = t
         if prev is not None:
-            finish(*prev)
+            comm.search_wait(idx, prev, block=True) if comm is not None else idx.search_wait(prev)
 
     run(1)
     ctx.profile(True)
@@ -419,7 +400,7 @@ def main():
             "recall_at_10": {"flat": 1.0},
         }
         if world == 1 and not args.no_cpu_baseline:
-            last = ptrs[(args.steps - 1) & 1]
+            last = ptrs[(args.steps - 1) % 3]
             ids = ctx.download(last[0], (B, K), np.uint32)
             sc = ctx.download(last[1], (B, K), np.float32)
             cn = ctx.download(last[2], (B,), np.int32)
@@ -444,9 +425,9 @@ def main():
             if "recall_at_10_vs_oracle_ivfpq" in line["ivfpq"]:
                 line["recall_at_10"]["ivfpq_vs_oracle_ivfpq"] = line["ivfpq"]["recall_at_10_vs_oracle_ivfpq"]
 
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
     if rank == 0:
         # RCCL writes its version banner through C stdio: flush that first so that the JSON line is the LAST line of stdout
         try:

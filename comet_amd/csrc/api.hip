@@ -309,6 +309,43 @@ int comet_index_search_wait(comet_index* idx, uint64_t ticket) {
     });
 }
 
+// lookupNodeVectors (flat_index_search.go:171-196 and siblings): stored vectors of the given node ids, in order
+int comet_index_fetch_vectors(comet_index* idx, const uint32_t* ids, int32_t n, float* out_vecs) {
+    return guarded([&] {
+        if (n <= 0) return (int)COMET_OK;
+        Ctx* c = idx->c; CallGuard g(c);
+        if (!idx->rows_dev() && idx->size() > 0) COMET_FAIL(COMET_ERR_UNSUPPORTED, "this index kind stores codes, not vectors: node-id queries need the caller's copy of the vector");
+        std::vector<int32_t> rows(n);
+        for (int i = 0; i < n; i++) {
+            const int64_t r = idx->row_of_id(ids[i]);
+            if (r < 0) { if (idx->kind == COMET_KIND_HNSW) COMET_FAIL(COMET_ERR_NOT_FOUND, "node ID %u not found or deleted", ids[i]); COMET_FAIL(COMET_ERR_NOT_FOUND, "node ID %u not found in index", ids[i]); }
+            if (idx->deleted.count(ids[i])) { if (idx->kind == COMET_KIND_HNSW) COMET_FAIL(COMET_ERR_NOT_FOUND, "node ID %u not found or deleted", ids[i]); COMET_FAIL(COMET_ERR_NOT_FOUND, "node ID %u not found in index (deleted)", ids[i]); }
+            rows[i] = (int32_t)r;
+        }
+        int32_t* dr = c->salloc<int32_t>(n);
+        float* padded = c->salloc<float>((size_t)n * idx->ld);
+        float* dense = c->salloc<float>((size_t)n * idx->dim);
+        c->h2d(dr, rows.data(), (size_t)n * 4);
+        launch_gather_rows(c, idx->rows_dev(), idx->ld, dr, n, padded);
+        launch_unpad_rows(c, padded, n, idx->ld, dense, idx->dim);
+        c->d2h(out_vecs, dense, (size_t)n * idx->dim * 4);
+        c->sync();
+        return (int)COMET_OK;
+    });
+}
+
+// ---- multi-GPU list sharding ------------------------------------------------------------------------------
+int comet_index_set_shard(comet_index* idx, int32_t rank, int32_t world) {
+    return guarded([&] {
+        if (world <= 0 || rank < 0 || rank >= world) COMET_FAIL(COMET_ERR_INVALID_ARG, "bad shard: rank %d of %d", rank, world);
+        if (idx->kind != COMET_KIND_IVF && idx->kind != COMET_KIND_IVFPQ) COMET_FAIL(COMET_ERR_UNSUPPORTED, "list sharding applies to IVF / IVFPQ indexes (shard Flat / PQ rows on the caller's side)");
+        if (idx->size() != 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "set the shard before adding vectors");
+        std::lock_guard<std::recursive_mutex> lk(idx->c->mu);
+        idx->shard_rank = rank; idx->shard_world = world;
+        return (int)COMET_OK;
+    });
+}
+
 // ---- persistence (io.WriterTo / io.ReaderFrom, index.go:58-60) -----------------------------------------
 int comet_index_write_to(comet_index* idx, comet_write_cb cb, void* user, int64_t* out_bytes) {
     return guarded([&] {

@@ -146,8 +146,8 @@ int comet_index_search_sharded_async(comet_index* idx, comet_comm* cm, const flo
         if (!p || B <= 0 || k_cap <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "bad batch size / k_cap");
         if (idx->c != cm->c) COMET_FAIL(COMET_ERR_INVALID_ARG, "index and communicator live on different contexts");
         Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->scratch_reset();
-        comet_comm::Slot* s = nullptr;
-        for (auto& sl : cm->slots) if (!sl.active) { s = &sl; break; }
+        comet_comm::Slot* s = &cm->slots[cm->next_ticket % comet_comm::kSlots];   // round robin: a slot is reused four searches later
+        if (s->active) s = nullptr;
         if (!s) COMET_FAIL(COMET_ERR_INVALID_ARG, "more than %d sharded searches in flight: wait for one first", comet_comm::kSlots);
         if (!s->searched) { HIP_CHECK(hipEventCreateWithFlags(&s->searched, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&s->merged, hipEventDisableTiming)); }
         const size_t words = (size_t)2 * B * k_cap + B;
@@ -157,6 +157,7 @@ int comet_index_search_sharded_async(comet_index* idx, comet_comm* cm, const flo
         uint32_t* pids = s->pack.as<uint32_t>(); float* psc = reinterpret_cast<float*>(pids + (size_t)B * k_cap); int32_t* pcn = reinterpret_cast<int32_t*>(pids + (size_t)2 * B * k_cap);
         s->search_ticket = idx->search_begin(queries_dev, B, *p, pids, psc, pcn, k_cap);
         s->idx = idx; s->B = B; s->k_cap = k_cap; s->k = p->k; s->out_ids = out_ids_dev; s->out_scores = out_scores_dev; s->out_counts = out_counts_dev;
+        HIP_CHECK(hipEventRecord(s->searched, c->stream));          // the exchange of this batch depends on THIS search only, not on later ones
         s->ticket = cm->next_ticket++; s->active = true;
         if (out_ticket) *out_ticket = s->ticket;
         return (int)COMET_OK;
@@ -172,8 +173,9 @@ int comet_index_search_sharded_wait(comet_index* idx, comet_comm* cm, uint64_t t
         comet_comm::Slot* s = nullptr;
         for (auto& sl : cm->slots) if (sl.active && sl.ticket == ticket) { s = &sl; break; }
         if (!s) { if (block) HIP_CHECK(hipStreamSynchronize(cm->xstream)); return (int)COMET_OK; }
-        idx->search_finish(s->search_ticket);                      // waits for THIS search only (its event), not for later ones
-        HIP_CHECK(hipEventRecord(s->searched, c->stream));          // everything up to here (incl. a rare strict re-run) produced the block
+        // waits for THIS search only (its event), not for later ones; a rare strict re-run of overflowed queries lands behind the
+        // later searches on the stream, so the dependency is re-recorded in that case
+        if (idx->search_finish(s->search_ticket)) HIP_CHECK(hipEventRecord(s->searched, c->stream));
         HIP_CHECK(hipStreamWaitEvent(cm->xstream, s->searched, 0));
         const size_t words = (size_t)2 * s->B * s->k_cap + s->B;
         {

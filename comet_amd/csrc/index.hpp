@@ -21,6 +21,11 @@ struct comet_index {
     std::unordered_set<uint32_t> deleted;
     comet::DevBuf deleted_dev; int n_deleted_dev = 0; bool deleted_dirty = false;
 
+    // multi-GPU list sharding (IVF / IVFPQ): this rank keeps only the members of lists l with l % shard_world == shard_rank;
+    // centroids / codebooks stay replicated, every rank ranks ALL centroids and probes the same lists, and the lists it does
+    // not own are simply empty here — table build, scan and selection all shrink with the rank count.
+    int shard_rank = 0, shard_world = 1;
+
     virtual ~comet_index() {}
     virtual int64_t size() const = 0;
     virtual int default_nprobes() const { return 0; }
@@ -30,6 +35,11 @@ struct comet_index {
     virtual int64_t add_dev(const uint32_t* ids_dev, const uint32_t* ids_host, const float* vecs_dev, int64_t n,
                             int64_t* zero_at, float* normalized_dev) = 0;
     virtual bool contains_id(uint32_t id) const = 0;
+    // row of the stored (preprocessed) vector of `id` in rows_dev(), the first one in the reference's lookup order
+    // (lookupNodeVectors flat_index_search.go:171-196, ivf_index_search.go:176-206, hnsw_index_search.go:212-226); -1: no such id.
+    // Index kinds that keep no vectors (PQ / IVFPQ store codes only) return nullptr from rows_dev().
+    virtual int64_t row_of_id(uint32_t /*id*/) { return -1; }
+    virtual const float* rows_dev() const { return nullptr; }
     virtual void flush() = 0;
     virtual void search_dev(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids,
                             float* out_scores, int32_t* out_counts, int k_cap) = 0;
@@ -37,7 +47,8 @@ struct comet_index {
     // (index kinds without deferred work run everything in begin)
     virtual uint64_t search_begin(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
                                   int32_t* out_counts, int k_cap) { search_dev(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap); return 0; }
-    virtual void search_finish(uint64_t /*ticket*/) {}
+    // returns true if it had to enqueue further device work (the Flat fast path's rare strict re-run)
+    virtual bool search_finish(uint64_t /*ticket*/) { return false; }
     virtual int64_t list_size(int /*list*/) const { return size(); }
     virtual void list_read(int /*list*/, uint32_t* /*ids*/, uint8_t* /*codes*/, float* /*vecs*/) const {}
     virtual void export_all(uint32_t* /*ids*/, int32_t* /*lists*/, uint8_t* /*codes*/) const { COMET_FAIL(COMET_ERR_UNSUPPORTED, "export not supported for this index kind"); }

@@ -68,6 +68,12 @@ struct FlatIndex : comet_index {
 
     int64_t size() const override { return n; }
     bool contains_id(uint32_t id) const override { return id_count.count(id) != 0; }
+    std::unordered_map<uint32_t, int64_t> first_row; bool first_row_dirty = true;
+    int64_t row_of_id(uint32_t id) override {
+        if (first_row_dirty) { first_row.clear(); for (int64_t i = n - 1; i >= 0; i--) first_row[ids[i]] = i; first_row_dirty = false; }
+        auto it = first_row.find(id); return it == first_row.end() ? -1 : it->second;
+    }
+    const float* rows_dev() const override { return X.as<float>(); }
     bool raw_ingest = false;   // ReadFrom: stored vectors are already preprocessed (flat_index.go:592 keeps them as read)
 
     // FlatIndex.Add flat_index.go:170-186, batched.
@@ -111,7 +117,7 @@ struct FlatIndex : comet_index {
             if (!(fn <= xmax_norm2)) xmax_norm2 = fn;
             ids.insert(ids.end(), ids_h, ids_h + added);
             for (int64_t i = 0; i < added; i++) id_count[ids_h[i]]++;
-            n += added;
+            n += added; first_row_dirty = true;
         }
         return added;
     }
@@ -148,7 +154,7 @@ struct FlatIndex : comet_index {
             launch_to_half_rows(c, X.as<float>(), (int64_t)nk, ld, Xh.p, ldh, 0, rn.as<float>(), nullptr);
             HIP_CHECK(hipStreamSynchronize(c->stream));
         }
-        ids.swap(nids); n = (int64_t)nk;
+        ids.swap(nids); n = (int64_t)nk; first_row_dirty = true;
         id_count.clear(); for (auto id : ids) id_count[id]++;
         deleted.clear(); deleted_dirty = true;
     }
@@ -276,10 +282,10 @@ struct FlatIndex : comet_index {
         return slot->ticket;
     }
 
-    void search_finish(uint64_t ticket) override {
+    bool search_finish(uint64_t ticket) override {
         Pending* slot = nullptr;
         for (auto& r : ring) if (r.active && r.ticket == ticket) { slot = &r; break; }
-        if (!slot) return;     // already finished (or never deferred)
+        if (!slot) return false;     // already finished (or never deferred)
         HIP_CHECK(hipEventSynchronize(slot->ev));
         slot->active = false;
         const int NB = flat_fast_batch();
@@ -300,6 +306,7 @@ struct FlatIndex : comet_index {
                         slot->out_counts + q, slot->k_cap, nullptr);
         }
         if (!redo.empty()) HIP_CHECK(hipStreamSynchronize(c->stream));
+        return !redo.empty();
     }
 
     void search_dev(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
@@ -373,7 +380,7 @@ struct FlatIndex : comet_index {
         for (auto& r : ring) if (r.active) search_finish(r.ticket);
         std::swap(X.p, t.X.p); std::swap(X.cap, t.X.cap); std::swap(ids_dev.p, t.ids_dev.p); std::swap(ids_dev.cap, t.ids_dev.cap);
         std::swap(Xh.p, t.Xh.p); std::swap(Xh.cap, t.Xh.cap); std::swap(rn.p, t.rn.p); std::swap(rn.cap, t.rn.cap);
-        ids.swap(t.ids); id_count.swap(t.id_count); n = t.n; xmax_abs = t.xmax_abs; xmax_norm2 = t.xmax_norm2;
+        ids.swap(t.ids); id_count.swap(t.id_count); n = t.n; xmax_abs = t.xmax_abs; xmax_norm2 = t.xmax_norm2; first_row_dirty = true;
         deleted.clear(); deleted.insert(del.begin(), del.end()); deleted_dirty = true;
     }
 

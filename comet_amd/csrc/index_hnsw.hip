@@ -264,6 +264,8 @@ struct HNSWIndex : comet_index {
 
     int64_t size() const override { return n; }
     bool contains_id(uint32_t id) const override { return id2idx.count(id) != 0; }
+    int64_t row_of_id(uint32_t id) override { auto it = id2idx.find(id); return it == id2idx.end() ? -1 : (int64_t)it->second; }
+    const float* rows_dev() const override { return V.as<float>(); }
     int64_t add_dev(const uint32_t*, const uint32_t*, const float*, int64_t, int64_t*, float*) override {
         COMET_FAIL(COMET_ERR_UNSUPPORTED, "HNSW graph construction on the GPU is not built yet: load a graph with comet_hnsw_load_graph");
     }

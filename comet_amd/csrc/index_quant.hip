@@ -176,6 +176,13 @@ static float* pad_raw(Ctx* c, const float* vecs_dev, int64_t n, int dim, int ld)
     return V;
 }
 
+// list sharding: positions (within a batch) of the rows whose list this rank owns
+static std::vector<int32_t> owned_rows(const std::vector<int32_t>& lists, int rank, int world) {
+    std::vector<int32_t> keep;
+    for (size_t i = 0; i < lists.size(); i++) if (lists[i] % world == rank) keep.push_back((int32_t)i);
+    return keep;
+}
+
 // ------------------------------------------------------------------------------------------------
 // IVFIndex
 // ------------------------------------------------------------------------------------------------
@@ -192,6 +199,16 @@ struct IVFIndex : comet_index {
         if (oids) std::copy(lay.ids.begin(), lay.ids.end(), oids);
         if (olists) std::copy(lay.list_of.begin(), lay.list_of.end(), olists);
     }
+    // first match in the reference's order: list by list, append order inside a list (ivf_index_search.go:183-198)
+    int64_t row_of_id(uint32_t id) override {
+        lay.compile(c);
+        int64_t best_slot = -1, best_row = -1;
+        if (!lay.id_count.count(id)) return -1;
+        for (int64_t s = 0; s < lay.nslots; s++) { const uint32_t r = lay.row_of_slot_h[s]; if (r != 0xFFFFFFFFu && lay.ids[r] == id) { best_slot = s; best_row = r; break; } }
+        (void)best_slot;
+        return best_row;
+    }
+    const float* rows_dev() const override { return V.as<float>(); }
 
     // IVFIndex.WriteTo ivf_index.go:468-588: Flush; "IVFX", version, dim, kind, nlist, trained byte, centroids
     // {size, floats} when trained, list count, per list {size, per vector {id, dim floats}}, empty bitmap.
@@ -300,8 +317,9 @@ struct IVFIndex : comet_index {
         *zero_at = -1;
         if (!trained) COMET_FAIL(COMET_ERR_NOT_TRAINED, "index must be trained before adding vectors");
         if (m <= 0) return 0;
-        V.reserve((size_t)(lay.n + m) * ld * sizeof(float), c->stream, (size_t)lay.n * ld * sizeof(float));
-        float* dst = V.as<float>() + (size_t)lay.n * ld;
+        const bool sharded = shard_world > 1;
+        if (!sharded) V.reserve((size_t)(lay.n + m) * ld * sizeof(float), c->stream, (size_t)lay.n * ld * sizeof(float));
+        float* dst = sharded ? c->salloc<float>((size_t)m * ld) : V.as<float>() + (size_t)lay.n * ld;
         int32_t* zf = c->salloc<int32_t>(m);
         launch_ingest_rows(c, metric, vecs_dev, m, dim, dst, ld, zf);
         int64_t added = m;
@@ -318,7 +336,21 @@ struct IVFIndex : comet_index {
             c->d2h(ah.data(), a, added * sizeof(int32_t));
             if (normalized_dev) launch_unpad_rows(c, dst, added, ld, normalized_dev, dim);
             HIP_CHECK(hipStreamSynchronize(c->stream));
-            lay.append(ids_h, ah.data(), added);
+            if (sharded) {     // keep the rows of the lists this rank owns
+                const std::vector<int32_t> keep = owned_rows(ah, shard_rank, shard_world);
+                if (!keep.empty()) {
+                    int32_t* kd = c->salloc<int32_t>(keep.size());
+                    c->h2d(kd, keep.data(), keep.size() * 4);
+                    V.reserve((size_t)(lay.n + keep.size()) * ld * sizeof(float), c->stream, (size_t)lay.n * ld * sizeof(float));
+                    launch_gather_rows(c, dst, ld, kd, (int64_t)keep.size(), V.as<float>() + (size_t)lay.n * ld);
+                    std::vector<uint32_t> kid(keep.size()); std::vector<int32_t> kl(keep.size());
+                    for (size_t i = 0; i < keep.size(); i++) { kid[i] = ids_h[keep[i]]; kl[i] = ah[keep[i]]; }
+                    HIP_CHECK(hipStreamSynchronize(c->stream));
+                    lay.append(kid.data(), kl.data(), (int64_t)keep.size());
+                }
+            } else {
+                lay.append(ids_h, ah.data(), added);
+            }
         }
         return added;
     }
@@ -473,24 +505,44 @@ struct PQFamilyIndex : comet_index {
             for (int64_t i = 0; i < m; i++) if (h[i]) { *zero_at = i; added = i; break; }
         }
         if (added <= 0) return 0;
-        codes_arr.reserve((size_t)(lay.n + added) * M4 * 4, c->stream, (size_t)lay.n * M4 * 4);
-        uint8_t* dst = (uint8_t*)codes_arr.p + (size_t)lay.n * M4 * 4;
-        c->zero(dst, (size_t)added * M4 * 4);
+        if (normalized_dev) launch_unpad_rows(c, P, added, ld, normalized_dev, dim);
         std::vector<int32_t> ah;
+        std::vector<uint32_t> kid;                       // ids of the rows this rank keeps (list sharding)
+        int32_t* a = nullptr;
+        int64_t kept = added;
         if (ivf) {
-            int32_t* a = c->salloc<int32_t>(added);
+            a = c->salloc<int32_t>(added);
             assign_nearest(c, metric, P, added, ld, centroids.as<float>(), nlist, a);
-            float* R = c->salloc<float>((size_t)added * ld);
-            launch_residual_rows(c, P, ld, added, centroids.as<float>(), a, R);
-            launch_pq_encode(c, R, ld, added, codebooks.as<float>(), M, Ksub, dsub, dst, M4 * 4);
             ah.resize(added);
             c->d2h(ah.data(), a, added * sizeof(int32_t));
-        } else {
-            launch_pq_encode(c, P, ld, added, codebooks.as<float>(), M, Ksub, dsub, dst, M4 * 4);
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (shard_world > 1) {                         // encode only the members of the lists this rank owns
+                const std::vector<int32_t> keep = owned_rows(ah, shard_rank, shard_world);
+                kept = (int64_t)keep.size();
+                if (kept == 0) return added;
+                int32_t* kd = c->salloc<int32_t>(kept);
+                c->h2d(kd, keep.data(), kept * 4);
+                float* P2 = c->salloc<float>((size_t)kept * ld);
+                launch_gather_rows(c, P, ld, kd, kept, P2);
+                std::vector<int32_t> kl(kept); kid.resize(kept);
+                for (int64_t i = 0; i < kept; i++) { kid[i] = ids_h[keep[i]]; kl[i] = ah[keep[i]]; }
+                ah.swap(kl);
+                c->h2d(a, ah.data(), kept * 4);
+                P = P2; ids_h = kid.data();
+            }
         }
-        if (normalized_dev) launch_unpad_rows(c, P, added, ld, normalized_dev, dim);
+        codes_arr.reserve((size_t)(lay.n + kept) * M4 * 4, c->stream, (size_t)lay.n * M4 * 4);
+        uint8_t* dst = (uint8_t*)codes_arr.p + (size_t)lay.n * M4 * 4;
+        c->zero(dst, (size_t)kept * M4 * 4);
+        if (ivf) {
+            float* R = c->salloc<float>((size_t)kept * ld);
+            launch_residual_rows(c, P, ld, kept, centroids.as<float>(), a, R);
+            launch_pq_encode(c, R, ld, kept, codebooks.as<float>(), M, Ksub, dsub, dst, M4 * 4);
+        } else {
+            launch_pq_encode(c, P, ld, kept, codebooks.as<float>(), M, Ksub, dsub, dst, M4 * 4);
+        }
         HIP_CHECK(hipStreamSynchronize(c->stream));
-        lay.append(ids_h, ivf ? ah.data() : nullptr, added);
+        lay.append(ids_h, ivf ? ah.data() : nullptr, kept);
         il_dirty = true;
         return added;
     }

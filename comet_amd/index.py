@@ -528,8 +528,14 @@ class VectorIndex:
         return ids, codes, vecs
 
     def _lookup_node_vectors(self, node_ids: list[int]) -> list[np.ndarray]:
-        # flatIndexSearch.lookupNodeVectors flat_index_search.go:171-196
-        raise NotImplementedError
+        # lookupNodeVectors flat_index_search.go:171-196 (+ the IVF / HNSW siblings): stored vectors by node id
+        ids = np.ascontiguousarray(node_ids, dtype=np.uint32)
+        out = np.empty((len(ids), self.dim), dtype=np.float32)
+        rc = self.lib.comet_index_fetch_vectors(self.h, ids.ctypes.data_as(C.c_void_p), len(ids), out.ctypes.data_as(C.c_void_p))
+        if rc == _lib.ERR_NOT_FOUND:
+            raise KeyError(self.lib.comet_last_error().decode())
+        check(rc)
+        return [out[i].copy() for i in range(len(ids))]
 
 
 class FlatIndex(VectorIndex):
@@ -561,18 +567,6 @@ class FlatIndex(VectorIndex):
         self._deleted.clear()
         return n
 
-    def _lookup_node_vectors(self, node_ids):
-        ids, _, vecs = self.list_read(0, want_vectors=True)
-        out = []
-        for nid in node_ids:
-            hits = np.nonzero(ids == np.uint32(nid))[0]
-            if hits.size == 0:
-                raise KeyError(f"node ID {nid} not found in index")
-            if nid in self._deleted:
-                raise KeyError(f"node ID {nid} not found in index (deleted)")
-            out.append(vecs[hits[0]].copy())
-        return out
-
 
 class _TrainedIndex(VectorIndex):
     not_trained_msg = "index must be trained before searching"
@@ -580,6 +574,10 @@ class _TrainedIndex(VectorIndex):
     def _check_searchable(self) -> None:
         if not self.trained():
             raise RuntimeError(self.not_trained_msg)
+
+    def set_shard(self, rank: int, world: int) -> None:
+        """Multi-GPU list sharding (IVF / IVFPQ): keep only the members of lists l with l % world == rank (before the first add)."""
+        check(self.lib.comet_index_set_shard(self.h, int(rank), int(world)))
 
     def centroids(self, nlist: int) -> np.ndarray:
         out = np.empty((nlist, self.dim), dtype=np.float32)

@@ -230,6 +230,12 @@ COMET_API int comet_comm_sync(comet_comm* comm);          /* wait for the contex
  * local results final, enqueues all-gather + merge on the exchange stream and — if block != 0 — returns when the MERGED
  * rows (same layout and meaning as comet_index_search_dev's outputs) are in the output buffers; with block == 0 they are
  * final after the next blocking wait / comet_comm_sync. Every rank must issue the same sequence of calls. */
+/* List sharding for IVF / IVFPQ (call before the first Add, after or before Train; every rank trains on the same vectors —
+ * the GPU k-means is deterministic, so centroids and codebooks are replicated bit for bit — and is handed EVERY vector):
+ * this rank keeps only the members of lists l with l % world == rank. All ranks rank all centroids and pick the same
+ * nprobe lists; lists a rank does not own are empty there, so its table build, scan and selection cover 1/world of the
+ * work. Remove / filters act on the local members (a Remove of an id stored on another rank reports NOT_FOUND here). */
+COMET_API int comet_index_set_shard(comet_index* idx, int32_t rank, int32_t world);
 COMET_API int comet_index_search_sharded_async(comet_index* idx, comet_comm* comm, const float* queries_dev, int32_t B,
                                                const comet_search_params* p, uint32_t* out_ids_dev, float* out_scores_dev,
                                                int32_t* out_counts_dev, int32_t k_cap, uint64_t* out_ticket);
@@ -262,6 +268,11 @@ COMET_API double comet_bm25_avg_doc_len(const comet_text_index* idx);
 COMET_API int comet_bm25_search(comet_text_index* idx, const uint32_t* q_tokens, const int32_t* q_offsets, int32_t B, int32_t k,
                                 const uint32_t* filter_ids, int32_t n_filter, uint32_t* out_ids, float* out_scores,
                                 double* out_scores64, int32_t* out_counts, int32_t k_cap);
+
+/* WithNode(nodeIDs...): the stored (preprocessed) vectors of the given node ids, n x dim, in order — lookupNodeVectors
+ * flat_index_search.go:171-196, ivf_index_search.go:176-206, hnsw_index_search.go:212-226 (first match in the reference's
+ * scan order; "node ID %d not found in index" / "... (deleted)"). PQ / IVFPQ keep codes only: UNSUPPORTED. */
+COMET_API int comet_index_fetch_vectors(comet_index* idx, const uint32_t* ids, int32_t n, float* out_vecs);
 
 /* Bulk export in arrival (Add) order: ids[n], list index per element lists[n] (0 for Flat / PQ), and M-byte
  * PQ codes codes[n*M] (PQ / IVFPQ only). Any pointer may be NULL. Used to hand a GPU-built index to the CPU

@@ -280,10 +280,11 @@ def test_merge_topk(ctx):
         ctx.free(p)
 
 
-@pytest.mark.parametrize("kind", ["ivf", "ivfpq"])
-def test_sharded_lists_merge_equals_unsharded(ctx, kind):
+@pytest.mark.parametrize("kind,policy", [("ivf", "members"), ("ivfpq", "members"), ("ivf", "lists"), ("ivfpq", "lists")])
+def test_sharded_lists_merge_equals_unsharded(ctx, kind, policy):
     """SURVEY §8(e) for the inverted-list indexes: every rank trains on the same vectors (the GPU k-means is deterministic,
-    so centroids / codebooks are replicated bit for bit), holds a round-robin share of the members, probes the same lists,
+    so centroids / codebooks are replicated bit for bit), holds a round-robin share of the members ("members") or the whole
+    lists l % R == r ("lists", comet_index_set_shard), probes the same lists,
     and the per-shard top-K merged by comet_merge_topk_dev equal the unsharded search (scores bit for bit; ids wherever the
     score is unique — inside runs of equal scores the merged order is (shard, position) instead of scan position)."""
     import ctypes as C
@@ -303,7 +304,13 @@ def test_sharded_lists_merge_equals_unsharded(ctx, kind):
     for r in range(R):
         sh = make()
         assert np.array_equal(sh.centroids(nlist), full.centroids(nlist))          # replicated quantiser
-        sh.add_batch(ids[r::R], X[r::R])
+        if policy == "members":
+            sh.add_batch(ids[r::R], X[r::R])
+        else:                                          # comet_index_set_shard: handed every vector, keeps the lists l % R == r
+            sh.set_shard(r, R)
+            sh.add_batch(ids, X)
+            sizes = [sh.list_size(l) for l in range(nlist)]
+            assert all(sizes[l] == (full.list_size(l) if l % R == r else 0) for l in range(nlist))
         all_ids[r], all_sc[r], all_cn[r] = sh.search_batch(Q, k, nprobes=5)
     bufs = [ctx.alloc(a.nbytes) for a in (all_ids, all_sc, all_cn)]
     for p, a in zip(bufs, (all_ids, all_sc, all_cn)):
