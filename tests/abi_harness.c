@@ -1,0 +1,153 @@
+/* abi_harness.c — drives libcomet_hip.so through include/comet_gpu.h exactly the way the cgo shim (go/cometgpu) does:
+ * plain C, no Python, caller-allocated buffers, callbacks for io.Writer / io.Reader, pthreads for concurrent Execute calls.
+ * Built by __graft_entry__.build() (gcc -pthread); run by tests/test_abi_harness.py (GPU) — exit code 0 = every check passed,
+ * 77 = no gfx950 device (what the CPU-only container gets), anything else = a failed check (message on stderr).
+ * Expected values are computed here with the reference's own arithmetic (sequential float32 sums, distance.go:158-165). */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "comet_gpu.h"
+
+#define CHECK(cond, ...) do { if (!(cond)) { fprintf(stderr, "abi_harness: %s:%d: ", __FILE__, __LINE__); fprintf(stderr, __VA_ARGS__); fprintf(stderr, " [last error: %s]\n", comet_last_error()); exit(1); } } while (0)
+#define OK(call) do { int _rc = (call); CHECK(_rc == COMET_OK, "%s -> %d", #call, _rc); } while (0)
+
+enum { DIM = 24, N = 5000, NQ = 16, K = 10, THREADS = 8 };
+static float X[N][DIM], Q[NQ][DIM];
+static uint32_t want_ids[NQ][K];
+static float want_sc[NQ][K];
+
+static uint64_t rng_state = 0x1234;
+static float frand(void) { rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull; return (float)((rng_state >> 40) & 0xFFFFFF) / 8388608.0f - 1.0f; }
+
+static float l2sq(const float* a, const float* b) {   /* distance.go:158-165: sequential float32, product rounded before the add */
+    volatile float sum = 0.0f;
+    for (int i = 0; i < DIM; i++) { volatile float d = a[i] - b[i]; volatile float sq = d * d; sum = sum + sq; }
+    return sum;
+}
+static void reference_topk(const float* q, int n, uint32_t* ids, float* sc) {   /* flat_index_search.go:221-294 with the canonical tie order */
+    for (int k = 0; k < K; k++) { ids[k] = 0; sc[k] = INFINITY; }
+    for (int i = 0; i < n; i++) {
+        float d = l2sq(q, X[i]);
+        int pos = K;
+        while (pos > 0 && d < sc[pos - 1]) pos--;
+        if (pos < K) { for (int j = K - 1; j > pos; j--) { sc[j] = sc[j - 1]; ids[j] = ids[j - 1]; } sc[pos] = d; ids[pos] = (uint32_t)(i + 1); }
+    }
+}
+
+struct membuf { uint8_t* p; size_t len, cap, off; };
+static int mem_write(void* u, const void* d, size_t n) { struct membuf* b = u; if (b->len + n > b->cap) { b->cap = (b->len + n) * 2; b->p = realloc(b->p, b->cap); } memcpy(b->p + b->len, d, n); b->len += n; return 0; }
+static int mem_read(void* u, void* d, size_t n) { struct membuf* b = u; if (b->off + n > b->len) return 1; memcpy(d, b->p + b->off, n); b->off += n; return 0; }
+
+struct worker { comet_index* idx; int tid; int failures; };
+static void* search_worker(void* arg) {
+    struct worker* w = arg;
+    comet_search_params p; memset(&p, 0, sizeof(p)); p.k = K;
+    for (int rep = 0; rep < 20; rep++) {
+        int q = (w->tid * 7 + rep) % NQ;
+        uint32_t ids[K]; float sc[K]; int32_t cnt = 0;
+        if (comet_index_search(w->idx, Q[q], 1, &p, ids, sc, &cnt, K) != COMET_OK) { w->failures++; continue; }   /* one query per call = the Go Execute() shape */
+        if (cnt != K || memcmp(ids, want_ids[q], sizeof(ids)) != 0 || memcmp(sc, want_sc[q], sizeof(sc)) != 0) w->failures++;
+    }
+    return NULL;
+}
+static void* add_worker(void* arg) {          /* vectors far outside the data: never in anybody's top-K */
+    struct worker* w = arg;
+    for (int i = 0; i < 40; i++) {
+        float v[DIM]; for (int j = 0; j < DIM; j++) v[j] = 100.0f + (float)i;
+        uint32_t id = 1000000u + (uint32_t)i; int64_t added = 0;
+        if (comet_index_add(w->idx, &id, v, 1, &added, NULL) != COMET_OK || added != 1) w->failures++;
+    }
+    return NULL;
+}
+
+int main(void) {
+    int ndev = 0;
+    comet_device_count(&ndev);
+    comet_ctx* ctx = NULL;
+    int rc = comet_ctx_create(0, &ctx);
+    if (rc == COMET_ERR_NO_DEVICE) { fprintf(stderr, "abi_harness: no gfx950 device (%s)\n", comet_last_error()); return 77; }
+    CHECK(rc == COMET_OK, "comet_ctx_create -> %d", rc);
+    for (int i = 0; i < N; i++) for (int j = 0; j < DIM; j++) X[i][j] = frand();
+    for (int i = 0; i < NQ; i++) for (int j = 0; j < DIM; j++) Q[i][j] = frand();
+
+    /* NewFlatIndex(24, L2Squared); Add one vector per call like idx.Add(*NewVectorNodeWithID(id, v)) for the first 100, then a batch */
+    comet_index* idx = NULL;
+    OK(comet_flat_create(ctx, DIM, COMET_L2SQ, &idx));
+    for (int i = 0; i < 100; i++) { uint32_t id = (uint32_t)(i + 1); int64_t added = 0; OK(comet_index_add(idx, &id, X[i], 1, &added, NULL)); CHECK(added == 1, "added %lld", (long long)added); }
+    { static uint32_t ids[N]; for (int i = 100; i < N; i++) ids[i] = (uint32_t)(i + 1); int64_t added = 0; OK(comet_index_add(idx, ids + 100, X[100], N - 100, &added, NULL)); CHECK(added == N - 100, "batch added %lld", (long long)added); }
+    CHECK(comet_index_size(idx) == N && comet_index_kind(idx) == COMET_KIND_FLAT && comet_index_dim(idx) == DIM && comet_index_trained(idx) == 1, "introspection");
+
+    /* batched search == NQ reference searches, bit for bit */
+    for (int q = 0; q < NQ; q++) reference_topk(Q[q], N, want_ids[q], want_sc[q]);
+    comet_search_params p; memset(&p, 0, sizeof(p)); p.k = K;
+    static uint32_t ids[NQ * K]; static float sc[NQ * K]; int32_t cnt[NQ];
+    for (int mode = 0; mode <= 1; mode++) {
+        p.mode = mode;
+        OK(comet_index_search(idx, &Q[0][0], NQ, &p, ids, sc, cnt, K));
+        for (int q = 0; q < NQ; q++) CHECK(cnt[q] == K && memcmp(ids + q * K, want_ids[q], K * 4) == 0 && memcmp(sc + q * K, want_sc[q], K * 4) == 0, "query %d differs from the reference arithmetic (mode %d)", q, mode);
+    }
+    p.mode = 0;
+    /* WithThreshold / WithDocumentIDs / k <= 0 */
+    p.threshold = want_sc[0][4]; OK(comet_index_search(idx, Q[0], 1, &p, ids, sc, cnt, K)); CHECK(cnt[0] == 5, "threshold kept %d", cnt[0]); p.threshold = 0;
+    { uint32_t flt[3] = {want_ids[0][7], want_ids[0][2], 4999999u}; p.filter_ids = flt; p.n_filter = 3; OK(comet_index_search(idx, Q[0], 1, &p, ids, sc, cnt, K));
+      CHECK(cnt[0] == 2 && ids[0] == want_ids[0][2] && ids[1] == want_ids[0][7], "filter"); p.filter_ids = NULL; p.n_filter = 0; }
+    /* errors mirror the reference: soft delete twice, unknown id, cosine zero vector */
+    OK(comet_index_remove(idx, want_ids[0][0]));
+    CHECK(comet_index_remove(idx, want_ids[0][0]) == COMET_ERR_ALREADY_DELETED && strstr(comet_last_error(), "already deleted"), "double remove");
+    CHECK(comet_index_remove(idx, 77777777u) == COMET_ERR_NOT_FOUND && strstr(comet_last_error(), "not found"), "remove unknown");
+    OK(comet_index_search(idx, Q[0], 1, &p, ids, sc, cnt, K)); CHECK(ids[0] == want_ids[0][1], "soft-deleted row still returned");
+    { comet_index* c = NULL; OK(comet_flat_create(ctx, 4, COMET_COSINE, &c)); float z[4] = {0, 0, 0, 0}; uint32_t id = 1; int64_t added = 0;
+      CHECK(comet_index_add(c, &id, z, 1, &added, NULL) == COMET_ERR_ZERO_VECTOR && added == 0, "zero vector accepted");
+      float v[4] = {3, 4, 0, 0}, n[4]; OK(comet_index_add(c, &id, v, 1, &added, n)); CHECK(fabsf(n[0] - 0.6f) < 1e-6f && fabsf(n[1] - 0.8f) < 1e-6f, "normalised write-back (flat_index.go:182)");
+      OK(comet_index_destroy(c)); }
+    { comet_index* bad = NULL; CHECK(comet_flat_create(ctx, 0, COMET_L2, &bad) == COMET_ERR_INVALID_ARG && bad == NULL, "dimension 0 accepted");
+      CHECK(comet_flat_create(ctx, 4, 9, &bad) == COMET_ERR_UNKNOWN_METRIC, "unknown metric accepted"); }
+
+    /* io.WriterTo / io.ReaderFrom through callbacks: flushes (the removed id disappears), round-trips, rejects a wrong magic */
+    struct membuf wb = {0};
+    int64_t nbytes = 0;
+    OK(comet_index_write_to(idx, mem_write, &wb, &nbytes));
+    CHECK((size_t)nbytes == wb.len && memcmp(wb.p, "FLAT", 4) == 0 && comet_index_size(idx) == N - 1, "write_to: %lld bytes", (long long)nbytes);
+    comet_index* idx2 = NULL;
+    OK(comet_flat_create(ctx, DIM, COMET_L2SQ, &idx2));
+    OK(comet_index_read_from(idx2, mem_read, &wb, &nbytes));
+    CHECK((size_t)nbytes == wb.len && comet_index_size(idx2) == N - 1, "read_from consumed %lld of %zu", (long long)nbytes, wb.len);
+    OK(comet_index_search(idx2, Q[0], 1, &p, ids, sc, cnt, K)); CHECK(ids[0] == want_ids[0][1] && sc[0] == want_sc[0][1], "reloaded index answers differently");
+    { comet_index* iv = NULL; OK(comet_ivf_create(ctx, DIM, COMET_L2SQ, 4, &iv)); wb.off = 0;
+      CHECK(comet_index_read_from(iv, mem_read, &wb, &nbytes) == COMET_ERR_FORMAT && strstr(comet_last_error(), "invalid magic number: expected 'IVFX', got 'FLAT'"), "wrong magic accepted");
+      OK(comet_index_destroy(iv)); }
+    OK(comet_index_destroy(idx2));
+
+    /* concurrent Execute()s racing Adds (flat_index_search_test.go:392-465): restore the removed row's absence in the expectation */
+    for (int q = 0; q < NQ; q++) {   /* expectations for the flushed index: recompute without the removed id */
+        uint32_t removed = want_ids[0][0];
+        uint32_t t_ids[K + 1]; float t_sc[K + 1]; int m = 0;
+        float best_d[K + 1]; (void)best_d;
+        /* simple re-evaluation: top-(K) over rows != removed */
+        for (int k = 0; k < K; k++) { t_ids[k] = 0; t_sc[k] = INFINITY; }
+        for (int i = 0; i < N; i++) {
+            if ((uint32_t)(i + 1) == removed) continue;
+            float d = l2sq(Q[q], X[i]); int pos = K;
+            while (pos > 0 && d < t_sc[pos - 1]) pos--;
+            if (pos < K) { for (int j = K - 1; j > pos; j--) { t_sc[j] = t_sc[j - 1]; t_ids[j] = t_ids[j - 1]; } t_sc[pos] = d; t_ids[pos] = (uint32_t)(i + 1); }
+        }
+        (void)m;
+        memcpy(want_ids[q], t_ids, sizeof(want_ids[q])); memcpy(want_sc[q], t_sc, sizeof(want_sc[q]));
+    }
+    pthread_t th[THREADS + 1]; struct worker ws[THREADS + 1];
+    for (int t = 0; t <= THREADS; t++) { ws[t].idx = idx; ws[t].tid = t; ws[t].failures = 0; pthread_create(&th[t], NULL, t < THREADS ? search_worker : add_worker, &ws[t]); }
+    int failures = 0;
+    for (int t = 0; t <= THREADS; t++) { pthread_join(th[t], NULL); failures += ws[t].failures; }
+    CHECK(failures == 0, "%d concurrent calls failed or returned different rows", failures);
+    CHECK(comet_index_size(idx) == N - 1 + 40, "size after concurrent adds: %lld", (long long)comet_index_size(idx));
+
+    OK(comet_index_destroy(idx));
+    OK(comet_ctx_destroy(ctx));
+    free(wb.p);
+    printf("abi_harness OK: create/add/search/filter/threshold/remove/errors/write_to/read_from/%d-thread concurrency through the C ABI\n", THREADS);
+    return 0;
+}
