@@ -200,7 +200,7 @@ struct FlatIndex : comet_index {
         const int64_t n_tiles = ceil_div(n, flat_fast_tile_rows()) * (flat_fast_tile_rows() / unit_rows);
         const int64_t ldS = round_up(2 * n_tiles, 16), ldB = round_up(n_tiles, 16);
         const int NB = flat_fast_batch();
-        void* Qh = c->scratch_alloc((size_t)NB * ldh * 2);
+        void* Qh = c->scratch_alloc((size_t)NB * ldh * 2 * 2);   // row-major copy + MFMA-fragment-ordered copy
         float* qn = c->salloc<float>(NB);
         float* err = c->salloc<float>(NB);
         int32_t* flags = c->salloc<int32_t>(kSliceInts);     // [256 overflow flags | 4 stats], copied to the host in one piece

@@ -309,6 +309,278 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_n64_kernel(const _Fl
     }
     scan_epilogue<MODE, 2, 1, 2>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
 }
+// ------------------------------------------------------------------------------------------------
+// Query-stationary scan tile (round 2): the 256-query batch never goes through LDS.
+//
+// What limited the 2 x 4 tile above was the CU's LDS path: per 64-wide K step it had to take 64 KiB of LDS-DMA (32 KiB of
+// corpus rows from HBM + 32 KiB of the SAME query slab again for every row tile) next to 192 KiB of fragment reads, and the
+// second-dispatched half of the waves spent 2000+ cycles per step just issuing its DMA pieces (profiles/r01_flat_scan_investigation.txt).
+// Here the eight waves split the QUERIES instead (wave w: queries 32w..32w+31 against all 256 rows, 8 accumulator tiles):
+//   * a wave's query fragments are private, 4 KiB per K step, and come straight from L2 into registers
+//     (global_load_dwordx4 from a fragment-ordered copy: one contiguous 1 KiB per instruction), one K step ahead;
+//   * only the corpus rows use LDS: a 4-stage ring of 32 KiB slabs filled by LDS-DMA two to three K steps ahead, so the HBM
+//     latency is covered by the ring and not by registers; half the DMA pieces per step (32 instead of 64);
+//   * one barrier per K step, waits are counted (vmcnt(4): the newest slab stays in flight across the barrier);
+//   * a wave owns whole (query, 128-row) key units, so the epilogue needs no cross-wave merge.
+// Per K step a wave issues 32 MFMAs, 32 ds_read_b128, 4 DMA pieces and 4 query loads.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// barrier that waits for this wave's LDS traffic only (not for the LDS-DMA of later slabs, which __syncthreads() would drain)
+__device__ __forceinline__ void __syncthreads_lds_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+constexpr int FQ_STAGES = 4, FQ_STAGE_BYTES = 32768;
+#ifndef FQ_PRIO_FROM
+#define FQ_PRIO_FROM 4
+#endif
+
+// slow path of the epilogues (last tile / soft deletes / filters): bit mb*16+e set if row mb*32 + (e&3) + 8*(e>>2) + rowbits of the
+// tile is a usable candidate. Kept out of line so that its address arithmetic is not hoisted into the persistent K loop.
+__device__ __attribute__((noinline)) unsigned long long unit_okmask(int rowbits, long nvalid, const unsigned char* __restrict__ elig, long row0) {
+    unsigned long long okmask = 0ull;
+    for (int mb = 0; mb < 4; mb++)
+        for (int e = 0; e < 16; e++) {
+            const long r = mb * 32 + (e & 3) + 8 * (e >> 2) + rowbits;
+            bool ok = r < nvalid;
+            if (ok && elig) ok = elig[row0 + r] != 0;
+            if (ok) okmask |= 1ull << (mb * 16 + e);
+        }
+    return okmask;
+}
+
+// keep the three LARGEST of (t0 >= t1 >= t2) U {v}, branch-free
+__device__ __forceinline__ void ins3max(float& t0, float& t1, float& t2, float v) {
+    const float n2 = __builtin_amdgcn_fmed3f(t1, t2, v);
+    const float n1 = __builtin_amdgcn_fmed3f(t0, t1, v);
+    t0 = fmaxf(t0, v); t1 = n1; t2 = n2;
+}
+
+// Epilogue of the query-stationary tile: wave `wid` owns queries 32*wid .. 32*wid+31 for all 256 rows, i.e. two whole
+// (query, 128-row) key units per lane pair (lane, lane ^ 32). Per accumulator 4 VALU (cosine) / 5 (L2 family):
+//   cosine : the key 1 - s is monotone in the score s, so the selection network runs on the raw scores (three LARGEST, with
+//            the row-in-unit packed into the low 8 mantissa bits) and only the three survivors are turned into keys;
+//   L2     : t = rn[row] - 2 s (one fma; the shadow norms of the tile's rows sit in LDS), three SMALLEST of the packed t,
+//            survivors get + qn.
+// Containment is unchanged: two emitted keys are real rows' approximate distances, the third is a lower bound of every
+// other row of the unit up to the packing perturbation (2^-15 relative to |s| resp. |t|, twice), which flat_post_kernel's
+// tau carries as an absolute slack (FAST_PACK_SLACK).
+template <int MODE, bool CHECK>
+__device__ __forceinline__ void scan_epilogue_q(f32x16 (&acc)[8], int wid, long tile, long row0, long n, const float* __restrict__ rn_lds /*256 floats, MODE 1*/,
+                                                const float* __restrict__ qn, const unsigned char* __restrict__ elig,
+                                                float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, unsigned long long* etr = nullptr) {
+    // C layout of the 32x32 MFMA: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); tile mb covers rows mb*32..
+    const int lane = threadIdx.x & 63, khalf = lane >> 5;
+    const int q = wid * 32 + (lane & 31);
+    const float INF = __builtin_inff();
+    const long nvalid = n - row0;
+    float qnv = 0.0f;
+    if constexpr (MODE == 1) qnv = qn[q];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {                               // key unit = 128 rows (tiles mb = 4u .. 4u+3)
+        if (etr) etr[u * 2] = __builtin_amdgcn_s_memtime();
+        const int lane_rowbits = 4 * khalf + 128 * u;
+        unsigned long long okmask = ~0ull;                      // CHECK: last tile / soft deletes / filters (a separate instantiation: the
+        if constexpr (CHECK) okmask = unit_okmask(lane_rowbits, nvalid, elig, row0);   // per-element selects cost more than the network itself)
+        // selection on v: cosine v = score (largest wins), L2 v = -(rn - 2 s) (largest wins as well: one network for both)
+        float t0 = -INF, t1 = -INF, t2 = -INF;
+#pragma unroll
+        for (int mb = 0; mb < 4; mb++) {
+#pragma unroll
+            for (int e4 = 0; e4 < 4; e4++) {
+                f32x4v rnv;
+                if constexpr (MODE == 1) rnv = *reinterpret_cast<const f32x4v*>(rn_lds + u * 128 + mb * 32 + 8 * e4 + 4 * khalf);   // rows e&3 = 0..3 are consecutive
+#pragma unroll
+                for (int e1 = 0; e1 < 4; e1++) {
+                    const int e = e4 * 4 + e1;
+                    const int rconst = mb * 32 + e1 + 8 * e4;              // compile-time part of the row-in-unit (bit 2 = lane >> 5 is added to the survivors)
+                    float v;
+                    if constexpr (MODE == 0) v = acc[4 * u + mb][e];
+                    else v = __builtin_fmaf(2.0f, acc[4 * u + mb][e], -rnv[e1]);
+                    v = __uint_as_float((__float_as_uint(v) & 0xFFFFFF00u) | (unsigned)rconst);
+                    if constexpr (CHECK) v = ((okmask >> (mb * 16 + e)) & 1ull) ? v : -INF;
+                    ins3max(t0, t1, t2, v);
+                }
+            }
+        }
+        if (etr) etr[u * 2 + 1] = __builtin_amdgcn_s_memtime();
+        const float o0 = __shfl_xor(t0, 32, 64), o1 = __shfl_xor(t1, 32, 64), o2 = __shfl_xor(t2, 32, 64);
+        const unsigned mybit = (unsigned)(4 * khalf), otherbit = (unsigned)(4 * (khalf ^ 1));
+        auto tag = [&](float v, unsigned bit) { return v == -INF ? v : __uint_as_float(__float_as_uint(v) | bit); };
+        t0 = tag(t0, mybit); t1 = tag(t1, mybit); t2 = tag(t2, mybit);
+        ins3max(t0, t1, t2, tag(o0, otherbit)); ins3max(t0, t1, t2, tag(o1, otherbit)); ins3max(t0, t1, t2, tag(o2, otherbit));
+        if (lane < 32) {
+            auto to_key = [&](float v) {
+                if (v == -INF) return INF;
+                const unsigned row = __float_as_uint(v) & 0xFFu;
+                const float clean = __uint_as_float(__float_as_uint(v) & 0xFFFFFF00u);
+                float a;
+                if constexpr (MODE == 0) a = 1.0f - clean; else a = qnv - clean;      // clean = -(rn - 2 s)
+                a = fmaxf(a, 0.0f);
+                return __uint_as_float((__float_as_uint(a) & 0xFFFFFF00u) | row);
+            };
+            const long un = tile * 2 + u;
+            S0[(long)q * ldS + 2 * un] = to_key(t0);
+            S0[(long)q * ldS + 2 * un + 1] = to_key(t1);
+            bound[(long)q * ldB + un] = to_key(t2);
+        }
+    }
+}
+
+// Persistent form: 256-ish workgroups (one per CU), each streams its share of the row tiles as ONE pipeline over (tile, K step)
+// pairs — the slab ring and the counted waits run straight across tile boundaries, so the first slabs of tile T+1 are in flight
+// while the waves run tile T's last K steps and its epilogue (a one-shot tile exposes ~4000 cycles of HBM latency before its
+// first MFMA: s_memtime trace in profiles/r02_flat_scan_investigation.txt).
+template <int MODE>
+__global__ __launch_bounds__(FB_THREADS) void flat_scan_q8_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
+                                                                  const _Float16* __restrict__ QF /*fragment-ordered queries*/,
+                                                                  const float* __restrict__ rn, const float* __restrict__ qn,
+                                                                  const unsigned char* __restrict__ elig,
+                                                                  float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles,
+                                                                  unsigned long long* __restrict__ trace /*nullable: s_memtime stamps of workgroup 8 (tools/scan_check)*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // FQ_STAGES x 32 KiB row slabs (+ 1 KiB of row norms, MODE 1)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware static split: workgroup b runs on XCD b % 8; every XCD owns a contiguous range of tiles, its workgroups take them round-robin
+    const long nx = 8, xcd = blockIdx.x % nx, wgx = blockIdx.x / nx, wgs_per_xcd = gridDim.x / nx;
+    const long tq = n_tiles / nx, trem = n_tiles % nx;
+    const long xbase = xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq, xcount = xcd < trem ? tq + 1 : tq;
+    const long my_tiles = wgx < xcount ? (xcount - wgx + wgs_per_xcd - 1) / wgs_per_xcd : 0;
+    if (my_tiles == 0) return;
+    const int nk = ldh / FB_K;
+    const long total = my_tiles * nk;                          // global steps of this workgroup
+    float* rn_lds = reinterpret_cast<float*>(smem + FQ_STAGES * FQ_STAGE_BYTES);
+
+    f32x16 acc[8];
+    // ---- row slabs: each wave moves 4 pieces (8 rows x 128 B) per K step, XOR swizzle on the source side ----
+    const int prow = lane >> 3, pslot = lane & 7;
+    int poff[4], ldsoff[4];                                   // byte offset of the piece inside a (tile, K step) slab pair / inside the ring stage
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = (wid * 4 + i) * 8 + prow;
+        const int ks = pslot ^ ((r >> 1) & 7);
+        poff[i] = ((ks >> 2) * 256 + r) * 64 + (ks & 3) * 16;
+        ldsoff[i] = (wid * 4 + i) * 8 * 128;
+    }
+    const long tile_bytes = (long)(ldh >> 5) * 256 * 64;       // fp16 shadow bytes of one 256-row tile
+    auto tile_of = [&](long j) { return xbase + wgx + j * wgs_per_xcd; };
+    // slab of a global step -> ring stage (step & 3). The source address of the slab THREE steps ahead is carried incrementally
+    // (no division in the K loop): `pre_ptr` walks K steps inside a tile and jumps to this workgroup's next tile at the wrap.
+    const char* pre_ptr = reinterpret_cast<const char*>(Xh) + tile_of(0) * tile_bytes;
+    int pre_kt = 0;
+    const long tile_jump = wgs_per_xcd * tile_bytes - (long)nk * (256 * 128);        // from the end of a tile's slabs to the next tile of this workgroup
+    auto pre_advance = [&]() { pre_ptr += 256 * 128; if (++pre_kt == nk) { pre_kt = 0; pre_ptr += tile_jump; } };
+    auto stage_piece = [&](long g, int i) {
+        unsigned char* xb = smem + (g & (FQ_STAGES - 1)) * FQ_STAGE_BYTES;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre_ptr + poff[i]), (__attribute__((address_space(3))) void*)(xb + ldsoff[i]), 16, 0, 0);
+    };
+    // ---- query fragments: [wave][K step][ks][lane] 16-byte pieces, 4 KiB contiguous per (wave, K step); the same for every tile ----
+    const char* qbase = reinterpret_cast<const char*>(QF) + ((long)wid * nk) * 4096 + lane * 16;
+#define FQ_LOADQ(DST, P, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(DST) : "v"(P) : "memory")
+    // wait-only statements: the fragment registers are INPUTS, so the compiler has nothing to merge or copy in front of the wait;
+    // the sched_barrier behind it keeps the register-only MFMAs below the wait
+#define FQ_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" :: "v"(qcur[0]), "v"(qcur[1]), "v"(qcur[2]), "v"(qcur[3]) : "memory")
+    const int arow = lane & 31, khalf = lane >> 5;
+    u32x4 qa[4], qb[4];
+    long cur_tile = tile_of(0);
+    const bool tr = trace != nullptr && blockIdx.x == 8 && lane == 0;
+    auto stamp = [&](long g, int slot) { if (tr && g < 2 * nk + 2) trace[(wid * 32 + g) * 4 + slot] = __builtin_amdgcn_s_memtime(); };
+
+    // prologue: X(0), Q(0), X(1), X(2); afterwards pre_ptr points at slab 3
+#pragma unroll
+    for (int i = 0; i < 4; i++) stage_piece(0, i);
+    pre_advance();
+    { const char* qp = qbase; FQ_LOADQ(qa[0], qp, 0); FQ_LOADQ(qa[1], qp, 1024); FQ_LOADQ(qa[2], qp, 2048); FQ_LOADQ(qa[3], qp, 3072); }
+    if (1 < total) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) stage_piece(1, i);
+    }
+    pre_advance();
+    if (2 < total) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) stage_piece(2, i);
+    }
+    pre_advance();
+
+    // One global step. Every step issues exactly 4 query loads (the last ones re-read: an inline-asm load on one side of a branch
+    // makes the compiler merge "loaded" and "not loaded" registers with copies placed before the data has landed) and then, if
+    // there is one, the 4 DMA pieces of the slab three steps ahead — the counted waits rely on this order.
+    auto step = [&](long g, int kt, u32x4 (&qcur)[4], u32x4 (&qnext)[4]) {
+        stamp(g, 0);
+        // X(g) and Q(g) have landed once at most the slabs issued AFTER Q(g) are outstanding: X(1), X(2) for g = 0, X(g+2) otherwise
+        const int newer = g == 0 ? ((1 < total) + (2 < total)) : (g + 2 < total ? 1 : 0);
+        if (newer == 2) FQ_WAIT(8); else if (newer == 1) FQ_WAIT(4); else FQ_WAIT(0);
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(g, 1);
+        if (kt == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[i][e] = 0.0f;
+        }
+        const unsigned char* xb = smem + (g & (FQ_STAGES - 1)) * FQ_STAGE_BYTES;
+        const int ktn = kt + 1 < nk ? kt + 1 : 0;                      // next step's K index (wraps into the next tile)
+        const char* qp = qbase + (long)(g + 1 < total ? ktn : kt) * 4096;
+        const bool more = g + 3 < total;                              // workgroup-uniform
+        // Row fragments double-buffered in registers in groups of four (group gi = rows 128*(gi&1).., sub-step gi>>1): the reads of
+        // group gi+1 are in flight under the 4 MFMAs of group gi. One vector-memory instruction follows every group instead of a
+        // burst at the top of the step, where all eight waves collide on the address path (~150 cycles per instruction for the
+        // younger half of the waves).
+        half8 a[2][8];                                                 // sub-step ks+1's eight fragments load under sub-step ks's eight MFMAs
+#pragma unroll
+        for (int mb = 0; mb < 8; mb++) a[0][mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, khalf));
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const half8 b = __builtin_bit_cast(half8, qcur[ks]);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+#pragma unroll
+                for (int m2 = 0; m2 < 4; m2++) {
+                    const int mb = h * 4 + m2;
+                    if (ks < 3) a[(ks + 1) & 1][mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, (ks + 1) * 2 + khalf));
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][mb], b, acc[mb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int gi = ks * 2 + h;
+                if (gi == 0) FQ_LOADQ(qnext[0], qp, 0);
+                else if (gi == 1) FQ_LOADQ(qnext[1], qp, 1024);
+                else if (gi == 2) FQ_LOADQ(qnext[2], qp, 2048);
+                else if (gi == 3) FQ_LOADQ(qnext[3], qp, 3072);
+                else if (more) stage_piece(g + 3, gi - 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        pre_advance();
+        stamp(g, 2);
+        if (kt == nk - 1) {                                            // tile finished: its epilogue runs while the next tile's slabs arrive
+            const long tile = cur_tile, row0 = tile * FB_M;
+            cur_tile += wgs_per_xcd;
+            if constexpr (MODE == 1) {
+                // shadow norms of the tile's rows -> LDS (behind the ring), read back as broadcast b128s
+                __builtin_amdgcn_s_barrier();
+                if (tid < FB_M) { const long r = row0 + tid; rn_lds[tid] = rn[r < n ? r : n - 1]; }
+                __syncthreads_lds_only();
+            }
+            unsigned long long* etr = (tr && g < 2 * nk + 2) ? trace + 8 * 32 * 4 + wid * 8 : nullptr;
+            if ((n - row0 < FB_M) || elig != nullptr) scan_epilogue_q<MODE, true>(acc, wid, tile, row0, n, rn_lds, qn, elig, S0, ldS, bound, ldB, etr);   // workgroup-uniform
+            else scan_epilogue_q<MODE, false>(acc, wid, tile, row0, n, rn_lds, qn, elig, S0, ldS, bound, ldB, etr);
+            stamp(g, 3);
+        }
+    };
+    // nk is even here (the launcher sends odd K-step counts to the 2 x 4 tile), so steps come in pairs with static fragment buffers
+    // the second-dispatched half of the waves loses every issue arbitration to the older half (priority, then age): one static
+    // s_setprio for it evens out the two waves of each SIMD (MI355X_MICROARCH.md "static priority for the younger half")
+    static_assert(FB_THREADS == 512, "wave 4..7 = the younger half");
+    if (wid >= FQ_PRIO_FROM) __builtin_amdgcn_s_setprio(1);
+    int kt = 0;
+    for (long g = 0; g < total; g += 2) {
+        step(g, kt, qa, qb);
+        step(g + 1, kt + 1, qb, qa);
+        kt += 2; if (kt == nk) kt = 0;
+    }
+    // the redundant query loads of the last step must be home before the wave may end
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(qa[0]), "v"(qa[1]), "v"(qa[2]), "v"(qa[3]), "v"(qb[0]), "v"(qb[1]), "v"(qb[2]), "v"(qb[3]) : "memory");
+#undef FQ_WAIT
+#undef FQ_LOADQ
+}
+
 // What limits this kernel (profiles/r01_flat_scan_investigation.txt): of a K step's ~3900 cycles the 2 x 32 MFMAs of a SIMD
 // need 2048. The CU accepts the step's 64 LDS-DMA pieces only over ~2400 cycles while fragment reads are in flight; the four
 // waves that win arbitration finish their pieces after ~800 cycles and run their MFMAs while the other four are still issuing,
@@ -317,6 +589,7 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_n64_kernel(const _Fl
 // depending on how many waves issue, tools/dma_issue_probe.hip, and 3-5x that next to ds_read traffic), 16-wave workgroups,
 // persistent tiles, wave priorities and classic register staging (global_load -> ds_write_b128, no LDS-DMA: 0.59 ms) were all
 // built and measured in round 1: 0.51-0.63 ms against 0.51-0.55 for this one.
+unsigned long long* g_scan_trace = nullptr;   // set by tools/scan_check.hip only
 void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, int nq_used, const float* rn, const float* qn,
                           const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB) {
     const long n_tiles = ceil_div(n, FB_M);
@@ -330,6 +603,23 @@ void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, 
         } else {
             HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_f16_n64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
             flat_scan_f16_n64_kernel<1><<<dim3((unsigned)gridn), dim3(FB_THREADS), ldsn, c->stream>>>((const _Float16*)Xh, n, ldh, (const _Float16*)Qh, rn, qn, elig, S0, ldS, bound, ldB, n_tiles);
+        }
+        LAUNCH_CHECK();
+        return;
+    }
+    static const int variant0 = [] { const char* e = getenv("COMET_SCAN_VARIANT"); return e ? atoi(e) : 0; }();
+    const char* rt = getenv("COMET_SCAN_VARIANT_RT");           // tools/scan_check.hip switches variants inside one process
+    const int variant = rt ? atoi(rt) : variant0;
+    if (variant == 0 && ((ldh / FB_K) & 1) == 0) {          // query-stationary tile (even K-step counts; the few odd ones keep the 2 x 4 tile): rows through a 4-stage LDS ring, query fragments straight from L2
+        const size_t ldsq = (size_t)FQ_STAGES * FQ_STAGE_BYTES + 1024;
+        const long gridq = std::min<long>(round_up(n_tiles, 8), (long)round_up(c->prop.multiProcessorCount, 8));   // persistent: one workgroup per CU
+        const _Float16* QF = (const _Float16*)Qh + (size_t)FB_N * ldh;
+        if (mode == 0) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_q8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
+            flat_scan_q8_kernel<0><<<dim3((unsigned)gridq), dim3(FB_THREADS), ldsq, c->stream>>>((const _Float16*)Xh, n, ldh, QF, rn, qn, elig, S0, ldS, bound, ldB, n_tiles, g_scan_trace);
+        } else {
+            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_q8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
+            flat_scan_q8_kernel<1><<<dim3((unsigned)gridq), dim3(FB_THREADS), ldsq, c->stream>>>((const _Float16*)Xh, n, ldh, QF, rn, qn, elig, S0, ldS, bound, ldB, n_tiles, g_scan_trace);
         }
         LAUNCH_CHECK();
         return;
@@ -360,10 +650,14 @@ __global__ __launch_bounds__(256) void prep_queries_fast_kernel(const float* __r
     if (stats4 && blockIdx.x == 0 && threadIdx.x < 4) stats4[threadIdx.x] = 0;   // the post stage accumulates into these
     if (q >= FB_N) return;
     _Float16* o = Qh + (long)q * ldh;
+    // second copy in MFMA fragment order for the query-stationary scan: [wave = q / 32][K step][ks][lane = khalf * 32 + q % 32][8 halves]
+    _Float16* qf = Qh + (long)FB_N * ldh;
+    const int nk = ldh >> 6;
     float s = 0.0f;
     for (int i = lane; i < ldh; i += 64) {
         float v = (q < B && i < ld) ? Qp[(long)q * ld + i] : 0.0f;
         o[i] = (_Float16)v;
+        qf[(((((long)(q >> 5) * nk + (i >> 6)) * 4 + ((i >> 4) & 3)) * 64) + ((i >> 3) & 1) * 32 + (q & 31)) * 8 + (i & 7)] = (_Float16)v;
         s += v * v;
     }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -374,6 +668,10 @@ __global__ __launch_bounds__(256) void prep_queries_fast_kernel(const float* __r
         // fp32 accumulation on either side (d * 2^-23)
         float edot = (1.0f / 1024.0f + 2.0f * d * 1.2e-7f) * nq * nx + 6.0e-8f * sqrtf(d) * (nq + nx);
         float e = mode == 0 ? edot : 2.0f * edot + (d + 8.0f) * 1.2e-7f * (nq + nx) * (nq + nx);
+        // key packing of the query-stationary scan: the row index replaces the low 8 mantissa bits of the score s (cosine) resp. of
+        // rn - 2 s (L2 family) BEFORE the final subtraction: 2^-15 relative to those magnitudes, once for the emitted key and once
+        // for the bound (FAST_PACK_SLACK; the older tiles pack the final distance, covered by the relative term in flat_post_kernel)
+        e += 6.2e-5f * (mode == 0 ? nq * nx : nx * nx + 2.0f * nq * nx);
         err_abs[q] = 1.25f * e;
     }
 }
