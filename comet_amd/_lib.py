@@ -95,6 +95,9 @@ def load() -> C.CDLL:
         "comet_pq_create": (i32, [p, i32, i32, i32, i32, pp]),
         "comet_ivfpq_create": (i32, [p, i32, i32, i32, i32, i32, pp]),
         "comet_hnsw_create": (i32, [p, i32, i32, i32, i32, i32, pp]),
+        "comet_hnsw_add_with_levels": (i32, [p, p, p, p, i64, C.POINTER(i64)]),
+        "comet_hnsw_set_level_seed": (i32, [p, u64]),
+        "comet_hnsw_export_graph": (i32, [p, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), p, p, p, p, p, C.POINTER(C.c_uint32), C.POINTER(i32)]),
         "comet_hnsw_load_graph": (i32, [p, i64, p, p, p, p, p, C.c_uint32, i32]),
         "comet_index_destroy": (i32, [p]),
         "comet_index_kind": (i32, [p]),

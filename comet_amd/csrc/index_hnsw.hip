@@ -104,78 +104,74 @@ __device__ __forceinline__ float wave_dists(const float* __restrict__ V, int ld,
     return hn_finish<METRIC>(acc);
 }
 
+// Graph in HBM: per (node, layer <= level) one edge SLOT. edge_off[s] is the slot's first entry in `edges` (dense node indices),
+// deg[s] its current length; a slot has a fixed CAPACITY edge_off[s+1] - edge_off[s] (M on the upper layers, 2M on layer 0 — what
+// pruneConnections keeps, hnsw_index.go:667-694 — or the list's length for a loaded graph that is longer), so that insertNode can
+// append and prune in place.
 struct HnswGraph {
     const float* V; int ld; long n;
-    const int* level; const long* slot_base; const long* edge_off; const unsigned* edges;
+    const int* level; const long* slot_base; const long* edge_off; const int* deg; unsigned* edges;
     unsigned entry; int max_level;
     const unsigned* deleted;   // bitmap over dense node indices (nullable)
 };
 __device__ __forceinline__ bool bit_get(const unsigned* bm, unsigned i) { return bm && ((bm[i >> 5] >> (i & 31)) & 1u); }
 
-template <int METRIC>
-__global__ __launch_bounds__(64) void hnsw_search_kernel(HnswGraph g, const float* __restrict__ Qp, int ef, unsigned* __restrict__ visited /*[B][vwords]*/,
-                                                         long vwords, unsigned* __restrict__ res_idx, float* __restrict__ res_dist,
-                                                         int* __restrict__ res_cnt, int* __restrict__ status, unsigned long long* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    HC* cand = reinterpret_cast<HC*>(smem);                                  // HN_CAND_CAP
-    HC* res = cand + HN_CAND_CAP;                                            // ef + 1
-    float* tile = reinterpret_cast<float*>(res + (HN_EF_MAX + 1));           // 64 x HN_LD
-    unsigned* rows = reinterpret_cast<unsigned*>(tile + 64 * HN_LD);         // 64
-    float* dd = reinterpret_cast<float*>(rows + 64);                         // 64
-    __shared__ unsigned s_cur; __shared__ int s_flag; __shared__ float s_dist;
-    const int q = blockIdx.x, lane = threadIdx.x;
-    const float* __restrict__ qv = Qp + (long)q * g.ld;
-    unsigned* vis = visited + (long)q * vwords;
-    unsigned long long n_eval = 0, n_exp = 0;
+// LDS work area of one wave (search and insert kernels)
+struct HnswLds { HC* cand; HC* res; float* tile; unsigned* rows; float* dd; unsigned* s_cur; int* s_flag; float* s_dist; };
 
-    // ---- phase 1: greedy descent through the upper layers (hnsw_index_search.go:271-296) ----
-    unsigned curr = g.entry;
-    if (lane == 0) rows[0] = curr;
-    __builtin_amdgcn_wave_barrier();
-    float d0 = wave_dists<METRIC>(g.V, g.ld, qv, rows, 1, tile);
-    float curr_dist = __shfl(d0, 0, 64);
-    n_eval += 1;
-    for (int lc = g.max_level; lc > 0; lc--) {
+// greedy descent through layers (from_layer .. to_layer+1): hnsw_index_search.go:274-300 / insertNode hnsw_index.go:497-518
+template <int METRIC>
+__device__ __forceinline__ void hn_descend(const HnswGraph& g, const float* __restrict__ qv, int from_layer, int to_layer, unsigned& curr, float& curr_dist,
+                                           const HnswLds& L, unsigned long long& n_eval) {
+    const int lane = threadIdx.x;
+    for (int lc = from_layer; lc > to_layer; lc--) {
         bool changed = true;
         while (changed) {
             changed = false;
             const unsigned node = curr;                 // `node := s.index.nodes[curr]` — its edge list is scanned to the end
             if (lc <= g.level[node]) {                  // `if lc < len(node.Edges)`
                 const long s = g.slot_base[node] + lc;
-                const long off = g.edge_off[s]; const int deg = (int)(g.edge_off[s + 1] - off);
+                const long off = g.edge_off[s]; const int deg = g.deg[s];
                 for (int b0 = 0; b0 < deg; b0 += 64) {
                     const int cnt = min(64, deg - b0);
                     unsigned nb = HN_NONE;
                     if (lane < cnt) { nb = g.edges[off + b0 + lane]; if (bit_get(g.deleted, nb)) nb = HN_NONE; }   // deleted neighbours are skipped
-                    rows[lane] = nb;
+                    L.rows[lane] = nb;
                     __builtin_amdgcn_wave_barrier();
-                    const float d = wave_dists<METRIC>(g.V, g.ld, qv, rows, cnt, tile);
-                    dd[lane] = d;
+                    const float d = wave_dists<METRIC>(g.V, g.ld, qv, L.rows, cnt, L.tile);
+                    L.dd[lane] = d;
                     __builtin_amdgcn_wave_barrier();
                     if (lane == 0) {
                         unsigned c = curr; float cd = curr_dist; int ch = 0;
-                        for (int j = 0; j < cnt; j++) if (rows[j] != HN_NONE && dd[j] < cd) { cd = dd[j]; c = rows[j]; ch = 1; }
-                        s_cur = c; s_flag = ch; s_dist = cd;
+                        for (int j = 0; j < cnt; j++) if (L.rows[j] != HN_NONE && L.dd[j] < cd) { cd = L.dd[j]; c = L.rows[j]; ch = 1; }
+                        *L.s_cur = c; *L.s_flag = ch; *L.s_dist = cd;
                     }
                     __builtin_amdgcn_wave_barrier();
-                    curr = s_cur; curr_dist = s_dist; if (s_flag) changed = true;
+                    curr = *L.s_cur; curr_dist = *L.s_dist; if (*L.s_flag) changed = true;
                     __builtin_amdgcn_wave_barrier();
                     n_eval += cnt;
                 }
             }
         }
     }
+}
 
-    // ---- phase 2: searchLayer(query, curr, ef, 0) (hnsw_index.go:565-629) ----
+// HNSWIndex.searchLayer (hnsw_index.go:565-629) on `layer` with Go container/heap semantics; leaves the result max-heap in L.res
+// (nres entries). `vis` must be all-clear on entry. Returns the overflow flag of the candidate heap.
+template <int METRIC>
+__device__ __forceinline__ int hn_search_layer(const HnswGraph& g, const float* __restrict__ qv, unsigned entry, int ef, int layer, unsigned* __restrict__ vis,
+                                               const HnswLds& L, int& nres_out, unsigned long long& n_eval, unsigned long long& n_exp) {
+    const int lane = threadIdx.x;
+    HC* cand = L.cand; HC* res = L.res;
     int ncand = 0, nres = 0, overflow = 0;
     {
-        const bool dead = bit_get(g.deleted, curr);
-        if (lane == 0) rows[0] = curr;
+        const bool dead = bit_get(g.deleted, entry);
+        if (lane == 0) L.rows[0] = entry;
         __builtin_amdgcn_wave_barrier();
-        const float d = wave_dists<METRIC>(g.V, g.ld, qv, rows, 1, tile);
+        const float d = wave_dists<METRIC>(g.V, g.ld, qv, L.rows, 1, L.tile);
         if (lane == 0) {
-            if (!dead) { HC x{curr, d}; heap_push<false>(cand, ncand, x); heap_push<true>(res, nres, x); }
-            atomicOr(&vis[curr >> 5], 1u << (curr & 31));
+            if (!dead) { HC x{entry, d}; heap_push<false>(cand, ncand, x); heap_push<true>(res, nres, x); }
+            atomicOr(&vis[entry >> 5], 1u << (entry & 31));
         }
         n_eval += 1;
     }
@@ -188,15 +184,16 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswGraph g, const floa
                 if (nres >= ef && cur.d > res[0].d) stop = 1;      // early termination hnsw_index.go:592-594
                 cid = cur.id;
             }
-            s_flag = stop; s_cur = cid;
+            *L.s_flag = stop; *L.s_cur = cid;
         }
         __builtin_amdgcn_wave_barrier();
-        const int stop = s_flag; const unsigned cid = s_cur;
+        const int stop = *L.s_flag; const unsigned cid = *L.s_cur;
         __builtin_amdgcn_wave_barrier();
         if (stop) break;
         n_exp += 1;
-        const long s = g.slot_base[cid];
-        const long off = g.edge_off[s]; const int deg = (int)(g.edge_off[s + 1] - off);
+        if (layer > g.level[cid]) continue;                                            // `if layer < len(node.Edges)`
+        const long s = g.slot_base[cid] + layer;
+        const long off = g.edge_off[s]; const int deg = g.deg[s];
         for (int b0 = 0; b0 < deg; b0 += 64) {
             const int cnt = min(64, deg - b0);
             unsigned nb = HN_NONE;
@@ -208,18 +205,18 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswGraph g, const floa
                     if ((old >> (nb & 31)) & 1u) nb = HN_NONE;
                 }
             }
-            rows[lane] = nb;
+            L.rows[lane] = nb;
             __builtin_amdgcn_wave_barrier();
-            const float d = wave_dists<METRIC>(g.V, g.ld, qv, rows, cnt, tile);
-            dd[lane] = d;
+            const float d = wave_dists<METRIC>(g.V, g.ld, qv, L.rows, cnt, L.tile);
+            L.dd[lane] = d;
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) {
                 for (int j = 0; j < cnt; j++) {
-                    if (rows[j] == HN_NONE) continue;
-                    const float dj = dd[j];
+                    if (L.rows[j] == HN_NONE) continue;
+                    const float dj = L.dd[j];
                     if (nres < ef || dj < res[0].d) {
                         if (ncand >= HN_CAND_CAP) { overflow = 1; continue; }
-                        HC x{rows[j], dj};
+                        HC x{L.rows[j], dj};
                         heap_push<false>(cand, ncand, x);
                         heap_push<true>(res, nres, x);
                         if (nres > ef) (void)heap_pop<true>(res, nres);
@@ -230,14 +227,152 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswGraph g, const floa
             n_eval += cnt;
         }
     }
+    // the heap sizes live in lane 0's registers: publish the result count
+    if (lane == 0) { *L.s_flag = nres; *L.s_cur = (unsigned)overflow; }
+    __builtin_amdgcn_wave_barrier();
+    nres_out = *L.s_flag; overflow = (int)*L.s_cur;
+    __builtin_amdgcn_wave_barrier();
+    return overflow;
+}
+
+__device__ __forceinline__ HnswLds hn_carve(unsigned char* smem, unsigned* s_cur, int* s_flag, float* s_dist) {
+    HnswLds L;
+    L.cand = reinterpret_cast<HC*>(smem);                                    // HN_CAND_CAP
+    L.res = L.cand + HN_CAND_CAP;                                            // ef + 1
+    L.tile = reinterpret_cast<float*>(L.res + (HN_EF_MAX + 1));              // 64 x HN_LD
+    L.rows = reinterpret_cast<unsigned*>(L.tile + 64 * HN_LD);               // 64
+    L.dd = reinterpret_cast<float*>(L.rows + 64);                            // 64
+    L.s_cur = s_cur; L.s_flag = s_flag; L.s_dist = s_dist;
+    return L;
+}
+constexpr size_t HN_LDS_BYTES = sizeof(HC) * (HN_CAND_CAP + HN_EF_MAX + 1) + sizeof(float) * 64 * HN_LD + 64 * 4 + 64 * 4 + 64;
+
+template <int METRIC>
+__global__ __launch_bounds__(64) void hnsw_search_kernel(HnswGraph g, const float* __restrict__ Qp, int ef, unsigned* __restrict__ visited /*[B][vwords]*/,
+                                                         long vwords, unsigned* __restrict__ res_idx, float* __restrict__ res_dist,
+                                                         int* __restrict__ res_cnt, int* __restrict__ status, unsigned long long* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned s_cur; __shared__ int s_flag; __shared__ float s_dist;
+    const HnswLds L = hn_carve(smem, &s_cur, &s_flag, &s_dist);
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const float* __restrict__ qv = Qp + (long)q * g.ld;
+    unsigned* vis = visited + (long)q * vwords;
+    unsigned long long n_eval = 0, n_exp = 0;
+
+    // ---- phase 1: greedy descent through the upper layers (hnsw_index_search.go:271-296) ----
+    unsigned curr = g.entry;
+    if (lane == 0) L.rows[0] = curr;
+    __builtin_amdgcn_wave_barrier();
+    float d0 = wave_dists<METRIC>(g.V, g.ld, qv, L.rows, 1, L.tile);
+    float curr_dist = __shfl(d0, 0, 64);
+    n_eval += 1;
+    hn_descend<METRIC>(g, qv, g.max_level, 0, curr, curr_dist, L, n_eval);
+
+    // ---- phase 2: searchLayer(query, curr, ef, 0) (hnsw_index.go:565-629) ----
+    int nres = 0;
+    const int overflow = hn_search_layer<METRIC>(g, qv, curr, ef, 0, vis, L, nres, n_eval, n_exp);
     // drain the result heap into an ascending array (hnsw_index.go:623-626)
     if (lane == 0) {
-        const int n = nres;
-        for (int i = n - 1; i >= 0; i--) { HC x = heap_pop<true>(res, nres); res_idx[(long)q * ef + i] = x.id; res_dist[(long)q * ef + i] = x.d; }
+        const int n = nres; int m = nres;
+        for (int i = n - 1; i >= 0; i--) { HC x = heap_pop<true>(L.res, m); res_idx[(long)q * ef + i] = x.id; res_dist[(long)q * ef + i] = x.d; }
         res_cnt[q] = n;
         if (overflow) *status = 1;
         if (stats) { atomicAdd(&stats[0], n_eval); atomicAdd(&stats[1], n_exp); }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// insertNode on the GPU (hnsw_index.go:493-552 with selectNeighbors :637-656 and pruneConnections :667-694), one wave, the
+// nodes of a batch strictly one after the other — the reference's semantics are sequential (every insertion searches the
+// graph the previous ones left behind), so the parallelism is the same as in the search: the neighbour batch.
+// The nodes [first, first + count) already have their vectors, levels and (empty) edge slots in place.
+// state[0] = maxLevel, state[1] = entry point (dense index), state[2] = 1 once the graph has an entry point.
+// Reference quirks kept: maxLevel is raised BEFORE the descent (hnsw_index.go:258-260) and the entry point never moves;
+// pruneConnections runs while the new node is not yet in idx.nodes (:281-282), so a full neighbour list drops the fresh
+// back-edge and is merely re-sorted by distance.
+// ------------------------------------------------------------------------------------------------
+template <int METRIC>
+__global__ __launch_bounds__(64) void hnsw_insert_kernel(HnswGraph g, int* __restrict__ deg_rw, long first, long count, int M, int efc, unsigned* __restrict__ vis,
+                                                         long vwords, int* __restrict__ state, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned s_cur; __shared__ int s_flag; __shared__ float s_dist;
+    const HnswLds L = hn_carve(smem, &s_cur, &s_flag, &s_dist);
+    unsigned* sel = reinterpret_cast<unsigned*>(smem + HN_LDS_BYTES);          // neighbours selected on the current layer (<= max(2M, efc))
+    float* pd = reinterpret_cast<float*>(sel + HN_EF_MAX + 1);                 // prune: distances of a neighbour's list (<= capacity)
+    unsigned* pe = reinterpret_cast<unsigned*>(pd + 256);                      // prune: the list itself
+    const int lane = threadIdx.x;
+    unsigned long long n_eval = 0, n_exp = 0;
+    int ml = state[0], entry = state[1], has_entry = state[2];                 // wave-uniform; written back at the end
+    for (long t = 0; t < count; t++) {
+        const unsigned ix = (unsigned)(first + t);
+        const int lx = g.level[ix];
+        const float* __restrict__ xv = g.V + (long)ix * g.ld;
+        if (lx > ml) ml = lx;                                                  // `if level > idx.maxLevel { idx.maxLevel = level }` before insertNode
+        if (!has_entry) { entry = (int)ix; has_entry = 1; continue; }          // first node of an empty graph: becomes the entry point (:266-271)
+        g.n = ix;                                                              // nodes visible to this insertion: everything before it
+        g.entry = (unsigned)entry; g.max_level = ml;
+        unsigned curr = g.entry;
+        if (lane == 0) L.rows[0] = curr;
+        __builtin_amdgcn_wave_barrier();
+        float d0 = wave_dists<METRIC>(g.V, g.ld, xv, L.rows, 1, L.tile);
+        float curr_dist = __shfl(d0, 0, 64);
+        hn_descend<METRIC>(g, xv, ml, lx, curr, curr_dist, L, n_eval);
+        for (int lc = lx; lc >= 0; lc--) {
+            for (long w = lane; w < vwords; w += 64) vis[w] = 0u;              // a fresh visited set per searchLayer call (:566)
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            int nres = 0;
+            if (hn_search_layer<METRIC>(g, xv, curr, efc, lc, vis, L, nres, n_eval, n_exp) && lane == 0) *status = 1;
+            // candidates ascending = the drained result heap (:623-626); selectNeighbors keeps the first Mmax (stable order)
+            const int Mmax = lc == 0 ? 2 * M : M;
+            if (lane == 0) {
+                int m = nres;
+                for (int i = nres - 1; i >= 0; i--) { HC x = heap_pop<true>(L.res, m); if (i < HN_EF_MAX + 1) sel[i] = x.id; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int nsel = min(nres, Mmax);
+            const long sx = g.slot_base[ix] + lc; const long offx = g.edge_off[sx];
+            for (int i = 0; i < nsel; i++) {
+                const unsigned nb = sel[i];
+                if (lane == 0) { g.edges[offx + i] = nb; }                      // node.Edges[lc] = append(node.Edges[lc], neighborID)
+                if (lc <= g.level[nb]) {
+                    const long sn = g.slot_base[nb] + lc; const long offn = g.edge_off[sn];
+                    const int dn = deg_rw[sn];
+                    if (dn < Mmax) {                                           // room: plain append of the back-edge
+                        if (lane == 0) { g.edges[offn + dn] = ix; deg_rw[sn] = dn + 1; }
+                    } else {
+                        // pruneConnections(nb, lc, Mmax) with len = Mmax + 1: the fresh back-edge is not in idx.nodes yet and is dropped,
+                        // the Mmax old entries are re-sorted by their distance to nb (stable: sort.Slice on distance, canonical order)
+                        const float* __restrict__ nv = g.V + (long)nb * g.ld;
+                        for (int b0 = 0; b0 < dn; b0 += 64) {
+                            const int cnt = min(64, dn - b0);
+                            unsigned e = HN_NONE;
+                            if (lane < cnt) e = g.edges[offn + b0 + lane];
+                            L.rows[lane] = e;
+                            __builtin_amdgcn_wave_barrier();
+                            const float d = wave_dists<METRIC>(g.V, g.ld, nv, L.rows, cnt, L.tile);
+                            if (lane < cnt) { pd[b0 + lane] = d; pe[b0 + lane] = e; }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        for (int j = lane; j < dn; j += 64) {                  // rank by counting: stable ascending
+                            const float dj = pd[j]; int rank = 0;
+                            for (int i2 = 0; i2 < dn; i2++) { const float di = pd[i2]; rank += (di < dj || (di == dj && i2 < j)) ? 1 : 0; }
+                            g.edges[offn + rank] = pe[j];
+                        }
+                        __threadfence_block();
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                __threadfence_block();
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (lane == 0) deg_rw[sx] = nsel;
+            if (nres > 0) curr = sel[0];                                       // `if len(candidates) > 0 { curr = candidates[0].id }`
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (lane == 0) { state[0] = ml; state[1] = entry; state[2] = has_entry; }
 }
 
 // D[q][i] = res_dist[q][i] unless the node is filtered out (hnsw_index_search.go:321-325)
@@ -254,7 +389,10 @@ __global__ __launch_bounds__(256) void hnsw_mask_kernel(const unsigned* __restri
 struct HNSWIndex : comet_index {
     int M = 16, efC = 200, efS = 200;
     int64_t n = 0; int max_level = -1; uint32_t entry = 0;   // entry: dense node index
-    DevBuf V, ids_dev, level, slot_base, edge_off, edges, del_bm;
+    DevBuf V, ids_dev, level, slot_base, edge_off, deg_dev, edges, del_bm, state_dev, ins_vis;
+    int64_t n_slots = 0, edge_cap = 0;       // slots (sum of level+1) and total edge capacity in use
+    bool mirror_dirty = false;               // the device graph changed (GPU insert): host mirror is rebuilt before Flush / WriteTo
+    uint64_t level_rng = 0x9E3779B97F4A7C15ull;
     std::vector<uint32_t> ids; std::unordered_map<uint32_t, uint32_t> id2idx;
     // host mirror of the graph as loaded (hnswNode{Level, Edges} hnsw_index.go:50-61): Flush and WriteTo work on it
     std::vector<int32_t> h_levels; std::vector<int64_t> h_eoff; std::vector<uint32_t> h_edges;   // h_edges: neighbour NODE IDS, per (node, layer)
@@ -266,8 +404,107 @@ struct HNSWIndex : comet_index {
     bool contains_id(uint32_t id) const override { return id2idx.count(id) != 0; }
     int64_t row_of_id(uint32_t id) override { auto it = id2idx.find(id); return it == id2idx.end() ? -1 : (int64_t)it->second; }
     const float* rows_dev() const override { return V.as<float>(); }
-    int64_t add_dev(const uint32_t*, const uint32_t*, const float*, int64_t, int64_t*, float*) override {
-        COMET_FAIL(COMET_ERR_UNSUPPORTED, "HNSW graph construction on the GPU is not built yet: load a graph with comet_hnsw_load_graph");
+    // randomLevel hnsw_index.go:474-484: geometric(p = 1/M), capped at 16. The reference draws from the unseeded global
+    // math/rand/v2, so no run of it is reproducible; this index draws from its own SplitMix64 stream (u = (next >> 11) * 2^-53).
+    int random_level() {
+        const double prob = 1.0 / (double)M; int lv = 0;
+        while (lv < 16) {
+            uint64_t z = (level_rng += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+            if (!((double)(z >> 11) * (1.0 / 9007199254740992.0) < prob)) break;
+            lv++;
+        }
+        return lv;
+    }
+    const int32_t* pending_levels = nullptr;    // comet_hnsw_add_with_levels: explicit levels for the next add_dev call
+
+    // HNSWIndex.Add hnsw_index.go:228-288 for a batch, inserted strictly in order by one wave (hnsw_insert_kernel)
+    int64_t add_dev(const uint32_t*, const uint32_t* ids_h, const float* vecs_dev, int64_t m, int64_t* zero_at, float* normalized_dev) override {
+        *zero_at = -1;
+        if (m <= 0) return 0;
+        if (2 * M > 256) COMET_FAIL(COMET_ERR_UNSUPPORTED, "GPU insertion supports M <= 128");
+        if (efC > HN_EF_MAX) COMET_FAIL(COMET_ERR_UNSUPPORTED, "efConstruction %d exceeds the on-device limit %d", efC, HN_EF_MAX);
+        V.reserve((size_t)(n + m) * ld * sizeof(float), c->stream, (size_t)n * ld * sizeof(float));
+        float* dst = V.as<float>() + (size_t)n * ld;
+        int32_t* zf = c->salloc<int32_t>(m);
+        launch_ingest_rows(c, metric, vecs_dev, m, dim, dst, ld, zf);
+        int64_t added = m;
+        if (metric == COMET_COSINE) {
+            std::vector<int32_t> h(m);
+            c->d2h(h.data(), zf, m * sizeof(int32_t));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            for (int64_t i = 0; i < m; i++) if (h[i]) { *zero_at = i; added = i; break; }
+        }
+        if (added <= 0) return 0;
+        for (int64_t i = 0; i < added; i++) {
+            if (ids_h[i] == 0) COMET_FAIL(COMET_ERR_UNSUPPORTED, "HNSW on the GPU needs explicit non-zero node ids (the reference auto-assigns ids for 0, hnsw_index.go:248-256)");
+            if (id2idx.count(ids_h[i])) COMET_FAIL(COMET_ERR_UNSUPPORTED, "node id %u is already in the graph (re-adding an id is not supported on the GPU)", ids_h[i]);
+        }
+        if (normalized_dev) launch_unpad_rows(c, dst, added, ld, normalized_dev, dim);
+        // levels + empty edge slots of the new nodes
+        std::vector<int32_t> lv(added); std::vector<int64_t> sb(added + 1), eo; std::vector<uint32_t> nid(ids_h, ids_h + added);
+        int64_t slots = n_slots, ecap = edge_cap;
+        for (int64_t i = 0; i < added; i++) {
+            lv[i] = pending_levels ? pending_levels[i] : random_level();
+            if (lv[i] < 0 || lv[i] > 64) COMET_FAIL(COMET_ERR_INVALID_ARG, "node level %d out of range", lv[i]);
+            sb[i] = slots;
+            for (int l = 0; l <= lv[i]; l++) { eo.push_back(ecap); ecap += (l == 0 ? 2 * M : M); }
+            slots += lv[i] + 1;
+        }
+        sb[added] = slots; eo.push_back(ecap);
+        level.reserve((size_t)(n + added) * 4, c->stream, (size_t)n * 4);
+        ids_dev.reserve((size_t)(n + added) * 4, c->stream, (size_t)n * 4);
+        slot_base.reserve((size_t)(n + added + 1) * 8, c->stream, (size_t)(n + 1) * 8);
+        edge_off.reserve((size_t)(slots + 1) * 8, c->stream, (size_t)(n_slots + 1) * 8);
+        deg_dev.reserve((size_t)std::max<int64_t>(slots, 1) * 4, c->stream, (size_t)n_slots * 4);
+        edges.reserve((size_t)std::max<int64_t>(ecap, 1) * 4, c->stream, (size_t)edge_cap * 4);
+        c->h2d(level.as<int32_t>() + n, lv.data(), added * 4);
+        c->h2d(ids_dev.as<uint32_t>() + n, nid.data(), added * 4);
+        c->h2d(slot_base.as<int64_t>() + n, sb.data(), (added + 1) * 8);
+        c->h2d(edge_off.as<int64_t>() + n_slots, eo.data(), eo.size() * 8);
+        c->zero(deg_dev.as<int32_t>() + n_slots, (size_t)(slots - n_slots) * 4);
+        state_dev.reserve(16, c->stream, 0);
+        const int32_t st[3] = {max_level, (int32_t)entry, (n > 0 && max_level >= 0) ? 1 : 0};
+        c->h2d(state_dev.p, st, sizeof(st));
+        const int64_t vwords = (n + added + 31) / 32;
+        ins_vis.reserve((size_t)vwords * 4, c->stream, 0);
+        int32_t* status = c->salloc<int32_t>(1);
+        c->zero(status, 4);
+        HIP_CHECK(hipStreamSynchronize(c->stream));          // the host vectors above are temporaries
+        HnswGraph g{V.as<float>(), ld, n, level.as<int>(), (const long*)slot_base.p, (const long*)edge_off.p, deg_dev.as<int>(), edges.as<uint32_t>(), entry, max_level, deleted_bitmap()};
+        const size_t lds = HN_LDS_BYTES + (HN_EF_MAX + 1 + 256 + 256) * 4;
+        {
+            ProfScope ps(c, "hnsw_insert");
+#define HI(MT) do { HIP_CHECK(hipFuncSetAttribute((const void*)hnsw_insert_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                    hnsw_insert_kernel<MT><<<dim3(1), dim3(64), lds, c->stream>>>(g, deg_dev.as<int>(), n, added, M, efC, ins_vis.as<uint32_t>(), vwords, state_dev.as<int>(), status); } while (0)
+            switch (metric) { case COMET_L2: HI(COMET_L2); break; case COMET_L2SQ: HI(COMET_L2SQ); break; default: HI(COMET_COSINE); break; }
+#undef HI
+            LAUNCH_CHECK();
+        }
+        int32_t hst[3], hs = 0;
+        c->d2h(hst, state_dev.p, sizeof(hst)); c->d2h(&hs, status, 4);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (hs) COMET_FAIL(COMET_ERR_UNSUPPORTED, "HNSW candidate heap overflow during insertion (more than %d live candidates): lower efConstruction", HN_CAND_CAP);
+        for (int64_t i = 0; i < added; i++) { id2idx[nid[i]] = (uint32_t)(n + i); ids.push_back(nid[i]); }
+        h_levels.insert(h_levels.end(), lv.begin(), lv.end());
+        max_level = hst[0]; entry = (uint32_t)hst[1]; entry_id = ids[entry];
+        n += added; n_slots = slots; edge_cap = ecap;
+        trained = true; del_dirty = true; mirror_dirty = true;
+        return added;
+    }
+
+    // rebuild the host mirror (edge lists as node ids) from the device graph after GPU insertions
+    void sync_mirror() {
+        if (!mirror_dirty) return;
+        std::vector<int64_t> eo(n_slots + 1); std::vector<int32_t> dg(std::max<int64_t>(n_slots, 1)); std::vector<uint32_t> ed(std::max<int64_t>(edge_cap, 1));
+        c->d2h(eo.data(), edge_off.p, (size_t)(n_slots + 1) * 8); c->d2h(dg.data(), deg_dev.p, (size_t)n_slots * 4); c->d2h(ed.data(), edges.p, (size_t)edge_cap * 4);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        h_eoff.assign(n_slots + 1, 0); h_edges.clear();
+        for (int64_t sl = 0; sl < n_slots; sl++) {
+            for (int j = 0; j < dg[sl]; j++) h_edges.push_back(ids[ed[eo[sl] + j]]);
+            h_eoff[sl + 1] = (int64_t)h_edges.size();
+        }
+        mirror_dirty = false;
     }
 
     // stored (preprocessed) vectors, dense n x dim, host
@@ -291,6 +528,7 @@ struct HNSWIndex : comet_index {
     // visited in ascending id order (first node at maxLevel, else the first node of the highest remaining level).
     void flush() override {
         if (deleted.empty()) return;
+        sync_mirror();
         std::vector<float> vecs = download_vectors();
         std::vector<int64_t> order(n);
         for (int64_t i = 0; i < n; i++) order[i] = i;
@@ -334,19 +572,27 @@ struct HNSWIndex : comet_index {
         // device copy: dense indices, duplicate neighbours inside one edge list removed (first occurrence kept). A duplicate
         // never changes the reference's result — the second occurrence is already in `visited` (hnsw_index.go:604), and in the
         // greedy descent it recomputes an equal distance — but it would make the kernel's parallel claim of `visited` unordered.
+        // every slot gets the capacity insertNode needs (2M on layer 0, M above; more if the loaded list is longer)
         std::vector<uint32_t> eidx; eidx.reserve(std::max<int64_t>(ne, 1));
-        std::vector<int64_t> deoff(slots + 1, 0);
+        std::vector<int64_t> deoff(slots + 1, 0); std::vector<int32_t> ddeg(std::max<int64_t>(slots, 1), 0);
         uint32_t new_entry = 0;
-        for (int64_t sl = 0; sl < slots; sl++) {
-            const size_t s0 = eidx.size();
-            for (int64_t e = eoff[sl]; e < eoff[sl + 1]; e++) {
-                auto it = nmap.find(edge_ids[e]);
-                if (it == nmap.end()) COMET_FAIL(COMET_ERR_INVALID_ARG, "edge references unknown node id %u", edge_ids[e]);
-                bool dup = false;
-                for (size_t j = s0; j < eidx.size(); j++) if (eidx[j] == it->second) { dup = true; break; }
-                if (!dup) eidx.push_back(it->second);
-            }
-            deoff[sl + 1] = (int64_t)eidx.size();
+        {
+            int64_t sl = 0;
+            for (int64_t i = 0; i < nn; i++)
+                for (int l = 0; l <= levels[i]; l++, sl++) {
+                    const size_t s0 = eidx.size();
+                    for (int64_t e = eoff[sl]; e < eoff[sl + 1]; e++) {
+                        auto it = nmap.find(edge_ids[e]);
+                        if (it == nmap.end()) COMET_FAIL(COMET_ERR_INVALID_ARG, "edge references unknown node id %u", edge_ids[e]);
+                        bool dup = false;
+                        for (size_t j = s0; j < eidx.size(); j++) if (eidx[j] == it->second) { dup = true; break; }
+                        if (!dup) eidx.push_back(it->second);
+                    }
+                    ddeg[sl] = (int32_t)(eidx.size() - s0);
+                    const size_t cap = std::max<size_t>(eidx.size() - s0, (size_t)(l == 0 ? 2 * M : M));
+                    eidx.resize(s0 + cap, 0u);
+                    deoff[sl + 1] = (int64_t)eidx.size();
+                }
         }
         if (eidx.empty()) eidx.push_back(0);
         if (nn > 0 && maxl >= 0) { auto it = nmap.find(entry_id_in); if (it == nmap.end()) COMET_FAIL(COMET_ERR_INVALID_ARG, "entry point %u is not a node", entry_id_in); new_entry = it->second; }
@@ -363,6 +609,8 @@ struct HNSWIndex : comet_index {
         }
         ids_dev.reserve(std::max<size_t>(4, nn * 4), c->stream, 0); level.reserve(std::max<size_t>(4, nn * 4), c->stream, 0);
         slot_base.reserve((nn + 1) * 8, c->stream, 0); edge_off.reserve((slots + 1) * 8, c->stream, 0); edges.reserve(eidx.size() * 4, c->stream, 0);
+        deg_dev.reserve(ddeg.size() * 4, c->stream, 0); c->h2d(deg_dev.p, ddeg.data(), ddeg.size() * 4);
+        n_slots = slots; edge_cap = deoff[slots]; mirror_dirty = false;
         c->h2d(ids_dev.p, ids.data(), nn * 4); c->h2d(level.p, levels, nn * 4);
         c->h2d(slot_base.p, sb.data(), (nn + 1) * 8); c->h2d(edge_off.p, deoff.data(), (slots + 1) * 8); c->h2d(edges.p, eidx.data(), eidx.size() * 4);
         HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -374,6 +622,7 @@ struct HNSWIndex : comet_index {
     // empty bitmap. Nodes in ascending id order (the reference ranges over a Go map).
     void write_to(Sink& s) override {
         flush();
+        sync_mirror();
         write_header(s, "HNSW", dim, metric);
         s.u32((uint32_t)M); s.u32((uint32_t)efC); s.u32((uint32_t)efS);
         s.f64(1.0 / go_log((double)M));                     // levelMult = 1/ln(M) hnsw_index.go:206
@@ -463,8 +712,8 @@ struct HNSWIndex : comet_index {
         int32_t* status = c->salloc<int32_t>(1);
         unsigned long long* st = c->salloc<unsigned long long>(2);
         c->zero(status, 4); c->zero(st, 16);
-        HnswGraph g{V.as<float>(), ld, n, level.as<int>(), (const long*)slot_base.p, (const long*)edge_off.p, edges.as<uint32_t>(), entry, max_level, deleted_bitmap()};
-        const size_t lds = sizeof(HC) * (HN_CAND_CAP + HN_EF_MAX + 1) + sizeof(float) * 64 * HN_LD + 64 * 4 + 64 * 4 + 64;
+        HnswGraph g{V.as<float>(), ld, n, level.as<int>(), (const long*)slot_base.p, (const long*)edge_off.p, deg_dev.as<int>(), edges.as<uint32_t>(), entry, max_level, deleted_bitmap()};
+        const size_t lds = HN_LDS_BYTES;
         {
             ProfScope ps(c, "hnsw_search");
 #define HS(MT) do { HIP_CHECK(hipFuncSetAttribute((const void*)hnsw_search_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -520,6 +769,49 @@ int comet_hnsw_create(comet_ctx* c, int dim, int metric, int m, int ef_construct
         h->c = c; h->kind = COMET_KIND_HNSW; h->dim = dim; h->ld = padded_dim(dim); h->metric = metric; h->M = m; h->efC = ef_construction; h->efS = ef_search;
         h->trained = true;
         *out = h;
+        return (int)COMET_OK;
+    });
+}
+
+// Add with explicit node levels (hnswNode.Level): what Add() does when randomLevel() returned levels[i] for vector i.
+int comet_hnsw_add_with_levels(comet_index* idx, const uint32_t* ids, const float* vecs, const int32_t* levels, int64_t n, int64_t* out_added) {
+    return guarded([&] {
+        if (out_added) *out_added = 0;
+        if (idx->kind != COMET_KIND_HNSW) COMET_FAIL(COMET_ERR_INVALID_ARG, "not an HNSW index");
+        if (n <= 0) return (int)COMET_OK;
+        auto* h = static_cast<HNSWIndex*>(idx);
+        h->pending_levels = levels;
+        const int rc = comet_index_add(idx, ids, vecs, n, out_added, nullptr);
+        h->pending_levels = nullptr;
+        return rc;
+    });
+}
+// seed of the index's own level stream (the reference's is the unseeded global math/rand/v2)
+int comet_hnsw_set_level_seed(comet_index* idx, uint64_t seed) {
+    return guarded([&] {
+        if (idx->kind != COMET_KIND_HNSW) COMET_FAIL(COMET_ERR_INVALID_ARG, "not an HNSW index");
+        static_cast<HNSWIndex*>(idx)->level_rng = seed;
+        return (int)COMET_OK;
+    });
+}
+// Export the graph as comet_hnsw_load_graph takes it: two-call protocol (NULL arrays -> sizes only).
+int comet_hnsw_export_graph(comet_index* idx, int64_t* out_n, int64_t* out_slots, int64_t* out_edges, uint32_t* ids, int32_t* levels, float* vecs,
+                            int64_t* edge_offsets, uint32_t* edges, uint32_t* out_entry_id, int32_t* out_max_level) {
+    return guarded([&] {
+        if (idx->kind != COMET_KIND_HNSW) COMET_FAIL(COMET_ERR_INVALID_ARG, "not an HNSW index");
+        auto* h = static_cast<HNSWIndex*>(idx);
+        Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->scratch_reset();
+        h->sync_mirror();
+        if (out_n) *out_n = h->n;
+        if (out_slots) *out_slots = (int64_t)h->h_eoff.size() - 1;
+        if (out_edges) *out_edges = (int64_t)h->h_edges.size();
+        if (out_entry_id) *out_entry_id = h->n > 0 ? h->entry_id : 0;
+        if (out_max_level) *out_max_level = h->max_level;
+        if (ids) std::copy(h->ids.begin(), h->ids.end(), ids);
+        if (levels) std::copy(h->h_levels.begin(), h->h_levels.end(), levels);
+        if (edge_offsets) std::copy(h->h_eoff.begin(), h->h_eoff.end(), edge_offsets);
+        if (edges) std::copy(h->h_edges.begin(), h->h_edges.end(), edges);
+        if (vecs && h->n > 0) { std::vector<float> v = h->download_vectors(); std::copy(v.begin(), v.begin() + (size_t)h->n * h->dim, vecs); }
         return (int)COMET_OK;
     });
 }

@@ -812,6 +812,30 @@ class HNSWIndex(VectorIndex):
                                              v.ctypes.data_as(C.c_void_p), eo.ctypes.data_as(C.c_void_p), ed.ctypes.data_as(C.c_void_p),
                                              C.c_uint32(int(entry_id)), int(max_level)))
 
+    def add_with_levels(self, ids, vectors, levels) -> None:
+        """Add(): insertNode on the GPU for every vector in order, with the given hnswNode levels (the reference draws them from an
+        unseeded RNG; plain add()/add_batch() draws them from the index's own seeded stream)."""
+        ids = np.ascontiguousarray(ids, np.uint32); v = _f32(vectors); lv = np.ascontiguousarray(levels, np.int32)
+        if v.ndim != 2 or v.shape[1] != self.dim or ids.shape[0] != v.shape[0] or lv.shape[0] != v.shape[0]:
+            raise ValueError("ids / vectors / levels shape mismatch")
+        added = C.c_int64()
+        check(self.lib.comet_hnsw_add_with_levels(self.h, ids.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), lv.ctypes.data_as(C.c_void_p),
+                                                  v.shape[0], C.byref(added)))
+
+    def set_level_seed(self, seed: int) -> None:
+        check(self.lib.comet_hnsw_set_level_seed(self.h, C.c_uint64(int(seed))))
+
+    def export_graph(self):
+        """(ids, levels, vectors, edge_offsets, edges, entry_id, max_level) — the arrays load_graph takes."""
+        n, slots, ne = C.c_int64(), C.c_int64(), C.c_int64()
+        ent, ml = C.c_uint32(), C.c_int32()
+        check(self.lib.comet_hnsw_export_graph(self.h, C.byref(n), C.byref(slots), C.byref(ne), None, None, None, None, None, C.byref(ent), C.byref(ml)))
+        ids = np.zeros(n.value, np.uint32); levels = np.zeros(n.value, np.int32); vecs = np.zeros((n.value, self.dim), np.float32)
+        eoff = np.zeros(slots.value + 1, np.int64); edges = np.zeros(max(1, ne.value), np.uint32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(self.lib.comet_hnsw_export_graph(self.h, None, None, None, p(ids), p(levels), p(vecs), p(eoff), p(edges), C.byref(ent), C.byref(ml)))
+        return ids, levels, vecs, eoff, edges[:ne.value], ent.value, ml.value
+
     def _k_cap(self, k, nprobes):
         n = len(self)
         return max(1, min(1024, n if (k <= 0 or k > n) else k))

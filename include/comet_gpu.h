@@ -117,9 +117,21 @@ COMET_API int comet_hnsw_create(comet_ctx* ctx, int dim, int metric, int m, int 
 /* Load a graph built by the reference (or the oracle): n nodes in any order with their ids, levels
  * (hnswNode.Level), stored (already preprocessed) vectors n x dim, and for every (node, layer <= level) in
  * node-major order an edge list: edge_offsets has sum(level+1)+1 entries into `edges` (neighbour NODE IDS,
- * hnswNode.Edges hnsw_index.go:50-61). Graph construction on the GPU (insertNode) is not built yet. */
+ * hnswNode.Edges hnsw_index.go:50-61). */
 COMET_API int comet_hnsw_load_graph(comet_index* idx, int64_t n, const uint32_t* ids, const int32_t* levels, const float* vecs,
                                     const int64_t* edge_offsets, const uint32_t* edges, uint32_t entry_id, int32_t max_level);
+/* HNSW construction on the GPU: comet_index_add on an HNSW index runs insertNode (hnsw_index.go:493-552, selectNeighbors :637-656,
+ * pruneConnections :667-694) for the batch strictly in order — one wave walks the graph exactly as the reference does, its neighbour
+ * batches evaluated 64 lanes wide — and keeps the reference's quirks (maxLevel raised before the descent, entry point never promoted,
+ * a full neighbour list drops the fresh back-edge). Node levels come from the index's own SplitMix64 stream (geometric p = 1/M, cap 16,
+ * randomLevel :474-484; the reference draws from the unseeded global RNG, so its graphs are not reproducible either) or, with
+ * comet_hnsw_add_with_levels, from the caller — which makes the graph bit-identical to an insertion sequence with those levels.
+ * Limits: explicit non-zero ids, no re-adding of an id, M <= 128, efConstruction <= 1024. */
+COMET_API int comet_hnsw_add_with_levels(comet_index* idx, const uint32_t* ids, const float* vecs, const int32_t* levels, int64_t n, int64_t* out_added);
+COMET_API int comet_hnsw_set_level_seed(comet_index* idx, uint64_t seed);
+/* the graph as comet_hnsw_load_graph takes it (sizes with NULL arrays first) */
+COMET_API int comet_hnsw_export_graph(comet_index* idx, int64_t* out_n, int64_t* out_slots, int64_t* out_edges, uint32_t* ids, int32_t* levels,
+                                      float* vecs, int64_t* edge_offsets, uint32_t* edges, uint32_t* out_entry_id, int32_t* out_max_level);
 COMET_API int comet_index_destroy(comet_index* idx);
 
 COMET_API int comet_index_kind(const comet_index* idx);

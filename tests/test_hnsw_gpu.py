@@ -81,7 +81,90 @@ def test_hnsw_empty_and_limits(ctx):
     g = HNSWIndex(ctx, 8, L2_SQUARED)
     assert g.new_search().with_query(np.zeros(8, np.float32)).execute() == []     # empty graph (:258)
     with pytest.raises(CometError):
-        g.add(1, np.ones(8, np.float32))                                          # construction is not on the GPU yet
+        g.add(0, np.ones(8, np.float32))                                          # the GPU insert wants explicit non-zero ids
+    g.add(1, np.ones(8, np.float32))
+    with pytest.raises(CometError):
+        g.add(1, np.ones(8, np.float32))                                          # no re-adding of a live id
+    assert [r.id for r in g.new_search().with_query(np.ones(8, np.float32)).with_k(3).execute()] == [1]
     g2, o, X = build(ctx, L2_SQUARED, 300, 8, 4, 20, 20)
     with pytest.raises(CometError):
         g2.search_batch(X[:2], 5, ef_search=5000)
+
+
+def levels_for(n, m, seed):
+    """geometric levels like randomLevel (hnsw_index.go:474-484): p = 1/M, capped at 16"""
+    r = np.random.default_rng(seed)
+    lv = np.zeros(n, np.int32)
+    for i in range(n):
+        while r.random() < 1.0 / m and lv[i] < 16:
+            lv[i] += 1
+    return lv
+
+
+def same_graph(g, o):
+    gi, gl, gv, go, ge, gent, gml = g.export_graph()
+    oi, ol, ov, oo, oe = o.export()
+    assert np.array_equal(gi, oi) and np.array_equal(gl, ol) and np.array_equal(bits(gv), bits(ov))
+    assert np.array_equal(go, oo), "edge-list lengths differ"
+    assert np.array_equal(ge[:go[-1]], oe[:oo[-1]]), "edge lists differ"
+    assert gent == o.entry() and gml == o.max_level()
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_hnsw_insert_on_gpu_builds_the_reference_graph(ctx, metric):
+    """insertNode on the GPU (hnsw_index.go:493-552) with the levels the oracle is given: the edge lists — order included,
+    since pruneConnections (:667-694) re-sorts and the search order depends on it — the entry point and maxLevel are identical."""
+    n, d, m = 1500, 32, 6
+    X = synth(21, n, d); lv = levels_for(n, m, 5)
+    o = orc.HNSW(d, metric, m, 40, 30, seed=1)
+    g = HNSWIndex(ctx, d, metric, m, 40, 30)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    for i in range(n):
+        assert o.add(int(ids[i]), X[i], int(lv[i])) == 0
+    g.add_with_levels(ids[:700], X[:700], lv[:700])            # two batches: state carries over between launches
+    g.add_with_levels(ids[700:], X[700:], lv[700:])
+    assert len(g) == n
+    same_graph(g, o)
+    Q = synth(22, 12, d)
+    check(g, o, Q, 10, ef=64)
+    assert g.to_bytes() == o.to_bytes()                         # WriteTo (hnsw_index_serialization.go)
+
+
+def test_hnsw_insert_after_load_remove_and_flush(ctx):
+    g, o, X = build(ctx, L2_SQUARED, 600, 16, 5, 30, 30)
+    Y = synth(31, 300, 16); lv = levels_for(300, 5, 9)
+    for i in (5, 77, 300):
+        g.remove(i); assert o.remove(i) == 0
+    ids = np.arange(1001, 1301, dtype=np.uint32)
+    for i in range(300):
+        assert o.add(int(ids[i]), Y[i], int(lv[i])) == 0
+    g.add_with_levels(ids, Y, lv)
+    same_graph(g, o)
+    check(g, o, synth(32, 8, 16), 10, ef=50)
+    g.flush(); o.flush()                             # Flush (:348): hard delete + edge clean-up
+    assert g.to_bytes() == o.to_bytes()
+    check(g, o, synth(32, 8, 16), 10, ef=50)
+    Z = synth(33, 50, 16); lz = levels_for(50, 5, 10); idz = np.arange(2001, 2051, dtype=np.uint32)
+    for i in range(50):
+        assert o.add(int(idz[i]), Z[i], int(lz[i])) == 0
+    g.add_with_levels(idz, Z, lz)                                # and insertion continues on the flushed graph
+    same_graph(g, o)
+    check(g, o, synth(34, 8, 16), 10, ef=50)
+
+
+def test_hnsw_own_levels_are_seeded_and_searchable(ctx):
+    """add() without levels draws them from the index's seeded stream: same seed -> same graph, and the oracle given those levels builds it too."""
+    n, d = 4000, 24
+    X = synth(41, n, d); ids = np.arange(1, n + 1, dtype=np.uint32)
+    a = HNSWIndex(ctx, d, L2_SQUARED, 8, 64, 64); a.set_level_seed(123); a.add_batch(ids, X)
+    b = HNSWIndex(ctx, d, L2_SQUARED, 8, 64, 64); b.set_level_seed(123); b.add_batch(ids, X)
+    assert a.to_bytes() == b.to_bytes()
+    lv = a.export_graph()[1]
+    assert 0.05 < (lv > 0).mean() < 0.25 and lv.max() <= 16       # P(level > 0) = 1/M = 0.125
+    # recall is whatever the reference's construction gives (see test_hnsw_wide_degree_and_recall): the check is that the
+    # oracle, fed the levels this index drew, builds the same bytes and answers the same
+    o = orc.HNSW(d, L2_SQUARED, 8, 64, 64, seed=1)
+    for i in range(n):
+        assert o.add(int(ids[i]), X[i], int(lv[i])) == 0
+    assert a.to_bytes() == o.to_bytes()
+    check(a, o, synth(42, 16, d), 10, ef=128)
