@@ -558,7 +558,7 @@ struct PQFamilyIndex : comet_index {
         lay.compile(c);
         if (!il_dirty) return;
         il_dirty = false;
-        codes_il.reserve(std::max<size_t>(4, (size_t)lay.nslots * M4 * 4), c->stream, 0);
+        codes_il.reserve((size_t)(lay.nslots + adc_codes_pad()) * M4 * 4 + 4, c->stream, 0);   // + the scan's read-ahead past the last block
         launch_interleave_codes(c, codes_arr.as<uint32_t>(), M4, lay.row_of_slot.as<uint32_t>(), lay.nslots, codes_il.as<uint32_t>());
         HIP_CHECK(hipStreamSynchronize(c->stream));
     }

@@ -75,6 +75,7 @@ void launch_dist_list(Ctx* c, int metric, const float* X, int ld, const float* Q
 void launch_finalize_probe(Ctx* c, const uint32_t* pos, int B, int k_cap, const uint32_t* probe_list, int ldp, const int32_t* seg_off, int np,
                            const int64_t* list_base, const uint32_t* ids_of_slot, const int32_t* zflag, uint32_t* out_ids, int32_t* counts);
 size_t adc_lds_bytes(int M, int Ksub, int dim);
+int64_t adc_codes_pad();    // code slots the ADC scan may read (never use) past the last list
 void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* centroids, const float* codebooks, int M, int Ksub, int dsub,
                      const uint32_t* codes, int M4, const int64_t* list_base, const int32_t* list_len, const uint32_t* probe_list, int ldp,
                      int np, const int32_t* seg_off, const uint8_t* elig, int B, int nlist, int max_list_len, float* D, int64_t ldD);

@@ -298,56 +298,72 @@ void launch_finalize_probe(Ctx* c, const uint32_t* pos, int B, int k_cap, const 
 // ------------------------------------------------------------------------------------------------
 // PQ asymmetric-distance search (pq_index_search.go:243-306, ivfpq_index_search.go:285-321,350-390), three kernels:
 //
-//  pq_lut_kernel      builds, for every (query, probed list) PAIR, the M x KL table
+//  adc_order_kernel   sorts the (query, probed list) PAIRS of a sub-batch by list into SLOTS, every list's run padded to an
+//                     even length: slots 2d and 2d+1 (a DUO) always name the same list, the second may be a hole. It also
+//                     builds the work queues of the scan: per XCD, the (duo, segment) items that have codes to scan.
+//  pq_lut_kernel      builds, for every pair, the M x KL table
 //                       LUT[m][k] = sum_i ((q[m*dsub+i] - centroid[m*dsub+i]) - cb[m][k][i])^2
 //                     (KL = min(Ksub,256): codes are uint8, entries >= 256 can never be addressed) in exact float32,
-//                     dimension order, and stores it to HBM. A thread keeps ONE codeword in registers and walks the
-//                     pairs, so the codebook is read once per 32 pairs instead of once per pair (a fused build re-reads
-//                     all 786 KiB of codebooks per pair and is L2-bandwidth bound: 15 us per pair on the whole chip).
-//  order_pairs_kernel sorts the pairs of a sub-batch by probed list: workgroups scanning the same inverted list then run
-//                     at the same time and the list's codes come from L2 / Infinity Cache for all but the first.
-//  adc_scan_kernel    persistent 1024-thread workgroups pull (pair, segment) items from eight XCD-affine queues
-//                     (adjacent sorted pairs share an XCD and therefore an L2), DMA the pair's table into LDS (96 KiB at
-//                     M=96, Ksub=256: fits because gfx950 has 160 KiB per CU), and stream the list's codes — stored as
-//                     64-code blocks, word-interleaved so that a wave reads 256 contiguous bytes per load. A lane owns
-//                     one code of up to four blocks (four independent serial float32 chains), sums LUT[m][code[m]] in m
-//                     order (the reference's serial sum), takes the correctly-rounded sqrt and writes the distance.
+//                     dimension order, and stores it to HBM INTERLEAVED with its duo partner's: entry (m, k) of a duo is
+//                     the float2 {LUT_A[m][k], LUT_B[m][k]}. A thread keeps ONE codeword in registers and walks the
+//                     slots, so the codebook is read once per 32 pairs instead of once per pair.
+//  adc_scan_kernel    persistent 1024-thread workgroups pull items from eight XCD-affine queues (adjacent duos share an XCD
+//                     and therefore an L2). The scan is bound by LDS gathers — a wave's 64 random table reads hit the 32
+//                     four-byte banks about 3.1 deep (measured, and what 32 balls in 32 bins give) — so every gather is
+//                     made to serve TWO queries: one ds_read_b64 of the interleaved table returns both queries' entries
+//                     for the code byte (same list, same codes), at the cost of one ds_read_b32. The duo's table
+//                     (2 x 96 KiB at M=96, Ksub=256) does not fit in the 160 KiB LDS, so it streams through a two-deep
+//                     ring of PHASES of `mp` subspaces (LDS-DMA of phase p+1 runs under the gathers of phase p, across
+//                     items too); a lane's partial sums for its codes of the segment stay in registers across phases.
+//                     Codes are stored as 64-code blocks, word-interleaved, so a wave reads 256 contiguous bytes per
+//                     load. A lane owns one code of up to four blocks per pass (independent serial float32 chains), sums
+//                     LUT[m][code[m]] in m order (the reference's serial sum), takes the correctly-rounded sqrt and
+//                     writes both queries' distances.
 // ------------------------------------------------------------------------------------------------
 constexpr int ADC_THREADS = 1024;
 constexpr int ADC_WAVES = ADC_THREADS / 64;
 constexpr int ADC_CHAINS = 4;
 constexpr int ADC_PASS_CODES = ADC_WAVES * ADC_CHAINS * 64;    // codes one workgroup scans per pass (one block per chain per wave)
-constexpr int ADC_SEG_PASSES = 4;
-constexpr int ADC_SEG_CODES = ADC_PASS_CODES * ADC_SEG_PASSES;  // codes per item: long lists re-use the table for up to four passes
-constexpr int ADC_XCD_CHUNK = 4;                               // adjacent sorted pairs kept on one XCD
+constexpr int ADC_SEG_PASSES = 2;
+constexpr int ADC_SEG_CODES = ADC_PASS_CODES * ADC_SEG_PASSES;  // codes per item: their partial sums live in registers across the phases
+constexpr int ADC_XCD_CHUNK = 4;                               // adjacent duos kept on one XCD
+constexpr int ADC_G = 2;                                       // code words (4 subspaces each) per software-pipelined group
+constexpr int ADC_BUF_BYTES = 64 * 1024;                       // one phase buffer; two of them in LDS
+constexpr unsigned ADC_HOLE = 0xFFFFFFFFu;
 constexpr int LUT_PAIRS_PER_WG = 32;
 constexpr int ORDER_MAX_LISTS = 36 * 1024;                     // counting-sort bins that fit in LDS
 typedef float f32x4q __attribute__((ext_vector_type(4)));
+typedef float f32x2q __attribute__((ext_vector_type(2)));
 
 template <bool HAS_CENTROID, int DSUB>
 __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ Qp, int ld, const float* __restrict__ centroids,
                                                      const float* __restrict__ codebooks, int M, int Ksub, int KL, int kl_shift, int dsub,
                                                      const unsigned* __restrict__ probe_list, int ldp, int np,
-                                                     const int* __restrict__ seg_off, int n_pairs, int ppw, float* __restrict__ lut) {
-    // workgroup = (256 >> kl_shift) consecutive subspaces x KL codewords, `ppw` consecutive pairs.
+                                                     const int* __restrict__ seg_off, const unsigned* __restrict__ order, int n_slots, int ppw,
+                                                     float* __restrict__ lut) {
+    // workgroup = (256 >> kl_shift) consecutive subspaces x KL codewords, `ppw` (even) consecutive slots.
     extern __shared__ __attribute__((aligned(16))) float rs[];  // [ppw][mw * d] residual slices, then [ppw] live flags (as int)
     const int d = DSUB > 0 ? DSUB : dsub;
     const int mw = 256 >> kl_shift;                             // subspaces per workgroup
     const int m_base = blockIdx.x * mw;
     const int wcols = min(mw, M - m_base) * d;                  // residual columns this workgroup needs
-    const int p0 = blockIdx.y * ppw, pn = min(n_pairs, p0 + ppw) - p0;
+    const int p0 = blockIdx.y * ppw, pn = min(n_slots, p0 + ppw) - p0;
     int* live = reinterpret_cast<int*>(rs + (long)ppw * mw * d);
-    // phase 1: every (pair, column) residual is formed once, all loads of the workgroup in flight together
+    // phase 1: every (slot, column) residual is formed once, all loads of the workgroup in flight together
     for (int e = threadIdx.x; e < pn * wcols; e += 256) {
         const int pl = e / wcols, col = e - pl * wcols;
-        const int pr = p0 + pl, q = pr / np, pi = pr - q * np;
-        const int* so = seg_off + (long)q * (np + 1) + pi;
-        const bool lv = so[1] != so[0];                         // empty list / unused probe slot: table never read
+        const unsigned pr = order[p0 + pl];
+        bool lv = pr != ADC_HOLE;
         float r = 0.0f;
         if (lv) {
-            const float qv = Qp[(long)q * ld + m_base * d + col];
-            if constexpr (HAS_CENTROID) r = qv - centroids[(long)probe_list[(long)q * ldp + pi] * ld + m_base * d + col];   // queryResidual[d] = q[d] - centroid[d]
-            else r = qv;
+            const int q = (int)pr / np, pi = (int)pr - q * np;
+            const int* so = seg_off + (long)q * (np + 1) + pi;
+            lv = so[1] != so[0];                                // empty list / unused probe slot: table never read
+            if (lv) {
+                const float qv = Qp[(long)q * ld + m_base * d + col];
+                if constexpr (HAS_CENTROID) r = qv - centroids[(long)probe_list[(long)q * ldp + pi] * ld + m_base * d + col];   // queryResidual[d] = q[d] - centroid[d]
+                else r = qv;
+            }
         }
         rs[(long)pl * mw * d + col] = r;
         if (col == 0) live[pl] = lv ? 1 : 0;
@@ -366,10 +382,8 @@ __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ Q
     }
     __syncthreads();
     if (m >= M) return;
-    // phase 2: a thread keeps ONE codeword in registers and walks the pairs (LDS broadcast reads of the residual slice)
-    float* __restrict__ out = lut + ((long)p0 * M + m) * KL + k;
-    for (int pl = 0; pl < pn; pl++) {
-        if (!live[pl]) continue;
+    // phase 2: a thread keeps ONE codeword in registers and walks the duos (LDS broadcast reads of the residual slices)
+    auto entry = [&](int pl) -> float {
         const float* r = rs + (long)pl * mw * d + mm * d;
         float dsum = 0.0f;
         if constexpr (DSUB > 0) {
@@ -378,7 +392,16 @@ __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ Q
         } else {
             for (int i = 0; i < d; i++) { const float diff = r[i] - cbp[i]; const float sq = diff * diff; dsum = dsum + sq; }
         }
-        out[(long)pl * M * KL] = dsum;
+        return dsum;
+    };
+    f32x2q* __restrict__ out = reinterpret_cast<f32x2q*>(lut) + ((long)(p0 >> 1) * M + m) * KL + k;
+    for (int pl = 0; pl < pn; pl += 2) {
+        const bool la = live[pl] != 0, lb = (pl + 1 < pn) && live[pl + 1] != 0;
+        if (!la && !lb) continue;
+        f32x2q v;
+        v[0] = la ? entry(pl) : 0.0f;
+        v[1] = lb ? entry(pl + 1) : 0.0f;
+        out[(long)(pl >> 1) * M * KL] = v;
     }
 }
 
@@ -419,158 +442,295 @@ __global__ __launch_bounds__(256) void iota_kernel(unsigned* __restrict__ p, int
     if (i < n) p[i] = (unsigned)i;
 }
 
-// one wave, C blocks (wid, wid+16, ...) of the segment: C serial float32 chains per lane. `cur` holds the code words of
-// the first group (requested by the caller before the table barrier). The main loop runs over groups of ADC_G FULL words
-// (4 codes each) without a branch so that the next group's loads and this group's 16*C table reads overlap the add chains;
-// words past the last full group (M not a multiple of 16) are handled one code at a time.
-constexpr int ADC_G = 4;
+
+// Slots and work queues of the ADC scan. One workgroup. `identity`: the list count does not fit the LDS bins — every pair
+// becomes a duo of its own (slot 2i = pair i, slot 2i+1 a hole).
+//   order[s]  pair of slot s (ADC_HOLE: none)          slist[s]  list of slot s (nlist: nothing to scan)
+//   qitems    8 queues x qcap items {duo, segment}; queue x holds the chunks c = x (mod 8) of ADC_XCD_CHUNK adjacent duos
+//   qcount    items per queue; queues[] (the scan's ticket counters) is zeroed here
+__global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restrict__ probe_list, int ldp, int np, const int* __restrict__ seg_off,
+                                                         int n_pairs, int nlist, int identity, const int* __restrict__ list_len, int n_slots,
+                                                         unsigned* __restrict__ order, unsigned* __restrict__ slist, uint2* __restrict__ qitems, int qcap,
+                                                         int* __restrict__ qcount, int* __restrict__ queues) {
+    extern __shared__ __attribute__((aligned(16))) int obin[];   // nlist + 1 counters (not used by the identity order)
+    __shared__ int part[1024];
+    __shared__ int wtot[16];
+    const int nb = nlist + 1, t = threadIdx.x;
+    auto key_of = [&](int i) {
+        const int q = i / np, pi = i - q * np;
+        const int* so = seg_off + (long)q * (np + 1) + pi;
+        return (so[1] == so[0]) ? nlist : (int)min(probe_list[(long)q * ldp + pi], (unsigned)(nlist - 1));
+    };
+    for (int i = t; i < n_slots; i += 1024) { order[i] = ADC_HOLE; slist[i] = (unsigned)nlist; }
+    if (identity) {
+        __syncthreads();
+        for (int i = t; i < n_pairs; i += 1024) { order[2 * i] = (unsigned)i; slist[2 * i] = (unsigned)key_of(i); }
+    } else {
+        for (int i = t; i < nb; i += 1024) obin[i] = 0;
+        __syncthreads();
+        for (int i = t; i < n_pairs; i += 1024) atomicAdd(&obin[key_of(i)], 1);
+        __syncthreads();
+        const int per = (nb + 1023) / 1024, lo = t * per, hi = min(nb, lo + per);
+        int s = 0;
+        for (int i = lo; i < hi; i++) s += (i < nlist) ? ((obin[i] + 1) & ~1) : obin[i];      // a list's run is padded to an even length
+        part[t] = s;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int v = (t >= off) ? part[t - off] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        int run = part[t] - s;                                      // exclusive prefix of this thread's bins
+        for (int i = lo; i < hi; i++) { const int cnt = obin[i]; obin[i] = run; run += (i < nlist) ? ((cnt + 1) & ~1) : cnt; }
+        __syncthreads();
+        for (int i = t; i < n_pairs; i += 1024) { const int k = key_of(i); const int pos = atomicAdd(&obin[k], 1); order[pos] = (unsigned)i; slist[pos] = (unsigned)k; }
+    }
+    __syncthreads();
+    // work queues: waves x and x + 8 build queue x (first and second half of its duos), two passes (count, then write)
+    const int lane = t & 63, w = t >> 6, x = w & 7, h = w >> 3;
+    const int n_duos = n_slots >> 1, n_chunks = (n_duos + ADC_XCD_CHUNK - 1) / ADC_XCD_CHUNK;
+    const int nu = ((n_chunks - x + 7) >> 3) * ADC_XCD_CHUNK;       // duo positions of queue x
+    const int umid = ((nu / 2 + 63) / 64) * 64, u0 = h ? min(umid, nu) : 0, u1 = h ? nu : min(umid, nu);
+    auto segs_of = [&](int u, int& duo) -> int {
+        duo = (x + 8 * (u / ADC_XCD_CHUNK)) * ADC_XCD_CHUNK + (u % ADC_XCD_CHUNK);
+        if (u >= u1 || duo >= n_duos) return 0;
+        const unsigned L = slist[2 * duo];
+        return L < (unsigned)nlist ? (list_len[L] + ADC_SEG_CODES - 1) / ADC_SEG_CODES : 0;
+    };
+    int tot = 0;
+    for (int u = u0 + lane; u < u1; u += 64) { int duo; tot += segs_of(u, duo); }
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    if (lane == 0) wtot[w] = tot;
+    __syncthreads();
+    int base = h ? wtot[x] : 0;
+    for (int ub = u0; ub < u1; ub += 64) {
+        int duo; const int ns = segs_of(ub + lane, duo);
+        int inc = ns;                                               // inclusive wave scan
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+        const int off = base + inc - ns;
+        for (int sgi = 0; sgi < ns; sgi++) if (off + sgi < qcap) qitems[(long)x * qcap + off + sgi] = make_uint2((unsigned)duo, (unsigned)sgi);
+        base += __shfl(inc, 63);
+    }
+    if (h && lane == 0) { qcount[x] = min(wtot[x] + wtot[x + 8], qcap); queues[x] = 0; }
+}
+
+// One wave, C blocks of a pass (chains), one PHASE of the duo's table: subspaces [4*w_lo, m_hi), table rows relative to 4*w_lo.
+// Code words come through buffer loads: a descriptor per item (base = the segment's first block), the wave-uniform part of
+// the address in soffset, the lane in voffset — no 64-bit per-lane addresses in VGPRs. `cur` holds the code words of the
+// first group; the main loop runs over groups of ADC_G full words (4 codes each) without a branch so that the next group's
+// loads and this group's gathers overlap the add chains; the last iteration fetches the first group of the wave's NEXT call
+// (descriptor nrs, word nx_word of the block at byte offset nx_off; blocks past the segment read other lists' codes or the
+// pad behind the last list — readable, never used). Words past the last full group are handled one code at a time.
+#define RFL(x) __builtin_amdgcn_readfirstlane(x)
+typedef __amdgpu_buffer_rsrc_t adc_rsrc_t;
+struct AdcItem {
+    int live, start, seg_end;
+    long offA, offB;            // row offsets of the two queries' distances (offB < 0: no second query)
+    long base_blk, duo;
+};
+__device__ __forceinline__ unsigned adc_ldw(adc_rsrc_t r, unsigned voff, int soff) { return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0); }
 template <int C>
-__device__ __forceinline__ void adc_chains(const float* __restrict__ lut, int M, int M4, int KL, const unsigned* __restrict__ cw, long blk_stride16,
-                                           unsigned (&cur)[ADC_CHAINS][ADC_G], float (&acc)[ADC_CHAINS]) {
+__device__ __forceinline__ void adc_chains2(const f32x2q* __restrict__ lut, int w_lo, int m_hi, int M4, int KL, adc_rsrc_t rs, int off, int stride16b,
+                                            adc_rsrc_t nrs, int nx_off, int nx_word, unsigned voff, unsigned (&cur)[ADC_CHAINS][ADC_G], f32x2q (&acc)[ADC_CHAINS]) {
     constexpr int G = ADC_G;
-    const int ngroups = (M >> 2) / G;
-    unsigned nxt[C][G];
+    const int ngroups = ((m_hi >> 2) - w_lo) / G;
+    unsigned nxt[ADC_CHAINS][G];
+    int nxw[G];                                      // byte offsets of the next call's first group (clamped: a table of < G words)
 #pragma unroll
-    for (int c = 0; c < C; c++) acc[c] = 0.0f;
+    for (int i = 0; i < G; i++) nxw[i] = nx_off + min(nx_word + i, M4 - 1) * 256;
     for (int g = 0; g < ngroups; g++) {
-        const int gn = min(g + 1, ngroups - 1);      // the last iteration re-reads its own group (never used)
+        if (g + 1 < ngroups) {
 #pragma unroll
-        for (int c = 0; c < C; c++)
+            for (int c = 0; c < C; c++)
 #pragma unroll
-            for (int i = 0; i < G; i++) nxt[c][i] = cw[c * blk_stride16 + (long)(gn * G + i) * 64];
-        const float* l0 = lut + (long)g * (G * 4) * KL;
+                for (int i = 0; i < G; i++) nxt[c][i] = adc_ldw(rs, voff, off + c * stride16b + (w_lo + (g + 1) * G + i) * 256);
+#pragma unroll
+            for (int c = C; c < ADC_CHAINS; c++)
+#pragma unroll
+                for (int i = 0; i < G; i++) nxt[c][i] = cur[c][i];
+        } else {
+#pragma unroll
+            for (int c = 0; c < ADC_CHAINS; c++)
+#pragma unroll
+                for (int i = 0; i < G; i++) nxt[c][i] = adc_ldw(nrs, voff, nxw[i] + c * stride16b);
+        }
+        const f32x2q* l0 = lut + (long)g * (G * 4) * KL;
 #pragma unroll
         for (int i = 0; i < G; i++) {
-            float v[C][4];
 #pragma unroll
-            for (int c = 0; c < C; c++) {
-                const unsigned w = cur[c][i];
-                v[c][0] = l0[(i * 4 + 0) * KL + (w & 255u)]; v[c][1] = l0[(i * 4 + 1) * KL + ((w >> 8) & 255u)];
-                v[c][2] = l0[(i * 4 + 2) * KL + ((w >> 16) & 255u)]; v[c][3] = l0[(i * 4 + 3) * KL + (w >> 24)];
+            for (int hb = 0; hb < 4; hb += 2) {          // two code bytes of every chain at a time: 2*C gathers in flight per wave
+                f32x2q v[C][2];
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const unsigned w = cur[c][i] >> (8 * hb);
+                    v[c][0] = l0[(i * 4 + hb) * KL + (w & 255u)]; v[c][1] = l0[(i * 4 + hb + 1) * KL + ((w >> 8) & 255u)];
+                }
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int c = 0; c < C; c++) { acc[c][0] = acc[c][0] + v[c][b][0]; acc[c][1] = acc[c][1] + v[c][b][1]; }
             }
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-#pragma unroll
-                for (int c = 0; c < C; c++) acc[c] = acc[c] + v[c][b];
         }
 #pragma unroll
-        for (int c = 0; c < C; c++)
+        for (int c = 0; c < ADC_CHAINS; c++)
 #pragma unroll
             for (int i = 0; i < G; i++) cur[c][i] = nxt[c][i];
     }
-    for (int w0 = ngroups * G; w0 < M4; w0++) {      // tail words
+    const int w_end = (m_hi + 3) >> 2;
+    if (w_lo + ngroups * G < w_end) {                 // tail words (M not a multiple of 4*G inside this phase)
+        for (int w0 = w_lo + ngroups * G; w0 < w_end; w0++) {
 #pragma unroll
-        for (int c = 0; c < C; c++) {
-            const unsigned w = cw[c * blk_stride16 + (long)w0 * 64];
-            for (int bb = 0; bb < 4 && w0 * 4 + bb < M; bb++) acc[c] = acc[c] + lut[(w0 * 4 + bb) * KL + ((w >> (8 * bb)) & 255u)];
+            for (int c = 0; c < C; c++) {
+                const unsigned w = adc_ldw(rs, voff, off + c * stride16b + w0 * 256);
+                for (int bb = 0; bb < 4 && w0 * 4 + bb < m_hi; bb++) {
+                    const f32x2q v = lut[(long)((w0 - w_lo) * 4 + bb) * KL + ((w >> (8 * bb)) & 255u)];
+                    acc[c][0] = acc[c][0] + v[0]; acc[c][1] = acc[c][1] + v[1];
+                }
+            }
+        }
+        if (ngroups == 0) {                            // the first group was never consumed: `cur` must still become the next call's
+#pragma unroll
+            for (int c = 0; c < ADC_CHAINS; c++)
+#pragma unroll
+                for (int i = 0; i < G; i++) cur[c][i] = adc_ldw(nrs, voff, nxw[i] + c * stride16b);
         }
     }
 }
 
-__global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const float* __restrict__ lutg, int M, int KL, const unsigned* __restrict__ codes, int M4,
-                                                               const long* __restrict__ list_base, const int* __restrict__ list_len,
-                                                               const unsigned* __restrict__ probe_list, int ldp, int np,
-                                                               const int* __restrict__ seg_off, const unsigned char* __restrict__ elig,
-                                                               const unsigned* __restrict__ order, int n_pairs, int segs_per_list,
-                                                               int* __restrict__ queues, float* __restrict__ D, long ldD) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* lut = lds;                               // M * KL
-    __shared__ int s_ticket[2];                     // [0] queue, [1] ticket of the NEXT item (-1: all queues drained)
-    const int n_ent = M * KL;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    // Eight queues, one per XCD (workgroup b runs on XCD b % 8). Queue x holds the chunks c = x (mod 8) of ADC_XCD_CHUNK
-    // adjacent sorted pairs, each pair with its segments; a drained workgroup steals from the next queue.
-    const int n_chunks = (n_pairs + ADC_XCD_CHUNK - 1) / ADC_XCD_CHUNK;
-    auto queue_items = [&](int x) { return ((n_chunks - x + 7) >> 3) * ADC_XCD_CHUNK * segs_per_list; };
+struct AdcArgs {
+    const float* lutg; const unsigned* codes; const long* list_base; const int* list_len; const int* seg_off; const unsigned char* elig;
+    const unsigned* order; const unsigned* slist; const uint2* qitems; const int* qcount; int* queues; float* D;
+    long ldD; int M, KL, mp, M4, np, qcap;
+};
+__global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // two phase buffers of ADC_BUF_BYTES
+    __shared__ int s_ticket[2][2];                                  // [item parity][0] queue, [1] ticket (-1: all queues drained)
+    const unsigned lane = threadIdx.x & 63u, voff = lane * 4u;
+    const int wid = RFL((int)(threadIdx.x >> 6));
+    const int M = a.M, KL = a.KL, mp = a.mp, M4 = a.M4;
+    const long n_ent = (long)M * KL;                                // float2 entries of a duo's table
+    const int P = (M + mp - 1) / mp;
+    const int stride16b = ADC_WAVES * M4 * 256;                     // bytes between a wave's chains (16 blocks)
+    // Eight queues, one per XCD (workgroup b runs on XCD b % 8); a drained workgroup steals from the next queue.
     auto take = [&](int& xq, int& tried) -> int {   // thread 0 only
         while (tried < 8) {
-            const int t = atomicAdd(&queues[xq], 1);
-            if (t < queue_items(xq)) return t;
+            const int t = atomicAdd(&a.queues[xq], 1);
+            if (t < a.qcount[xq]) return t;
             xq = (xq + 1) & 7; tried++;
         }
         return -1;
     };
-    int my_q = blockIdx.x & 7, tried = 0;
-    if (threadIdx.x == 0) { const int t = take(my_q, tried); s_ticket[0] = my_q; s_ticket[1] = t; }
-    __syncthreads();
-    while (true) {
-        const int xq = s_ticket[0], ticket = s_ticket[1];
-        if (ticket < 0) break;
-        __syncthreads();                            // everyone has read the ticket; previous table no longer in use
-        const int lsp = ticket / segs_per_list, s = ticket - lsp * segs_per_list;
-        const int sp = ((lsp / ADC_XCD_CHUNK) * 8 + xq) * ADC_XCD_CHUNK + (lsp % ADC_XCD_CHUNK);
-        bool live = sp < n_pairs;
-        int pair = 0, q = 0, so = 0, len = 0, start = 0;
-        unsigned L = 0;
-        if (live) {
-            pair = (int)order[sp];
-            q = pair / np; const int p = pair - q * np;
-            so = seg_off[(long)q * (np + 1) + p];
-            start = s * ADC_SEG_CODES;
-            if (seg_off[(long)q * (np + 1) + p + 1] == so) live = false;
-            else { L = probe_list[(long)q * ldp + p]; len = list_len[L]; live = start < len; }
+    auto rfl64 = [](long v) -> long { return ((long)RFL((int)(v >> 32)) << 32) | (unsigned)RFL((int)(v & 0xFFFFFFFFl)); };
+    auto decode = [&](int xq, int ticket) -> AdcItem {
+        AdcItem it; it.live = 0; it.start = it.seg_end = 0; it.offA = 0; it.offB = -1; it.base_blk = 0; it.duo = 0;
+        xq = RFL(xq); ticket = RFL(ticket);              // read from LDS: uniform, but only the hardware knows — keep the item in SGPRs
+        if (ticket < 0) return it;
+        const uint2 e = a.qitems[(long)xq * a.qcap + ticket];
+        const unsigned duo = RFL(e.x), sg = RFL(e.y);
+        const unsigned pa = RFL(a.order[2 * duo]), pb = RFL(a.order[2 * duo + 1]);
+        const unsigned L = RFL(a.slist[2 * duo]);
+        const int len = RFL(a.list_len[L]);
+        const int np = a.np;
+        it.live = 1; it.duo = duo;
+        const int qA = (int)pa / np;
+        it.offA = (long)qA * a.ldD + RFL(a.seg_off[(long)qA * (np + 1) + ((int)pa - qA * np)]);
+        if (pb != ADC_HOLE) { const int qB = (int)pb / np; it.offB = (long)qB * a.ldD + RFL(a.seg_off[(long)qB * (np + 1) + ((int)pb - qB * np)]); }
+        it.start = (int)sg * ADC_SEG_CODES; it.seg_end = min(len, it.start + ADC_SEG_CODES);
+        it.base_blk = rfl64(a.list_base[L] >> 6);        // list bases are multiples of 64
+        return it;
+    };
+    auto chains_of = [&](const AdcItem& it, int ps) -> int {        // blocks wid, wid+16, ... of pass ps that exist
+        const int pstart = it.start + ps * ADC_PASS_CODES;
+        if (!it.live || pstart >= it.seg_end) return 0;
+        const int nblk = (min(it.seg_end, pstart + ADC_PASS_CODES) - pstart + 63) >> 6;
+        return wid < nblk ? (nblk - wid + ADC_WAVES - 1) / ADC_WAVES : 0;
+    };
+    auto rsrc_of = [&](const AdcItem& it) -> adc_rsrc_t {           // the segment's first block
+        const unsigned* b = a.codes + (it.base_blk + (it.start >> 6)) * (long)M4 * 64;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, 0x7FFFFFFF, 0x00020000);
+    };
+    auto off_of = [&](int ps) -> int { return (ps * (ADC_PASS_CODES >> 6) + wid) * M4 * 256; };    // the wave's first block of pass ps, bytes
+    auto issue_table = [&](const AdcItem& it, int ph, int buf) {
+        const float* __restrict__ src = a.lutg + (it.duo * n_ent + (long)ph * mp * KL) * 2;
+        const int cnt = (min(M, (ph + 1) * mp) - ph * mp) * KL * 2;  // floats; a multiple of 4
+        float* dst = lds + (long)buf * (ADC_BUF_BYTES / 4);
+        for (int e = wid * 256; e < cnt; e += ADC_THREADS * 4) {     // LDS-DMA: each wave moves 1 KiB per instruction, lane-linear destination
+            if (e + (int)lane * 4 < cnt)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + e + lane * 4),
+                                                 (__attribute__((address_space(3))) void*)(dst + e), 16, 0, 0);
         }
-        // code words of the first group (of the first pass) are requested before the table so that both are in flight together
-        unsigned cur[ADC_CHAINS][ADC_G];
-        int seg_end = 0, nact = 0, blk0 = 0;
-        long base_slot = 0;
-        const unsigned* __restrict__ cw = codes;
-        const long stride16 = (long)ADC_WAVES * M4 * 64;
-        auto pass_setup = [&](int pstart) {              // blocks wid, wid+16, ... of the pass that starts at code pstart
-            const int pend = min(seg_end, pstart + ADC_PASS_CODES);
-            const int nblk = (pend - pstart + 63) >> 6;  // 1..64
-            nact = wid < nblk ? (nblk - wid + ADC_WAVES - 1) / ADC_WAVES : 0;
-            blk0 = (pstart >> 6) + wid;
-            cw = codes + ((base_slot >> 6) + blk0) * (long)M4 * 64 + lane;
-            if ((M >> 2) >= ADC_G) {
+    };
+    int my_q = blockIdx.x & 7, tried = 0, parity = 0;
+    if (threadIdx.x == 0) { const int t = take(my_q, tried); s_ticket[0][0] = my_q; s_ticket[0][1] = t; }
+    __syncthreads();
+    AdcItem cur = decode(s_ticket[0][0], s_ticket[0][1]);
+    if (!cur.live) return;
+    issue_table(cur, 0, 0);
+    unsigned cw_cur[ADC_CHAINS][ADC_G];
+    adc_rsrc_t rs_cur = rsrc_of(cur);
+#pragma unroll
+    for (int c = 0; c < ADC_CHAINS; c++)
+#pragma unroll
+        for (int i = 0; i < ADC_G; i++) cw_cur[c][i] = adc_ldw(rs_cur, voff, off_of(0) + c * stride16b + min(i, M4 - 1) * 256);
+    int stage = 0;
+    while (true) {
+        if (threadIdx.x == 0) { const int t = take(my_q, tried); s_ticket[parity ^ 1][0] = my_q; s_ticket[parity ^ 1][1] = t; }   // next item's ticket
+        AdcItem nxt = decode(0, -1);
+        adc_rsrc_t rs_nxt = rs_cur;
+        f32x2q acc[ADC_SEG_PASSES][ADC_CHAINS];
+#pragma unroll
+        for (int ps = 0; ps < ADC_SEG_PASSES; ps++)
+#pragma unroll
+            for (int c = 0; c < ADC_CHAINS; c++) { acc[ps][c][0] = 0.0f; acc[ps][c][1] = 0.0f; }
+        const int na0 = chains_of(cur, 0), na1 = chains_of(cur, 1);
+        for (int ph = 0; ph < P; ph++, stage++) {
+            __syncthreads();        // table (cur, ph) has landed (the barrier drains vmcnt); nobody still reads the other buffer; ticket visible
+            if (ph == 0) { nxt = decode(s_ticket[parity ^ 1][0], s_ticket[parity ^ 1][1]); if (nxt.live) rs_nxt = rsrc_of(nxt); }
+            const bool last_ph = ph + 1 == P;
+            if (!last_ph) issue_table(cur, ph + 1, (stage + 1) & 1);
+            else if (nxt.live) issue_table(nxt, 0, (stage + 1) & 1);
+            const bool to_next = last_ph && nxt.live && chains_of(nxt, 0) > 0;   // the wave's next call belongs to the next item
+            if (to_next && na0 == 0) {                               // idle in this item: fetch the next item's first code words now
 #pragma unroll
                 for (int c = 0; c < ADC_CHAINS; c++)
-                    if (c < nact) {
 #pragma unroll
-                        for (int i = 0; i < ADC_G; i++) cur[c][i] = cw[c * stride16 + (long)i * 64];
-                    }
+                    for (int i = 0; i < ADC_G; i++) cw_cur[c][i] = adc_ldw(rs_nxt, voff, off_of(0) + c * stride16b + min(i, M4 - 1) * 256);
             }
-        };
-        if (live) {
-            seg_end = min(len, start + ADC_SEG_CODES);
-            base_slot = list_base[L];                   // multiple of 64
-            pass_setup(start);
-        }
-        if (live) {                                 // workgroup-uniform
-            const float* __restrict__ src = lutg + (long)pair * n_ent;
-            if ((n_ent & 3) == 0) {
-                // LDS-DMA: each wave moves 1 KiB per instruction, lane-linear destination
-                for (int e = wid * 256; e < n_ent; e += ADC_THREADS * 4) {
-                    if (e + lane * 4 < n_ent)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + e + lane * 4),
-                                                         (__attribute__((address_space(3))) void*)(lut + e), 16, 0, 0);
+            const f32x2q* lut = reinterpret_cast<const f32x2q*>(lds + (long)(stage & 1) * (ADC_BUF_BYTES / 4));
+            const int w_lo = (ph * mp) >> 2, m_hi = min(M, (ph + 1) * mp);
+            const int w_next = last_ph ? 0 : ((ph + 1) * mp) >> 2;   // first word of the wave's next call after this phase's last pass
+#pragma unroll
+            for (int ps = 0; ps < ADC_SEG_PASSES; ps++) {
+                const int na = ps == 0 ? na0 : na1;
+                if (na == 0) continue;
+                const bool more = ps == 0 && na1 > 0;
+                const adc_rsrc_t nrs = (!more && to_next) ? rs_nxt : rs_cur;
+                const int nx_off = more ? off_of(1) : off_of(0);
+                const int nxw = more ? w_lo : w_next;
+                switch (na) {
+                    case 1: adc_chains2<1>(lut, w_lo, m_hi, M4, KL, rs_cur, off_of(ps), stride16b, nrs, nx_off, nxw, voff, cw_cur, acc[ps]); break;
+                    case 2: adc_chains2<2>(lut, w_lo, m_hi, M4, KL, rs_cur, off_of(ps), stride16b, nrs, nx_off, nxw, voff, cw_cur, acc[ps]); break;
+                    case 3: adc_chains2<3>(lut, w_lo, m_hi, M4, KL, rs_cur, off_of(ps), stride16b, nrs, nx_off, nxw, voff, cw_cur, acc[ps]); break;
+                    default: adc_chains2<4>(lut, w_lo, m_hi, M4, KL, rs_cur, off_of(ps), stride16b, nrs, nx_off, nxw, voff, cw_cur, acc[ps]); break;
                 }
-            } else {
-                for (int e = threadIdx.x; e < n_ent; e += ADC_THREADS) lut[e] = src[e];
             }
         }
-        if (threadIdx.x == 0) { const int t = take(my_q, tried); s_ticket[0] = my_q; s_ticket[1] = t; }   // overlaps the table load
-        __syncthreads();                            // table in LDS (the compiler drains vmcnt before the barrier), next ticket published
-        if (!live) continue;
-        for (int pstart = start; pstart < seg_end; pstart += ADC_PASS_CODES) {
-            if (pstart != start) pass_setup(pstart);
-            float acc[ADC_CHAINS];
-            switch (nact) {
-                case 1: adc_chains<1>(lut, M, M4, KL, cw, stride16, cur, acc); break;
-                case 2: adc_chains<2>(lut, M, M4, KL, cw, stride16, cur, acc); break;
-                case 3: adc_chains<3>(lut, M, M4, KL, cw, stride16, cur, acc); break;
-                case 4: adc_chains<4>(lut, M, M4, KL, cw, stride16, cur, acc); break;
-                default: break;
-            }
+#pragma unroll
+        for (int ps = 0; ps < ADC_SEG_PASSES; ps++) {
+            const int na = ps == 0 ? na0 : na1;
 #pragma unroll
             for (int c = 0; c < ADC_CHAINS; c++) {
-                const int j = (blk0 + c * ADC_WAVES) * 64 + lane;
-                if (c < nact && j < seg_end) {
-                    const bool ok = elig ? (elig[base_slot + j] != 0) : true;
-                    D[(long)q * ldD + so + j] = ok ? go_sqrt32q(acc[c]) : __uint_as_float(EXCLUDED_BITS);
+                const int j = ((cur.start >> 6) + ps * (ADC_PASS_CODES >> 6) + c * ADC_WAVES + wid) * 64 + (int)lane;
+                if (c < na && j < cur.seg_end) {
+                    const bool ok = a.elig ? (a.elig[(cur.base_blk << 6) + j] != 0) : true;
+                    a.D[cur.offA + j] = ok ? go_sqrt32q(acc[ps][c][0]) : __uint_as_float(EXCLUDED_BITS);
+                    if (cur.offB >= 0) a.D[cur.offB + j] = ok ? go_sqrt32q(acc[ps][c][1]) : __uint_as_float(EXCLUDED_BITS);
                 }
             }
         }
+        if (!nxt.live) break;
+        cur = nxt; rs_cur = rs_nxt; parity ^= 1;
     }
 }
 // pairs of a (sub-)batch grouped by probed list; falls back to the identity order when the list count does not fit in LDS
@@ -587,7 +747,8 @@ bool launch_order_pairs(Ctx* c, const uint32_t* probe_list, int ldp, int np, con
     LAUNCH_CHECK();
     return sorted;     // false: identity order, olist not written (the caller must not group by list)
 }
-size_t adc_lds_bytes(int M, int Ksub, int dim) { (void)dim; int KL = Ksub < 256 ? Ksub : 256; return (size_t)M * KL * sizeof(float); }
+int64_t adc_codes_pad() { return (int64_t)ADC_PASS_CODES; }
+size_t adc_lds_bytes(int M, int Ksub, int dim) { (void)M; (void)Ksub; (void)dim; return 2 * (size_t)ADC_BUF_BYTES; }
 static size_t adc_lut_budget() {
     static size_t b = [] { const char* e = getenv("COMET_ADC_LUT_MB"); long mb = e ? atol(e) : 1024; if (mb < 1) mb = 1; return (size_t)mb << 20; }();
     return b;
@@ -599,38 +760,54 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
     const int KL = Ksub < 256 ? Ksub : 256;
     const int kl_shift = 31 - __builtin_clz((unsigned)KL);
     const size_t lds = adc_lds_bytes(M, Ksub, dim);
-    if (lds > 158 * 1024) COMET_FAIL(COMET_ERR_UNSUPPORTED, "PQ lookup table (%zu bytes) exceeds the 160 KiB LDS of a gfx950 CU", lds);
+    const int mp = std::max(16, (int)(ADC_BUF_BYTES / ((size_t)KL * 8)) / 16 * 16);        // subspaces per phase buffer (KL <= 256: >= 32)
     const size_t lut_pair = (size_t)M * KL * sizeof(float);
+    const bool identity = nlist > ORDER_MAX_LISTS;
     // queries per sub-batch: tables of a sub-batch live in HBM between the two kernels
     int64_t qc = std::max<int64_t>(1, (int64_t)(adc_lut_budget() / (lut_pair * (size_t)np)));
     qc = std::min<int64_t>(qc, B);
-    ScratchMark mark(c);
-    float* lut = c->salloc<float>((size_t)qc * np * M * KL);
-    uint32_t* order = c->salloc<uint32_t>((size_t)qc * np);
-    int32_t* queues = c->salloc<int32_t>(8);
+    auto slots_for = [&](int64_t n_pairs) { return identity ? 2 * n_pairs : round_up(n_pairs + std::min<int64_t>(nlist, n_pairs), 2); };
+    const int64_t max_slots = slots_for(qc * np);
     const int segs = (int)ceil_div(max_list_len, ADC_SEG_CODES);
+    const int64_t max_chunks = ceil_div(max_slots / 2, ADC_XCD_CHUNK);
+    const int64_t qcap = ceil_div(max_chunks, 8) * ADC_XCD_CHUNK * segs;
+    if (qcap > (int64_t)1 << 28) COMET_FAIL(COMET_ERR_UNSUPPORTED, "ADC work queue too large (%lld items)", (long long)qcap);
+    ScratchMark mark(c);
+    float* lut = c->salloc<float>((size_t)max_slots * M * KL);
+    uint32_t* order = c->salloc<uint32_t>((size_t)max_slots);
+    uint32_t* slist = c->salloc<uint32_t>((size_t)max_slots);
+    uint2* qitems = c->salloc<uint2>((size_t)8 * qcap);
+    int32_t* qcount = c->salloc<int32_t>(8);
+    int32_t* queues = c->salloc<int32_t>(8);
     const int mw = 256 >> kl_shift;
     int ppw = LUT_PAIRS_PER_WG;
-    while (ppw > 1 && (size_t)ppw * mw * dsub * 4 > 48 * 1024) ppw >>= 1;
+    while (ppw > 2 && (size_t)ppw * mw * dsub * 4 > 48 * 1024) ppw >>= 1;
     const size_t lut_lds = (size_t)ppw * mw * dsub * 4 + (size_t)ppw * 4;
     if (lut_lds > 150 * 1024) COMET_FAIL(COMET_ERR_UNSUPPORTED, "PQ subspace slice too wide for the table-build kernel (%zu bytes of LDS)", lut_lds);
     static bool attr_done = false;
     if (!attr_done) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-        HIP_CHECK(hipFuncSetAttribute((const void*)order_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (ORDER_MAX_LISTS + 1) * 4));
+        HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)adc_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (ORDER_MAX_LISTS + 1) * 4));
         attr_done = true;
     }
     for (int b0 = 0; b0 < B; b0 += (int)qc) {
         const int bn = std::min<int>((int)qc, B - b0);
         const int n_pairs = bn * np;
+        const int n_slots = (int)slots_for(n_pairs);
         const float* Qb = Qp + (size_t)b0 * ld;
         const uint32_t* pl = probe_list + (size_t)b0 * ldp;
         const int32_t* so = seg_off + (size_t)b0 * (np + 1);
         {
+            ProfScope ps(c, "adc_order");
+            adc_order_kernel<<<dim3(1), dim3(1024), identity ? 0 : (size_t)(nlist + 1) * 4, c->stream>>>(pl, ldp, np, so, n_pairs, nlist, identity ? 1 : 0, list_len,
+                                                                                                       n_slots, order, slist, qitems, (int)qcap, qcount, queues);
+            LAUNCH_CHECK();
+        }
+        {
             ProfScope ps(c, "pq_lut");
-            dim3 grid((unsigned)ceil_div(M, mw), (unsigned)ceil_div(n_pairs, ppw)), blk(256);
+            dim3 grid((unsigned)ceil_div(M, mw), (unsigned)ceil_div(n_slots, ppw)), blk(256);
 #define LUT_LAUNCH(HC, DS) do { if (lut_lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)pq_lut_kernel<HC, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lut_lds)); \
-        pq_lut_kernel<HC, DS><<<grid, blk, lut_lds, c->stream>>>(Qb, ld, centroids, codebooks, M, Ksub, KL, kl_shift, dsub, pl, ldp, np, so, n_pairs, ppw, lut); } while (0)
+        pq_lut_kernel<HC, DS><<<grid, blk, lut_lds, c->stream>>>(Qb, ld, centroids, codebooks, M, Ksub, KL, kl_shift, dsub, pl, ldp, np, so, order, n_slots, ppw, lut); } while (0)
 #define LUT_DS(HC) do { switch (dsub) { case 2: LUT_LAUNCH(HC, 2); break; case 4: LUT_LAUNCH(HC, 4); break; case 8: LUT_LAUNCH(HC, 8); break; \
                                        case 16: LUT_LAUNCH(HC, 16); break; default: LUT_LAUNCH(HC, 0); break; } } while (0)
             if (centroids) LUT_DS(true); else LUT_DS(false);
@@ -639,22 +816,12 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
             LAUNCH_CHECK();
         }
         {
-            ProfScope ps(c, "adc_order");
-            if (nlist <= ORDER_MAX_LISTS && n_pairs > 1) {
-                order_pairs_kernel<<<dim3(1), dim3(1024), (size_t)(nlist + 1) * 4, c->stream>>>(pl, ldp, np, so, n_pairs, nlist, order, nullptr);
-            } else {
-                iota_kernel<<<dim3((unsigned)ceil_div(n_pairs, 256)), dim3(256), 0, c->stream>>>(order, n_pairs);
-            }
-            LAUNCH_CHECK();
-            c->zero(queues, 8 * sizeof(int32_t));
-        }
-        {
             ProfScope ps(c, "adc_scan");
-            const long n_items = (long)n_pairs * segs;
+            const long n_items = (long)(n_slots / 2) * segs;
             long g = std::min<long>(n_items, (long)c->prop.multiProcessorCount);
             g = std::max<long>(8, (g + 7) / 8 * 8);          // a multiple of the XCD count so that blockIdx % 8 is the XCD of every slot
-            adc_scan_kernel<<<dim3((unsigned)g), dim3(ADC_THREADS), lds, c->stream>>>(lut, M, KL, codes, M4, (const long*)list_base, list_len, pl, ldp, np, so,
-                                                                                     elig, order, n_pairs, segs, queues, D + (size_t)b0 * ldD, ldD);
+            AdcArgs a{lut, codes, (const long*)list_base, list_len, so, elig, order, slist, qitems, qcount, queues, D + (size_t)b0 * ldD, (long)ldD, M, KL, mp, M4, np, (int)qcap};
+            adc_scan_kernel<<<dim3((unsigned)g), dim3(ADC_THREADS), lds, c->stream>>>(a);
             LAUNCH_CHECK();
         }
     }
