@@ -117,7 +117,7 @@ struct HnswGraph {
 __device__ __forceinline__ bool bit_get(const unsigned* bm, unsigned i) { return bm && ((bm[i >> 5] >> (i & 31)) & 1u); }
 
 // LDS work area of one wave (search and insert kernels)
-struct HnswLds { HC* cand; HC* res; float* tile; unsigned* rows; float* dd; unsigned* s_cur; int* s_flag; float* s_dist; };
+struct HnswLds { HC* cand; HC* res; float* tile; unsigned* rows; float* dd; unsigned* s_cur; int* s_flag; float* s_dist; int cand_cap; };
 
 // greedy descent through layers (from_layer .. to_layer+1): hnsw_index_search.go:274-300 / insertNode hnsw_index.go:497-518
 template <int METRIC>
@@ -215,7 +215,7 @@ __device__ __forceinline__ int hn_search_layer(const HnswGraph& g, const float* 
                     if (L.rows[j] == HN_NONE) continue;
                     const float dj = L.dd[j];
                     if (nres < ef || dj < res[0].d) {
-                        if (ncand >= HN_CAND_CAP) { overflow = 1; continue; }
+                        if (ncand >= L.cand_cap) { overflow = 1; continue; }
                         HC x{L.rows[j], dj};
                         heap_push<false>(cand, ncand, x);
                         heap_push<true>(res, nres, x);
@@ -242,7 +242,7 @@ __device__ __forceinline__ HnswLds hn_carve(unsigned char* smem, unsigned* s_cur
     L.tile = reinterpret_cast<float*>(L.res + (HN_EF_MAX + 1));              // 64 x HN_LD
     L.rows = reinterpret_cast<unsigned*>(L.tile + 64 * HN_LD);               // 64
     L.dd = reinterpret_cast<float*>(L.rows + 64);                            // 64
-    L.s_cur = s_cur; L.s_flag = s_flag; L.s_dist = s_dist;
+    L.s_cur = s_cur; L.s_flag = s_flag; L.s_dist = s_dist; L.cand_cap = HN_CAND_CAP;
     return L;
 }
 constexpr size_t HN_LDS_BYTES = sizeof(HC) * (HN_CAND_CAP + HN_EF_MAX + 1) + sizeof(float) * 64 * HN_LD + 64 * 4 + 64 * 4 + 64;
@@ -250,11 +250,16 @@ constexpr size_t HN_LDS_BYTES = sizeof(HC) * (HN_CAND_CAP + HN_EF_MAX + 1) + siz
 template <int METRIC>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswGraph g, const float* __restrict__ Qp, int ef, unsigned* __restrict__ visited /*[B][vwords]*/,
                                                          long vwords, unsigned* __restrict__ res_idx, float* __restrict__ res_dist,
-                                                         int* __restrict__ res_cnt, int* __restrict__ status, unsigned long long* __restrict__ stats) {
+                                                         int* __restrict__ res_cnt, int* __restrict__ status, unsigned long long* __restrict__ stats,
+                                                         HC* __restrict__ spill /*nullable: heaps in HBM*/, long spill_cand, long spill_res, int ef_ld) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned s_cur; __shared__ int s_flag; __shared__ float s_dist;
-    const HnswLds L = hn_carve(smem, &s_cur, &s_flag, &s_dist);
+    HnswLds L = hn_carve(smem, &s_cur, &s_flag, &s_dist);
     const int q = blockIdx.x, lane = threadIdx.x;
+    if (spill) {        // ef beyond the LDS heaps (or a candidate heap that outgrew them): same code, heaps in HBM, one slab per query
+        L.cand = spill + (long)q * (spill_cand + spill_res); L.res = L.cand + spill_cand;
+        L.cand_cap = (int)min(spill_cand, 0x7FFFFFFFl);
+    }
     const float* __restrict__ qv = Qp + (long)q * g.ld;
     unsigned* vis = visited + (long)q * vwords;
     unsigned long long n_eval = 0, n_exp = 0;
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswGraph g, const floa
     // drain the result heap into an ascending array (hnsw_index.go:623-626)
     if (lane == 0) {
         const int n = nres; int m = nres;
-        for (int i = n - 1; i >= 0; i--) { HC x = heap_pop<true>(L.res, m); res_idx[(long)q * ef + i] = x.id; res_dist[(long)q * ef + i] = x.d; }
+        for (int i = n - 1; i >= 0; i--) { HC x = heap_pop<true>(L.res, m); res_idx[(long)q * ef_ld + i] = x.id; res_dist[(long)q * ef_ld + i] = x.d; }
         res_cnt[q] = n;
         if (overflow) *status = 1;
         if (stats) { atomicAdd(&stats[0], n_eval); atomicAdd(&stats[1], n_exp); }
@@ -701,44 +706,61 @@ struct HNSWIndex : comet_index {
             launch_finalize(c, nullptr, pos, B, k_cap, zflag, out_ids, out_counts);
             return;
         }
-        int ef = p.ef_search > 0 ? p.ef_search : efS;    // :302-305
-        if (ef > HN_EF_MAX) COMET_FAIL(COMET_ERR_UNSUPPORTED, "efSearch %d exceeds the on-device limit %d", ef, HN_EF_MAX);
+        const int ef = p.ef_search > 0 ? p.ef_search : efS;    // :302-305
+        // the result heap never holds more than min(ef, live nodes) entries, the candidate heap never more than n (a node is pushed once)
+        const int ef_ld = (int)std::min<int64_t>(ef, n);
         const int64_t vwords = (n + 31) / 32;
         uint32_t* vis = c->salloc<uint32_t>((size_t)B * vwords);
-        c->zero(vis, (size_t)B * vwords * 4);
-        uint32_t* res_idx = c->salloc<uint32_t>((size_t)B * ef);
-        float* res_dist = c->salloc<float>((size_t)B * ef);
+        uint32_t* res_idx = c->salloc<uint32_t>((size_t)B * ef_ld);
+        float* res_dist = c->salloc<float>((size_t)B * ef_ld);
         int32_t* res_cnt = c->salloc<int32_t>(B);
         int32_t* status = c->salloc<int32_t>(1);
         unsigned long long* st = c->salloc<unsigned long long>(2);
-        c->zero(status, 4); c->zero(st, 16);
+        c->zero(st, 16);
         HnswGraph g{V.as<float>(), ld, n, level.as<int>(), (const long*)slot_base.p, (const long*)edge_off.p, deg_dev.as<int>(), edges.as<uint32_t>(), entry, max_level, deleted_bitmap()};
         const size_t lds = HN_LDS_BYTES;
-        {
-            ProfScope ps(c, "hnsw_search");
+        // heaps in LDS (ef <= 1024, <= 4096 live candidates) or, beyond that, in HBM: one slab per query, queries in sub-batches of <= 2 GiB
+        auto run = [&](bool spill) {
+            c->zero(vis, (size_t)B * vwords * 4); c->zero(status, 4);
+            ScratchMark mark(c);
+            const int64_t s_cand = n, s_res = (int64_t)ef_ld + 1;
+            const int bs = spill ? (int)std::max<int64_t>(1, std::min<int64_t>(B, ((int64_t)2 << 30) / ((s_cand + s_res) * (int64_t)sizeof(HC)))) : B;
+            HC* slab = spill ? c->salloc<HC>((size_t)bs * (s_cand + s_res)) : nullptr;
+            ProfScope ps(c, spill ? "hnsw_search_spill" : "hnsw_search");
+            for (int b0 = 0; b0 < B; b0 += bs) {
+                const int bn = std::min(bs, B - b0);
 #define HS(MT) do { HIP_CHECK(hipFuncSetAttribute((const void*)hnsw_search_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                    hnsw_search_kernel<MT><<<dim3(B), dim3(64), lds, c->stream>>>(g, Qp, ef, vis, vwords, res_idx, res_dist, res_cnt, status, st); } while (0)
-            switch (metric) { case COMET_L2: HS(COMET_L2); break; case COMET_L2SQ: HS(COMET_L2SQ); break; default: HS(COMET_COSINE); break; }
+                    hnsw_search_kernel<MT><<<dim3(bn), dim3(64), lds, c->stream>>>(g, Qp + (size_t)b0 * ld, ef, vis + (size_t)b0 * vwords, vwords, res_idx + (size_t)b0 * ef_ld, \
+                        res_dist + (size_t)b0 * ef_ld, res_cnt + b0, status, st, slab, s_cand, s_res, ef_ld); } while (0)
+                switch (metric) { case COMET_L2: HS(COMET_L2); break; case COMET_L2SQ: HS(COMET_L2SQ); break; default: HS(COMET_COSINE); break; }
 #undef HS
-            LAUNCH_CHECK();
+                LAUNCH_CHECK();
+            }
+        };
+        bool spill = ef > HN_EF_MAX;
+        run(spill);
+        if (!spill) {         // more than HN_CAND_CAP live candidates: the same search again with the heaps in HBM
+            int32_t hs = 0;
+            c->d2h(&hs, status, 4);
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (hs) { c->zero(st, 16); run(true); }
         }
         // phase 3: document filter + threshold applied AFTER the search (can return < k), sort, top-k (:321-351)
         const uint8_t* elig = nullptr;
         int nf = 0;
         const uint32_t* flt = filter_sorted_scratch(p, &nf);
         if (nf > 0) { uint8_t* e = c->salloc<uint8_t>(n); launch_build_elig(c, ids_dev.as<uint32_t>(), n, nullptr, 0, flt, nf, e); elig = e; }
-        float* D = c->salloc<float>((size_t)B * ef);
-        hnsw_mask_kernel<<<dim3((unsigned)ceil_div((int64_t)B * ef, 256)), dim3(256), 0, c->stream>>>(res_idx, res_dist, res_cnt, ef, B, elig, D);
+        float* D = c->salloc<float>((size_t)B * ef_ld);
+        hnsw_mask_kernel<<<dim3((unsigned)ceil_div((int64_t)B * ef_ld, 256)), dim3(256), 0, c->stream>>>(res_idx, res_dist, res_cnt, ef_ld, B, elig, D);
         LAUNCH_CHECK();
         uint32_t* pos2 = c->salloc<uint32_t>((size_t)B * k_cap);
-        launch_select_topk(c, D, ef, B, ef, res_cnt, p.threshold, p.k, pos2, out_scores, out_counts, k_cap);
-        launch_gather_indirect(c, res_idx, ef, pos2, B, k_cap, pos);
+        launch_select_topk(c, D, ef_ld, B, ef_ld, res_cnt, p.threshold, p.k, pos2, out_scores, out_counts, k_cap);
+        launch_gather_indirect(c, res_idx, ef_ld, pos2, B, k_cap, pos);
         launch_finalize(c, ids_dev.as<uint32_t>(), pos, B, k_cap, zflag, out_ids, out_counts);
-        int32_t hs = 0; unsigned long long hst[2];
-        c->d2h(&hs, status, 4); c->d2h(hst, st, 16);
+        unsigned long long hst[2];
+        c->d2h(hst, st, 16);
         HIP_CHECK(hipStreamSynchronize(c->stream));
         st_evals = hst[0]; st_exp = hst[1];
-        if (hs) COMET_FAIL(COMET_ERR_UNSUPPORTED, "HNSW candidate heap overflow (more than %d live candidates): lower efSearch", HN_CAND_CAP);
     }
     bool get_stat(const char* name, double* out) const override {
         std::string k(name);

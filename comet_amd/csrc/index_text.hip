@@ -21,12 +21,15 @@ struct comet_ctx : comet::Ctx {};
 namespace comet {
 
 // ---- scoring: one launch per query-token position ---------------------------------------------------
+// The accumulator is a dense float64 row per query that is all-zero between searches: a posting that finds 0.0 is the
+// document's first touch (scores are > 0: idf = ln(1 + ...) > 0, tf > 0) and appends it to the query's TOUCHED LIST; selection
+// walks that list only and zeroes exactly those entries again, so a search costs O(postings touched), not O(documents).
 struct TermRef { int off; int df; double idf; };   // per (query, position); df == 0 -> no such term / padding
 
 __global__ __launch_bounds__(256) void bm25_score_kernel(const TermRef* __restrict__ refs /*[B]*/, const int* __restrict__ post_doc,
                                                          const int* __restrict__ post_tf, const int* __restrict__ doc_len,
                                                          const unsigned char* __restrict__ elig, double avg_doc_len,
-                                                         double* __restrict__ acc, long nd) {
+                                                         double* __restrict__ acc, long nd, int* __restrict__ touched, long tcap, int* __restrict__ tcount) {
     const int q = blockIdx.y;
     const TermRef r = refs[q];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -42,11 +45,13 @@ __global__ __launch_bounds__(256) void bm25_score_kernel(const TermRef* __restri
     const double den = tfv + 1.2 * inner;
     const double num = r.idf * (tfv * 2.2);
     const double score = num / den;
-    acc[(long)q * nd + doc] = acc[(long)q * nd + doc] + score;
+    const double old = acc[(long)q * nd + doc];           // one thread per (query, document) in a launch: no race
+    if (old == 0.0) { const int s = atomicAdd(&tcount[q], 1); if (s < tcap) touched[(long)q * tcap + s] = doc; }
+    acc[(long)q * nd + doc] = old + score;
 }
 
 // ---- top-k by (score desc, doc index asc) on float64 ------------------------------------------------
-// key = ~ordered(score): ascending key == descending score; untouched documents (acc == 0) are skipped
+// key = ~ordered(score): ascending key == descending score
 __device__ __forceinline__ unsigned long long d2key_desc(double v) {
     unsigned long long u = (unsigned long long)__double_as_longlong(v);
     u = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
@@ -58,37 +63,37 @@ __device__ __forceinline__ double key2d_desc(unsigned long long k) {
     return __longlong_as_double((long long)u);
 }
 constexpr int BM_THREADS = 1024;
-constexpr int BM_KMAX = 2048;
+constexpr int BM_KMAX = 2048;        // selections up to this size sort in LDS, larger ones in a slab in HBM
 struct KP { unsigned long long key; unsigned pos; unsigned pad; };
 
-__global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(const double* __restrict__ acc, long nd, int K, const unsigned* __restrict__ doc_ids,
+// One workgroup per query. The touched list is unordered, so the reference's canonical order (score descending, then
+// document index ascending) is a radix select on the 96-bit composite (key, doc index): 8 byte-passes over the keys, 4 over the
+// doc indices of the documents that tie with the k-th key. Then exactly kq composites are gathered and sorted.
+__global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(double* __restrict__ acc, long nd, const int* __restrict__ touched, long tcap,
+                                                               const int* __restrict__ tcount, unsigned long long* __restrict__ tkeys, int K,
+                                                               const unsigned* __restrict__ doc_ids, KP* __restrict__ slab, long slab_ld,
                                                                unsigned* __restrict__ out_ids, float* __restrict__ out_scores,
                                                                double* __restrict__ out_scores64, int* __restrict__ out_counts, int k_cap) {
     __shared__ unsigned hist[256];
-    __shared__ int s_total, s_bin, s_before, s_less, s_eqbase;
-    __shared__ int wsum[BM_THREADS / 64];
-    __shared__ KP sel[BM_KMAX];
+    __shared__ int s_bin, s_before, s_n;
+    __shared__ KP sel_lds[BM_KMAX];
     const int q = blockIdx.x, t = threadIdx.x;
-    const double* row = acc + (long)q * nd;
-    // pass 0: count touched documents
-    if (t == 0) { s_total = 0; s_less = 0; s_eqbase = 0; }
+    double* row = acc + (long)q * nd;
+    const int* tl = touched + (long)q * tcap;
+    unsigned long long* tk = tkeys + (long)q * tcap;
+    const int total = (int)min((long)tcount[q], tcap);
+    // pass 0: keys of the touched documents; their accumulator entries go back to zero for the next search
+    for (int i = t; i < total; i += BM_THREADS) { const int doc = tl[i]; tk[i] = d2key_desc(row[doc]); row[doc] = 0.0; }
     __syncthreads();
-    int mine = 0;
-    for (long i = t; i < nd; i += BM_THREADS) mine += (row[i] != 0.0);
-    if (mine) atomicAdd(&s_total, mine);
-    __syncthreads();
-    const int total = s_total;
-    int kq = (K <= 0 || K >= total) ? total : K;          // `k <= 0 || k >= len(scores)` -> all (:330)
-    if (kq > BM_KMAX) kq = BM_KMAX;                        // caller guarantees k_cap <= BM_KMAX
+    const int kq_all = (K <= 0 || K >= total) ? total : K;          // `k <= 0 || k >= len(scores)` -> all (:330)
+    const int kq = kq_all < k_cap ? kq_all : k_cap;                 // what the caller's rows can hold
+    KP* sel = (kq > BM_KMAX) ? slab + (long)q * slab_ld : sel_lds;
     if (kq > 0) {
         unsigned long long prefix = 0, mask = 0; int remaining = kq;
         for (int shift = 56; shift >= 0; shift -= 8) {
             if (t < 256) hist[t] = 0;
             __syncthreads();
-            for (long i = t; i < nd; i += BM_THREADS) {
-                const double v = row[i];
-                if (v != 0.0) { const unsigned long long k = d2key_desc(v); if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255ull], 1u); }
-            }
+            for (int i = t; i < total; i += BM_THREADS) { const unsigned long long k = tk[i]; if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255ull], 1u); }
             __syncthreads();
             if (t == 0) {
                 int run = 0, b = 0;
@@ -100,29 +105,30 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(const double* __r
             __syncthreads();
         }
         const unsigned long long keystar = prefix;
-        const int r = remaining;            // equal-to-key* documents to take, lowest doc index first
-        const int n_less = kq - r;
-        // ordered sweep in chunks of BM_THREADS documents
-        for (long base = 0; base < nd; base += BM_THREADS) {
-            const long i = base + t;
-            unsigned long long k = ~0ull; bool lt = false, eq = false;
-            if (i < nd) { const double v = row[i]; if (v != 0.0) { k = d2key_desc(v); lt = k < keystar; eq = k == keystar; } }
-            if (lt) { int s = atomicAdd(&s_less, 1); sel[s].key = k; sel[s].pos = (unsigned)i; }
-            // rank among equals: block prefix
-            int e = eq ? 1 : 0, incl = e;
-            const int lane = t & 63, w = t >> 6;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { int y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
-            if (lane == 63) wsum[w] = incl;
+        // `remaining` documents with key == key* are taken, lowest document index first: select on the index
+        unsigned pprefix = 0, pmask = 0;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (t < 256) hist[t] = 0;
             __syncthreads();
-            int before = s_eqbase;
-            for (int j = 0; j < w; j++) before += wsum[j];
-            const int rank = before + incl - e;
-            if (eq && rank < r) { sel[n_less + rank].key = k; sel[n_less + rank].pos = (unsigned)i; }
+            for (int i = t; i < total; i += BM_THREADS) { if (tk[i] == keystar) { const unsigned p = (unsigned)tl[i]; if ((p & pmask) == pprefix) atomicAdd(&hist[(p >> shift) & 255u], 1u); } }
             __syncthreads();
-            if (t == BM_THREADS - 1) s_eqbase = before + incl;
+            if (t == 0) {
+                int run = 0, b = 0;
+                for (b = 0; b < 256; b++) { if (run + (int)hist[b] >= remaining) break; run += (int)hist[b]; }
+                s_bin = b; s_before = run;
+            }
+            __syncthreads();
+            pprefix |= ((unsigned)s_bin) << shift; pmask |= 255u << shift; remaining -= s_before;
             __syncthreads();
         }
+        const unsigned posstar = pprefix;
+        if (t == 0) s_n = 0;
+        __syncthreads();
+        for (int i = t; i < total; i += BM_THREADS) {
+            const unsigned long long k = tk[i]; const unsigned p = (unsigned)tl[i];
+            if (k < keystar || (k == keystar && p <= posstar)) { const int s = atomicAdd(&s_n, 1); sel[s].key = k; sel[s].pos = p; }
+        }
+        __syncthreads();
         // sort the kq selected (key, pos) pairs
         int n2 = 1; while (n2 < kq) n2 <<= 1;
         for (int i = kq + t; i < n2; i += BM_THREADS) { sel[i].key = ~0ull; sel[i].pos = 0xFFFFFFFFu; }
@@ -144,16 +150,16 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(const double* __r
     }
     for (int i = t; i < k_cap; i += BM_THREADS) {
         if (i < kq) {
-            const double s = key2d_desc(sel[i].key);
+            const double sc = key2d_desc(sel[i].key);
             out_ids[(long)q * k_cap + i] = doc_ids[sel[i].pos];
-            out_scores[(long)q * k_cap + i] = (float)s;                 // Score: float32(r.Score) (:392)
-            if (out_scores64) out_scores64[(long)q * k_cap + i] = s;
+            out_scores[(long)q * k_cap + i] = (float)sc;                // Score: float32(r.Score) (:392)
+            if (out_scores64) out_scores64[(long)q * k_cap + i] = sc;
         } else {
             out_ids[(long)q * k_cap + i] = 0; out_scores[(long)q * k_cap + i] = 0.0f;
             if (out_scores64) out_scores64[(long)q * k_cap + i] = 0.0;
         }
     }
-    if (t == 0) out_counts[q] = (K <= 0 || K >= total) ? total : K;
+    if (t == 0) out_counts[q] = kq_all;
 }
 
 }  // namespace comet
@@ -173,6 +179,7 @@ struct comet_text_index {
     bool dirty = true;
     std::vector<uint32_t> doc_ids_h; std::unordered_map<uint32_t, int> term_index; std::vector<int> term_off_h;
     DevBuf doc_ids, doc_len_dev, post_doc, post_tf, deleted_dev;
+    DevBuf acc; int64_t acc_rows = 0, acc_nd = -1; bool acc_clean = false;   // dense float64 rows, all-zero between searches
     int64_t nd = 0;
 
     void update_avg() { avg_doc_len = num_docs == 0 ? 0 : (double)total_tokens / (double)num_docs; }   // bm25_index.go updateAvgDocLen
@@ -263,7 +270,7 @@ int comet_bm25_search(comet_text_index* ix, const uint32_t* q_tokens, const int3
                       int32_t* out_counts, int32_t k_cap) {
     return guarded([&] {
         if (B <= 0) return (int)COMET_OK;
-        if (k_cap <= 0 || k_cap > BM_KMAX) COMET_FAIL(COMET_ERR_UNSUPPORTED, "k_cap must be in [1,%d]", BM_KMAX);
+        if (k_cap <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "k_cap must be positive");
         Ctx* c = ix->c;
         std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->scratch_reset();
         ix->compile();
@@ -289,16 +296,15 @@ int comet_bm25_search(comet_text_index* ix, const uint32_t* q_tokens, const int3
             launch_build_elig(c, ix->doc_ids.as<uint32_t>(), nd, dd, (int)del.size(), df, (int)flt.size(), e);
             elig = e;
         }
-        double* acc = c->salloc<double>((size_t)B * nd);
-        c->zero(acc, sizeof(double) * (size_t)B * nd);
         int maxlen = 0;
         for (int b = 0; b < B; b++) maxlen = std::max(maxlen, q_offsets[b + 1] - q_offsets[b]);
         std::vector<TermRef> refs((size_t)std::max(1, maxlen) * B);
-        int maxdf = 0;
-        for (int j = 0; j < maxlen; j++)
-            for (int b = 0; b < B; b++) {
+        int maxdf = 0; int64_t tcap = 1;
+        for (int b = 0; b < B; b++) {
+            int64_t touched_max = 0;
+            const int len = q_offsets[b + 1] - q_offsets[b];
+            for (int j = 0; j < maxlen; j++) {
                 TermRef r{0, 0, 0.0};
-                const int len = q_offsets[b + 1] - q_offsets[b];
                 if (j < len) {
                     auto it = ix->term_index.find(q_tokens[q_offsets[b] + j]);
                     if (it != ix->term_index.end()) {
@@ -307,30 +313,53 @@ int comet_bm25_search(comet_text_index* ix, const uint32_t* q_tokens, const int3
                         const double df = (double)r.df;
                         r.idf = go_log((N - df + 0.5) / (df + 0.5) + 1.0);     // :306
                         maxdf = std::max(maxdf, r.df);
+                        touched_max += r.df;
                     }
                 }
                 refs[(size_t)j * B + b] = r;
             }
+            tcap = std::max(tcap, std::min<int64_t>(touched_max, nd));
+        }
+        // the dense accumulator persists in the index (all-zero between searches); queries go through it in sub-batches of <= 4 GiB
+        const int64_t rows = std::max<int64_t>(1, std::min<int64_t>(B, ((int64_t)4 << 30) / (nd * 8)));
+        if (ix->acc_nd != nd || ix->acc_rows < rows || !ix->acc_clean) {
+            ix->acc.reserve((size_t)rows * nd * 8, c->stream, 0);
+            ix->acc_rows = rows; ix->acc_nd = nd;
+            c->zero(ix->acc.p, (size_t)rows * nd * 8);
+        }
+        ix->acc_clean = false;                      // an error between here and the last selection leaves touched entries behind
+        double* acc = ix->acc.as<double>();
         TermRef* drefs = c->salloc<TermRef>(refs.size());
         c->h2d(drefs, refs.data(), refs.size() * sizeof(TermRef));
-        if (maxdf > 0) {
-            for (int j = 0; j < maxlen; j++) {
-                ProfScope ps(c, "bm25_score");
-                bm25_score_kernel<<<dim3((unsigned)ceil_div(maxdf, 256), B), dim3(256), 0, c->stream>>>(drefs + (size_t)j * B, ix->post_doc.as<int>(), ix->post_tf.as<int>(),
-                                                                                                   ix->doc_len_dev.as<int>(), elig, ix->avg_doc_len, acc, nd);
+        int32_t* touched = c->salloc<int32_t>((size_t)rows * tcap);
+        unsigned long long* tkeys = c->salloc<unsigned long long>((size_t)rows * tcap);
+        int32_t* tcount = c->salloc<int32_t>(rows);
+        int64_t slab_ld = 1; while (slab_ld < std::min<int64_t>(k_cap, tcap)) slab_ld <<= 1;
+        KP* slab = (std::min<int64_t>(k_cap, tcap) > BM_KMAX) ? c->salloc<KP>((size_t)rows * slab_ld) : nullptr;
+        for (int b0 = 0; b0 < B; b0 += (int)rows) {
+            const int bn = std::min<int>((int)rows, B - b0);
+            c->zero(tcount, sizeof(int32_t) * bn);
+            if (maxdf > 0) {
+                for (int j = 0; j < maxlen; j++) {
+                    ProfScope ps(c, "bm25_score");
+                    bm25_score_kernel<<<dim3((unsigned)ceil_div(maxdf, 256), bn), dim3(256), 0, c->stream>>>(drefs + (size_t)j * B + b0, ix->post_doc.as<int>(), ix->post_tf.as<int>(),
+                                                                                                        ix->doc_len_dev.as<int>(), elig, ix->avg_doc_len, acc, nd, touched, tcap, tcount);
+                    LAUNCH_CHECK();
+                }
+            }
+            {
+                ProfScope ps(c, "bm25_topk");
+                bm25_topk_kernel<<<dim3(bn), dim3(BM_THREADS), 0, c->stream>>>(acc, nd, touched, tcap, tcount, tkeys, k, ix->doc_ids.as<uint32_t>(), slab, slab_ld,
+                                                                              d_ids + (size_t)b0 * k_cap, d_sc + (size_t)b0 * k_cap, d_sc64 + (size_t)b0 * k_cap, d_cn + b0, k_cap);
                 LAUNCH_CHECK();
             }
-        }
-        {
-            ProfScope ps(c, "bm25_topk");
-            bm25_topk_kernel<<<dim3(B), dim3(BM_THREADS), 0, c->stream>>>(acc, nd, k, ix->doc_ids.as<uint32_t>(), d_ids, d_sc, d_sc64, d_cn, k_cap);
-            LAUNCH_CHECK();
         }
         c->d2h(out_ids, d_ids, (size_t)B * k_cap * 4);
         c->d2h(out_scores, d_sc, (size_t)B * k_cap * 4);
         if (out_scores64) c->d2h(out_scores64, d_sc64, (size_t)B * k_cap * 8);
         c->d2h(out_counts, d_cn, (size_t)B * 4);
         c->sync();
+        ix->acc_clean = true;
         return (int)COMET_OK;
     });
 }

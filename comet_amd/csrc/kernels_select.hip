@@ -25,7 +25,7 @@ constexpr int SEL_CHUNK = SEL_THREADS * SEL_EPT;    // 4096 candidates per workg
 constexpr int SEL_BINS = 4096;
 constexpr int SORT_MAX = 4096;                      // max K sorted in LDS
 
-int select_max_k() { return SORT_MAX; }   // for candidate rows longer than SMALL_MAX; shorter rows have no limit
+int select_max_k() { return 0x7FFFFFFF; }   // no limit: selections of more than SORT_MAX results sort in global memory
 
 struct SelState {
     unsigned prefix;     // bits of key* decided so far
@@ -285,6 +285,74 @@ __global__ __launch_bounds__(1024) void sel_sort_kernel(const unsigned long long
         }
     }
     if (threadIdx.x == 0) out_counts[q] = kq;
+}
+
+// ---- rows of 64-bit composites sorted in global memory: selections larger than the LDS sort --------------
+// Bitonic network over B rows of ld (a power of two) composites: 4096-element tiles take every step with j < 4096 in LDS,
+// the wider steps are one launch each. Nothing here is on a hot path (k > 4096 on rows longer than 8192 candidates).
+constexpr int GS_TILE = 4096;
+template <bool INIT>
+__global__ __launch_bounds__(1024) void bitonic_tile_kernel(unsigned long long* __restrict__ comp, long ld, int k_fixed) {
+    __shared__ unsigned long long sm[GS_TILE];
+    unsigned long long* row = comp + (long)blockIdx.y * ld;
+    const long base = (long)blockIdx.x * GS_TILE;
+    const int n = (int)(ld < GS_TILE ? ld : GS_TILE);
+    for (int i = threadIdx.x; i < n; i += 1024) sm[i] = row[base + i];
+    __syncthreads();
+    auto step = [&](long k, int j) {
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const int ixj = i ^ j;
+            if (ixj > i) {
+                const unsigned long long a = sm[i], b = sm[ixj];
+                const bool up = (((base + i) & k) == 0);
+                if ((a > b) == up) { sm[i] = b; sm[ixj] = a; }
+            }
+        }
+        __syncthreads();
+    };
+    if (INIT) { for (int k = 2; k <= n; k <<= 1) for (int j = k >> 1; j > 0; j >>= 1) step(k, j); }
+    else { for (int j = GS_TILE >> 1; j > 0; j >>= 1) step((long)k_fixed, j); }
+    for (int i = threadIdx.x; i < n; i += 1024) row[base + i] = sm[i];
+}
+__global__ __launch_bounds__(256) void bitonic_global_kernel(unsigned long long* __restrict__ comp, long ld, long k, long j) {
+    unsigned long long* row = comp + (long)blockIdx.y * ld;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;           // one compare-exchange per thread
+    if (t >= ld / 2) return;
+    const long i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
+    const unsigned long long a = row[i], b = row[ixj];
+    const bool up = ((i & k) == 0);
+    if ((a > b) == up) { row[i] = b; row[ixj] = a; }
+}
+void sort_rows_u64(Ctx* c, unsigned long long* comp, int64_t ld, int B) {
+    ProfScope ps(c, "select_sort_global");
+    const unsigned tiles = (unsigned)std::max<int64_t>(1, ld / GS_TILE);
+    bitonic_tile_kernel<true><<<dim3(tiles, B), dim3(1024), 0, c->stream>>>(comp, ld, 0);
+    for (int64_t k = 2 * GS_TILE; k <= ld; k <<= 1) {
+        for (int64_t j = k >> 1; j >= GS_TILE; j >>= 1)
+            bitonic_global_kernel<<<dim3((unsigned)ceil_div(ld / 2, 256), B), dim3(256), 0, c->stream>>>(comp, ld, k, j);
+        bitonic_tile_kernel<false><<<dim3(tiles, B), dim3(1024), 0, c->stream>>>(comp, ld, (int)k);
+    }
+    LAUNCH_CHECK();
+}
+// comp rows hold kq composites each: everything behind them sorts last
+__global__ __launch_bounds__(256) void sel_pad_kernel(unsigned long long* __restrict__ comp, long ld, const SelState* __restrict__ st) {
+    const int q = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < ld && i >= st[q].kq) comp[(long)q * ld + i] = ~0ull;
+}
+__global__ __launch_bounds__(256) void sel_emit_kernel(const unsigned long long* __restrict__ comp, long ld, const SelState* __restrict__ st,
+                                                       unsigned* __restrict__ out_pos, float* __restrict__ out_scores, int* __restrict__ out_counts, int k_cap) {
+    const int q = blockIdx.y, kq = st[q].kq;
+    const int nw = kq < k_cap ? kq : k_cap;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < k_cap) {
+        if (i < nw) {
+            const unsigned long long cc = comp[(long)q * ld + i];
+            out_pos[(long)q * k_cap + i] = (unsigned)(cc & 0xFFFFFFFFull);
+            out_scores[(long)q * k_cap + i] = __uint_as_float(key2f((unsigned)(cc >> 32)));
+        } else { out_pos[(long)q * k_cap + i] = 0xFFFFFFFFu; out_scores[(long)q * k_cap + i] = 0.0f; }
+    }
+    if (i == 0) out_counts[q] = kq;
 }
 
 // ---- small candidate rows (C <= 8192): one workgroup per query, everything in LDS ---------------------
@@ -679,13 +747,13 @@ void launch_select_topk(Ctx* c, const float* D, int64_t ldD, int B, int64_t C, c
         return;
     }
     const int64_t kmax = (K <= 0 || K > C) ? C : K;
-    if (kmax > SORT_MAX) COMET_FAIL(COMET_ERR_UNSUPPORTED, "top-k of %lld exceeds the on-device selection limit %d", (long long)kmax, SORT_MAX);
+    const bool big = kmax > SORT_MAX;                 // the final sort does not fit in LDS: radix select as usual, then a sort in global memory
     const int nchunks = (int)ceil_div(C, SEL_CHUNK);
     dim3 grid(nchunks, B), blk(SEL_THREADS);
     // sample-bound path: expected kept candidates K*C/S held near 512 (BOUND_CAP = 8x that); needs K >= 1
     int* rowlist = nullptr;
     static const bool bound_off = getenv("COMET_SELECT_NO_BOUND") != nullptr;
-    if (K >= 1 && !bound_off) {
+    if (K >= 1 && !bound_off && !big) {
         int64_t S = std::max<int64_t>(SMALL_MAX, round_up((int64_t)K * C / 512, 1024));
         if (S <= BOUND_SAMPLE_MAX && S * 2 <= C) {
             unsigned* bound = c->salloc<unsigned>(B);
@@ -710,7 +778,7 @@ void launch_select_topk(Ctx* c, const float* D, int64_t ldD, int B, int64_t C, c
     SelState* st = c->salloc<SelState>(B);
     unsigned* hist = c->salloc<unsigned>((size_t)B * SEL_BINS);
     int* eqcnt = c->salloc<int>((size_t)B * nchunks);
-    int comp_ld = 1; while (comp_ld < kmax) comp_ld <<= 1;
+    int64_t comp_ld = 1; while (comp_ld < kmax) comp_ld <<= 1;
     unsigned long long* comp = c->salloc<unsigned long long>((size_t)B * comp_ld);
     c->zero(st, sizeof(SelState) * B);
     c->zero(hist, sizeof(unsigned) * (size_t)B * SEL_BINS);
@@ -727,6 +795,13 @@ void launch_select_topk(Ctx* c, const float* D, int64_t ldD, int B, int64_t C, c
       sel_scan_eq_kernel<<<dim3(B), blk, 0, c->stream>>>(eqcnt, nchunks, rowlist); LAUNCH_CHECK(); }
     { ProfScope ps(c, "select_gather");
       sel_gather_kernel<<<grid, blk, 0, c->stream>>>(D, ldD, C, cnts, thr, st, eqcnt, nchunks, comp, comp_ld, rowlist); LAUNCH_CHECK(); }
+    if (big) {
+        sel_pad_kernel<<<dim3((unsigned)ceil_div(comp_ld, 256), B), dim3(256), 0, c->stream>>>(comp, comp_ld, st);
+        sort_rows_u64(c, comp, comp_ld, B);
+        sel_emit_kernel<<<dim3((unsigned)ceil_div(k_cap, 256), B), dim3(256), 0, c->stream>>>(comp, comp_ld, st, out_pos, out_scores, out_counts, k_cap);
+        LAUNCH_CHECK();
+        return;
+    }
     { ProfScope ps(c, "select_sort");
       int threads = comp_ld >= 2048 ? 1024 : (comp_ld >= 512 ? 256 : 64);
       sel_sort_kernel<<<dim3(B), dim3(threads), sizeof(unsigned long long) * comp_ld, c->stream>>>(comp, comp_ld, st, out_pos, out_scores, out_counts, k_cap, rowlist);
@@ -783,15 +858,60 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const unsigned* __rest
     }
     if (threadIdx.x == 0) out_counts[q] = total < 0 ? total : kq;
 }
+// the same merge for R x k_cap beyond the LDS: build composites, sort_rows_u64, emit
+__global__ __launch_bounds__(256) void merge_build_kernel(const float* __restrict__ scores, const int* __restrict__ counts, int R, int k_cap,
+                                                          unsigned long long* __restrict__ comp, long n2, long rs, long rsc) {
+    const int q = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n2) return;
+    unsigned long long v = ~0ull;
+    if (i < (long)R * k_cap) {
+        const int r = (int)(i / k_cap), j = (int)(i - (long)r * k_cap);
+        int cnt = counts[r * rsc + q]; if (cnt > k_cap) cnt = k_cap;
+        if (j < cnt) v = ((unsigned long long)f2key(__float_as_uint(scores[r * rs + (long)q * k_cap + j])) << 32) | (unsigned)i;
+    }
+    comp[(long)q * n2 + i] = v;
+}
+__global__ __launch_bounds__(256) void merge_emit_kernel(const unsigned* __restrict__ ids, const int* __restrict__ counts, const unsigned long long* __restrict__ comp,
+                                                         int R, int k_cap, int k, unsigned* __restrict__ out_ids, float* __restrict__ out_scores,
+                                                         int* __restrict__ out_counts, long n2, long rs, long rsc) {
+    const int q = blockIdx.y;
+    int total = 0;
+    for (int r = 0; r < R; r++) { int cnt = counts[r * rsc + q]; if (cnt < 0) { total = cnt; break; } total += cnt < k_cap ? cnt : k_cap; }
+    int kq = total < 0 ? 0 : ((k <= 0 || k > total) ? total : k);
+    if (kq > k_cap) kq = k_cap;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < k_cap) {
+        unsigned id = 0; float sc = 0.0f;
+        if (i < kq) {
+            const unsigned long long cmp = comp[(long)q * n2 + i];
+            const unsigned src = (unsigned)(cmp & 0xFFFFFFFFull);
+            const int r = src / k_cap, j = src - r * k_cap;
+            id = ids[r * rs + (long)q * k_cap + j];
+            sc = __uint_as_float(key2f((unsigned)(cmp >> 32)));
+        }
+        out_ids[(long)q * k_cap + i] = id; out_scores[(long)q * k_cap + i] = sc;
+    }
+    if (i == 0) out_counts[q] = total < 0 ? total : kq;
+}
 void launch_merge_topk(Ctx* c, const uint32_t* ids, const float* scores, const int32_t* counts, int R, int B, int k_cap, int k,
                        uint32_t* out_ids, float* out_scores, int32_t* out_counts, int64_t rank_stride, int64_t rank_stride_counts) {
     if (B <= 0) return;
     const long rs = rank_stride > 0 ? rank_stride : (long)B * k_cap, rsc = rank_stride_counts > 0 ? rank_stride_counts : B;
-    int n2 = 1; while (n2 < R * k_cap) n2 <<= 1;
-    if (n2 > 2 * SORT_MAX) COMET_FAIL(COMET_ERR_UNSUPPORTED, "merge of %d x %d candidates exceeds the on-device limit", R, k_cap);
+    int64_t n2 = 1; while (n2 < (int64_t)R * k_cap) n2 <<= 1;
+    if (n2 > 2 * SORT_MAX) {            // does not fit in LDS: composites to global memory, global sort, emit
+        ScratchMark mark(c);
+        unsigned long long* comp = c->salloc<unsigned long long>((size_t)B * n2);
+        { ProfScope ps(c, "merge_topk");
+          merge_build_kernel<<<dim3((unsigned)ceil_div(n2, 256), B), dim3(256), 0, c->stream>>>(scores, counts, R, k_cap, comp, n2, rs, rsc); LAUNCH_CHECK(); }
+        sort_rows_u64(c, comp, n2, B);
+        { ProfScope ps(c, "merge_topk");
+          merge_emit_kernel<<<dim3((unsigned)ceil_div(k_cap, 256), B), dim3(256), 0, c->stream>>>(ids, counts, comp, R, k_cap, k, out_ids, out_scores, out_counts, n2, rs, rsc); LAUNCH_CHECK(); }
+        return;
+    }
     ProfScope ps(c, "merge_topk");
     int threads = n2 >= 2048 ? 1024 : (n2 >= 512 ? 256 : 64);
-    merge_topk_kernel<<<dim3(B), dim3(threads), sizeof(unsigned long long) * n2, c->stream>>>(ids, scores, counts, R, B, k_cap, k, out_ids, out_scores, out_counts, n2, rs, rsc);
+    merge_topk_kernel<<<dim3(B), dim3(threads), sizeof(unsigned long long) * n2, c->stream>>>(ids, scores, counts, R, B, k_cap, k, out_ids, out_scores, out_counts, (int)n2, rs, rsc);
     LAUNCH_CHECK();
 }
 

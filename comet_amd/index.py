@@ -725,7 +725,8 @@ class TextSearch:
         if not self.queries:
             raise ValueError("must specify either queries or node IDs")
         agg = self.aggregation or SUM_AGGREGATION
-        k_cap = max(1, min(2048, self.k if self.k > 0 else 2048))
+        nd = max(1, self.index.num_docs())
+        k_cap = max(1, min(nd, self.k if self.k > 0 else nd))
         ids, sc, _, cnt = self.index.search_batch(self.queries, self.k, document_ids=self.document_ids, k_cap=k_cap)
         allr = [TextResult(int(ids[b, i]), np.float32(sc[b, i])) for b in range(len(self.queries)) for i in range(min(cnt[b], k_cap))]
         res = aggregate_text(allr, agg)
@@ -775,7 +776,8 @@ class BM25SearchIndex:
 
     def search_batch(self, queries, k: int, document_ids: Iterable[int] = (), k_cap: int | None = None):
         B = len(queries)
-        k_cap = k_cap or max(1, min(2048, k if k > 0 else 2048))
+        nd = max(1, self.num_docs())
+        k_cap = k_cap or max(1, min(nd, k if k > 0 else nd))
         offs = np.zeros(B + 1, dtype=np.int32)
         for i, qt in enumerate(queries):
             offs[i + 1] = offs[i] + len(qt)
@@ -838,4 +840,4 @@ class HNSWIndex(VectorIndex):
 
     def _k_cap(self, k, nprobes):
         n = len(self)
-        return max(1, min(1024, n if (k <= 0 or k > n) else k))
+        return max(1, n if (k <= 0 or k > n) else k)
