@@ -80,6 +80,7 @@ int comet_synth_mixture_dev(comet_ctx* c, uint64_t seed, int32_t n_centers, floa
 }
 
 int comet_profile_enable(comet_ctx* c, int on) { return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->sync(); c->profile = on != 0; return COMET_OK; }); }
+int comet_profile_only(comet_ctx* c, const char* name) { return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->sync(); c->prof_only = name ? name : ""; return COMET_OK; }); }
 int comet_profile_reset(comet_ctx* c) { return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->sync(); c->prof.clear(); return COMET_OK; }); }
 int comet_profile_get(comet_ctx* c, const char* prefix, double* total_ms, int64_t* launches) {
     return guarded([&] {

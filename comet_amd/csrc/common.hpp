@@ -86,6 +86,8 @@ struct Ctx {
     void* pinned = nullptr; size_t pinned_cap = 0;
     // profiling
     bool profile = false;
+    std::string prof_only;       // non-empty: only scopes of this name are timed (event records are barrier packets: ~5 us each in a chain of short kernels)
+    bool prof_open = false;
     struct Pending { std::string name; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::map<std::string, ProfEntry> prof;
@@ -126,14 +128,16 @@ struct Ctx {
     void zero(void* dst, size_t bytes) { if (bytes) HIP_CHECK(hipMemsetAsync(dst, 0, bytes, stream)); }
 
     void prof_begin(const char* name) {
-        if (!profile) return;
+        prof_open = profile && (prof_only.empty() || prof_only == name);
+        if (!prof_open) return;
         Pending p; p.name = name;
         HIP_CHECK(hipEventCreate(&p.a)); HIP_CHECK(hipEventCreate(&p.b));
         HIP_CHECK(hipEventRecord(p.a, stream));
         pending.push_back(p);
     }
     void prof_end() {
-        if (!profile) return;
+        if (!prof_open) return;
+        prof_open = false;
         (void)hipEventRecord(pending.back().b, stream);
     }
     void collect_profile() {

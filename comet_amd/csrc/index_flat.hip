@@ -58,12 +58,16 @@ struct FlatIndex : comet_index {
         const float* queries = nullptr; comet_search_params p{}; std::vector<uint32_t> flt;
         uint32_t* out_ids = nullptr; float* out_scores = nullptr; int32_t* out_counts = nullptr;
         int32_t* flags = nullptr;   // pinned: per fast slice [256 overflow flags | 4 stats]
+        int32_t* dflags = nullptr;  // the same slices in HBM: written by the post stage, copied to `flags` on the copy stream
+        hipEvent_t ev_post = nullptr;
     };
+    hipStream_t copy_stream = nullptr;   // the flag copy runs beside the next batch's kernels instead of between them
     static constexpr int kRing = 8, kSliceInts = 260, kMaxSlices = 64;
     Pending ring[kRing];
     uint64_t next_ticket = 1;
     ~FlatIndex() override {
-        for (auto& r : ring) { if (r.ev) (void)hipEventDestroy(r.ev); if (r.flags) (void)hipHostFree(r.flags); }
+        for (auto& r : ring) { if (r.ev) (void)hipEventDestroy(r.ev); if (r.ev_post) (void)hipEventDestroy(r.ev_post); if (r.flags) (void)hipHostFree(r.flags); if (r.dflags) (void)hipFree(r.dflags); }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
     }
 
     int64_t size() const override { return n; }
@@ -191,9 +195,10 @@ struct FlatIndex : comet_index {
         return ok && n >= (int64_t)flat_fast_unit_rows(256) * 4 * keff;
     }
 
-    // MFMA fast path for up to 256 prepared queries; writes the final ids / scores / counts of the slice
-    void search_fast(const float* Qp, const int32_t* zflag, int bn, const comet_search_params& p, const uint8_t* elig, uint32_t* out_ids,
-                     float* out_scores, int32_t* out_counts, int k_cap, Pending* pend) {
+    // MFMA fast path for up to 256 prepared queries; writes the final ids / scores / counts of the slice.
+    // raw_queries != nullptr: the queries are not preprocessed yet — one fused launch does Distance.Preprocess and the fp16 side.
+    void search_fast(const float* Qp, int32_t* zflag, int bn, const comet_search_params& p, const uint8_t* elig, uint32_t* out_ids,
+                     float* out_scores, int32_t* out_counts, int k_cap, Pending* pend, const float* raw_queries = nullptr) {
         ScratchMark sm(c);
         // key units: the scan emits, per query, 2 keys + 1 bound for every 128-row unit (64-row unit on the narrow tile for <= 64 queries)
         const int unit_rows = flat_fast_unit_rows(bn);
@@ -203,10 +208,12 @@ struct FlatIndex : comet_index {
         void* Qh = c->scratch_alloc((size_t)NB * ldh * 2 * 2);   // row-major copy + MFMA-fragment-ordered copy
         float* qn = c->salloc<float>(NB);
         float* err = c->salloc<float>(NB);
-        int32_t* flags = c->salloc<int32_t>(kSliceInts);     // [256 overflow flags | 4 stats], copied to the host in one piece
+        int32_t* flags = pend->dflags + (size_t)pend->nfast_slices * kSliceInts;     // [256 overflow flags | 4 stats] of this slice
         int32_t* ovf = flags; int32_t* st = flags + 256;
         const int fmode = metric == COMET_COSINE ? 0 : 1;
-        launch_prep_queries_fast(c, Qp, bn, ld, dim, Qh, ldh, qn, err, fmode, metric == COMET_COSINE ? 1.0002f : xmax_norm2, st);
+        const float xn2 = metric == COMET_COSINE ? 1.0002f : xmax_norm2;
+        if (raw_queries) launch_prep_queries_fused(c, metric, raw_queries, bn, dim, const_cast<float*>(Qp), ld, zflag, Qh, ldh, qn, err, fmode, xn2, st);
+        else launch_prep_queries_fast(c, Qp, bn, ld, dim, Qh, ldh, qn, err, fmode, xn2, st);
         float* S0 = c->salloc<float>((size_t)NB * ldS);
         float* bound = c->salloc<float>((size_t)NB * ldB);
         launch_flat_scan_f16(c, fmode, Xh.p, n, ldh, Qh, bn, rn.as<float>(), qn, elig, S0, ldS, bound, ldB);
@@ -216,17 +223,18 @@ struct FlatIndex : comet_index {
         // if the unit keys cannot even supply K values (tiny index / huge K) tau = +inf: every unit is expanded
         launch_flat_post(c, metric, S0, ldS, bound, ldB, n_tiles, unit_rows, n, elig, err, p.k, (Kq == keff) ? Kq : 0, p.threshold, X.as<float>(), ld, Qp, bn,
                          ids_dev.as<uint32_t>(), zflag, out_ids, out_scores, out_counts, k_cap, ovf, st);
-        // overflow flags + statistics go to pinned host memory asynchronously; search_finish() acts on them
-        int32_t* hf = pend->flags + (size_t)pend->nfast_slices * kSliceInts;
-        c->d2h(hf, flags, kSliceInts * sizeof(int32_t));
-        pend->nfast_slices++;
+        pend->nfast_slices++;                        // search_begin copies the slices to pinned host memory on the copy stream
     }
 
     // flatIndexSearch.searchSingleQuery flat_index_search.go:221-294 for B queries at once (enqueue only).
     void search_core(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
                      int32_t* out_counts, int k_cap, Pending* pend) {
         float* Qp; int32_t* zflag;
-        prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag);
+        const int NB = flat_fast_batch();
+        // one fast slice: Distance.Preprocess is fused into the fast path's query kernel (search_fast with the raw queries)
+        const bool fuse_prep = pend && n > 0 && B <= NB && fast_usable(B, p) && prep_queries_fused_ok(dim);
+        if (fuse_prep) { Qp = c->salloc<float>((size_t)B * ld); zflag = c->salloc<int32_t>(B); }
+        else prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag);
         if (n == 0) {   // empty index: zero results (sanitizeK(k, 0) == 0)
             uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
             launch_select_topk(c, nullptr, 0, B, 0, nullptr, 0.0f, p.k, pos, out_scores, out_counts, k_cap);
@@ -245,11 +253,11 @@ struct FlatIndex : comet_index {
             elig = e;
         }
         if (p.mode == 2 && !fast_usable(B, p)) COMET_FAIL(COMET_ERR_UNSUPPORTED, "fast path unavailable for this index / k (values beyond fp16 range or k > 1024)");
-        const int NB = flat_fast_batch();
         if (pend && fast_usable(B, p) && ceil_div(B, NB) <= kMaxSlices) {
             for (int b0 = 0; b0 < B; b0 += NB) {
                 const int bn = std::min(NB, B - b0);
-                search_fast(Qp + (size_t)b0 * ld, zflag + b0, bn, p, elig, out_ids + (size_t)b0 * k_cap, out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap, pend);
+                search_fast(Qp + (size_t)b0 * ld, zflag + b0, bn, p, elig, out_ids + (size_t)b0 * k_cap, out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap, pend,
+                            fuse_prep ? queries_dev : nullptr);
             }
             return;                                  // the post stage wrote ids and statuses itself
         }
@@ -271,13 +279,23 @@ struct FlatIndex : comet_index {
         }
         if (!slot->ev) HIP_CHECK(hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
         if (!slot->flags) HIP_CHECK(hipHostMalloc((void**)&slot->flags, sizeof(int32_t) * kSliceInts * kMaxSlices, hipHostMallocDefault));
+        if (!slot->dflags) HIP_CHECK(hipMalloc((void**)&slot->dflags, sizeof(int32_t) * kSliceInts * kMaxSlices));
+        if (!slot->ev_post) HIP_CHECK(hipEventCreateWithFlags(&slot->ev_post, hipEventDisableTiming));
+        if (!copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         slot->ticket = next_ticket++; slot->B = B; slot->k_cap = k_cap; slot->nfast_slices = 0; slot->queries = queries_dev;
         slot->p = p; slot->flt.clear();
         if (p.filter_ids && p.n_filter > 0) { slot->flt.assign(p.filter_ids, p.filter_ids + p.n_filter); slot->p.filter_ids = slot->flt.data(); }
         slot->out_ids = out_ids; slot->out_scores = out_scores; slot->out_counts = out_counts;
         st_candidates = st_overflows = st_expansions = st_fast_queries = st_strict_queries = 0;
         search_core(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap, slot);
-        HIP_CHECK(hipEventRecord(slot->ev, c->stream));
+        if (slot->nfast_slices > 0) {
+            // overflow flags + statistics go to pinned host memory on the copy stream: the copy (a kernel of its own plus two launch
+            // gaps) leaves the chain of the next batch; search_finish() waits for it and therefore for everything before it
+            HIP_CHECK(hipEventRecord(slot->ev_post, c->stream));
+            HIP_CHECK(hipStreamWaitEvent(copy_stream, slot->ev_post, 0));
+            HIP_CHECK(hipMemcpyAsync(slot->flags, slot->dflags, sizeof(int32_t) * kSliceInts * slot->nfast_slices, hipMemcpyDeviceToHost, copy_stream));
+            HIP_CHECK(hipEventRecord(slot->ev, copy_stream));
+        } else HIP_CHECK(hipEventRecord(slot->ev, c->stream));
         slot->active = true;
         return slot->ticket;
     }

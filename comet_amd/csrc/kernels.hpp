@@ -96,6 +96,9 @@ void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const fl
                       const float* err_abs, int K, int kappa_rank, float thr, const float* X, int ld, const float* Qp, int B,
                       const uint32_t* ids_table, const int32_t* zflag, uint32_t* out_ids, float* out_scores, int32_t* out_counts, int k_cap,
                       int32_t* overflow, int32_t* stats);
+bool prep_queries_fused_ok(int dim);
+void launch_prep_queries_fused(Ctx* c, int metric, const float* src, int B, int dim, float* Qp, int ld, int32_t* zero_flag, void* Qh, int ldh, float* qn,
+                               float* err_abs, int mode, float xmax_norm2, int32_t* stats4);
 void launch_prep_queries_fast(Ctx* c, const float* Qp, int B, int ld, int dim, void* Qh, int ldh, float* qn, float* err_abs, int mode, float xmax_norm2,
                               int32_t* stats4);
 

@@ -20,11 +20,13 @@
 //               re-scored in the reference's float32 order and selected exactly: ids and scores are
 //               bit-identical to the strict path; a query whose candidate list overflows is flagged and
 //               re-run on the strict path.
+#include <type_traits>
 #include "kernels.hpp"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 namespace comet {
 
@@ -681,6 +683,72 @@ void launch_prep_queries_fast(Ctx* c, const float* Qp, int B, int ld, int dim, v
     LAUNCH_CHECK();
 }
 
+// Distance.Preprocess(query) (the cosine normalisation of ingest_rows_wave_kernel: serial float32 norm, same order as the Go loop)
+// and the fp16 / fragment-ordered / error-bound side of prep_queries_fast_kernel in ONE launch, a wave per query: a search step
+// is a chain of short dependent kernels, and every link costs a ~6 us launch gap on top of its own time.
+constexpr int PREPF_MAX_D = 2048;
+__global__ __launch_bounds__(256) void prep_queries_fused_kernel(int metric, const float* __restrict__ src, int B, int d, float* __restrict__ Qp, int ld,
+                                                                 int* __restrict__ zero_flag, _Float16* __restrict__ Qh, int ldh, float* __restrict__ qn,
+                                                                 float* __restrict__ err_abs, int mode, float xmax_norm2, int* __restrict__ stats4) {
+    extern __shared__ __attribute__((aligned(16))) float sq[];   // [4 waves][dpad]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + w;
+    if (stats4 && blockIdx.x == 0 && threadIdx.x < 4) stats4[threadIdx.x] = 0;   // the post stage accumulates into these
+    if (q >= FB_N) return;
+    const int dpad = (d + 3) & ~3;
+    float* my = sq + (long)w * dpad;
+    const float* sp = src + (long)q * d;
+    float scale = 1.0f; int zf = 0;
+    const bool live = q < B;
+    if (live && metric == COMET_COSINE) {
+        for (int i = lane; i < dpad; i += 64) { const float v = i < d ? sp[i] : 0.0f; my[i] = v * v; }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        float sum = 0.0f;
+        if (lane == 0) {
+#pragma unroll 8
+            for (int i = 0; i < dpad; i += 4) {
+                const f32x4v p = *reinterpret_cast<const f32x4v*>(&my[i]);
+                sum = sum + p[0]; sum = sum + p[1]; sum = sum + p[2]; sum = sum + p[3];
+            }
+        }
+        sum = __shfl(sum, 0, 64);
+        const float norm = (float)__builtin_sqrt((double)sum);      // float32(math.Sqrt(float64(sum)))
+        if (norm == 0.0f) zf = 1; else scale = 1.0f / norm;
+    }
+    _Float16* o = Qh + (long)q * ldh;
+    _Float16* qf = Qh + (long)FB_N * ldh;
+    const int nk = ldh >> 6;
+    float s = 0.0f;
+    for (int i = lane; i < ldh; i += 64) {
+        float v = 0.0f;
+        if (live && i < d) { v = sp[i]; if (metric == COMET_COSINE && !zf) v = v * scale; }
+        if (live && i < ld) Qp[(long)q * ld + i] = v;
+        o[i] = (_Float16)v;
+        qf[(((((long)(q >> 5) * nk + (i >> 6)) * 4 + ((i >> 4) & 3)) * 64) + ((i >> 3) & 1) * 32 + (q & 31)) * 8 + (i & 7)] = (_Float16)v;
+        s += v * v;
+    }
+    if (live) for (int i = ldh + lane; i < ld; i += 64) Qp[(long)q * ld + i] = 0.0f;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) {
+        if (live && zero_flag) zero_flag[q] = zf;
+        qn[q] = s;
+        const float nq = sqrtf(s) * 1.0001f, nx = sqrtf(xmax_norm2) * 1.0001f, dd = (float)d;
+        float edot = (1.0f / 1024.0f + 2.0f * dd * 1.2e-7f) * nq * nx + 6.0e-8f * sqrtf(dd) * (nq + nx);
+        float e = mode == 0 ? edot : 2.0f * edot + (dd + 8.0f) * 1.2e-7f * (nq + nx) * (nq + nx);
+        e += 6.2e-5f * (mode == 0 ? nq * nx : nx * nx + 2.0f * nq * nx);
+        err_abs[q] = 1.25f * e;
+    }
+}
+bool prep_queries_fused_ok(int dim) { return dim <= PREPF_MAX_D; }
+void launch_prep_queries_fused(Ctx* c, int metric, const float* src, int B, int dim, float* Qp, int ld, int32_t* zero_flag, void* Qh, int ldh, float* qn,
+                               float* err_abs, int mode, float xmax_norm2, int32_t* stats4) {
+    ProfScope ps(c, "prep_queries");
+    const size_t lds = (size_t)4 * ((dim + 3) & ~3) * sizeof(float);
+    prep_queries_fused_kernel<<<dim3(FB_N / 4), dim3(256), lds, c->stream>>>(metric, src, B, dim, Qp, ld, zero_flag, (_Float16*)Qh, ldh, qn, err_abs, mode, xmax_norm2, stats4);
+    LAUNCH_CHECK();
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // fused post-scan stage: ONE workgroup per query does what used to be five launches (K-th tile key, candidate
@@ -772,8 +840,10 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
                                                                  float thr, const float* __restrict__ X, int ld, const float* __restrict__ Qp,
                                                                  const unsigned* __restrict__ ids_table, const int* __restrict__ zflag,
                                                                  unsigned* __restrict__ out_ids, float* __restrict__ out_scores, int* __restrict__ out_counts,
-                                                                 int k_cap, int* __restrict__ overflow, int* __restrict__ stats) {
+                                                                 int k_cap, int* __restrict__ overflow, int* __restrict__ stats, unsigned long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    unsigned long long tr_prev = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto TR = [&](int ph) { if (trace && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); atomicAdd(&trace[ph], now - tr_prev); tr_prev = now; } };
     unsigned* hist = reinterpret_cast<unsigned*>(psm) + POST_MAXKEYS;       // [4096]; the 64 KiB in front: rescoring slices, then the sort buffer
     unsigned* lst = hist + 4096;                                             // [POST_CAP] candidate rows
     float* sc = reinterpret_cast<float*>(lst + POST_CAP);                    // [POST_CAP] exact scores
@@ -782,36 +852,53 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
     const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int nkeys = (int)(2 * n_tiles);
     const float* s0 = S0 + (long)q * ldS;
+    const float* bd = bound + (long)q * ldB;
     const float INF = __builtin_inff();
     if (t == 0) { s_cnt = 0; s_exp = 0; s_valid = 0; }
+    // The query's unit keys (two per unit) and unit bounds are read ONCE, into registers, when they fit (<= POST_RU units per
+    // thread: 1M rows at 128-row units); every pass below then runs out of registers. Longer rows are streamed from L2 per pass.
+    constexpr int POST_RU = 8;
+    const bool reg = n_tiles <= (long)POST_RU * POST_THREADS;
+    f32x2v kreg[POST_RU]; float breg[POST_RU];
+    if (reg) {
+#pragma unroll
+        for (int j = 0; j < POST_RU; j++) {
+            const long tl = (long)j * POST_THREADS + t;
+            const bool lv = tl < n_tiles;
+            kreg[j] = lv ? *reinterpret_cast<const f32x2v*>(s0 + 2 * tl) : f32x2v{INF, INF};
+            breg[j] = lv ? bd[tl] : INF;
+        }
+    }
+    auto for_keys = [&](auto&& f) {                 // f(key) over every unit key of the query, in no particular order
+        if (reg) {
+#pragma unroll
+            for (int j = 0; j < POST_RU; j++) { f(kreg[j][0]); f(kreg[j][1]); }
+        } else {
+            for (int i = t; i < nkeys; i += POST_THREADS) f(s0[i]);
+        }
+    };
     // ---- 1. kappa ----
     float tau = INF;
     if (kappa_rank > 0) {
-        // the unit keys are streamed from global memory in every pass (a query's row is 31 KiB at 1M rows and L2-resident;
-        // no size limit), keys >= 0 so bit order = value order
-        int mine = 0;
-        for (int i = t; i < nkeys; i += POST_THREADS) { if (s0[i] != INF) mine++; }
-        __syncthreads();
-        if (mine) atomicAdd(&s_valid, mine);
-        __syncthreads();
-        if (s_valid >= kappa_rank) {
-            // The keys of a query crowd into a few exponent bins, so radix histograms serialise on LDS atomics. Bin them
-            // LINEARLY over [min, max] instead (monotone: float subtract, multiply and floor are), locate the bin of the
-            // K-th smallest, and rank the handful of keys inside it directly.
-            float lo = INF, hi = 0.0f;
-            for (int i = t; i < nkeys; i += POST_THREADS) { const float v = s0[i]; if (v != INF) { lo = fminf(lo, v); hi = fmaxf(hi, v); } }
+        // keys >= 0 so bit order = value order. The keys of a query crowd into a few exponent bins, so radix histograms
+        // serialise on LDS atomics: bin them LINEARLY over [min, max] instead (monotone: float subtract, multiply and floor
+        // are), locate the bin of the K-th smallest, and rank the handful of keys inside it directly.
+        int mine = 0; float lo = INF, hi = 0.0f;
+        for_keys([&](float v) { if (v != INF) { mine++; lo = fminf(lo, v); hi = fmaxf(hi, v); } });
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
-            float* wlo = reinterpret_cast<float*>(hist); float* whi = wlo + 16;
-            if (lane == 0) { wlo[wid] = lo; whi[wid] = hi; }
-            __syncthreads();
-            for (int w = 0; w < POST_WAVES; w++) { lo = fminf(lo, wlo[w]); hi = fmaxf(hi, whi[w]); }
-            __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); mine += __shfl_xor(mine, off, 64); }
+        float* wlo = reinterpret_cast<float*>(hist); float* whi = wlo + 16; int* wct = reinterpret_cast<int*>(whi + 16);
+        if (lane == 0) { wlo[wid] = lo; whi[wid] = hi; wct[wid] = mine; }
+        __syncthreads();
+        int valid = 0;
+        for (int w = 0; w < POST_WAVES; w++) { lo = fminf(lo, wlo[w]); hi = fmaxf(hi, whi[w]); valid += wct[w]; }
+        __syncthreads();
+        if (valid >= kappa_rank) {
             const float scale = hi > lo ? 4095.0f / (hi - lo) : 0.0f;
             auto bin_of = [&](unsigned k) { const int bq = (int)((__uint_as_float(k) - lo) * scale); return bq < 0 ? 0 : (bq > 4095 ? 4095 : bq); };
             for (int i = t; i < 4096; i += POST_THREADS) hist[i] = 0;
             __syncthreads();
-            for (int i = t; i < nkeys; i += POST_THREADS) { const unsigned k = __float_as_uint(s0[i]); if (k != 0x7F800000u) atomicAdd(&hist[bin_of(k)], 1u); }
+            for_keys([&](float v) { const unsigned k = __float_as_uint(v); if (k != 0x7F800000u) atomicAdd(&hist[bin_of(k)], 1u); });
             __syncthreads();
             post_find_bin(hist, kappa_rank, wsum, &s_bin, &s_before);
             const int kbin = s_bin, rank_in = kappa_rank - s_before, members = (int)hist[kbin];
@@ -821,7 +908,7 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
                 unsigned* mem = lst;                      // the candidate list is not in use yet
                 if (t == 0) s_cnt = 0;
                 __syncthreads();
-                for (int i = t; i < nkeys; i += POST_THREADS) { const unsigned k = __float_as_uint(s0[i]); if (k != 0x7F800000u && bin_of(k) == kbin) mem[atomicAdd(&s_cnt, 1)] = k; }
+                for_keys([&](float v) { const unsigned k = __float_as_uint(v); if (k != 0x7F800000u && bin_of(k) == kbin) mem[atomicAdd(&s_cnt, 1)] = k; });
                 __syncthreads();
                 if (t < members) {
                     const unsigned me = mem[t]; int less = 0;
@@ -840,10 +927,10 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
                     for (int i = t; i < 4096; i += POST_THREADS) hist[i] = 0;
                     __syncthreads();
                     const unsigned bm = (1u << nbits[p]) - 1u;
-                    for (int i = t; i < nkeys; i += POST_THREADS) {
-                        const unsigned k = __float_as_uint(s0[i]);
+                    for_keys([&](float v) {
+                        const unsigned k = __float_as_uint(v);
                         if (k != 0x7F800000u && bin_of(k) == kbin && (k & mask) == prefix) atomicAdd(&hist[(k >> shifts[p]) & bm], 1u);
-                    }
+                    });
                     __syncthreads();
                     post_find_bin(hist, rank, wsum, &s_bin, &s_before);
                     prefix |= ((unsigned)s_bin) << shifts[p]; mask |= bm << shifts[p]; rank -= s_before;
@@ -856,12 +943,12 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
         }
     }
     __syncthreads();
+    TR(0);
     // ---- 2. candidates ----
-    const float* bd = bound + (long)q * ldB;
-    for (long t0 = 0; t0 < n_tiles; t0 += POST_THREADS) {
+    auto candidates_of = [&](long t0, float bnd, float k0, float k1) {
         const long tl = t0 + t;
         const bool live = tl < n_tiles;
-        const bool expand = live && bd[tl] <= tau;
+        const bool expand = live && bnd <= tau;
         // rare: some non-emitted row of a tile may qualify -> take the whole tile; the wave does it together, one tile at a time
         unsigned long long em = __ballot(expand);
         while (em) {
@@ -875,11 +962,22 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
         }
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-            const float key = (live && !expand) ? s0[2 * tl + e] : INF;
+            const float key = (live && !expand) ? (e ? k1 : k0) : INF;
             post_append(key <= tau && key != INF, (unsigned)(tl * unit_rows + (__float_as_uint(key) & (unsigned)(unit_rows - 1))), lst, &s_cnt, POST_CAP);
+        }
+    };
+    if (reg) {
+#pragma unroll
+        for (int j = 0; j < POST_RU; j++) if ((long)j * POST_THREADS < n_tiles) candidates_of((long)j * POST_THREADS, breg[j], kreg[j][0], kreg[j][1]);
+    } else {
+        for (long t0 = 0; t0 < n_tiles; t0 += POST_THREADS) {
+            const long tl = t0 + t;
+            const bool lv = tl < n_tiles;
+            candidates_of(t0, lv ? bd[tl] : INF, lv ? s0[2 * tl] : INF, lv ? s0[2 * tl + 1] : INF);
         }
     }
     __syncthreads();
+    TR(1);
     const int cnt = s_cnt;
     if (cnt > POST_CAP) {                              // empty row; the host re-runs this query on the strict path
         for (int i = t; i < k_cap; i += POST_THREADS) { out_ids[(long)q * k_cap + i] = 0u; out_scores[(long)q * k_cap + i] = 0.0f; }
@@ -890,51 +988,66 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
     for (int i = cnt + t; i < n2; i += POST_THREADS) lst[i] = 0xFFFFFFFFu;
     __syncthreads();
     post_sort(lst, cnt, n2, hist);                     // ascending row = canonical tie order of the strict path (hist: 16 KiB scratch)
+    TR(2);
     // ---- 3. exact distances ----
     float* terms = reinterpret_cast<float*>(psm) + wid * (POST_CPW * POST_CHUNK);   // 4 KiB per wave over the key area
+    // The query is staged in LDS (the 16 KiB histogram area is idle here): read from global memory inside the slice loop it
+    // would be the youngest load of every iteration, and waiting for it (loads return in order) would also wait for the
+    // row slices just requested — the whole prefetch pipeline would drain once per slice.
     const float* __restrict__ qv = Qp + (long)q * ld;
+    const bool q_lds = ld <= 4096;
+    float* qs = reinterpret_cast<float*>(hist);      // stays an LDS pointer for the compiler (a generic one would make the reads
+    if (q_lds) {                                     // flat loads, which count in vmcnt AND lgkmcnt and drain both every slice)
+        for (int i = t * 4; i < ld; i += POST_THREADS * 4) *reinterpret_cast<f32x4v*>(qs + i) = *reinterpret_cast<const f32x4v*>(qv + i);
+        __syncthreads();
+    }
     const int sub = lane / POST_LPC, lp = lane % POST_LPC;   // a load instruction covers POST_CPI candidates x POST_CHUNK floats
-    for (int c0 = wid * POST_CPW; c0 < cnt; c0 += POST_WAVES * POST_CPW) {
-        const float* xr[POST_NJ];
+    // Row slices are random 128-byte reads and a candidate's sum is one serial chain, so the stage is latency-bound: spread the
+    // candidates over all 16 waves (8, 16 or 32 per wave) and keep more slices in flight the fewer candidates a wave has.
+    auto rescore = [&](auto njc, auto depthc, auto qldsc) {
+    constexpr int NJ = decltype(njc)::value, POST_DEPTH = decltype(depthc)::value, CPW = NJ * POST_CPI;
+    constexpr bool QLDS = decltype(qldsc)::value;
+    for (int c0 = wid * CPW; c0 < cnt; c0 += POST_WAVES * CPW) {
+        const float* xr[NJ];
 #pragma unroll
-        for (int j = 0; j < POST_NJ; j++) { const int ci = c0 + j * POST_CPI + sub; xr[j] = X + (long)lst[ci < cnt ? ci : c0] * ld + lp * 4; }
+        for (int j = 0; j < NJ; j++) { const int ci = c0 + j * POST_CPI + sub; xr[j] = X + (long)lst[ci < cnt ? ci : c0] * ld + lp * 4; }
         float acc = 0.0f;
-        // row slices are random 128-byte reads: keep POST_DEPTH slices per candidate in flight
-        constexpr int POST_DEPTH = 3;
-        f32x4v xb[POST_DEPTH][POST_NJ];
+        // A block of POST_DEPTH slices per candidate is requested at once and consumed in order (counted waits: only the block's
+        // first slice pays the random-read latency). A register ring refilled slot by slot compiles to vmcnt(0) in every
+        // iteration — the rotation copies make the compiler wait for everything — and pays that latency per slice.
         const int nsl = ld / POST_CHUNK;                 // ld is a multiple of 32 = POST_CHUNK
+        for (int sb = 0; sb < nsl; sb += POST_DEPTH) {
+            f32x4v xb[POST_DEPTH][NJ];
 #pragma unroll
-        for (int d = 0; d < POST_DEPTH; d++)
+            for (int d = 0; d < POST_DEPTH; d++)
 #pragma unroll
-            for (int j = 0; j < POST_NJ; j++) xb[d][j] = *reinterpret_cast<const f32x4v*>(xr[j] + min(d, nsl - 1) * POST_CHUNK);
-        for (int s0i = 0; s0i < nsl; s0i += POST_DEPTH) {
+                for (int j = 0; j < NJ; j++) xb[d][j] = *reinterpret_cast<const f32x4v*>(xr[j] + min(sb + d, nsl - 1) * POST_CHUNK);
 #pragma unroll
             for (int d = 0; d < POST_DEPTH; d++) {
-                const int sl = s0i + d;
+                const int sl = sb + d;
                 if (sl < nsl) {                          // wave-uniform
-                    f32x4v xv[POST_NJ];
+                    f32x4v qq;
+                    if constexpr (QLDS) qq = *reinterpret_cast<const f32x4v*>(qs + sl * POST_CHUNK + lp * 4);
+                    else qq = *reinterpret_cast<const f32x4v*>(qv + sl * POST_CHUNK + lp * 4);
 #pragma unroll
-                    for (int j = 0; j < POST_NJ; j++) xv[j] = xb[d][j];
-                    const int nx = min(sl + POST_DEPTH, nsl - 1);     // refill this slot (past the end: a harmless re-read)
-#pragma unroll
-                    for (int j = 0; j < POST_NJ; j++) xb[d][j] = *reinterpret_cast<const f32x4v*>(xr[j] + nx * POST_CHUNK);
-                    const f32x4v qq = *reinterpret_cast<const f32x4v*>(qv + sl * POST_CHUNK + lp * 4);
-#pragma unroll
-                    for (int j = 0; j < POST_NJ; j++) {
+                    for (int j = 0; j < NJ; j++) {
+                        const f32x4v xv = xb[d][j];
                         f32x4v tt;
-                        if constexpr (METRIC == COMET_COSINE) { tt[0] = qq[0] * xv[j][0]; tt[1] = qq[1] * xv[j][1]; tt[2] = qq[2] * xv[j][2]; tt[3] = qq[3] * xv[j][3]; }
+                        if constexpr (METRIC == COMET_COSINE) { tt[0] = qq[0] * xv[0]; tt[1] = qq[1] * xv[1]; tt[2] = qq[2] * xv[2]; tt[3] = qq[3] * xv[3]; }
                         else {
-                            const float d0 = qq[0] - xv[j][0], d1 = qq[1] - xv[j][1], d2 = qq[2] - xv[j][2], d3 = qq[3] - xv[j][3];
+                            const float d0 = qq[0] - xv[0], d1 = qq[1] - xv[1], d2 = qq[2] - xv[2], d3 = qq[3] - xv[3];
                             tt[0] = d0 * d0; tt[1] = d1 * d1; tt[2] = d2 * d2; tt[3] = d3 * d3;
                         }
-                        *reinterpret_cast<f32x4v*>(&terms[(j * POST_CPI + sub) * POST_CHUNK + lp * 4]) = tt;
+                        const int cand = j * POST_CPI + sub;     // 16-byte pieces XOR-swizzled by candidate: the summing lanes (stride 128 B) would
+                        *reinterpret_cast<f32x4v*>(&terms[cand * POST_CHUNK + ((lp ^ ((cand >> 1) & 7)) * 4)]) = tt;   // otherwise hit two bank groups, 8 deep
                     }
                     __builtin_amdgcn_wave_barrier();
-                    if (lane < POST_CPW) {
+                    if (lane < CPW) {
                         const float* tp = terms + lane * POST_CHUNK;
+                        const int sw = (lane >> 1) & 7;
 #pragma unroll
-                        for (int i = 0; i < POST_CHUNK; i += 4) {
-                            const f32x4v p = *reinterpret_cast<const f32x4v*>(tp + i);
+                        for (int i = 0; i < POST_CHUNK / 4; i++) {
+                            const f32x4v p = *reinterpret_cast<const f32x4v*>(tp + ((i ^ sw) * 4));
                             acc = acc + p[0]; acc = acc + p[1]; acc = acc + p[2]; acc = acc + p[3];
                         }
                     }
@@ -942,7 +1055,7 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
                 }
             }
         }
-        if (lane < POST_CPW && c0 + lane < cnt) {
+        if (lane < CPW && c0 + lane < cnt) {
             float v;
             if constexpr (METRIC == COMET_COSINE) { float a = acc; if (a > 1.0f) a = 1.0f; else if (a < -1.0f) a = -1.0f; v = 1.0f - a; }   // distance.go:209-213
             else if constexpr (METRIC == COMET_L2) v = (float)__builtin_sqrt((double)acc);
@@ -950,7 +1063,18 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
             sc[c0 + lane] = v;
         }
     }
+    };
+    {
+        const int per = (cnt + POST_WAVES - 1) / POST_WAVES;
+        using T = std::true_type; using F = std::false_type;
+        if (q_lds) {
+            if (per <= 8) rescore(std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{}, T{});
+            else if (per <= 16) rescore(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{}, T{});
+            else rescore(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{}, T{});
+        } else rescore(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{}, F{});
+    }
     __syncthreads();
+    TR(3);
     // ---- 4. final order: (score, row position) ----
     unsigned long long* comp = reinterpret_cast<unsigned long long*>(psm);   // POST_CAP composites (32 KiB) over the slices
     int mine = 0;
@@ -986,19 +1110,31 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
         overflow[q] = 0;
         if (stats) { atomicAdd(&stats[0], cnt); atomicAdd(&stats[2], s_exp); }
     }
+    TR(4);
+    if (trace && threadIdx.x == 0) { atomicAdd(&trace[5], (unsigned long long)cnt); atomicAdd(&trace[6], 1ull); }
 }
 void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const float* bound, int64_t ldB, int64_t n_tiles, int unit_rows, int64_t n, const uint8_t* elig,
                       const float* err_abs, int K, int kappa_rank, float thr, const float* X, int ld, const float* Qp, int B,
                       const uint32_t* ids_table, const int32_t* zflag, uint32_t* out_ids, float* out_scores, int32_t* out_counts, int k_cap,
                       int32_t* overflow, int32_t* stats) {
     if (B <= 0) return;
+    static unsigned long long* trace = [] { unsigned long long* p = nullptr; if (getenv("COMET_POST_TRACE")) { HIP_CHECK(hipMalloc(&p, 64)); HIP_CHECK(hipMemset(p, 0, 64)); } return p; }();
     ProfScope ps(c, "flat_post");
 #define POST(M) do { HIP_CHECK(hipFuncSetAttribute((const void*)flat_post_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POST_LDS)); \
         flat_post_kernel<M><<<dim3(B), dim3(POST_THREADS), POST_LDS, c->stream>>>(S0, ldS, bound, ldB, n_tiles, unit_rows, n, elig, err_abs, K, kappa_rank, thr, X, ld, Qp, \
-                                                                                 ids_table, zflag, out_ids, out_scores, out_counts, k_cap, overflow, stats); } while (0)
+                                                                                 ids_table, zflag, out_ids, out_scores, out_counts, k_cap, overflow, stats, trace); } while (0)
     switch (metric) { case COMET_L2: POST(COMET_L2); break; case COMET_L2SQ: POST(COMET_L2SQ); break; default: POST(COMET_COSINE); break; }
 #undef POST
     LAUNCH_CHECK();
+    if (trace) {          // COMET_POST_TRACE: cumulative s_memtime ticks (100 MHz) per phase, printed every 64 launches
+        static int calls = 0;
+        if ((++calls & 63) == 0) {
+            unsigned long long h[8]; HIP_CHECK(hipStreamSynchronize(c->stream)); HIP_CHECK(hipMemcpy(h, trace, 64, hipMemcpyDeviceToHost));
+            const double wg = (double)h[6];
+            fprintf(stderr, "[post trace] per query, us: kappa %.1f  candidates %.1f  sort %.1f  rescoring %.1f  final %.1f   (%.0f candidates)\n", h[0] / wg / 100.0, h[1] / wg / 100.0,
+                    h[2] / wg / 100.0, h[3] / wg / 100.0, h[4] / wg / 100.0, h[5] / wg);
+        }
+    }
 }
 
 }  // namespace comet

@@ -100,6 +100,10 @@ class Context:
     def profile(self, on: bool = True):
         check(self.lib.comet_profile_enable(self.h, 1 if on else 0))
 
+    def profile_only(self, name: str | None) -> None:
+        """time only the launches of one profiling scope (None: all of them)"""
+        check(self.lib.comet_profile_only(self.h, (name or "").encode()))
+
     def profile_reset(self):
         check(self.lib.comet_profile_reset(self.h))
 

@@ -84,6 +84,9 @@ COMET_API int comet_synth_mixture_dev(comet_ctx* ctx, uint64_t seed, int32_t n_c
 /* per-kernel timing (HIP events recorded on the context's stream around each launch) */
 COMET_API int comet_profile_enable(comet_ctx* ctx, int on);
 COMET_API int comet_profile_reset(comet_ctx* ctx);
+/* time only the scopes called `name` (NULL or "": all). Every timed scope costs two event records — barrier packets in the
+ * stream — which is ~10 us in a chain of short dependent kernels; a benchmark times just the kernel its roofline is about. */
+COMET_API int comet_profile_only(comet_ctx* ctx, const char* name);
 /* total milliseconds and launch count of kernels whose name starts with `prefix` since the last reset */
 COMET_API int comet_profile_get(comet_ctx* ctx, const char* prefix, double* out_total_ms, int64_t* out_launches);
 /* writes a '\n'-separated "name total_ms launches" listing into buf */
