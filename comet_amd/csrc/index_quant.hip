@@ -591,15 +591,22 @@ struct PQFamilyIndex : comet_index {
             }
             const int64_t ldD = round_up(Cmax, 16);
             const size_t budget = (size_t)2 << 30;
-            const int qb = (int)std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(budget / ((size_t)ldD * 4))));
-            float* D = c->salloc<float>((size_t)qb * ldD);
+            static const bool fuse_off = getenv("COMET_ADC_NO_FUSE") != nullptr;
+            const bool fuse = !fuse_off && p.k >= 1 && p.k <= ADC_FILTER_MAX_K && p.k <= k_cap;
+            // fused: the scan keeps only the candidates under a running per-query bound (8-byte composites in a row as long as the
+            // candidate row, almost all of it never touched); otherwise it writes the distance matrix for the generic selection
+            const int qb = (int)std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(budget / ((size_t)ldD * (fuse ? 8 : 4)))));
+            float* D = fuse ? nullptr : c->salloc<float>((size_t)qb * ldD);
+            AdcFilter afl{};
+            if (fuse) { afl.cand = c->salloc<unsigned long long>((size_t)qb * ldD); afl.cursor = c->salloc<int32_t>(qb); afl.tq = c->salloc<uint32_t>(qb); afl.K = p.k; afl.thr = p.threshold; }
             for (int b0 = 0; b0 < B; b0 += qb) {
                 const int bn = std::min(qb, B - b0);
                 launch_adc_scan(c, Qp + (size_t)b0 * ld, ld, dim, ivf ? centroids.as<float>() : nullptr, codebooks.as<float>(), M, Ksub, dsub,
                                 codes_il.as<uint32_t>(), M4, lay.list_base.as<int64_t>(), lay.list_len.as<int32_t>(),
-                                probe_list + (size_t)b0 * np, np, np, seg_off + (size_t)b0 * (np + 1), elig, bn, ivf ? nlist : 1, lay.max_len, D, ldD);
-                launch_select_topk(c, D, ldD, bn, Cmax, cnts + b0, p.threshold, p.k, pos + (size_t)b0 * k_cap,
-                                   out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);
+                                probe_list + (size_t)b0 * np, np, np, seg_off + (size_t)b0 * (np + 1), elig, bn, ivf ? nlist : 1, lay.max_len, D, ldD, fuse ? &afl : nullptr);
+                if (fuse) launch_select_composites(c, afl.cand, ldD, afl.cursor, bn, p.k, pos + (size_t)b0 * k_cap, out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);
+                else launch_select_topk(c, D, ldD, bn, Cmax, cnts + b0, p.threshold, p.k, pos + (size_t)b0 * k_cap,
+                                        out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);
             }
         } else {
             launch_select_topk(c, nullptr, 0, B, 0, nullptr, 0.0f, p.k, pos, out_scores, out_counts, k_cap);

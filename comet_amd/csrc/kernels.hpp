@@ -49,6 +49,9 @@ int select_max_k();
 // merge R per-shard sorted top-k lists per query (ties: lower shard, then lower position). R*k_cap <= select_max_k().
 void launch_merge_topk(Ctx* c, const uint32_t* ids, const float* scores, const int32_t* counts, int R, int B, int k_cap, int k,
                        uint32_t* out_ids, float* out_scores, int32_t* out_counts, int64_t rank_stride = 0, int64_t rank_stride_counts = 0);
+// top-K of rows of (key << 32 | position) composites already filtered by a producer kernel (cursor[q] of them per row)
+void launch_select_composites(Ctx* c, const unsigned long long* comp, int64_t ld, const int32_t* cursor, int B, int K, uint32_t* out_pos, float* out_scores,
+                              int32_t* out_counts, int k_cap);
 void launch_select_topk(Ctx* c, const float* D, int64_t ldD, int B, int64_t C, const int32_t* cnts, float thr, int K,
                         uint32_t* out_pos, float* out_scores, int32_t* out_counts, int k_cap);
 
@@ -76,9 +79,12 @@ void launch_finalize_probe(Ctx* c, const uint32_t* pos, int B, int k_cap, const 
                            const int64_t* list_base, const uint32_t* ids_of_slot, const int32_t* zflag, uint32_t* out_ids, int32_t* counts);
 size_t adc_lds_bytes(int M, int Ksub, int dim);
 int64_t adc_codes_pad();    // code slots the ADC scan may read (never use) past the last list
+// fused top-K filter of the ADC scan (K in [1, ADC_FILTER_MAX_K]): survivors as composites in cand[q * ldD ..], cursor[q] of them
+constexpr int ADC_FILTER_MAX_K = 64;
+struct AdcFilter { unsigned long long* cand; int32_t* cursor; uint32_t* tq; int K; float thr; };
 void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* centroids, const float* codebooks, int M, int Ksub, int dsub,
                      const uint32_t* codes, int M4, const int64_t* list_base, const int32_t* list_len, const uint32_t* probe_list, int ldp,
-                     int np, const int32_t* seg_off, const uint8_t* elig, int B, int nlist, int max_list_len, float* D, int64_t ldD);
+                     int np, const int32_t* seg_off, const uint8_t* elig, int B, int nlist, int max_list_len, float* D, int64_t ldD, const AdcFilter* flt = nullptr);
 
 // ---- kernels_fast.hip (MFMA fast path of the Flat scan) ------------------------------------------
 int flat_fast_tile_rows();

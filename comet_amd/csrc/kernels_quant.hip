@@ -451,8 +451,11 @@ __global__ __launch_bounds__(256) void iota_kernel(unsigned* __restrict__ p, int
 __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restrict__ probe_list, int ldp, int np, const int* __restrict__ seg_off,
                                                          int n_pairs, int nlist, int identity, const int* __restrict__ list_len, int n_slots,
                                                          unsigned* __restrict__ order, unsigned* __restrict__ slist, uint2* __restrict__ qitems, int qcap,
-                                                         int* __restrict__ qcount, int* __restrict__ queues) {
+                                                         int* __restrict__ qcount, int* __restrict__ queues, unsigned* __restrict__ tq, int* __restrict__ cursor, int n_q, int lead) {
+    // lead (fused filter, np >= 2): every query's NEAREST list (probe 0) gets a duo of its own in the first 2 * n_q slots, so that
+    // those pairs are scanned first and seed the per-query bound before the bulk of the candidates is tested against it.
     extern __shared__ __attribute__((aligned(16))) int obin[];   // nlist + 1 counters (not used by the identity order)
+    if (tq) for (int i = threadIdx.x; i < n_q; i += 1024) { tq[i] = 0x7F800000u; cursor[i] = 0; }   // fused filter: bound = +inf (float bits of a sum), no survivors yet
     __shared__ int part[1024];
     __shared__ int wtot[16];
     const int nb = nlist + 1, t = threadIdx.x;
@@ -462,13 +465,16 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
         return (so[1] == so[0]) ? nlist : (int)min(probe_list[(long)q * ldp + pi], (unsigned)(nlist - 1));
     };
     for (int i = t; i < n_slots; i += 1024) { order[i] = ADC_HOLE; slist[i] = (unsigned)nlist; }
+    const int lead0 = (lead && !identity) ? 2 * n_q : 0;            // slots of the leading region
+    auto in_bulk = [&](int i) { return lead0 == 0 || (i % np) != 0; };
     if (identity) {
         __syncthreads();
         for (int i = t; i < n_pairs; i += 1024) { order[2 * i] = (unsigned)i; slist[2 * i] = (unsigned)key_of(i); }
     } else {
         for (int i = t; i < nb; i += 1024) obin[i] = 0;
         __syncthreads();
-        for (int i = t; i < n_pairs; i += 1024) atomicAdd(&obin[key_of(i)], 1);
+        if (lead0) for (int qq = t; qq < n_q; qq += 1024) { order[2 * qq] = (unsigned)(qq * np); slist[2 * qq] = (unsigned)key_of(qq * np); }
+        for (int i = t; i < n_pairs; i += 1024) if (in_bulk(i)) atomicAdd(&obin[key_of(i)], 1);
         __syncthreads();
         const int per = (nb + 1023) / 1024, lo = t * per, hi = min(nb, lo + per);
         int s = 0;
@@ -481,10 +487,10 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
             part[t] += v;
             __syncthreads();
         }
-        int run = part[t] - s;                                      // exclusive prefix of this thread's bins
+        int run = lead0 + part[t] - s;                              // exclusive prefix of this thread's bins (behind the leading region)
         for (int i = lo; i < hi; i++) { const int cnt = obin[i]; obin[i] = run; run += (i < nlist) ? ((cnt + 1) & ~1) : cnt; }
         __syncthreads();
-        for (int i = t; i < n_pairs; i += 1024) { const int k = key_of(i); const int pos = atomicAdd(&obin[k], 1); order[pos] = (unsigned)i; slist[pos] = (unsigned)k; }
+        for (int i = t; i < n_pairs; i += 1024) if (in_bulk(i)) { const int k = key_of(i); const int pos = atomicAdd(&obin[k], 1); order[pos] = (unsigned)i; slist[pos] = (unsigned)k; }
     }
     __syncthreads();
     // work queues: waves x and x + 8 build queue x (first and second half of its duos), two passes (count, then write)
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
 typedef __amdgpu_buffer_rsrc_t adc_rsrc_t;
 struct AdcItem {
     int live, start, seg_end;
-    long offA, offB;            // row offsets of the two queries' distances (offB < 0: no second query)
+    int qA, soA, qB, soB;       // the two queries and the offsets of this list inside their candidate rows (qB < 0: no second query)
     long base_blk, duo;
 };
 __device__ __forceinline__ unsigned adc_ldw(adc_rsrc_t r, unsigned voff, int soff) { return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0); }
@@ -602,7 +608,11 @@ struct AdcArgs {
     const float* lutg; const unsigned* codes; const long* list_base; const int* list_len; const int* seg_off; const unsigned char* elig;
     const unsigned* order; const unsigned* slist; const uint2* qitems; const int* qcount; int* queues; float* D;
     long ldD; int M, KL, mp, M4, np, qcap;
+    // fused top-K filter (cand != nullptr; K in [1, 64]): no distance matrix — survivors of the per-query running bound tq[] go to
+    // cand[q * ldD + cursor[q]++] as (order-preserving key << 32 | position in the query's candidate row)
+    unsigned long long* cand; int* cursor; unsigned* tq; int K; float thr;
 };
+__device__ __forceinline__ unsigned adc_f2key(unsigned u) { return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // two phase buffers of ADC_BUF_BYTES
     __shared__ int s_ticket[2][2];                                  // [item parity][0] queue, [1] ticket (-1: all queues drained)
@@ -623,7 +633,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
     };
     auto rfl64 = [](long v) -> long { return ((long)RFL((int)(v >> 32)) << 32) | (unsigned)RFL((int)(v & 0xFFFFFFFFl)); };
     auto decode = [&](int xq, int ticket) -> AdcItem {
-        AdcItem it; it.live = 0; it.start = it.seg_end = 0; it.offA = 0; it.offB = -1; it.base_blk = 0; it.duo = 0;
+        AdcItem it; it.live = 0; it.start = it.seg_end = 0; it.qA = it.soA = it.soB = 0; it.qB = -1; it.base_blk = 0; it.duo = 0;
         xq = RFL(xq); ticket = RFL(ticket);              // read from LDS: uniform, but only the hardware knows — keep the item in SGPRs
         if (ticket < 0) return it;
         const uint2 e = a.qitems[(long)xq * a.qcap + ticket];
@@ -633,9 +643,9 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
         const int len = RFL(a.list_len[L]);
         const int np = a.np;
         it.live = 1; it.duo = duo;
-        const int qA = (int)pa / np;
-        it.offA = (long)qA * a.ldD + RFL(a.seg_off[(long)qA * (np + 1) + ((int)pa - qA * np)]);
-        if (pb != ADC_HOLE) { const int qB = (int)pb / np; it.offB = (long)qB * a.ldD + RFL(a.seg_off[(long)qB * (np + 1) + ((int)pb - qB * np)]); }
+        it.qA = (int)pa / np;
+        it.soA = RFL(a.seg_off[(long)it.qA * (np + 1) + ((int)pa - it.qA * np)]);
+        if (pb != ADC_HOLE) { it.qB = (int)pb / np; it.soB = RFL(a.seg_off[(long)it.qB * (np + 1) + ((int)pb - it.qB * np)]); }
         it.start = (int)sg * ADC_SEG_CODES; it.seg_end = min(len, it.start + ADC_SEG_CODES);
         it.base_blk = rfl64(a.list_base[L] >> 6);        // list bases are multiples of 64
         return it;
@@ -716,16 +726,84 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
                 }
             }
         }
+        if (a.cand == nullptr) {
 #pragma unroll
-        for (int ps = 0; ps < ADC_SEG_PASSES; ps++) {
-            const int na = ps == 0 ? na0 : na1;
+            for (int ps = 0; ps < ADC_SEG_PASSES; ps++) {
+                const int na = ps == 0 ? na0 : na1;
 #pragma unroll
-            for (int c = 0; c < ADC_CHAINS; c++) {
-                const int j = ((cur.start >> 6) + ps * (ADC_PASS_CODES >> 6) + c * ADC_WAVES + wid) * 64 + (int)lane;
-                if (c < na && j < cur.seg_end) {
-                    const bool ok = a.elig ? (a.elig[(cur.base_blk << 6) + j] != 0) : true;
-                    a.D[cur.offA + j] = ok ? go_sqrt32q(acc[ps][c][0]) : __uint_as_float(EXCLUDED_BITS);
-                    if (cur.offB >= 0) a.D[cur.offB + j] = ok ? go_sqrt32q(acc[ps][c][1]) : __uint_as_float(EXCLUDED_BITS);
+                for (int c = 0; c < ADC_CHAINS; c++) {
+                    const int j = ((cur.start >> 6) + ps * (ADC_PASS_CODES >> 6) + c * ADC_WAVES + wid) * 64 + (int)lane;
+                    if (c < na && j < cur.seg_end) {
+                        const bool ok = a.elig ? (a.elig[(cur.base_blk << 6) + j] != 0) : true;
+                        a.D[(long)cur.qA * a.ldD + cur.soA + j] = ok ? go_sqrt32q(acc[ps][c][0]) : __uint_as_float(EXCLUDED_BITS);
+                        if (cur.qB >= 0) a.D[(long)cur.qB * a.ldD + cur.soB + j] = ok ? go_sqrt32q(acc[ps][c][1]) : __uint_as_float(EXCLUDED_BITS);
+                    }
+                }
+            }
+        } else if (na0 > 0) {
+            // Fused top-K filter (ivfpq_index_search.go:310-321 keeps every candidate and sorts; only the K best matter). tq[q] is an
+            // upper bound on the K-th smallest SUM of the query (the square root is monotone, so its root bounds the K-th smallest
+            // distance): the K-th smallest of ANY K+ of a query's candidates is one, so every wave offers the K-th smallest of its
+            // lanes' minima and applies it to its own candidates at once; the shared bound only ever tightens (atomicMin), and a
+            // candidate above the bound it was tested against can never be among the K best, whichever bound that was. Most items
+            // (the far lists) have nothing under the bound and leave after eight compares — without taking a single square root.
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int q = h ? cur.qB : cur.qA, so = h ? cur.soB : cur.soA;
+                if (q < 0) continue;
+                const unsigned T = __builtin_nontemporal_load(&a.tq[q]);                  // float bits of a sum >= 0: unsigned order = value order
+                const unsigned Ts = __float_as_uint(__uint_as_float(T) * 1.0000005f);     // sums within 4 ulp above the bound may round to the same distance
+                unsigned keys[ADC_SEG_PASSES][ADC_CHAINS];
+                unsigned lmin = 0xFFFFFFFFu;
+#pragma unroll
+                for (int ps = 0; ps < ADC_SEG_PASSES; ps++) {
+                    const int na = ps == 0 ? na0 : na1;
+#pragma unroll
+                    for (int c = 0; c < ADC_CHAINS; c++) {
+                        keys[ps][c] = 0xFFFFFFFFu;
+                        if (c >= na) continue;                               // wave-uniform
+                        const int j = ((cur.start >> 6) + ps * (ADC_PASS_CODES >> 6) + c * ADC_WAVES + wid) * 64 + (int)lane;
+                        bool ok = j < cur.seg_end;
+                        if (ok && a.elig) ok = a.elig[(cur.base_blk << 6) + j] != 0;     // soft-deleted / filtered candidates never count
+                        if (ok) { keys[ps][c] = __float_as_uint(acc[ps][c][h]); lmin = min(lmin, keys[ps][c]); }
+                    }
+                }
+                if (__ballot(lmin <= Ts) == 0ull) continue;                  // nothing of this wave can matter (and its K-th minimum is above the bound)
+                // K-th smallest lane minimum, bit by bit from the top (ballots only: the LDS pipe is the kernel's bottleneck)
+                unsigned kth = 0xFFFFFFFFu;
+                if ((int)__builtin_popcountll(__ballot(lmin != 0xFFFFFFFFu)) >= a.K) {
+                    kth = 0u;
+#pragma unroll
+                    for (int bit = 31; bit >= 0; bit--) {
+                        const unsigned tv = kth | ((1u << bit) - 1u);
+                        if ((int)__builtin_popcountll(__ballot(lmin <= tv)) < a.K) kth |= 1u << bit;
+                    }
+                }
+                if (lane == 0 && kth < T) atomicMin(&a.tq[q], kth);
+                const unsigned bnd = min(T, kth);
+                const unsigned bs = bnd >= 0x7F800000u ? 0x7F800000u : __float_as_uint(__uint_as_float(bnd) * 1.0000005f);
+                const float Td = go_sqrt32q(__uint_as_float(bnd));           // the bound as a distance
+#pragma unroll
+                for (int ps = 0; ps < ADC_SEG_PASSES; ps++) {
+                    const int na = ps == 0 ? na0 : na1;
+#pragma unroll
+                    for (int c = 0; c < ADC_CHAINS; c++) {
+                        if (c >= na) continue;
+                        bool keep = keys[ps][c] <= bs;                       // (excluded candidates are 0xFFFFFFFF)
+                        if (__ballot(keep) == 0ull) continue;
+                        const float d = go_sqrt32q(acc[ps][c][h]);
+                        keep = keep && d <= Td && !(a.thr > 0.0f && d > a.thr);          // `s.threshold > 0 && dist > s.threshold`
+                        const unsigned long long m = __ballot(keep);
+                        if (m) {
+                            const int j = ((cur.start >> 6) + ps * (ADC_PASS_CODES >> 6) + c * ADC_WAVES + wid) * 64 + (int)lane;
+                            const int leader = __builtin_ctzll(m);
+                            int base = 0;
+                            if ((int)lane == leader) base = atomicAdd(&a.cursor[q], (int)__builtin_popcountll(m));
+                            base = __shfl(base, leader, 64);
+                            if (keep) a.cand[(long)q * a.ldD + base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] =
+                                ((unsigned long long)adc_f2key(__float_as_uint(d)) << 32) | (unsigned)(so + j);
+                        }
+                    }
                 }
             }
         }
@@ -755,7 +833,7 @@ static size_t adc_lut_budget() {
 }
 void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* centroids, const float* codebooks, int M, int Ksub, int dsub,
                      const uint32_t* codes, int M4, const int64_t* list_base, const int32_t* list_len, const uint32_t* probe_list, int ldp,
-                     int np, const int32_t* seg_off, const uint8_t* elig, int B, int nlist, int max_list_len, float* D, int64_t ldD) {
+                     int np, const int32_t* seg_off, const uint8_t* elig, int B, int nlist, int max_list_len, float* D, int64_t ldD, const AdcFilter* flt) {
     if (B <= 0 || np <= 0 || max_list_len <= 0) return;
     const int KL = Ksub < 256 ? Ksub : 256;
     const int kl_shift = 31 - __builtin_clz((unsigned)KL);
@@ -766,7 +844,8 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
     // queries per sub-batch: tables of a sub-batch live in HBM between the two kernels
     int64_t qc = std::max<int64_t>(1, (int64_t)(adc_lut_budget() / (lut_pair * (size_t)np)));
     qc = std::min<int64_t>(qc, B);
-    auto slots_for = [&](int64_t n_pairs) { return identity ? 2 * n_pairs : round_up(n_pairs + std::min<int64_t>(nlist, n_pairs), 2); };
+    const bool lead = flt != nullptr && np >= 2 && !identity;
+    auto slots_for = [&](int64_t n_pairs) { return identity ? 2 * n_pairs : (lead ? 2 * (n_pairs / np) : 0) + round_up(n_pairs + std::min<int64_t>(nlist, n_pairs), 2); };
     const int64_t max_slots = slots_for(qc * np);
     const int segs = (int)ceil_div(max_list_len, ADC_SEG_CODES);
     const int64_t max_chunks = ceil_div(max_slots / 2, ADC_XCD_CHUNK);
@@ -800,7 +879,8 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
         {
             ProfScope ps(c, "adc_order");
             adc_order_kernel<<<dim3(1), dim3(1024), identity ? 0 : (size_t)(nlist + 1) * 4, c->stream>>>(pl, ldp, np, so, n_pairs, nlist, identity ? 1 : 0, list_len,
-                                                                                                       n_slots, order, slist, qitems, (int)qcap, qcount, queues);
+                                                                                                       n_slots, order, slist, qitems, (int)qcap, qcount, queues,
+                                                                                                       flt ? flt->tq + b0 : nullptr, flt ? flt->cursor + b0 : nullptr, bn, lead ? 1 : 0);
             LAUNCH_CHECK();
         }
         {
@@ -820,7 +900,8 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
             const long n_items = (long)(n_slots / 2) * segs;
             long g = std::min<long>(n_items, (long)c->prop.multiProcessorCount);
             g = std::max<long>(8, (g + 7) / 8 * 8);          // a multiple of the XCD count so that blockIdx % 8 is the XCD of every slot
-            AdcArgs a{lut, codes, (const long*)list_base, list_len, so, elig, order, slist, qitems, qcount, queues, D + (size_t)b0 * ldD, (long)ldD, M, KL, mp, M4, np, (int)qcap};
+            AdcArgs a{lut, codes, (const long*)list_base, list_len, so, elig, order, slist, qitems, qcount, queues, D ? D + (size_t)b0 * ldD : nullptr, (long)ldD, M, KL, mp, M4, np, (int)qcap,
+                      flt ? flt->cand + (size_t)b0 * ldD : nullptr, flt ? flt->cursor + b0 : nullptr, flt ? flt->tq + b0 : nullptr, flt ? flt->K : 0, flt ? flt->thr : 0.0f};
             adc_scan_kernel<<<dim3((unsigned)g), dim3(ADC_THREADS), lds, c->stream>>>(a);
             LAUNCH_CHECK();
         }

@@ -727,6 +727,78 @@ __global__ __launch_bounds__(1024) void sel_row_kernel(const float* __restrict__
     if (t == 0) out_counts[q] = kq;
 }
 
+// ---- top-K of rows of COMPOSITES (key << 32 | position) that a producer kernel already filtered ---------------------
+// (the ADC scan's fused filter: survivors of a per-query running bound, m = cursor[q] of them in comp[q*ld ..]). One workgroup
+// per row: up to SORT_MAX survivors are sorted in LDS; more than that (a bound that stayed loose: descending data, mass ties)
+// first finds the K-th smallest composite by an 8-pass byte radix select over the row in HBM, then sorts the K it keeps.
+__global__ __launch_bounds__(1024) void sel_composites_kernel(const unsigned long long* __restrict__ comp, long ld, const int* __restrict__ cursor, int K,
+                                                              unsigned* __restrict__ out_pos, float* __restrict__ out_scores, int* __restrict__ out_counts, int k_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];   // SORT_MAX composites
+    __shared__ unsigned hist[256];
+    __shared__ int s_bin, s_before, s_n;
+    const int q = blockIdx.x, t = threadIdx.x;
+    const unsigned long long* row = comp + (long)q * ld;
+    const int m = cursor[q];
+    const int kq = (K <= 0 || K > m) ? m : K;        // fewer survivors than K only when the whole row holds fewer than K valid candidates
+    int n = m;                                       // composites to sort
+    if (m > SORT_MAX) {
+        unsigned long long prefix = 0, mask = 0; int remaining = kq;
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            if (t < 256) hist[t] = 0;
+            __syncthreads();
+            for (int i = t; i < m; i += 1024) { const unsigned long long k = row[i]; if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255ull], 1u); }
+            __syncthreads();
+            if (t == 0) {
+                int run = 0, b = 0;
+                for (b = 0; b < 256; b++) { if (run + (int)hist[b] >= remaining) break; run += (int)hist[b]; }
+                s_bin = b; s_before = run;
+            }
+            __syncthreads();
+            prefix |= ((unsigned long long)s_bin) << shift; mask |= 255ull << shift; remaining -= s_before;
+            __syncthreads();
+        }
+        if (t == 0) s_n = 0;
+        __syncthreads();
+        for (int i = t; i < m; i += 1024) { const unsigned long long k = row[i]; if (k <= prefix) { const int sl = atomicAdd(&s_n, 1); if (sl < SORT_MAX) sm[sl] = k; } }   // composites are unique: exactly kq
+        __syncthreads();
+        n = min(s_n, SORT_MAX);
+    } else {
+        for (int i = t; i < m; i += 1024) sm[i] = row[i];
+    }
+    if (n <= 1024) {
+        // short lists (the usual case: a few hundred survivors): rank by counting — one pass of broadcast LDS reads instead of a
+        // ladder of ~50 barriers. Composites are unique, so ranks are a permutation.
+        __syncthreads();
+        unsigned long long me = ~0ull; int rank = 0;
+        if (t < n) { me = sm[t]; for (int j = 0; j < n; j++) rank += (sm[j] < me) ? 1 : 0; }
+        __syncthreads();
+        if (t < n) sm[rank] = me;
+        __syncthreads();
+    } else {
+        int n2 = 64; while (n2 < n) n2 <<= 1;
+        for (int i = n + t; i < n2; i += 1024) sm[i] = ~0ull;
+        __syncthreads();
+        bitonic_sort_lds(sm, n2);
+    }
+    const int nw = kq < k_cap ? kq : k_cap;
+    for (int i = t; i < k_cap; i += 1024) {
+        if (i < nw && i < n) {
+            const unsigned long long cc = sm[i];
+            out_pos[(long)q * k_cap + i] = (unsigned)(cc & 0xFFFFFFFFull);
+            out_scores[(long)q * k_cap + i] = __uint_as_float(key2f((unsigned)(cc >> 32)));
+        } else { out_pos[(long)q * k_cap + i] = 0xFFFFFFFFu; out_scores[(long)q * k_cap + i] = 0.0f; }
+    }
+    if (t == 0) out_counts[q] = kq;
+}
+int select_composites_max_k() { return SORT_MAX; }
+void launch_select_composites(Ctx* c, const unsigned long long* comp, int64_t ld, const int32_t* cursor, int B, int K, uint32_t* out_pos, float* out_scores,
+                              int32_t* out_counts, int k_cap) {
+    if (B <= 0) return;
+    ProfScope ps(c, "select_composites");
+    sel_composites_kernel<<<dim3(B), dim3(1024), sizeof(unsigned long long) * SORT_MAX, c->stream>>>(comp, ld, cursor, K, out_pos, out_scores, out_counts, k_cap);
+    LAUNCH_CHECK();
+}
+
 void launch_select_topk(Ctx* c, const float* D, int64_t ldD, int B, int64_t C, const int32_t* cnts, float thr, int K,
                         uint32_t* out_pos, float* out_scores, int32_t* out_counts, int k_cap) {
     if (B <= 0) return;

@@ -1,0 +1,13 @@
+#!/bin/bash
+# usage (on the GPU box): tools/profile_bench.sh <tag>
+#   1. the driver's bench line (with the CPU baseline)            -> gpurun_out/<tag>_bench_line.json
+#   2. rocprofv3 --kernel-trace --stats of a short run             -> gpurun_out/<tag>_bench_rocprofv3_kernel_stats.txt
+#   3. separate rocprofv3 --pmc passes (tools/pmc_bench.sh)        -> gpurun_out/<tag>_bench_pmc.json
+# Copy what should be judged into profiles/ afterwards.
+T=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
+cd $R && timeout 900 python bench.py 2> $O/${T}_bench.err | tail -1 > $O/${T}_bench_line.json
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/rp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rp -- python $R/bench.py --no-cpu-baseline --regions 2 --steps 10 > /tmp/rp.log 2>&1
+DB=$(find /tmp/rp -name "*.db" | head -1); CSV=$(find /tmp/rp -name "*kernel_stats.csv" | head -1)
+python $R/tools/rocprof_summary.py "${DB:-$CSV}" $O/${T}_bench_rocprofv3_kernel_stats.txt
+sed -i "1s/.*/# rocprofv3 --kernel-trace --stats of \`python bench.py --no-cpu-baseline --regions 2 --steps 10\` (all legs: Flat cosine, Flat L2^2 B=1\/64\/256, IVFPQ incl. GPU train + add), MI355X, $T/" $O/${T}_bench_rocprofv3_kernel_stats.txt
+cd $R && tools/pmc_bench.sh ${T}_bench_pmc
