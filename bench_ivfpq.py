@@ -51,21 +51,17 @@ def main():
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or os.environ.get("COMET_BENCH_FORCE_DIST") == "1"
-    dist = None
-    if use_dist:
-        # SURVEY §8(e) for IVFPQ: every rank trains on the same vectors (deterministic GPU k-means -> replicated centroids and
-        # codebooks), holds a round-robin share of the rows, probes the same lists; per-shard top-K are all-gathered and merged
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if world == 1:
-            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29578")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # SURVEY §8(e) for IVFPQ: every rank trains on the same vectors (deterministic GPU k-means -> replicated centroids and
+    # codebooks) and owns the lists l % world == rank (comet_index_set_shard: members of other lists are dropped on add); the
+    # per-shard top-K are all-gathered and merged inside the library (RCCL, comet_amd.dist.Comm) — no torch, no host sync
     import comet_amd as ca
     from comet_amd._lib import check
     import oracle_lib as orc
     ctx = ca.Context(local_rank)
+    comm = None
+    if use_dist:
+        from comet_amd.dist import Comm
+        comm = Comm.from_env(ctx)
     d, n = args.dim, args.rows
     ntrain = min(n, args.train or args.nlist * 100)
 
@@ -83,6 +79,8 @@ def main():
     idx = ca.IVFPQIndex(ctx, d, ca.L2_SQUARED, args.nlist, args.M, args.nbits)
     t0 = time.time()
     idx.train(rows(0, ntrain))
+    if world > 1:
+        idx.set_shard(rank, world)
     train_s = time.time() - t0
     t0 = time.time()
     chunk = 131072
@@ -91,10 +89,8 @@ def main():
         hi = min(n, lo + chunk)
         X = rows(lo, hi)
         ids = np.arange(lo + 1, hi + 1, dtype=np.uint32)
-        if world > 1:                                  # this rank's round-robin share of the chunk
-            X, ids = X[rank::world], ids[rank::world]
-        idx.add_batch(ids, X)
-        if flat is not None:
+        idx.add_batch(ids, X)                          # list-sharded: the index keeps only the members of this rank's lists
+        if flat is not None and world == 1:
             flat.add_batch(ids, X)
     add_s = time.time() - t0
     B, K = args.batch, args.k
@@ -102,52 +98,57 @@ def main():
     Q = np.vstack([rows(int(r), int(r) + 1) for r in qrows]) + orc.synth(0xBEEF + 4, 0, B * d).reshape(B, d) * np.float32(0.05)
 
     q_dev = ctx.alloc(B * d * 4); ctx.upload(q_dev, Q)
-    ex = None
-    if use_dist:
-        from comet_amd.dist import TopKExchange
-        ex = TopKExchange(B, K, torch.device("cuda", local_rank), ctx=ctx)
-        oi, os_, oc = ex.local_ptrs()
-    else:
-        oi, os_, oc = ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)
+    bufs = [(ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)) for _ in range(2)]
+    oi, os_, oc = bufs[0]
 
-    def step():
-        idx.search_batch_dev(q_dev, B, K, oi, os_, oc, K, nprobes=args.nprobe)
-        if ex is not None:
-            ctx.sync()
-            ex.exchange_and_merge(K)
+    def run(nsteps):            # batch i+1 is enqueued before batch i is waited for
+        prev = None
+        for i in range(nsteps):
+            w = i & 1
+            if comm is not None:
+                t = comm.search_async(idx, q_dev, B, K, bufs[w][0], bufs[w][1], bufs[w][2], K, nprobes=args.nprobe)
+            else:
+                t = idx.search_batch_dev_async(q_dev, B, K, bufs[w][0], bufs[w][1], bufs[w][2], K, nprobes=args.nprobe)
+            if prev is not None:
+                comm.search_wait(idx, prev, block=False) if comm is not None else idx.search_wait(prev)
+            prev = t
+        if prev is not None:
+            comm.search_wait(idx, prev, block=True) if comm is not None else idx.search_wait(prev)
 
     def barrier():
         ctx.sync()
-        if use_dist:
-            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
+        if comm is not None:
+            comm.sync(); comm.barrier()
+    run(max(1, args.warmup))
     barrier()
-    ctx.profile(True); ctx.profile_reset()
+    ctx.profile_only("adc_scan"); ctx.profile(True); ctx.profile_reset()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     barrier()
     el = time.perf_counter() - t0
-    prof = ctx.profile_dump(); ctx.profile(False)
-    if use_dist:
-        t = torch.tensor([el], dtype=torch.float64, device=torch.device("cuda", local_rank))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    if ex is not None:
-        ctx.sync()
-        g_ids = ex.m_ids.cpu().numpy().view(np.uint32); g_sc = ex.m_scores.cpu().numpy(); g_cn = ex.m_counts.cpu().numpy()
+    prof = ctx.profile_dump()
+    ctx.profile_only(None); ctx.profile_reset()
+    run(args.steps); barrier()
+    allk = ctx.profile_dump(); ctx.profile(False)
+    prof_all = {k: round(v[0] / args.steps, 4) for k, v in sorted(allk.items())}
+    if comm is not None:
+        el = comm.allreduce_max(el)
+    # one more search into buffer set 0 for the parity / recall sections below
+    if comm is not None:
+        comm.search_wait(idx, comm.search_async(idx, q_dev, B, K, oi, os_, oc, K, nprobes=args.nprobe), block=True); comm.sync()
     else:
-        g_ids = ctx.download(oi, (B, K), np.uint32); g_sc = ctx.download(os_, (B, K), np.float32); g_cn = ctx.download(oc, (B,), np.int32)
+        idx.search_batch_dev(q_dev, B, K, oi, os_, oc, K, nprobes=args.nprobe)
+    ctx.sync()
+    g_ids = ctx.download(oi, (B, K), np.uint32); g_sc = ctx.download(os_, (B, K), np.float32); g_cn = ctx.download(oc, (B,), np.int32)
     if world > 1:
         # multi-GPU line: throughput only (the exported single-rank index needed for the roofline / oracle sections lives on one rank)
         if rank == 0:
-            print(json.dumps({"metric": "queries/sec, IVFPQ search, rows sharded round-robin over the ranks (RCCL all-gather of per-shard top-K)",
+            print(json.dumps({"metric": "queries/sec, IVFPQ search, inverted lists sharded over the ranks (in-library RCCL all-gather of per-shard top-K)",
                               "value": B * args.steps / el, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
                               "config": {"workload": f"IVFPQ L2^2 {n}x{d}, nlist={args.nlist} nprobe={args.nprobe} M={args.M} nbits={args.nbits}, batch={B}, K={K}"},
-                              "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())}}), flush=True)
-        dist.destroy_process_group()
+                              "kernels_ms_per_step": prof_all}), flush=True)
+        comm.close()
         return
 
     # ---- algorithmic bytes of the ADC scan: recompute the probed lists on the host from the exported state ----
@@ -176,7 +177,7 @@ def main():
                      "traffic": None, "avg_kernel_ms": adc_avg_ms, "algorithmic_bytes_per_launch": code_bytes,
                      "algorithmic_bytes_per_launch_with_ids": cand * (args.M + 4), "candidates_per_query": cand / B,
                      "lds_lookups_per_s": cand * args.M / (adc_avg_ms * 1e-3) if adc_avg_ms > 0 else 0.0},
-        "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
+        "kernels_ms_per_step": prof_all,
     }
     if flat is not None:
         f_ids = flat.search_batch(Q, K, mode=1)[0]
@@ -209,8 +210,8 @@ def main():
         line["cpu_baseline"] = {"value": nq / cel, "unit": "queries/s", "cores": T, "kind": "port",
                                 "sample": f"{nq} of the batch's queries on the GPU-built index (quantizers + codes exported), {T} threads, {cel:.2f}s",
                                 "parity_checked_queries": nq, "parity_mismatches": len(bad)}
-    if use_dist:
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.close()
         try:                                   # RCCL's version banner goes through C stdio: keep the JSON line last
             C.CDLL(None).fflush(None)
         except Exception:
