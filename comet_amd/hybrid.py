@@ -118,3 +118,44 @@ class HybridSearch:
         res = [HybridSearchResult(i, s) for i, s in comb.items()]
         res.sort(key=lambda r: -r.score)      # sort.Slice(desc) hybrid_search_index.go:603
         return res[:self.k] if len(res) > self.k else res
+
+
+# ---- segment layer (storage.go:489-626): one hybrid index per memtable / segment, results merged on the host -------------
+def merge_results(results: list[HybridSearchResult]) -> list[HybridSearchResult] | None:
+    """mergeResults storage_merge.go:13-46: deduplicate by document id, keep the HIGHEST score; nil for no input.
+    (The reference's output order is Go map order — unspecified; this mirror keeps first-seen order.)"""
+    if not results:
+        return None
+    best: dict[int, float] = {}
+    for r in results:
+        if r.id not in best or r.score > best[r.id]:
+            best[r.id] = r.score
+    return [HybridSearchResult(i, s) for i, s in best.items()]
+
+
+def sort_results_by_score(results: list[HybridSearchResult]) -> None:
+    """sortResultsByScore storage_merge.go:50-54: descending, in place."""
+    results.sort(key=lambda r: -r.score)
+
+
+class SegmentedHybridSearch:
+    """persistentHybridSearch.Execute storage.go:489-626 without the storage engine: the same query runs against every
+    segment's (vector index, text index) pair — newest first, as the reference walks memtables then segments — and the
+    per-segment lists are merged (highest score per id), sorted and cut to k. Every per-segment search is a GPU search
+    through the C ABI; the merge is O(segments * k) on the host, exactly where the reference has it."""
+
+    def __init__(self, segments):
+        self.segments = list(segments)          # [(vector_index | None, text_index | None), ...], oldest first
+        self.configure = lambda s: s            # applied to every per-segment HybridSearch (with_vector / with_text / ...)
+        self.k = 10
+
+    def with_k(self, k): self.k = int(k); return self
+    def with_query(self, fn): self.configure = fn; return self
+
+    def execute(self) -> list[HybridSearchResult]:
+        allr: list[HybridSearchResult] = []
+        for vec, txt in reversed(self.segments):
+            allr.extend(self.configure(HybridSearch(vec, txt).with_k(self.k)).execute())
+        merged = merge_results(allr) or []
+        sort_results_by_score(merged)
+        return merged[:self.k] if 0 < self.k < len(merged) else merged

@@ -195,7 +195,11 @@ typedef struct {
  * results the reference would return for that query (rows hold min(count, k_cap) entries). */
 COMET_API int comet_index_search(comet_index* idx, const float* queries, int32_t B, const comet_search_params* p,
                                  uint32_t* out_ids, float* out_scores, int32_t* out_counts, int32_t k_cap);
-/* Same with device-resident queries and outputs; asynchronous on the context's stream. */
+/* Same with device-resident queries and outputs; asynchronous on the context's stream.
+ * Per-query failures: the device entry points never synchronise, so a query the reference would fail as a whole (a zero
+ * vector on a cosine index: ErrZeroVector, distance.go:12) is reported ONLY as out_counts[q] = -COMET_ERR_ZERO_VECTOR (a
+ * negative count; its row is cleared) while the call and the other queries of the batch succeed. Read counts as signed.
+ * The host-pointer comet_index_search above additionally returns COMET_ERR_ZERO_VECTOR when any query of the batch failed. */
 COMET_API int comet_index_search_dev(comet_index* idx, const float* queries_dev, int32_t B,
                                      const comet_search_params* p, uint32_t* out_ids_dev, float* out_scores_dev,
                                      int32_t* out_counts_dev, int32_t k_cap);

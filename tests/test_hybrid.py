@@ -72,3 +72,42 @@ def test_config5_hybrid_ivf_bm25_rrf(ctx):
         want = sorted(zip(os_[:m].tolist(), oi[:m].tolist()), key=lambda t: -t[0])[:k]
         assert sorted(r.score for r in res) == sorted(s for s, _ in want)
         assert {r.id for r in res if r.score > want[-1][0]} == {i for s, i in want if s > want[-1][0]}
+
+
+def test_merge_results_reference_kats():
+    """storage_merge_test.go:8-101 (TestMergeResults, TestMergeResults_Nil) and :103-190 (TestSortResultsByScore)."""
+    from comet_amd.hybrid import HybridSearchResult as R, merge_results, sort_results_by_score
+    cases = [([(1, 0.5), (2, 0.8), (3, 0.3)], {1: 0.5, 2: 0.8, 3: 0.3}),
+             ([(1, 0.5), (2, 0.8), (1, 0.9), (3, 0.3), (2, 0.6)], {1: 0.9, 2: 0.8, 3: 0.3}),
+             ([(1, 0.1), (1, 0.5), (1, 0.9), (1, 0.3)], {1: 0.9})]
+    for inp, want in cases:
+        got = merge_results([R(i, s) for i, s in inp])
+        assert {r.id: r.score for r in got} == want and len(got) == len(want)
+    assert merge_results(None) is None and merge_results([]) is None
+    rs = [R(1, 0.3), R(2, 0.9), R(3, 0.5), R(4, 0.7)]
+    sort_results_by_score(rs)
+    assert [r.id for r in rs] == [2, 4, 3, 1]
+    e = []; sort_results_by_score(e); assert e == []
+    one = [R(1, 0.5)]; sort_results_by_score(one); assert one[0].id == 1
+
+
+@pytest.mark.gpu
+def test_segmented_search_equals_one_index(ctx):
+    """storage.go:489-626: the same vector query over three segment indexes, merged on the host, returns what one index
+    holding all the rows returns (vector-only queries keep the distances as scores, so 'highest score' keeps the WORST copy of
+    a duplicated id, as in the reference; ids here are unique across segments)."""
+    import numpy as np
+    import oracle_lib as orc
+    from comet_amd import FlatIndex, L2_SQUARED
+    from comet_amd.hybrid import HybridSearch, SegmentedHybridSearch
+    n, d = 3000, 32
+    X = orc.synth(91, 0, n * d).reshape(n, d); q = orc.synth(92, 0, d)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    whole = FlatIndex(ctx, d, L2_SQUARED); whole.add_batch(ids, X)
+    segs = []
+    for lo, hi in ((0, 1000), (1000, 1800), (1800, 3000)):
+        f = FlatIndex(ctx, d, L2_SQUARED); f.add_batch(ids[lo:hi], X[lo:hi]); segs.append((f, None))
+    k = 3000          # hybrid results sort by score DESCENDING (hybrid_search_index.go:603): compare the full lists
+    one = HybridSearch(whole, None).with_vector(q).with_k(k).execute()
+    many = SegmentedHybridSearch(segs).with_k(k).with_query(lambda s: s.with_vector(q)).execute()
+    assert [(r.id, r.score) for r in one] == [(r.id, r.score) for r in many]
