@@ -158,7 +158,8 @@ static void compact_rows(Ctx* c, DevBuf& buf, size_t row_bytes, const std::vecto
 
 // coarse step shared by IVF and IVFPQ (ivf_index_search.go:246-261): rank all centroids, keep nprobes.
 // probe_list[q][0..np) = centroid indices sorted by (distance, index).
-static void coarse_probe(Ctx* c, int metric, const float* centroids, int nlist, int ld, const float* Qp, int B, int np, uint32_t* probe_list) {
+static void coarse_probe(Ctx* c, int metric, const float* centroids, int nlist, int ld, int dim, const float* Qp, int B, int np, uint32_t* probe_list) {
+    if (launch_coarse_probe_fast(c, metric, centroids, nlist, ld, dim, Qp, B, np, probe_list)) return;     // approximate ranking + exact re-scoring of the few that matter
     const int64_t ldDc = round_up(nlist, 16);
     float* Dc = c->salloc<float>((size_t)B * ldDc);
     launch_dist_exact(c, metric, centroids, nlist, ld, Qp, B, Dc, ldDc, nullptr);
@@ -370,7 +371,7 @@ struct IVFIndex : comet_index {
         prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag);
         const int np = sanitize_nprobes(p.nprobes, nlist);
         uint32_t* probe_list = c->salloc<uint32_t>((size_t)B * np);
-        coarse_probe(c, metric, centroids.as<float>(), nlist, ld, Qp, B, np, probe_list);
+        coarse_probe(c, metric, centroids.as<float>(), nlist, ld, dim, Qp, B, np, probe_list);
         int32_t* seg_off = c->salloc<int32_t>((size_t)B * (np + 1));
         int32_t* cnts = c->salloc<int32_t>(B);
         launch_probe_segments(c, probe_list, np, nullptr, lay.list_len.as<int32_t>(), B, np, seg_off, cnts);
@@ -571,7 +572,7 @@ struct PQFamilyIndex : comet_index {
         prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag);
         const int np = ivf ? sanitize_nprobes(p.nprobes, nlist) : 1;
         uint32_t* probe_list = c->salloc<uint32_t>((size_t)B * np);
-        if (ivf) coarse_probe(c, metric, centroids.as<float>(), nlist, ld, Qp, B, np, probe_list);
+        if (ivf) coarse_probe(c, metric, centroids.as<float>(), nlist, ld, dim, Qp, B, np, probe_list);
         else c->zero(probe_list, sizeof(uint32_t) * (size_t)B);
         int32_t* seg_off = c->salloc<int32_t>((size_t)B * (np + 1));
         int32_t* cnts = c->salloc<int32_t>(B);

@@ -20,6 +20,8 @@ void launch_unpad_rows(Ctx* c, const float* src, int64_t n, int ld, float* dst, 
 // Exact-arithmetic distances: D[q][row] = Calculate(Q[q], X[row]) with the reference's float32
 // evaluation order (sequential over the dimension, no FMA). X: n x ld, Q: B x ld, D: B x ldD.
 // elig (nullable): per-row eligibility bytes; ineligible rows get the EXCLUDED sentinel in D.
+// coarse quantiser: probe_list[q][0..np) = the np nearest centroids by (exact distance, index); false = not applicable here
+bool launch_coarse_probe_fast(Ctx* c, int metric, const float* C, int nlist, int ld, int dim, const float* Qp, int B, int np, uint32_t* probe_list);
 void launch_dist_exact(Ctx* c, int metric, const float* X, int64_t n, int ld, const float* Q, int B, float* D, int64_t ldD,
                        const uint8_t* elig);
 // ineligible / excluded candidates carry this bit pattern (a NaN the arithmetic cannot produce) in distance matrices

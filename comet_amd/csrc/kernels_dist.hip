@@ -269,6 +269,180 @@ void launch_dist_exact(Ctx* c, int metric, const float* X, int64_t n, int ld, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Coarse quantiser, fast form (ivf_index_search.go:246-261: distances to ALL centroids, full sort, first nprobes).
+// Ranking nlist centroids exactly costs B * nlist serial 768-term chains for the sake of the nprobes nearest. Here:
+//   coarse_dot_kernel   S = Q . C^T in plain float32 FMAs (any order), plus ||q||^2 and ||c||^2
+//   coarse_pick_kernel  one workgroup per query: approximate distances A from S (L2 family: ||q||^2 + ||c||^2 - 2S; cosine:
+//                       1 - clamp(S)), kappa = the nprobes-th smallest A (32-step bit search on the keys in LDS), every centroid
+//                       with A <= kappa + 2E is re-scored EXACTLY (the reference's serial float32 chain: acc_step / acc_finish),
+//                       the (exact distance, index) order of those gives the probe list.
+// Containment as for the Flat fast path: |A - exact| <= E for every centroid (E covers the FMA sums on this side and the
+// rounding of the reference's own chain against the real value), so the nprobes centroids with the smallest A have exact
+// distance <= kappa + E, hence the exact nprobes-th distance <= kappa + E and every exact top-nprobes centroid has A <= kappa + 2E.
+// Euclidean ranks in the squared domain (+ a relative slack for sums that round to the same root). The probe list is
+// bit-identical to the exact path's; the chains actually run are ~nprobes + a few per query instead of nlist.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned cq_f2key(unsigned u) { return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ unsigned cq_key2f(unsigned k) { return (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; }
+constexpr int CQ_T = 32, CQ_LD = 36, CQ_MAX_LISTS = 8192;
+__global__ __launch_bounds__(256) void coarse_dot_kernel(const float* __restrict__ Q, int B, const float* __restrict__ C, int nlist, int ld,
+                                                         float* __restrict__ S, long ldS, float* __restrict__ qn, float* __restrict__ cn) {
+    __shared__ __attribute__((aligned(16))) float Qs[CQ_T * CQ_LD], Cs[CQ_T * CQ_LD];
+    const int t = threadIdx.x, q0 = blockIdx.y * CQ_T, l0 = blockIdx.x * CQ_T;
+    const int tq = t >> 3, tl = (t & 7) * 4;             // this thread: query tq, centroids tl..tl+3 of the tile
+    const int lrow = t >> 3, lc4 = (t & 7) * 4;          // loader: one float4 of each tile per K chunk
+    const float* qsrc = Q + (long)min(q0 + lrow, B - 1) * ld + lc4;
+    const float* csrc = C + (long)min(l0 + lrow, nlist - 1) * ld + lc4;
+    f32x4 pq = *reinterpret_cast<const f32x4*>(qsrc), pc = *reinterpret_cast<const f32x4*>(csrc);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, qq = 0.f, cc[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_q = blockIdx.x == 0 && tl == 0, do_c = blockIdx.y == 0 && tq == 0;
+    for (int k0 = 0; k0 < ld; k0 += CQ_T) {
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(&Qs[lrow * CQ_LD + lc4]) = pq;
+        *reinterpret_cast<f32x4*>(&Cs[lrow * CQ_LD + lc4]) = pc;
+        __syncthreads();
+        const int kn = (k0 + CQ_T < ld) ? k0 + CQ_T : k0;
+        pq = *reinterpret_cast<const f32x4*>(qsrc + kn); pc = *reinterpret_cast<const f32x4*>(csrc + kn);
+#pragma unroll
+        for (int k = 0; k < CQ_T; k += 4) {
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(&Qs[tq * CQ_LD + k]);
+            if (do_q) qq = __builtin_fmaf(qv[0], qv[0], __builtin_fmaf(qv[1], qv[1], __builtin_fmaf(qv[2], qv[2], __builtin_fmaf(qv[3], qv[3], qq))));
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f32x4 cv = *reinterpret_cast<const f32x4*>(&Cs[(tl + j) * CQ_LD + k]);
+                acc[j] = __builtin_fmaf(qv[0], cv[0], __builtin_fmaf(qv[1], cv[1], __builtin_fmaf(qv[2], cv[2], __builtin_fmaf(qv[3], cv[3], acc[j]))));
+                if (do_c) cc[j] = __builtin_fmaf(cv[0], cv[0], __builtin_fmaf(cv[1], cv[1], __builtin_fmaf(cv[2], cv[2], __builtin_fmaf(cv[3], cv[3], cc[j]))));
+            }
+        }
+    }
+    if (q0 + tq < B) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (l0 + tl + j < nlist) S[(long)(q0 + tq) * ldS + l0 + tl + j] = acc[j];
+        if (do_q) qn[q0 + tq] = qq;
+    }
+    if (do_c) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (l0 + tl + j < nlist) cn[l0 + tl + j] = cc[j];
+    }
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void coarse_pick_kernel(const float* __restrict__ S, long ldS, const float* __restrict__ qn, const float* __restrict__ cn,
+                                                          const float* __restrict__ C, int nlist, int ld, int dim, const float* __restrict__ Qp, int np,
+                                                          int n2, unsigned* __restrict__ probe_list) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cqs[];
+    unsigned long long* comp = reinterpret_cast<unsigned long long*>(cqs);                 // [n2] composites of the re-scored centroids
+    unsigned* keys = reinterpret_cast<unsigned*>(comp + n2);                                  // [nlist] keys of the approximate distances
+    unsigned* list = keys + nlist;                                                            // [nlist] candidate centroids
+    float* qs = reinterpret_cast<float*>(list + nlist);                                       // [ld] the query
+    __shared__ int wcnt[2][4];
+    __shared__ float wmax[4];
+    __shared__ int s_n;
+    const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    for (int i = t; i < ld; i += 256) qs[i] = Qp[(long)q * ld + i];
+    const float qnv = qn[q];
+    float cmax = 0.0f;
+    for (int l = t; l < nlist; l += 256) {
+        const float cv = cn[l], sv = S[(long)q * ldS + l];
+        cmax = fmaxf(cmax, cv);
+        float a;
+        if constexpr (METRIC == COMET_COSINE) { float d = sv; if (d > 1.0f) d = 1.0f; else if (d < -1.0f) d = -1.0f; a = 1.0f - d; }
+        else a = qnv + cv - 2.0f * sv;
+        keys[l] = cq_f2key(__float_as_uint(a));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
+    if (lane == 0) wmax[w] = cmax;
+    if (t == 0) s_n = 0;
+    __syncthreads();
+    cmax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    const float nq = sqrtf(qnv) * 1.0001f, nc = sqrtf(cmax) * 1.0001f, u = 6.0e-8f;
+    float E;
+    if constexpr (METRIC == COMET_COSINE) E = 4.0f * ((float)dim + 2.0f) * u * nq * nc + 2.0e-7f;
+    else E = 4.0f * ((float)dim + 3.0f) * u * (nq + nc) * (nq + nc);
+    // kappa: the np-th smallest key, bit by bit from the top (one barrier per bit: the wave counts alternate between two slots;
+    // a nibble per step with 16 ballot counters was measured and is slower: 0.041 vs 0.037 ms)
+    unsigned kth = 0u;
+    for (int bit = 31; bit >= 0; bit--) {
+        const unsigned tv = kth | ((1u << bit) - 1u);
+        int cnt = 0;
+        for (int l = t; l < nlist; l += 256) cnt += (keys[l] <= tv) ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if (lane == 0) wcnt[bit & 1][w] = cnt;
+        __syncthreads();
+        const int tot = wcnt[bit & 1][0] + wcnt[bit & 1][1] + wcnt[bit & 1][2] + wcnt[bit & 1][3];
+        if (tot < np) kth |= 1u << bit;
+    }
+    const float kappa = __uint_as_float(cq_key2f(kth));
+    const float tau = kappa + 2.0f * E + 2.0e-6f * fabsf(kappa);
+    for (int l = t; l < nlist; l += 256) {
+        const float a = __uint_as_float(cq_key2f(keys[l]));
+        if (a <= tau) list[atomicAdd(&s_n, 1)] = (unsigned)l;
+    }
+    __syncthreads();
+    const int ncand = s_n;
+    for (int ci = t; ci < ncand; ci += 256) {
+        const unsigned l = list[ci];
+        const float* __restrict__ cr = C + (long)l * ld;
+        float acc = 0.0f;
+        for (int i = 0; i < ld; i += 4) {
+            const f32x4 cv = *reinterpret_cast<const f32x4*>(cr + i);
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + i);
+            acc = acc_step<METRIC>(acc, qv[0], cv[0]); acc = acc_step<METRIC>(acc, qv[1], cv[1]);
+            acc = acc_step<METRIC>(acc, qv[2], cv[2]); acc = acc_step<METRIC>(acc, qv[3], cv[3]);
+        }
+        const float d = acc_finish<METRIC>(acc);
+        comp[ci] = ((unsigned long long)cq_f2key(__float_as_uint(d)) << 32) | l;
+    }
+    __syncthreads();
+    if (ncand <= 1024) {
+        // rank by counting (composites are unique): the first np ranks are the probe list
+        for (int ci = t; ci < ncand; ci += 256) {
+            const unsigned long long me = comp[ci];
+            int rank = 0;
+            for (int j = 0; j < ncand; j++) rank += (comp[j] < me) ? 1 : 0;
+            if (rank < np) probe_list[(long)q * np + rank] = (unsigned)(me & 0xFFFFFFFFull);
+        }
+    } else {
+        int m2 = 64; while (m2 < ncand) m2 <<= 1;
+        for (int i = ncand + t; i < m2; i += 256) comp[i] = ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= m2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = t; i < m2; i += 256) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) { const unsigned long long a = comp[i], b = comp[ixj]; if ((a > b) == ((i & k) == 0)) { comp[i] = b; comp[ixj] = a; } }
+                }
+                __syncthreads();
+            }
+        for (int i = t; i < np; i += 256) probe_list[(long)q * np + i] = (unsigned)(comp[i] & 0xFFFFFFFFull);
+    }
+}
+// false: not applicable (too many lists for the LDS of the pick kernel, or most lists are probed anyway) — use the exact ranking
+bool launch_coarse_probe_fast(Ctx* c, int metric, const float* C, int nlist, int ld, int dim, const float* Qp, int B, int np, uint32_t* probe_list) {
+    static const bool off = getenv("COMET_COARSE_EXACT") != nullptr;
+    if (off || nlist > CQ_MAX_LISTS || nlist < 64 || (int64_t)np * 4 > nlist || B <= 0) return false;
+    ScratchMark mark(c);
+    const int64_t ldS = round_up(nlist, 16);
+    float* S = c->salloc<float>((size_t)B * ldS);
+    float* qn = c->salloc<float>(B);
+    float* cn = c->salloc<float>(nlist);
+    { ProfScope ps(c, "coarse_dot");
+      coarse_dot_kernel<<<dim3((unsigned)ceil_div(nlist, CQ_T), (unsigned)ceil_div(B, CQ_T)), dim3(256), 0, c->stream>>>(Qp, B, C, nlist, ld, S, ldS, qn, cn);
+      LAUNCH_CHECK(); }
+    int n2 = 64; while (n2 < nlist) n2 <<= 1;
+    const size_t lds = (size_t)n2 * 8 + (size_t)nlist * 8 + (size_t)ld * 4;
+    { ProfScope ps(c, "coarse_pick");
+#define CP(M) do { HIP_CHECK(hipFuncSetAttribute((const void*)coarse_pick_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                   coarse_pick_kernel<M><<<dim3(B), dim3(256), lds, c->stream>>>(S, ldS, qn, cn, C, nlist, ld, dim, Qp, np, n2, probe_list); } while (0)
+      switch (metric) { case COMET_L2: CP(COMET_L2); break; case COMET_L2SQ: CP(COMET_L2SQ); break; default: CP(COMET_COSINE); break; }
+#undef CP
+      LAUNCH_CHECK(); }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // IVF list scan, list-ordered (ivf_index_search.go:277-301). One lane per candidate, the same LDS-transposed 128-byte-chunk
 // pipeline as dist_exact_kernel (row indirection is free because each row chunk is fetched independently anyway); the work
 // is laid out by (query, probed list) PAIR in list order: blockIdx.y walks the pairs sorted by list, so the workgroups

@@ -100,6 +100,22 @@ def build_ivf(ctx, metric, X, train, nlist):
 
 
 @pytest.mark.parametrize("metric", METRICS)
+def test_ivf_coarse_fast_ranking_matches_exact(ctx, metric):
+    """nlist >= 64 and nprobes <= nlist / 4: the coarse quantiser ranks the centroids with approximate (float32 FMA) distances
+    and re-scores exactly only the ones that can be among the nprobes nearest (coarse_dot / coarse_pick kernels); the probe
+    lists — and with them every result — must equal the exact ranking's (oracle), incl. queries sitting ON a centroid and
+    queries far outside the data."""
+    n, d, nlist = 9000, 40, 256
+    X = synth(71, n, d) * np.float32(2.0)
+    g, o = build_ivf(ctx, metric, X, X[:5120], nlist)
+    C = g.centroids(nlist)
+    Q = np.vstack([synth(72, 24, d), X[:4], C[5:7], synth(73, 2, d) * np.float32(50.0)])
+    for nprobes in (1, 8, 64, 65):                        # 65 > nlist / 4: the exact ranking
+        check_search(g, o, Q, 10, nprobes)
+    check_search(g, o, Q, 0, 3)
+
+
+@pytest.mark.parametrize("metric", METRICS)
 def test_ivf_matches_oracle(ctx, metric):
     n, d, nlist = 3000, 48, 24
     X = clustered(31, n, d, 20)
