@@ -443,15 +443,18 @@ __global__ __launch_bounds__(256) void iota_kernel(unsigned* __restrict__ p, int
 }
 
 
+struct __attribute__((aligned(16))) AdcRec { unsigned duo; int start, seg_end, qA, soA, qB, soB; unsigned base_lo, base_hi, pad0, pad1, pad2; };   // 48 bytes
 // Slots and work queues of the ADC scan. One workgroup. `identity`: the list count does not fit the LDS bins — every pair
 // becomes a duo of its own (slot 2i = pair i, slot 2i+1 a hole).
 //   order[s]  pair of slot s (ADC_HOLE: none)          slist[s]  list of slot s (nlist: nothing to scan)
-//   qitems    8 queues x qcap items {duo, segment}; queue x holds the chunks c = x (mod 8) of ADC_XCD_CHUNK adjacent duos
+//   qitems    8 queues x qcap item RECORDS (everything the scan needs about a (duo, segment) item, so that it decodes an item with ONE
+//             48-byte load instead of a chain of five dependent ones); queue x holds the chunks c = x (mod 8) of ADC_XCD_CHUNK adjacent duos
 //   qcount    items per queue; queues[] (the scan's ticket counters) is zeroed here
 __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restrict__ probe_list, int ldp, int np, const int* __restrict__ seg_off,
                                                          int n_pairs, int nlist, int identity, const int* __restrict__ list_len, int n_slots,
-                                                         unsigned* __restrict__ order, unsigned* __restrict__ slist, uint2* __restrict__ qitems, int qcap,
-                                                         int* __restrict__ qcount, int* __restrict__ queues, unsigned* __restrict__ tq, int* __restrict__ cursor, int n_q, int lead) {
+                                                         unsigned* __restrict__ order, unsigned* __restrict__ slist, AdcRec* __restrict__ qitems, int qcap,
+                                                         int* __restrict__ qcount, int* __restrict__ queues, unsigned* __restrict__ tq, int* __restrict__ cursor, int n_q, int lead,
+                                                         const long* __restrict__ list_base) {
     // lead (fused filter, np >= 2): every query's NEAREST list (probe 0) gets a duo of its own in the first 2 * n_q slots, so that
     // those pairs are scanned first and seed the per-query bound before the bulk of the candidates is tested against it.
     extern __shared__ __attribute__((aligned(16))) int obin[];   // nlist + 1 counters (not used by the identity order)
@@ -510,13 +513,34 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
     if (lane == 0) wtot[w] = tot;
     __syncthreads();
     int base = h ? wtot[x] : 0;
-    for (int ub = u0; ub < u1; ub += 64) {
-        int duo; const int ns = segs_of(ub + lane, duo);
-        int inc = ns;                                               // inclusive wave scan
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
-        const int off = base + inc - ns;
-        for (int sgi = 0; sgi < ns; sgi++) if (off + sgi < qcap) qitems[(long)x * qcap + off + sgi] = make_uint2((unsigned)duo, (unsigned)sgi);
-        base += __shfl(inc, 63);
+    constexpr int NBK = 4;                                          // 64-duo blocks gathered together: their (dependent) loads overlap
+    for (int ub0 = u0; ub0 < u1; ub0 += 64 * NBK) {
+        AdcRec r[NBK]; int ns[NBK], len[NBK];
+#pragma unroll
+        for (int b = 0; b < NBK; b++) {
+            int duo; ns[b] = segs_of(ub0 + b * 64 + lane, duo);
+            r[b].duo = (unsigned)duo; len[b] = 0;
+            if (ns[b] > 0) {
+                const unsigned pa = order[2 * duo], pb = order[2 * duo + 1], L = slist[2 * duo];
+                len[b] = list_len[L];
+                const long bb = list_base[L] >> 6;                  // list bases are multiples of 64
+                r[b].qA = (int)pa / np; r[b].soA = seg_off[(long)r[b].qA * (np + 1) + ((int)pa - r[b].qA * np)];
+                r[b].qB = -1; r[b].soB = 0;
+                if (pb != ADC_HOLE) { r[b].qB = (int)pb / np; r[b].soB = seg_off[(long)r[b].qB * (np + 1) + ((int)pb - r[b].qB * np)]; }
+                r[b].base_lo = (unsigned)(bb & 0xFFFFFFFFl); r[b].base_hi = (unsigned)(bb >> 32); r[b].pad0 = r[b].pad1 = r[b].pad2 = 0;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NBK; b++) {
+            int inc = ns[b];                                        // inclusive wave scan
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+            const int off = base + inc - ns[b];
+            for (int sgi = 0; sgi < ns[b]; sgi++) if (off + sgi < qcap) {
+                r[b].start = sgi * ADC_SEG_CODES; r[b].seg_end = min(len[b], r[b].start + ADC_SEG_CODES);
+                qitems[(long)x * qcap + off + sgi] = r[b];
+            }
+            base += __shfl(inc, 63);
+        }
     }
     if (h && lane == 0) { qcount[x] = min(wtot[x] + wtot[x + 8], qcap); queues[x] = 0; }
 }
@@ -606,7 +630,7 @@ __device__ __forceinline__ void adc_chains2(const f32x2q* __restrict__ lut, int 
 
 struct AdcArgs {
     const float* lutg; const unsigned* codes; const long* list_base; const int* list_len; const int* seg_off; const unsigned char* elig;
-    const unsigned* order; const unsigned* slist; const uint2* qitems; const int* qcount; int* queues; float* D;
+    const unsigned* order; const unsigned* slist; const AdcRec* qitems; const int* qcount; int* queues; float* D;
     long ldD; int M, KL, mp, M4, np, qcap;
     // fused top-K filter (cand != nullptr; K in [1, 64]): no distance matrix — survivors of the per-query running bound tq[] go to
     // cand[q * ldD + cursor[q]++] as (order-preserving key << 32 | position in the query's candidate row)
@@ -631,23 +655,15 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
         }
         return -1;
     };
-    auto rfl64 = [](long v) -> long { return ((long)RFL((int)(v >> 32)) << 32) | (unsigned)RFL((int)(v & 0xFFFFFFFFl)); };
     auto decode = [&](int xq, int ticket) -> AdcItem {
         AdcItem it; it.live = 0; it.start = it.seg_end = 0; it.qA = it.soA = it.soB = 0; it.qB = -1; it.base_blk = 0; it.duo = 0;
         xq = RFL(xq); ticket = RFL(ticket);              // read from LDS: uniform, but only the hardware knows — keep the item in SGPRs
         if (ticket < 0) return it;
-        const uint2 e = a.qitems[(long)xq * a.qcap + ticket];
-        const unsigned duo = RFL(e.x), sg = RFL(e.y);
-        const unsigned pa = RFL(a.order[2 * duo]), pb = RFL(a.order[2 * duo + 1]);
-        const unsigned L = RFL(a.slist[2 * duo]);
-        const int len = RFL(a.list_len[L]);
-        const int np = a.np;
-        it.live = 1; it.duo = duo;
-        it.qA = (int)pa / np;
-        it.soA = RFL(a.seg_off[(long)it.qA * (np + 1) + ((int)pa - it.qA * np)]);
-        if (pb != ADC_HOLE) { it.qB = (int)pb / np; it.soB = RFL(a.seg_off[(long)it.qB * (np + 1) + ((int)pb - it.qB * np)]); }
-        it.start = (int)sg * ADC_SEG_CODES; it.seg_end = min(len, it.start + ADC_SEG_CODES);
-        it.base_blk = rfl64(a.list_base[L] >> 6);        // list bases are multiples of 64
+        const uint4* rp = reinterpret_cast<const uint4*>(a.qitems + ((long)xq * a.qcap + ticket));
+        const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2];      // {duo, start, seg_end, qA} {soA, qB, soB, base_lo} {base_hi, -, -, -}
+        it.live = 1; it.duo = RFL(r0.x); it.start = RFL((int)r0.y); it.seg_end = RFL((int)r0.z);
+        it.qA = RFL((int)r0.w); it.soA = RFL((int)r1.x); it.qB = RFL((int)r1.y); it.soB = RFL((int)r1.z);
+        it.base_blk = ((long)RFL((int)r2.x) << 32) | (unsigned)RFL((int)r1.w);
         return it;
     };
     auto chains_of = [&](const AdcItem& it, int ps) -> int {        // blocks wid, wid+16, ... of pass ps that exist
@@ -855,7 +871,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
     float* lut = c->salloc<float>((size_t)max_slots * M * KL);
     uint32_t* order = c->salloc<uint32_t>((size_t)max_slots);
     uint32_t* slist = c->salloc<uint32_t>((size_t)max_slots);
-    uint2* qitems = c->salloc<uint2>((size_t)8 * qcap);
+    AdcRec* qitems = c->salloc<AdcRec>((size_t)8 * qcap);
     int32_t* qcount = c->salloc<int32_t>(8);
     int32_t* queues = c->salloc<int32_t>(8);
     const int mw = 256 >> kl_shift;
@@ -880,7 +896,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
             ProfScope ps(c, "adc_order");
             adc_order_kernel<<<dim3(1), dim3(1024), identity ? 0 : (size_t)(nlist + 1) * 4, c->stream>>>(pl, ldp, np, so, n_pairs, nlist, identity ? 1 : 0, list_len,
                                                                                                        n_slots, order, slist, qitems, (int)qcap, qcount, queues,
-                                                                                                       flt ? flt->tq + b0 : nullptr, flt ? flt->cursor + b0 : nullptr, bn, lead ? 1 : 0);
+                                                                                                       flt ? flt->tq + b0 : nullptr, flt ? flt->cursor + b0 : nullptr, bn, lead ? 1 : 0, (const long*)list_base);
             LAUNCH_CHECK();
         }
         {
