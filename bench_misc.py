@@ -132,6 +132,10 @@ def main():
         for _ in range(args.steps):
             r = g.search_batch(queries, 10)
         el = (time.perf_counter() - t0) / args.steps
+        ctx.profile(True); ctx.profile_reset()
+        for _ in range(args.steps):
+            g.search_batch(queries, 10)
+        bm_prof = {k: round(v[0] / args.steps, 4) for k, v in sorted(ctx.profile_dump().items())}; ctx.profile(False)
         txt_res = r
         nq = min(B, cores)
         bad = []
@@ -144,7 +148,7 @@ def main():
         cel = threads_run(work, nq, nq)
         out["bm25"] = {"workload": f"BM25 over {nd} docs (zipf token ids, 20-120 tokens), batch={B} 4-token queries, K=10 (both indexes built in {build_s:.0f}s)",
                        "gpu_qps_host_buffers": B / el, "ms_per_batch": el * 1e3, "cpu_oracle_qps": nq / cel, "cpu_threads": nq,
-                       "parity_checked": nq, "parity_mismatches": len(bad)}
+                       "parity_checked": nq, "parity_mismatches": len(bad), "kernels_ms_per_batch": bm_prof}
 
     if vec_res is not None and txt_res is not None:
         t0 = time.perf_counter()

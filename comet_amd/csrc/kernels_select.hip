@@ -762,6 +762,33 @@ __global__ __launch_bounds__(1024) void sel_composites_kernel(const unsigned lon
         for (int i = t; i < m; i += 1024) { const unsigned long long k = row[i]; if (k <= prefix) { const int sl = atomicAdd(&s_n, 1); if (sl < SORT_MAX) sm[sl] = k; } }   // composites are unique: exactly kq
         __syncthreads();
         n = min(s_n, SORT_MAX);
+    } else if (m > 1024 && kq <= 16) {
+        // a few thousand survivors, a handful wanted: every wave sorts 64-composite chunks in registers (bitonic network over the
+        // lanes, no barriers) and keeps each chunk's kq smallest — the row's kq smallest are among them — at most 64 * 16 = 1024
+        // composites, which the counting rank below finishes. (A 2048-wide LDS bitonic sort is 66 barrier steps: the slowest
+        // row of a batch set the kernel's time.)
+        if (t == 0) s_n = 0;
+        __syncthreads();
+        const int lane = t & 63, w = t >> 6, nchunks = (m + 63) >> 6;
+        for (int ch = w; ch < nchunks; ch += 16) {
+            const int i = ch * 64 + lane;
+            unsigned long long v = i < m ? row[i] : ~0ull;
+#pragma unroll
+            for (int k2 = 2; k2 <= 64; k2 <<= 1)
+#pragma unroll
+                for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(v & 0xFFFFFFFFull), j2, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), j2, 64);
+                    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+                    const bool up = ((lane & k2) == 0), low = ((lane & j2) == 0);
+                    v = (up == low) ? (v < o ? v : o) : (v > o ? v : o);
+                }
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_n, kq);
+            base = __shfl(base, 0, 64);
+            if (lane < kq) sm[base + lane] = v;               // lanes 0..kq-1 hold the chunk's kq smallest (padding sorts last)
+        }
+        __syncthreads();
+        n = s_n;
     } else {
         for (int i = t; i < m; i += 1024) sm[i] = row[i];
     }
@@ -782,7 +809,7 @@ __global__ __launch_bounds__(1024) void sel_composites_kernel(const unsigned lon
     }
     const int nw = kq < k_cap ? kq : k_cap;
     for (int i = t; i < k_cap; i += 1024) {
-        if (i < nw && i < n) {
+        if (i < nw && i < n && sm[i] != ~0ull) {
             const unsigned long long cc = sm[i];
             out_pos[(long)q * k_cap + i] = (unsigned)(cc & 0xFFFFFFFFull);
             out_scores[(long)q * k_cap + i] = __uint_as_float(key2f((unsigned)(cc >> 32)));
