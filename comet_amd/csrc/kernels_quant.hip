@@ -459,7 +459,6 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
     // those pairs are scanned first and seed the per-query bound before the bulk of the candidates is tested against it.
     extern __shared__ __attribute__((aligned(16))) int obin[];   // nlist + 1 counters (not used by the identity order)
     if (tq) for (int i = threadIdx.x; i < n_q; i += 1024) { tq[i] = 0x7F800000u; cursor[i] = 0; }   // fused filter: bound = +inf (float bits of a sum), no survivors yet
-    __shared__ int part[1024];
     __shared__ int wtot[16];
     const int nb = nlist + 1, t = threadIdx.x;
     auto key_of = [&](int i) {
@@ -477,23 +476,34 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
         for (int i = t; i < nb; i += 1024) obin[i] = 0;
         __syncthreads();
         if (lead0) for (int qq = t; qq < n_q; qq += 1024) { order[2 * qq] = (unsigned)(qq * np); slist[2 * qq] = (unsigned)key_of(qq * np); }
-        for (int i = t; i < n_pairs; i += 1024) if (in_bulk(i)) atomicAdd(&obin[key_of(i)], 1);
+        // a pair's key costs two dependent loads: computed once, kept in registers for the scatter (up to KC pairs per thread)
+        constexpr int KC = 16;
+        int kc[KC];
+#pragma unroll
+        for (int j = 0; j < KC; j++) { const int i = t + j * 1024; kc[j] = (i < n_pairs && in_bulk(i)) ? key_of(i) : -1; }
+#pragma unroll
+        for (int j = 0; j < KC; j++) if (kc[j] >= 0) atomicAdd(&obin[kc[j]], 1);
+        for (int i = t + KC * 1024; i < n_pairs; i += 1024) if (in_bulk(i)) atomicAdd(&obin[key_of(i)], 1);
         __syncthreads();
         const int per = (nb + 1023) / 1024, lo = t * per, hi = min(nb, lo + per);
         int s = 0;
         for (int i = lo; i < hi; i++) s += (i < nlist) ? ((obin[i] + 1) & ~1) : obin[i];      // a list's run is padded to an even length
-        part[t] = s;
+        // exclusive prefix over the 1024 threads: wave scan + the 16 wave totals (3 barriers instead of 20)
+        const int lane_ = t & 63, w_ = t >> 6;
+        int inc = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane_ >= o) inc += v; }
+        if (lane_ == 63) wtot[w_] = inc;
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const int v = (t >= off) ? part[t - off] : 0;
-            __syncthreads();
-            part[t] += v;
-            __syncthreads();
-        }
-        int run = lead0 + part[t] - s;                              // exclusive prefix of this thread's bins (behind the leading region)
+        int wbase = 0;
+        for (int j = 0; j < w_; j++) wbase += wtot[j];
+        __syncthreads();                                            // wtot is reused by the queue builder below
+        int run = lead0 + wbase + inc - s;                          // exclusive prefix of this thread's bins (behind the leading region)
         for (int i = lo; i < hi; i++) { const int cnt = obin[i]; obin[i] = run; run += (i < nlist) ? ((cnt + 1) & ~1) : cnt; }
         __syncthreads();
-        for (int i = t; i < n_pairs; i += 1024) if (in_bulk(i)) { const int k = key_of(i); const int pos = atomicAdd(&obin[k], 1); order[pos] = (unsigned)i; slist[pos] = (unsigned)k; }
+#pragma unroll
+        for (int j = 0; j < KC; j++) if (kc[j] >= 0) { const int pos = atomicAdd(&obin[kc[j]], 1); order[pos] = (unsigned)(t + j * 1024); slist[pos] = (unsigned)kc[j]; }
+        for (int i = t + KC * 1024; i < n_pairs; i += 1024) if (in_bulk(i)) { const int k = key_of(i); const int pos = atomicAdd(&obin[k], 1); order[pos] = (unsigned)i; slist[pos] = (unsigned)k; }
     }
     __syncthreads();
     // work queues: waves x and x + 8 build queue x (first and second half of its duos), two passes (count, then write)
