@@ -279,7 +279,10 @@ def leg_flat_l2(ctx, ca, args, timer, flat2, q_dev):
     return out
 
 
-def leg_ivfpq(ctx, ca, args, timer, flat2, q_dev, Q_host):
+def leg_ivfpq(ctx, ca, args, timer, flat2, q_dev, Q_host, comm=None, rank=0, world=1):
+    """world > 1: every rank trains on the same vectors (deterministic GPU k-means: replicated quantisers), owns the inverted lists
+    l % world == rank (comet_index_set_shard) and adds every row (foreign members are dropped); searches go through the in-library
+    RCCL exchange, so every rank ends up with the merged global top-K."""
     B, K, d, n = args.batch, args.ivfpq_k, args.dim, args.rows
     idx = ca.IVFPQIndex(ctx, d, ca.L2_SQUARED, args.nlist, args.M, args.nbits)
     ntrain = min(n, args.nlist * 100)
@@ -290,6 +293,8 @@ def leg_ivfpq(ctx, ca, args, timer, flat2, q_dev, Q_host):
     check(ctx.lib.comet_index_train_dev(idx.h, C.c_void_p(tbuf), ntrain))
     train_s = time.time() - t0
     ctx.free(tbuf)
+    if world > 1:
+        idx.set_shard(rank, world)
     t0 = time.time()
     add_rows(ctx, idx, 0, n, d, lambda buf, lo, m: ctx.synth_mixture(buf, MIX_SEED, MIX_CENTERS, MIX_SIGMA, MIX_SUB, MIX_NOISE, lo, m, d))
     ctx.sync()
@@ -301,15 +306,22 @@ def leg_ivfpq(ctx, ca, args, timer, flat2, q_dev, Q_host):
         prev = None
         for i in range(nsteps):
             w = i & 1
-            t = idx.search_batch_dev_async(q_dev, B, K, bufs[w][0], bufs[w][1], bufs[w][2], K, nprobes=args.nprobe)
+            if comm is not None:
+                t = comm.search_async(idx, q_dev, B, K, bufs[w][0], bufs[w][1], bufs[w][2], K, nprobes=args.nprobe)
+            else:
+                t = idx.search_batch_dev_async(q_dev, B, K, bufs[w][0], bufs[w][1], bufs[w][2], K, nprobes=args.nprobe)
             if prev is not None:
-                idx.search_wait(prev)
+                comm.search_wait(idx, prev, block=False) if comm is not None else idx.search_wait(prev)
             prev = t
         if prev is not None:
-            idx.search_wait(prev)
+            comm.search_wait(idx, prev, block=True) if comm is not None else idx.search_wait(prev)
     step(2)
     med, times, prof, allk = timed(ctx, timer, step, args, "adc_scan")
-    idx.search_batch_dev(q_dev, B, K, oi, os_, oc, K, nprobes=args.nprobe)
+    if comm is not None:
+        comm.search_wait(idx, comm.search_async(idx, q_dev, B, K, oi, os_, oc, K, nprobes=args.nprobe), block=True); comm.sync()
+    else:
+        idx.search_batch_dev(q_dev, B, K, oi, os_, oc, K, nprobes=args.nprobe)
+    ctx.sync()
     g_ids = ctx.download(oi, (B, K), np.uint32); g_sc = ctx.download(os_, (B, K), np.float32); g_cn = ctx.download(oc, (B,), np.int32)
     # exact Flat L2^2 top-K on the same corpus (strict kernels): the recall reference
     f_ids = flat2.search_batch(Q_host, K, mode=1)[0]
@@ -327,7 +339,8 @@ def leg_ivfpq(ctx, ca, args, timer, flat2, q_dev, Q_host):
     adc_per_step = adc_ms / total_steps                      # a step may split the batch over several launches: per-step time is the launch-equivalent
     ach = cand * args.M / (adc_per_step * 1e-3) / 1e9 if adc_per_step > 0 else 0.0
     traffic, src = pmc_traffic("adc_scan", n)
-    out = {"workload": f"IVFPQ l2_squared {n}x{d} (clustered corpus), nlist={args.nlist} nprobe={args.nprobe} M={args.M} nbits={args.nbits}, batch={B}, K={K}",
+    out = {"workload": f"IVFPQ l2_squared {n}x{d} (clustered corpus), nlist={args.nlist} nprobe={args.nprobe} M={args.M} nbits={args.nbits}, batch={B}, K={K}"
+                       + (f"; inverted lists sharded over {world} ranks (roofline block: rank 0's lists)" if world > 1 else ""),
            "qps": B * args.steps / med, "ms_per_step": med / args.steps * 1e3, "region_ms": [round(t * 1e3, 3) for t in times],
            "recall_at_10_vs_exact_flat": recall, "train_vectors": ntrain, "train_s": round(train_s, 2), "add_s": round(add_s, 2),
            "max_list_len": int(list_len.max()), "mean_list_len": float(list_len.mean()), "candidates_per_query": cand / B,
@@ -342,7 +355,7 @@ def leg_ivfpq(ctx, ca, args, timer, flat2, q_dev, Q_host):
                                 "bank pairs, ~3.5 deep): 256 CUs x 2.4 GHz x 128 values / 7 cycles = 11.2e12 lookups/s.",
                         "lds_gather_frac_of_model_ceiling": (cand * args.M / (adc_per_step * 1e-3) / 11.2e12) if adc_per_step > 0 else 0.0},
            "kernels_ms_per_step": allk}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         blob = idx.to_bytes()                                 # the reference's IVPQ on-disk layout (flushes; nothing is soft-deleted)
         cb = cpu_baseline_ivfpq(args, blob, Q_host, K, g_ids, g_sc, g_cn, f_ids)
         out["cpu_baseline"] = cb
@@ -422,6 +435,9 @@ def main():
             "kernels_ms_per_step": allk,
             "fast_path": {k: idx.stat(k) for k in ("fast_queries", "strict_queries", "fast_candidates", "fast_expansions", "fast_overflows")},
             "recall_at_10": {"flat": 1.0},
+            "scaling_note": None if world == 1 else "strong scaling of the named config: the 1M-row corpus is split over the ranks and every rank searches its shard for the "
+                            "same 256 queries; per batch a rank keeps ~0.15 ms that does not shrink with its shard (post stage per shard, query preparation, "
+                            "exchange + merge, launch gaps), so the measured single-GPU shard timings predict 1.6x / 2.3x / 2.8x at 2 / 4 / 8 GPUs (DESIGN.md 3.9)",
         }
         if world == 1 and not args.no_cpu_baseline:
             last = ptrs[(args.steps - 1) % 3]
@@ -432,8 +448,8 @@ def main():
         else:
             line["cpu_baseline"] = None
 
-    # ---------------------------------------------------------------- N = 1: Flat L2^2 at HBM-binding batches + IVFPQ
-    if world == 1 and (legs & {"flat_l2", "ivfpq"}):
+    # ---------------------------------------------------------------- Flat L2^2 at HBM-binding batches (N = 1) + IVFPQ (any N: list shards)
+    if legs & ({"flat_l2", "ivfpq"} if world == 1 else {"ivfpq"}):
         flat2 = ca.FlatIndex(ctx, args.dim, ca.L2_SQUARED)
         add_rows(ctx, flat2, 0, args.rows, args.dim, lambda buf, r0, m: ctx.synth_mixture(buf, MIX_SEED, MIX_CENTERS, MIX_SIGMA, MIX_SUB, MIX_NOISE, r0, m, args.dim))
         # queries: fresh draws from the same mixture (rows past the corpus)
@@ -441,10 +457,12 @@ def main():
         ctx.synth_mixture(q2_dev, MIX_SEED, MIX_CENTERS, MIX_SIGMA, MIX_SUB, MIX_NOISE, args.rows + 7, B, args.dim)
         ctx.sync()
         Q2 = ctx.download(q2_dev, (B, args.dim), np.float32)
-        if "flat_l2" in legs:
+        if "flat_l2" in legs and world == 1:
             line["flat_l2"] = leg_flat_l2(ctx, ca, args, timer, flat2, q2_dev)
         if "ivfpq" in legs:
-            line["ivfpq"] = leg_ivfpq(ctx, ca, args, timer, flat2, q2_dev, Q2)
+            iv = leg_ivfpq(ctx, ca, args, timer, flat2, q2_dev, Q2, comm, rank, world)
+        if "ivfpq" in legs and rank == 0:
+            line["ivfpq"] = iv
             line["recall_at_10"]["ivfpq_vs_exact_flat"] = line["ivfpq"]["recall_at_10_vs_exact_flat"]
             if "recall_at_10_vs_oracle_ivfpq" in line["ivfpq"]:
                 line["recall_at_10"]["ivfpq_vs_oracle_ivfpq"] = line["ivfpq"]["recall_at_10_vs_oracle_ivfpq"]
