@@ -293,16 +293,21 @@ __global__ __launch_bounds__(256) void coarse_dot_kernel(const float* __restrict
     const int lrow = t >> 3, lc4 = (t & 7) * 4;          // loader: one float4 of each tile per K chunk
     const float* qsrc = Q + (long)min(q0 + lrow, B - 1) * ld + lc4;
     const float* csrc = C + (long)min(l0 + lrow, nlist - 1) * ld + lc4;
-    f32x4 pq = *reinterpret_cast<const f32x4*>(qsrc), pc = *reinterpret_cast<const f32x4*>(csrc);
+    // two K chunks of both tiles are kept in flight (registers): with one workgroup per CU a single chunk of look-ahead leaves
+    // most of the load latency exposed
+    const int nch = ld / CQ_T;                           // ld is a multiple of 32
+    f32x4 pq[2], pc[2];
+#pragma unroll
+    for (int d = 0; d < 2; d++) { const int kk = min(d, nch - 1) * CQ_T; pq[d] = *reinterpret_cast<const f32x4*>(qsrc + kk); pc[d] = *reinterpret_cast<const f32x4*>(csrc + kk); }
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, qq = 0.f, cc[4] = {0.f, 0.f, 0.f, 0.f};
     const bool do_q = blockIdx.x == 0 && tl == 0, do_c = blockIdx.y == 0 && tq == 0;
-    for (int k0 = 0; k0 < ld; k0 += CQ_T) {
+    auto chunk = [&](int c, f32x4& rq, f32x4& rc) {
         __syncthreads();
-        *reinterpret_cast<f32x4*>(&Qs[lrow * CQ_LD + lc4]) = pq;
-        *reinterpret_cast<f32x4*>(&Cs[lrow * CQ_LD + lc4]) = pc;
+        *reinterpret_cast<f32x4*>(&Qs[lrow * CQ_LD + lc4]) = rq;
+        *reinterpret_cast<f32x4*>(&Cs[lrow * CQ_LD + lc4]) = rc;
         __syncthreads();
-        const int kn = (k0 + CQ_T < ld) ? k0 + CQ_T : k0;
-        pq = *reinterpret_cast<const f32x4*>(qsrc + kn); pc = *reinterpret_cast<const f32x4*>(csrc + kn);
+        const int kn = min(c + 2, nch - 1) * CQ_T;       // refill this slot two chunks ahead (past the end: a harmless re-read)
+        rq = *reinterpret_cast<const f32x4*>(qsrc + kn); rc = *reinterpret_cast<const f32x4*>(csrc + kn);
 #pragma unroll
         for (int k = 0; k < CQ_T; k += 4) {
             const f32x4 qv = *reinterpret_cast<const f32x4*>(&Qs[tq * CQ_LD + k]);
@@ -314,6 +319,10 @@ __global__ __launch_bounds__(256) void coarse_dot_kernel(const float* __restrict
                 if (do_c) cc[j] = __builtin_fmaf(cv[0], cv[0], __builtin_fmaf(cv[1], cv[1], __builtin_fmaf(cv[2], cv[2], __builtin_fmaf(cv[3], cv[3], cc[j]))));
             }
         }
+    };
+    for (int c = 0; c < nch; c += 2) {
+        chunk(c, pq[0], pc[0]);
+        if (c + 1 < nch) chunk(c + 1, pq[1], pc[1]);
     }
     if (q0 + tq < B) {
 #pragma unroll
