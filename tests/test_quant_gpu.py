@@ -178,6 +178,38 @@ def test_pq_matches_oracle(ctx, metric, d, M, nbits):
     assert len(g) == n - 3
 
 
+def test_adc_fused_filter_edges(ctx):
+    """The ADC scan's fused top-K filter (K <= 64) on a PQ index whose single list spans several 8192-code segments: odd batch
+    sizes (a duo with a hole), K at and beyond the fused limit, duplicated vectors (equal distances: the tie order is the scan
+    position), thresholds, document filters, soft deletes — and a corpus of identical vectors, where every candidate ties with
+    the bound and all of them survive the filter (select-from-composites' radix path). Always the oracle's ids and scores."""
+    n, d, M, nbits = 21000, 32, 8, 6
+    X = clustered(61, n, d, 40)
+    X[9000:9300] = X[10:310]                               # 300 exact duplicates in another segment
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    g = PQIndex(ctx, d, L2_SQUARED, M, nbits); o = orc.PQ(d, L2_SQUARED, M, nbits)
+    g.train(X[:2000]); assert o.train(X[:2000]) == 0
+    g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
+    for B in (1, 3, 8):
+        Q = np.vstack([clustered(62, B - 1, d, 40) + np.float32(0.01), X[10:11]]) if B > 1 else X[10:11].copy()
+        for k in (1, 10, 64, 65):
+            check_search(g, o, Q, k, None)
+    Q = np.vstack([clustered(63, 4, d, 40), X[12:13]])
+    ref = o.search(Q[0], 200)[2]
+    check_search(g, o, Q, 20, None, threshold=float(ref[7]))              # fewer than k within the threshold
+    check_search(g, o, Q, 12, None, filter_ids=list(range(5, 9500, 3)))
+    for i in (11, 13, 9011, 20999):
+        g.remove(i); assert o.remove(i) == 0
+    check_search(g, o, Q, 12, None)
+    # mass ties
+    Y = np.repeat(X[:1], 9000, axis=0)
+    g2 = PQIndex(ctx, d, L2_SQUARED, M, nbits); o2 = orc.PQ(d, L2_SQUARED, M, nbits)
+    g2.train(X[:2000]); assert o2.train(X[:2000]) == 0
+    g2.add_batch(ids[:9000], Y); assert o2.add_batch(ids[:9000], Y) == 0
+    check_search(g2, o2, Q[:3], 10, None)
+    check_search(g2, o2, Q[:3], 64, None)
+
+
 def test_pq_reference_fixture_shape(ctx):
     """pq_index_search_test.go:9-53: dim 8, M 4, nbits 4 (Ksub 16), vec[j] = (i*dim+j) % 10 — heavy ties."""
     d, M, nbits, n = 8, 4, 4, 100
@@ -263,6 +295,16 @@ def test_ivfpq_wide_codes_m96(ctx):
     g, o = build_ivfpq(ctx, L2_SQUARED, X, X[:600], nlist, M, nbits)
     check_search(g, o, Q, 10, 3)
     check_search(g, o, Q, 10, 8)
+
+
+def test_ivfpq_table_sub_batches(ctx):
+    """360 queries x 32 probes x 96 KiB of tables exceed the 1 GiB table budget: the batch goes through the table / scan kernels
+    in sub-batches, each with its own slots, queues and filter bounds."""
+    n, d, nlist, M, nbits = 3000, 768, 32, 96, 8
+    X = clustered(61, n, d, 12, sigma=0.3)
+    g, o = build_ivfpq(ctx, L2_SQUARED, X, X[:600], nlist, M, nbits)
+    Q = clustered(62, 360, d, 12, sigma=0.3) + np.float32(0.01)
+    check_search(g, o, Q, 10, 32)
 
 
 def test_merge_topk(ctx):
