@@ -700,8 +700,27 @@ __global__ __launch_bounds__(256) void prep_queries_fused_kernel(int metric, con
     const float* sp = src + (long)q * d;
     float scale = 1.0f; int zf = 0;
     const bool live = q < B;
+    // a lane owns 8 consecutive dimensions: two 16-byte loads, and 16-byte stores of the fp16 row and of the fragment-ordered
+    // copy (8 consecutive dimensions are contiguous there); rows are only 4-byte aligned when d % 4 != 0 -> scalar loads then
+    const bool vec = (d & 3) == 0 && ((unsigned long long)src & 15ull) == 0ull;
+    auto load8 = [&](int i0, float (&v)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = 0.0f;
+        if (!live) return;
+        if (vec && i0 + 8 <= d) {
+            const f32x4v a = *reinterpret_cast<const f32x4v*>(sp + i0), b = *reinterpret_cast<const f32x4v*>(sp + i0 + 4);
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) if (i0 + e < d) v[e] = sp[i0 + e];
+        }
+    };
     if (live && metric == COMET_COSINE) {
-        for (int i = lane; i < dpad; i += 64) { const float v = i < d ? sp[i] : 0.0f; my[i] = v * v; }
+        for (int i0 = lane * 8; i0 < dpad; i0 += 512) {
+            float v[8]; load8(i0, v);
+#pragma unroll
+            for (int e = 0; e < 8; e++) if (i0 + e < dpad) my[i0 + e] = v[e] * v[e];
+        }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         float sum = 0.0f;
@@ -719,14 +738,23 @@ __global__ __launch_bounds__(256) void prep_queries_fused_kernel(int metric, con
     _Float16* o = Qh + (long)q * ldh;
     _Float16* qf = Qh + (long)FB_N * ldh;
     const int nk = ldh >> 6;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     float s = 0.0f;
-    for (int i = lane; i < ldh; i += 64) {
-        float v = 0.0f;
-        if (live && i < d) { v = sp[i]; if (metric == COMET_COSINE && !zf) v = v * scale; }
-        if (live && i < ld) Qp[(long)q * ld + i] = v;
-        o[i] = (_Float16)v;
-        qf[(((((long)(q >> 5) * nk + (i >> 6)) * 4 + ((i >> 4) & 3)) * 64) + ((i >> 3) & 1) * 32 + (q & 31)) * 8 + (i & 7)] = (_Float16)v;
-        s += v * v;
+    for (int i0 = lane * 8; i0 < ldh; i0 += 512) {               // ldh is a multiple of 64
+        float v[8]; load8(i0, v);
+        h8 hv;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            if (metric == COMET_COSINE && !zf) v[e] = v[e] * scale;
+            hv[e] = (_Float16)v[e];
+            s += v[e] * v[e];
+        }
+        if (live && i0 < ld) {                                    // ld is a multiple of 32
+            *reinterpret_cast<f32x4v*>(Qp + (long)q * ld + i0) = f32x4v{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4v*>(Qp + (long)q * ld + i0 + 4) = f32x4v{v[4], v[5], v[6], v[7]};
+        }
+        *reinterpret_cast<h8*>(o + i0) = hv;
+        *reinterpret_cast<h8*>(qf + (((((long)(q >> 5) * nk + (i0 >> 6)) * 4 + ((i0 >> 4) & 3)) * 64) + ((i0 >> 3) & 1) * 32 + (q & 31)) * 8) = hv;
     }
     if (live) for (int i = ldh + lane; i < ld; i += 64) Qp[(long)q * ld + i] = 0.0f;
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -763,7 +791,7 @@ void launch_prep_queries_fused(Ctx* c, int metric, const float* src, int B, int 
 //   4. (score, row) sort, threshold + sanitizeK, ids / scores / count written (count = -ErrZeroVector for a zero cosine query)
 // ------------------------------------------------------------------------------------------------
 constexpr int POST_THREADS = 1024, POST_WAVES = 16, POST_MAXKEYS = 16384, POST_CAP = 4096, POST_CPW = 32, POST_CHUNK = 32;
-constexpr int POST_LPC = POST_CHUNK / 4, POST_CPI = 64 / POST_LPC, POST_NJ = POST_CPW / POST_CPI;   // lanes per candidate slice, candidates per load instruction, instructions per slice
+constexpr int POST_LPC = POST_CHUNK / 4, POST_CPI = 64 / POST_LPC;   // lanes per candidate slice, candidates per load instruction
 constexpr size_t POST_LDS = (size_t)POST_MAXKEYS * 4 + 4096 * 4 + (size_t)POST_CAP * 4 + (size_t)POST_CAP * 4;   // keys|hist , list , scores
 
 __device__ __forceinline__ unsigned pf2key(unsigned u) { return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
