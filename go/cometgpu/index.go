@@ -231,3 +231,48 @@ func (ix *vectorIndex) nodeVectors(ids []uint32) ([][]float32, error) {
 }
 
 var _ = unsafe.Pointer(nil)
+
+// ---- HNSW construction extras (no counterpart in the reference, whose randomLevel draws from the unseeded global RNG) ------
+
+// HNSWBuilder is implemented by the HNSW index returned from NewHNSWIndex: Add (VectorIndex) inserts on the GPU with levels
+// from the index's own seeded stream; these two make a build reproducible.
+type HNSWBuilder interface {
+	// AddWithLevels inserts the nodes in order with the given hnswNode levels (insertNode hnsw_index.go:493-552).
+	AddWithLevels(nodes []comet.VectorNode, levels []int32) error
+	// SetLevelSeed seeds the index's level stream (geometric, p = 1/M, capped at 16: randomLevel hnsw_index.go:474-484).
+	SetLevelSeed(seed uint64) error
+}
+
+func (ix *vectorIndex) AddWithLevels(nodes []comet.VectorNode, levels []int32) error {
+	if ix.kind != comet.HNSWIndexKind {
+		return fmt.Errorf("AddWithLevels: not an HNSW index")
+	}
+	if len(nodes) != len(levels) {
+		return fmt.Errorf("AddWithLevels: %d nodes, %d levels", len(nodes), len(levels))
+	}
+	if len(nodes) == 0 {
+		return nil
+	}
+	ids := make([]uint32, len(nodes))
+	flat := make([]float32, 0, len(nodes)*ix.dim)
+	for i, v := range nodes {
+		if len(v.Vector()) != ix.dim {
+			return fmt.Errorf("vector dimension mismatch: expected %d, got %d", ix.dim, len(v.Vector()))
+		}
+		ids[i] = v.ID()
+		flat = append(flat, v.Vector()...)
+	}
+	ix.mu.Lock()
+	defer ix.mu.Unlock()
+	var added C.int64_t
+	return lastError(C.comet_hnsw_add_with_levels(ix.h, (*C.uint32_t)(&ids[0]), (*C.float)(&flat[0]), (*C.int32_t)(&levels[0]), C.int64_t(len(nodes)), &added))
+}
+
+func (ix *vectorIndex) SetLevelSeed(seed uint64) error {
+	if ix.kind != comet.HNSWIndexKind {
+		return fmt.Errorf("SetLevelSeed: not an HNSW index")
+	}
+	ix.mu.Lock()
+	defer ix.mu.Unlock()
+	return lastError(C.comet_hnsw_set_level_seed(ix.h, C.uint64_t(seed)))
+}
