@@ -79,3 +79,32 @@ def test_merge_host_orders_ties_by_shard_then_position():
     i, s, c = merge_topk_host(ids, sc, cnt, 0)
     assert c[0] == 3                       # k_cap bounds the row
     assert [shard_bounds(10, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 10)]
+
+
+def _rdzv_worker(rank, world, port, q):
+    import ctypes as C
+    from comet_amd.dist import _rendezvous_id
+
+    class FakeLib:                       # stands in for libcomet_hip.so: rank 0 "creates" the 128-byte RCCL id
+        @staticmethod
+        def comet_comm_unique_id(buf):
+            for i in range(128):
+                buf[i] = (i * 7 + 3) & 0xFF
+            return 0
+    q.put((rank, _rendezvous_id(FakeLib, rank, world, "127.0.0.1", port, timeout_s=30.0)))
+
+
+def test_comm_id_rendezvous_three_ranks():
+    """The only host-side step of the in-library RCCL path: rank 0 hands the 128-byte unique id to the other ranks over TCP on
+    127.0.0.1 (comet_amd.dist._rendezvous_id, what Comm.from_env does under torch.distributed.run). Late and early joiners."""
+    import multiprocessing as mp
+    import time
+    ctx = mp.get_context("spawn")
+    port, q, world = _free_port(), ctx.Queue(), 3
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, world, port, q)) for r in (1, 0, 2)]   # a client starts before the server
+    procs[0].start(); time.sleep(0.5); procs[1].start(); procs[2].start()
+    got = dict(q.get(timeout=60) for _ in range(world))
+    for p in procs:
+        p.join(30); assert p.exitcode == 0
+    want = bytes((i * 7 + 3) & 0xFF for i in range(128))
+    assert got == {0: want, 1: want, 2: want}
