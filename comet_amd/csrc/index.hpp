@@ -93,7 +93,8 @@ comet_index* make_pq(Ctx* c, int dim, int metric, int M, int nbits);
 comet_index* make_ivfpq(Ctx* c, int dim, int metric, int nlist, int M, int nbits);
 
 // preprocess B queries (dense B x dim) into padded B x ld; zflag[q] = 1 for zero-norm cosine queries
-void prepare_queries(Ctx* c, int metric, const float* queries_dev, int B, int dim, int ld, float** Qp, int32_t** zflag);
+// may_alias: the caller never offsets zflag and accepts Qp == queries_dev (+ zflag == nullptr) when no preprocessing is needed
+void prepare_queries(Ctx* c, int metric, const float* queries_dev, int B, int dim, int ld, float** Qp, int32_t** zflag, bool may_alias = false);
 // out_ids[q][i] = ids[pos[q][i]] ; counts[q] = -COMET_ERR_ZERO_VECTOR where zflag[q]
 void launch_finalize(Ctx* c, const uint32_t* ids_table, const uint32_t* pos, int B, int k_cap, const int32_t* zflag,
                      uint32_t* out_ids, int32_t* counts);

@@ -9,7 +9,13 @@ namespace comet {
 // ------------------------------------------------------------------------------------------------
 // shared helpers
 // ------------------------------------------------------------------------------------------------
-void prepare_queries(Ctx* c, int metric, const float* queries_dev, int B, int dim, int ld, float** Qp, int32_t** zflag) {
+void prepare_queries(Ctx* c, int metric, const float* queries_dev, int B, int dim, int ld, float** Qp, int32_t** zflag, bool may_alias) {
+    if (may_alias && metric != COMET_COSINE && dim == ld && ((uintptr_t)queries_dev & 15) == 0) {
+        // Preprocess is the identity for the L2 family (distance.go:138-147,182-191) and the rows are already padded: search the
+        // caller's buffer in place — one launch (and its gap) less in a chain of short kernels; no query can fail (no zero flag)
+        *Qp = const_cast<float*>(queries_dev); *zflag = nullptr;
+        return;
+    }
     *Qp = c->salloc<float>((size_t)B * ld);
     *zflag = c->salloc<int32_t>(B);
     // Distance.Preprocess(query): normalised copy for cosine, unchanged for L2 (flat_index_search.go:236)

@@ -699,7 +699,7 @@ struct HNSWIndex : comet_index {
     void search_dev(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
                     int32_t* out_counts, int k_cap) override {
         float* Qp; int32_t* zflag;
-        prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag);
+        prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag, true);
         uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
         if (n == 0 || max_level == -1) {      // empty graph -> [] (:258)
             launch_select_topk(c, nullptr, 0, B, 0, nullptr, 0.0f, p.k, pos, out_scores, out_counts, k_cap);

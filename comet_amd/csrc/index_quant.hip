@@ -368,7 +368,7 @@ struct IVFIndex : comet_index {
         if (!trained) COMET_FAIL(COMET_ERR_NOT_TRAINED, "index must be trained before searching");
         lay.compile(c);
         float* Qp; int32_t* zflag;
-        prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag);
+        prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag, true);
         const int np = sanitize_nprobes(p.nprobes, nlist);
         uint32_t* probe_list = c->salloc<uint32_t>((size_t)B * np);
         coarse_probe(c, metric, centroids.as<float>(), nlist, ld, dim, Qp, B, np, probe_list);
@@ -569,7 +569,7 @@ struct PQFamilyIndex : comet_index {
         if (!trained) { if (ivf) COMET_FAIL(COMET_ERR_NOT_TRAINED, "index must be trained before searching"); COMET_FAIL(COMET_ERR_NOT_TRAINED, "index not trained"); }
         compile();
         float* Qp; int32_t* zflag;
-        prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag);
+        prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag, true);
         const int np = ivf ? sanitize_nprobes(p.nprobes, nlist) : 1;
         uint32_t* probe_list = c->salloc<uint32_t>((size_t)B * np);
         if (ivf) coarse_probe(c, metric, centroids.as<float>(), nlist, ld, dim, Qp, B, np, probe_list);

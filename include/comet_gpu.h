@@ -196,7 +196,8 @@ typedef struct {
 COMET_API int comet_index_search(comet_index* idx, const float* queries, int32_t B, const comet_search_params* p,
                                  uint32_t* out_ids, float* out_scores, int32_t* out_counts, int32_t k_cap);
 /* Same with device-resident queries and outputs; asynchronous on the context's stream.
- * Per-query failures: the device entry points never synchronise, so a query the reference would fail as a whole (a zero
+ * The query buffer must stay valid and unchanged until the search has completed (comet_index_search_wait / a context sync): it may
+ * be read in place. Per-query failures: the device entry points never synchronise, so a query the reference would fail as a whole (a zero
  * vector on a cosine index: ErrZeroVector, distance.go:12) is reported ONLY as out_counts[q] = -COMET_ERR_ZERO_VECTOR (a
  * negative count; its row is cleared) while the call and the other queries of the batch succeed. Read counts as signed.
  * The host-pointer comet_index_search above additionally returns COMET_ERR_ZERO_VECTOR when any query of the batch failed. */
