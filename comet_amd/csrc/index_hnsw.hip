@@ -245,6 +245,31 @@ __device__ __forceinline__ HnswLds hn_carve(unsigned char* smem, unsigned* s_cur
     L.s_cur = s_cur; L.s_flag = s_flag; L.s_dist = s_dist; L.cand_cap = HN_CAND_CAP;
     return L;
 }
+// The result max-heap drained into ascending order (hnsw_index.go:623-626: pop everything, fill from the back). Popping is a
+// chain of dependent LDS round trips on one lane (~800 cycles per pop); when all distances are distinct the popped order is
+// simply the sorted order, which the whole wave finds by counting ranks. Equal distances (duplicated vectors) keep the serial
+// pops: their order depends on the heap's shape. emit(i, id, d) receives position i of the ascending list.
+template <class Emit>
+__device__ __forceinline__ void hn_drain(HC* res, int nres, const HnswLds& L, Emit emit) {
+    const int lane = threadIdx.x;
+    bool tie = false;
+    for (int i = lane; i < nres && !tie; i += 64) {
+        const float di = res[i].d;
+        for (int j = 0; j < nres; j++) if (j != i && res[j].d == di) { tie = true; break; }
+    }
+    if (__ballot(tie) == 0ull) {
+        for (int i = lane; i < nres; i += 64) {
+            const HC me = res[i]; int rank = 0;
+            for (int j = 0; j < nres; j++) rank += (res[j].d < me.d) ? 1 : 0;
+            emit(rank, me.id, me.d);
+        }
+    } else if (lane == 0) {
+        int m = nres;
+        for (int i = nres - 1; i >= 0; i--) { const HC x = heap_pop<true>(res, m); emit(i, x.id, x.d); }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 constexpr size_t HN_LDS_BYTES = sizeof(HC) * (HN_CAND_CAP + HN_EF_MAX + 1) + sizeof(float) * 64 * HN_LD + 64 * 4 + 64 * 4 + 64;
 
 template <int METRIC>
@@ -277,9 +302,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswGraph g, const floa
     int nres = 0;
     const int overflow = hn_search_layer<METRIC>(g, qv, curr, ef, 0, vis, L, nres, n_eval, n_exp);
     // drain the result heap into an ascending array (hnsw_index.go:623-626)
+    hn_drain(L.res, nres, L, [&](int i, unsigned id, float d) { res_idx[(long)q * ef_ld + i] = id; res_dist[(long)q * ef_ld + i] = d; });
     if (lane == 0) {
-        const int n = nres; int m = nres;
-        for (int i = n - 1; i >= 0; i--) { HC x = heap_pop<true>(L.res, m); res_idx[(long)q * ef_ld + i] = x.id; res_dist[(long)q * ef_ld + i] = x.d; }
+        const int n = nres;
         res_cnt[q] = n;
         if (overflow) *status = 1;
         if (stats) { atomicAdd(&stats[0], n_eval); atomicAdd(&stats[1], n_exp); }
@@ -330,10 +355,8 @@ __global__ __launch_bounds__(64) void hnsw_insert_kernel(HnswGraph g, int* __res
             if (hn_search_layer<METRIC>(g, xv, curr, efc, lc, vis, L, nres, n_eval, n_exp) && lane == 0) *status = 1;
             // candidates ascending = the drained result heap (:623-626); selectNeighbors keeps the first Mmax (stable order)
             const int Mmax = lc == 0 ? 2 * M : M;
-            if (lane == 0) {
-                int m = nres;
-                for (int i = nres - 1; i >= 0; i--) { HC x = heap_pop<true>(L.res, m); if (i < HN_EF_MAX + 1) sel[i] = x.id; }
-            }
+            hn_drain(L.res, nres, L, [&](int i, unsigned id, float) { if (i < HN_EF_MAX + 1) sel[i] = id; });
+            __threadfence_block();
             __builtin_amdgcn_wave_barrier();
             const int nsel = min(nres, Mmax);
             const long sx = g.slot_base[ix] + lc; const long offx = g.edge_off[sx];
