@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswGraph g, const floa
 // back-edge and is merely re-sorted by distance.
 // ------------------------------------------------------------------------------------------------
 template <int METRIC>
-__global__ __launch_bounds__(64) void hnsw_insert_kernel(HnswGraph g, int* __restrict__ deg_rw, long first, long count, int M, int efc, unsigned* __restrict__ vis,
+__global__ __launch_bounds__(64) void hnsw_insert_kernel(HnswGraph g, int* __restrict__ deg_rw, unsigned char* __restrict__ sorted, long first, long count, int M, int efc, unsigned* __restrict__ vis,
                                                          long vwords, int* __restrict__ state, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned s_cur; __shared__ int s_flag; __shared__ float s_dist;
@@ -368,6 +368,9 @@ __global__ __launch_bounds__(64) void hnsw_insert_kernel(HnswGraph g, int* __res
                     const int dn = deg_rw[sn];
                     if (dn < Mmax) {                                           // room: plain append of the back-edge
                         if (lane == 0) { g.edges[offn + dn] = ix; deg_rw[sn] = dn + 1; }
+                    } else if (dn == Mmax && sorted[sn]) {
+                        // pruneConnections on a list an earlier prune already sorted: dropping the fresh back-edge and re-sorting the
+                        // same Mmax entries (stable) changes nothing — a full list only ever sees this case again
                     } else {
                         // pruneConnections(nb, lc, Mmax) with len = Mmax + 1: the fresh back-edge is not in idx.nodes yet and is dropped,
                         // the Mmax old entries are re-sorted by their distance to nb (stable: sort.Slice on distance, canonical order)
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(64) void hnsw_insert_kernel(HnswGraph g, int* __res
                             for (int i2 = 0; i2 < dn; i2++) { const float di = pd[i2]; rank += (di < dj || (di == dj && i2 < j)) ? 1 : 0; }
                             g.edges[offn + rank] = pe[j];
                         }
+                        if (lane == 0 && dn == Mmax) sorted[sn] = 1;
                         __threadfence_block();
                         __builtin_amdgcn_wave_barrier();
                     }
@@ -418,6 +422,7 @@ struct HNSWIndex : comet_index {
     int M = 16, efC = 200, efS = 200;
     int64_t n = 0; int max_level = -1; uint32_t entry = 0;   // entry: dense node index
     DevBuf V, ids_dev, level, slot_base, edge_off, deg_dev, edges, del_bm, state_dev, ins_vis;
+    DevBuf sorted_dev;          // per edge slot: 1 once a full list has been re-sorted by pruneConnections (a further prune is then a no-op)
     int64_t n_slots = 0, edge_cap = 0;       // slots (sum of level+1) and total edge capacity in use
     bool mirror_dirty = false;               // the device graph changed (GPU insert): host mirror is rebuilt before Flush / WriteTo
     uint64_t level_rng = 0x9E3779B97F4A7C15ull;
@@ -491,6 +496,8 @@ struct HNSWIndex : comet_index {
         c->h2d(slot_base.as<int64_t>() + n, sb.data(), (added + 1) * 8);
         c->h2d(edge_off.as<int64_t>() + n_slots, eo.data(), eo.size() * 8);
         c->zero(deg_dev.as<int32_t>() + n_slots, (size_t)(slots - n_slots) * 4);
+        sorted_dev.reserve((size_t)std::max<int64_t>(slots, 1), c->stream, (size_t)n_slots);
+        c->zero(sorted_dev.as<uint8_t>() + n_slots, (size_t)(slots - n_slots));
         state_dev.reserve(16, c->stream, 0);
         const int32_t st[3] = {max_level, (int32_t)entry, (n > 0 && max_level >= 0) ? 1 : 0};
         c->h2d(state_dev.p, st, sizeof(st));
@@ -504,7 +511,7 @@ struct HNSWIndex : comet_index {
         {
             ProfScope ps(c, "hnsw_insert");
 #define HI(MT) do { HIP_CHECK(hipFuncSetAttribute((const void*)hnsw_insert_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                    hnsw_insert_kernel<MT><<<dim3(1), dim3(64), lds, c->stream>>>(g, deg_dev.as<int>(), n, added, M, efC, ins_vis.as<uint32_t>(), vwords, state_dev.as<int>(), status); } while (0)
+                    hnsw_insert_kernel<MT><<<dim3(1), dim3(64), lds, c->stream>>>(g, deg_dev.as<int>(), sorted_dev.as<uint8_t>(), n, added, M, efC, ins_vis.as<uint32_t>(), vwords, state_dev.as<int>(), status); } while (0)
             switch (metric) { case COMET_L2: HI(COMET_L2); break; case COMET_L2SQ: HI(COMET_L2SQ); break; default: HI(COMET_COSINE); break; }
 #undef HI
             LAUNCH_CHECK();
@@ -638,6 +645,7 @@ struct HNSWIndex : comet_index {
         ids_dev.reserve(std::max<size_t>(4, nn * 4), c->stream, 0); level.reserve(std::max<size_t>(4, nn * 4), c->stream, 0);
         slot_base.reserve((nn + 1) * 8, c->stream, 0); edge_off.reserve((slots + 1) * 8, c->stream, 0); edges.reserve(eidx.size() * 4, c->stream, 0);
         deg_dev.reserve(ddeg.size() * 4, c->stream, 0); c->h2d(deg_dev.p, ddeg.data(), ddeg.size() * 4);
+        sorted_dev.reserve(std::max<size_t>(ddeg.size(), 1), c->stream, 0); c->zero(sorted_dev.p, std::max<size_t>(ddeg.size(), 1));   // loaded lists: order unknown
         n_slots = slots; edge_cap = deoff[slots]; mirror_dirty = false;
         c->h2d(ids_dev.p, ids.data(), nn * 4); c->h2d(level.p, levels, nn * 4);
         c->h2d(slot_base.p, sb.data(), (nn + 1) * 8); c->h2d(edge_off.p, deoff.data(), (slots + 1) * 8); c->h2d(edges.p, eidx.data(), eidx.size() * 4);
