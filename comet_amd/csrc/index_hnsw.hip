@@ -58,6 +58,54 @@ template <bool MAXHEAP> __device__ HC heap_pop(HC* h, int& n) {
     return h[m];
 }
 
+// The same two operations with the whole wave cooperating (every lane calls them with the same arguments and gets the same
+// result). Heap traffic — not the memory round trips of the traversal — is what a search spends most of its time on (about a
+// thousand cycles per push or pop when one lane chases dependent LDS reads level by level), so:
+//   push: the ancestors of the new slot are known up front, a_k = ((n + 1) >> k) - 1: lane k reads ancestor k, a ballot finds the
+//         first one the new element does not beat, the ancestors below it move down one level each and the element lands — one
+//         read and one write round instead of one per level. The final array is exactly what heap.go's up() leaves.
+//   pop:  down() must follow the better child level by level, but the moving element stays in registers and both children
+//         arrive in one round trip per level (every lane reads the same two slots: broadcasts).
+typedef unsigned long long hc_bits;
+__device__ __forceinline__ HC hc_load(const HC* p) { const hc_bits v = *reinterpret_cast<const hc_bits*>(p); HC r; r.id = (unsigned)(v & 0xFFFFFFFFull); r.d = __uint_as_float((unsigned)(v >> 32)); return r; }
+__device__ __forceinline__ void hc_store(HC* p, HC x) { *reinterpret_cast<hc_bits*>(p) = ((hc_bits)__float_as_uint(x.d) << 32) | x.id; }
+template <bool MAXHEAP> __device__ __forceinline__ void heap_push_wave(HC* h, int& n, HC x) {
+    const int lane = threadIdx.x & 63;
+    const int p1 = n + 1;                                   // 1-based position of the new slot
+    const bool valid = lane >= 1 && lane < 31 && (p1 >> lane) >= 1;      // lane k: k-th ancestor exists
+    const int ak = valid ? (p1 >> lane) - 1 : 0;
+    HC v = hc_load(h + ak);
+    const unsigned long long stopm = __ballot(valid && !hless<MAXHEAP>(x, v));
+    const unsigned long long validm = __ballot(valid);
+    int depth = validm ? 64 - __builtin_clzll(validm) : 1;  // ancestors are lanes 1 .. depth-1
+    const int t = stopm ? __builtin_ctzll(stopm) : depth;   // first ancestor x does not beat (depth: x becomes the root)
+    // ancestors 1 .. t-1 move down to the slot of their child on the path (a_{k-1}); x takes a_{t-1}
+    if (valid && lane < t) hc_store(h + ((p1 >> (lane - 1)) - 1), v);
+    if (lane == 0) hc_store(h + ((p1 >> (t - 1)) - 1), x);
+    n = n + 1;
+    __builtin_amdgcn_wave_barrier();
+}
+template <bool MAXHEAP> __device__ __forceinline__ HC heap_pop_wave(HC* h, int& n) {
+    const int m = n - 1;
+    const HC root = hc_load(h), y = hc_load(h + m);         // h.Swap(0, m): y sifts down among the first m slots, the old root leaves
+    int i = 0;
+    for (;;) {
+        const int j1 = 2 * i + 1;
+        if (j1 >= m || j1 < 0) break;
+        const HC c1 = hc_load(h + j1), c2 = hc_load(h + (j1 + 1 < m ? j1 + 1 : j1));
+        int j = j1; HC c = c1;
+        if (j1 + 1 < m && hless<MAXHEAP>(c2, c1)) { j = j1 + 1; c = c2; }
+        if (!hless<MAXHEAP>(c, y)) break;
+        if ((threadIdx.x & 63) == 0) hc_store(h + i, c);
+        __builtin_amdgcn_wave_barrier();
+        i = j;
+    }
+    if ((threadIdx.x & 63) == 0) { hc_store(h + i, y); hc_store(h + m, root); }
+    __builtin_amdgcn_wave_barrier();
+    n = m;
+    return root;
+}
+
 // exact distances from the query to up to 64 rows (rows[j] == HN_NONE -> skipped); lane j gets row j's distance.
 // The 256-byte row pieces of slice k+1 are requested (into registers) before slice k is summed: the traversal is a chain of
 // dependent random reads, so every exposed load latency is paid once per expansion.
@@ -163,75 +211,57 @@ __device__ __forceinline__ int hn_search_layer(const HnswGraph& g, const float* 
                                                const HnswLds& L, int& nres_out, unsigned long long& n_eval, unsigned long long& n_exp) {
     const int lane = threadIdx.x;
     HC* cand = L.cand; HC* res = L.res;
-    int ncand = 0, nres = 0, overflow = 0;
+    int ncand = 0, nres = 0, overflow = 0;                  // wave-uniform: every lane runs the control flow, the heap ops are cooperative
     {
         const bool dead = bit_get(g.deleted, entry);
         if (lane == 0) L.rows[0] = entry;
         __builtin_amdgcn_wave_barrier();
-        const float d = wave_dists<METRIC>(g.V, g.ld, qv, L.rows, 1, L.tile);
-        if (lane == 0) {
-            if (!dead) { HC x{entry, d}; heap_push<false>(cand, ncand, x); heap_push<true>(res, nres, x); }
-            atomicOr(&vis[entry >> 5], 1u << (entry & 31));
-        }
+        const float d = __shfl(wave_dists<METRIC>(g.V, g.ld, qv, L.rows, 1, L.tile), 0, 64);
+        if (!dead) { const HC x{entry, d}; heap_push_wave<false>(cand, ncand, x); heap_push_wave<true>(res, nres, x); }
+        if (lane == 0) atomicOr(&vis[entry >> 5], 1u << (entry & 31));
         n_eval += 1;
     }
     for (;;) {
-        if (lane == 0) {
-            int stop = 0; unsigned cid = 0;
-            if (ncand == 0) stop = 1;
-            else {
-                HC cur = heap_pop<false>(cand, ncand);
-                if (nres >= ef && cur.d > res[0].d) stop = 1;      // early termination hnsw_index.go:592-594
-                cid = cur.id;
-            }
-            *L.s_flag = stop; *L.s_cur = cid;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int stop = *L.s_flag; const unsigned cid = *L.s_cur;
-        __builtin_amdgcn_wave_barrier();
-        if (stop) break;
+        if (ncand == 0) break;
+        const HC cur = heap_pop_wave<false>(cand, ncand);
+        if (nres >= ef && cur.d > hc_load(res).d) break;    // early termination hnsw_index.go:592-594
+        const unsigned cid = cur.id;
         n_exp += 1;
         if (layer > g.level[cid]) continue;                                            // `if layer < len(node.Edges)`
         const long s = g.slot_base[cid] + layer;
         const long off = g.edge_off[s]; const int deg = g.deg[s];
         for (int b0 = 0; b0 < deg; b0 += 64) {
             const int cnt = min(64, deg - b0);
-            unsigned nb = HN_NONE;
+            // The traversal is a chain of dependent memory round trips, so the visited test-and-set and the soft-delete lookup are
+            // only REQUESTED here; the neighbours' rows are fetched and their distances evaluated meanwhile, and a neighbour that
+            // turns out visited or deleted is dropped afterwards (a lane per neighbour: the wasted evaluations cost no time).
+            unsigned nb = HN_NONE, vold = 0u; bool dead = false;
             if (lane < cnt) {
                 nb = g.edges[off + b0 + lane];
-                if (bit_get(g.deleted, nb)) nb = HN_NONE;                                  // SOFT DELETE CHECK
-                else {
-                    const unsigned old = atomicOr(&vis[nb >> 5], 1u << (nb & 31));          // !visited.Contains -> visited.Add
-                    if ((old >> (nb & 31)) & 1u) nb = HN_NONE;
-                }
+                dead = bit_get(g.deleted, nb);                                             // SOFT DELETE CHECK
+                if (!dead) vold = atomicOr(&vis[nb >> 5], 1u << (nb & 31));                // !visited.Contains -> visited.Add
             }
             L.rows[lane] = nb;
             __builtin_amdgcn_wave_barrier();
             const float d = wave_dists<METRIC>(g.V, g.ld, qv, L.rows, cnt, L.tile);
-            L.dd[lane] = d;
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) {
-                for (int j = 0; j < cnt; j++) {
-                    if (L.rows[j] == HN_NONE) continue;
-                    const float dj = L.dd[j];
-                    if (nres < ef || dj < res[0].d) {
-                        if (ncand >= L.cand_cap) { overflow = 1; continue; }
-                        HC x{L.rows[j], dj};
-                        heap_push<false>(cand, ncand, x);
-                        heap_push<true>(res, nres, x);
-                        if (nres > ef) (void)heap_pop<true>(res, nres);
-                    }
+            if (lane < cnt && (dead || ((vold >> (nb & 31)) & 1u))) nb = HN_NONE;
+            // the batch in edge-list order (hnsw_index.go:600-619), every lane following along: lane j's pair is broadcast
+            unsigned long long todo = __ballot(lane < cnt && nb != HN_NONE);
+            while (todo) {
+                const int j = __builtin_ctzll(todo); todo &= todo - 1ull;
+                const float dj = __shfl(d, j, 64); const unsigned idj = (unsigned)__shfl((int)nb, j, 64);
+                if (nres < ef || dj < hc_load(res).d) {
+                    if (ncand >= L.cand_cap) { overflow = 1; continue; }
+                    const HC x{idj, dj};
+                    heap_push_wave<false>(cand, ncand, x);
+                    heap_push_wave<true>(res, nres, x);
+                    if (nres > ef) (void)heap_pop_wave<true>(res, nres);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
             n_eval += cnt;
         }
     }
-    // the heap sizes live in lane 0's registers: publish the result count
-    if (lane == 0) { *L.s_flag = nres; *L.s_cur = (unsigned)overflow; }
-    __builtin_amdgcn_wave_barrier();
-    nres_out = *L.s_flag; overflow = (int)*L.s_cur;
-    __builtin_amdgcn_wave_barrier();
+    nres_out = nres;
     return overflow;
 }
 
