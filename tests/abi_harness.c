@@ -146,8 +146,36 @@ int main(void) {
     CHECK(comet_index_size(idx) == N - 1 + 40, "size after concurrent adds: %lld", (long long)comet_index_size(idx));
 
     OK(comet_index_destroy(idx));
+    /* HNSW: built on the GPU with given levels, serialised with the two-call protocol, read back into a fresh index: the copy
+     * answers the same (hnsw_index.go:228-288 Add, :701-1096 WriteTo / ReadFrom). Its nearest neighbour of a stored vector is
+     * that vector at distance 0. */
+    {
+        enum { HN = 600 };
+        comet_index *h = NULL, *h2 = NULL;
+        OK(comet_hnsw_create(ctx, DIM, COMET_L2SQ, 8, 40, 40, &h));
+        static uint32_t hid[HN]; static int32_t hlv[HN];
+        for (int i = 0; i < HN; i++) { hid[i] = (uint32_t)(i + 1); hlv[i] = (i % 9 == 0) ? 1 : ((i % 50 == 0) ? 2 : 0); }
+        int64_t added = 0;
+        OK(comet_hnsw_add_with_levels(h, hid, &X[0][0], hlv, HN, &added)); CHECK(added == HN && comet_index_size(h) == HN, "hnsw add_with_levels: %lld", (long long)added);
+        CHECK(comet_index_add(h, hid, &X[0][0], 1, &added, NULL) != COMET_OK, "re-adding a live HNSW id accepted");
+        comet_search_params hp; memset(&hp, 0, sizeof(hp)); hp.k = 3; hp.ef_search = 64;
+        uint32_t a_ids[3], b_ids[3]; float a_sc[3], b_sc[3]; int32_t a_cnt = 0, b_cnt = 0;
+        OK(comet_index_search(h, X[17], 1, &hp, a_ids, a_sc, &a_cnt, 3));
+        CHECK(a_cnt == 3 && a_ids[0] == 18 && a_sc[0] == 0.0f, "hnsw self query: id %u score %g", a_ids[0], a_sc[0]);
+        size_t need = 0, used = 0;
+        OK(comet_index_serialize(h, NULL, 0, &need)); CHECK(need > 4, "hnsw image size");
+        uint8_t* img = malloc(need);
+        OK(comet_index_serialize(h, img, need, &used)); CHECK(used == need && memcmp(img, "HNSW", 4) == 0, "hnsw image: %zu of %zu bytes", used, need);
+        OK(comet_hnsw_create(ctx, DIM, COMET_L2SQ, 8, 40, 40, &h2));
+        OK(comet_index_deserialize(h2, img, need, &used)); CHECK(used == need && comet_index_size(h2) == HN, "hnsw image consumed %zu of %zu", used, need);
+        OK(comet_index_search(h2, X[17], 1, &hp, b_ids, b_sc, &b_cnt, 3));
+        CHECK(b_cnt == a_cnt && memcmp(a_ids, b_ids, sizeof(a_ids)) == 0 && memcmp(a_sc, b_sc, sizeof(a_sc)) == 0, "hnsw copy answers differently");
+        CHECK(comet_index_deserialize(h2, img, need / 2, &used) == COMET_ERR_FORMAT || comet_index_deserialize(h2, img, need / 2, &used) == COMET_ERR_IO, "truncated hnsw image accepted");
+        free(img);
+        OK(comet_index_destroy(h)); OK(comet_index_destroy(h2));
+    }
     OK(comet_ctx_destroy(ctx));
     free(wb.p);
-    printf("abi_harness OK: create/add/search/filter/threshold/remove/errors/write_to/read_from/%d-thread concurrency through the C ABI\n", THREADS);
+    printf("abi_harness OK: create/add/search/filter/threshold/remove/errors/write_to/read_from/%d-thread concurrency/hnsw build+serialize through the C ABI\n", THREADS);
     return 0;
 }
