@@ -23,7 +23,8 @@ int main(int argc, char** argv) {
     for (int i = 0; i < B; i++) { double s = 0; for (int j = 0; j < dim; j++) { Q[i * ld + j] = U(rng); s += Q[i * ld + j] * Q[i * ld + j]; } for (int j = 0; j < dim; j++) Q[i * ld + j] /= (float)std::sqrt(s); }
     if (argc > 5) { const float sc = (float)atof(argv[5]); for (auto& v : X) v *= sc; }      // argv[5] = 0: zero corpus (clock / power experiment)
     float *dX, *dQ, *rn, *qn, *err; void *Xh, *Qh; uint32_t* stats; int32_t* st4;
-    const long tiles = ceil_div(n, 256), units = tiles * 2, ldS = round_up(2 * units, 16), ldB = round_up(units, 16);
+    const int unit = B <= 64 ? 64 : 128;          // the narrow tiles (<= 64 queries) emit per 64-row unit
+    const long tiles = ceil_div(n, 256), units = tiles * (256 / unit), ldS = round_up(2 * units, 16), ldB = round_up(units, 16);
     HIP_CHECK(hipMalloc(&dX, X.size() * 4)); HIP_CHECK(hipMalloc(&dQ, Q.size() * 4)); HIP_CHECK(hipMalloc(&rn, n * 4)); HIP_CHECK(hipMalloc(&qn, 1024)); HIP_CHECK(hipMalloc(&err, 1024));
     HIP_CHECK(hipMalloc(&Xh, (size_t)tiles * 256 * ldh * 2)); HIP_CHECK(hipMalloc(&Qh, (size_t)256 * ldh * 2 * 2)); HIP_CHECK(hipMalloc(&stats, 8)); HIP_CHECK(hipMalloc(&st4, 16));
     HIP_CHECK(hipMemset(Xh, 0, (size_t)tiles * 256 * ldh * 2)); HIP_CHECK(hipMemset(stats, 0, 8));
@@ -42,18 +43,18 @@ int main(int argc, char** argv) {
     for (int variant : {0, 1}) {
         setenv("COMET_SCAN_VARIANT_RT", variant ? "1" : "0", 1);
         HIP_CHECK(hipMemset(S0, 0xFF, (size_t)256 * ldS * 4)); HIP_CHECK(hipMemset(bound, 0xFF, (size_t)256 * ldB * 4));
-        launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, 256, rn, qn, nullptr, S0, ldS, bound, ldB);
+        launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, B, rn, qn, nullptr, S0, ldS, bound, ldB);
         HIP_CHECK(hipStreamSynchronize(c.stream));
         std::vector<float> hS((size_t)256 * ldS), hB((size_t)256 * ldB);
         HIP_CHECK(hipMemcpy(hS.data(), S0, hS.size() * 4, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(hB.data(), bound, hB.size() * 4, hipMemcpyDeviceToHost));
         int bad = 0; double maxerr = 0;
         for (int q = 0; q < B && bad < 10; q += 7) for (long u = 0; u < units; u++) {
             std::vector<std::pair<double, int>> d;
-            for (int r = 0; r < 128; r++) { const long row = u * 128 + r; if (row >= n) break; double s = 0; for (int j = 0; j < dim; j++) s += (double)Xr[row * ld + j] * Qr[q * ld + j]; d.push_back({std::max(0.0, 1.0 - s), r}); }
+            for (int r = 0; r < unit; r++) { const long row = u * unit + r; if (row >= n) break; double s = 0; for (int j = 0; j < dim; j++) s += (double)Xr[row * ld + j] * Qr[q * ld + j]; d.push_back({std::max(0.0, 1.0 - s), r}); }
             std::sort(d.begin(), d.end());
             for (int e = 0; e < 2 && e < (int)d.size(); e++) {
                 const float key = hS[(size_t)q * ldS + 2 * u + e]; uint32_t kb; memcpy(&kb, &key, 4);
-                const int row = kb & 127; uint32_t vb = kb & 0xFFFFFF00u; float v; memcpy(&v, &vb, 4);
+                const int row = kb & (unit - 1); uint32_t vb = kb & 0xFFFFFF00u; float v; memcpy(&v, &vb, 4);
                 const double want = d[e].first; maxerr = std::max(maxerr, std::fabs(v - want));
                 if (std::fabs(v - want) > 2e-3 || (row != d[e].second && std::fabs(d[e].first - (e + 1 < (int)d.size() ? d[e + 1].first : 9)) > 1e-3 && std::fabs(v - want) > 1e-4)) { if (bad++ < 5) printf("variant %d q %d unit %ld e %d: got %.6f row %d, want %.6f row %d\n", variant, q, u, e, v, row, want, d[e].second); }
             }
@@ -77,12 +78,12 @@ int main(int argc, char** argv) {
         bad_total += bad;
         if (iters > 0) {
             hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-            for (int i = 0; i < 3; i++) launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, 256, rn, qn, nullptr, S0, ldS, bound, ldB);
+            for (int i = 0; i < 3; i++) launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, B, rn, qn, nullptr, S0, ldS, bound, ldB);
             HIP_CHECK(hipEventRecord(a, c.stream));
-            for (int i = 0; i < iters; i++) launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, 256, rn, qn, nullptr, S0, ldS, bound, ldB);
+            for (int i = 0; i < iters; i++) launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, B, rn, qn, nullptr, S0, ldS, bound, ldB);
             HIP_CHECK(hipEventRecord(b, c.stream)); HIP_CHECK(hipEventSynchronize(b));
             float ms; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
-            printf("variant %d: %.4f ms per launch (%ld rows x %d, %d queries)\n", variant, ms / iters, n, dim, 256);
+            printf("variant %d: %.4f ms per launch (%ld rows x %d, %d queries)\n", variant, ms / iters, n, dim, B);
         }
     }
     return bad_total ? 1 : 0;
