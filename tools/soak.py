@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""soak.py — randomized differential test: random index kinds / parameters / query options on the GPU against the CPU oracle, bit for
+bit, for a wall-clock budget (default 240 s). usage (on a GPU box): python tools/soak.py [seconds] [seed]"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import oracle_lib as orc  # noqa: E402
+import comet_amd as ca  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+ctx = ca.Context(0)
+METRICS = [ca.EUCLIDEAN, ca.L2_SQUARED, ca.COSINE]
+bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def data(n, d, clusters):
+    seed = int(rng.integers(1, 1 << 30))
+    c = orc.synth(seed, 0, clusters * d).reshape(clusters, d)
+    x = c[np.arange(n) % clusters] + orc.synth(seed + 1, 0, n * d).reshape(n, d) * np.float32(rng.choice([0.05, 0.2, 0.5]))
+    if rng.random() < 0.3:                                   # exact duplicates: score ties
+        k = int(rng.integers(1, max(2, n // 10))); x[n - k:] = x[:k]
+    return x.astype(np.float32)
+
+
+def compare(g, o, Q, k, tag, **kw):
+    opts = dict(threshold=kw.get("threshold", 0.0), document_ids=kw.get("filter_ids", ()))
+    if "nprobes" in kw: opts["nprobes"] = kw["nprobes"]
+    ids, sc, cnt = g.search_batch(Q, k, **opts)
+    for b, q in enumerate(Q):
+        if "nprobes" in kw:
+            n, oi, os_ = o.search(q, k, kw["nprobes"], threshold=opts["threshold"], filter_ids=opts["document_ids"])
+        else:
+            n, oi, os_ = o.search(q, k, threshold=opts["threshold"], filter_ids=opts["document_ids"])
+        m = min(n, ids.shape[1])
+        if not (cnt[b] == n and np.array_equal(ids[b, :m], oi[:m]) and np.array_equal(bits(sc[b, :m]), bits(os_[:m]))):
+            raise SystemExit(f"MISMATCH {tag} query {b}: gpu cnt {cnt[b]} ids {ids[b, :8]} vs oracle cnt {n} ids {oi[:8]}")
+
+
+t_end, rounds, kinds = time.time() + budget, 0, {}
+while time.time() < t_end:
+    kind = rng.choice(["flat", "ivf", "pq", "ivfpq"])
+    metric = METRICS[int(rng.integers(0, 3))]
+    d = int(rng.choice([8, 16, 24, 32, 48, 64, 96]))
+    n = int(rng.integers(1500, 9000)) if kind != "flat" else int(rng.integers(6000, 30000))
+    X = data(n, d, int(rng.integers(5, 60)))
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    B = int(rng.choice([1, 3, 8, 17, 40]))
+    Q = np.vstack([data(B, d, 7)[:max(1, B - 1)], X[:1]])[:B]
+    k = int(rng.choice([0, 1, 5, 10, 33, 64, 65, 200]))
+    kw = {}
+    tag = f"{kind} {metric} n={n} d={d} B={B} k={k}"
+    if kind == "flat":
+        g = ca.FlatIndex(ctx, d, metric); o = orc.Flat(d, metric)
+        g.add_batch(ids, X); o.add_batch(ids, X)
+    elif kind == "ivf":
+        nlist = int(rng.choice([8, 64, 128, 256])); ntr = min(n, max(nlist * 20, 1000))
+        g = ca.IVFIndex(ctx, d, nlist, metric); o = orc.IVF(d, metric, nlist)
+        g.train(X[:ntr]); assert o.train(X[:ntr]) == 0
+        g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
+        kw["nprobes"] = int(rng.choice([1, 2, max(1, nlist // 8), max(1, nlist // 4), nlist]))
+        tag += f" nlist={nlist} nprobe={kw['nprobes']}"
+    else:
+        Ms = [m for m in (2, 4, 8, 16) if d % m == 0]; M = int(rng.choice(Ms)); nbits = int(rng.choice([3, 4, 6, 8]))
+        ntr = min(n, max((1 << nbits) * 4, 1000))
+        if kind == "pq":
+            g = ca.PQIndex(ctx, d, metric, M, nbits); o = orc.PQ(d, metric, M, nbits)
+        else:
+            nlist = int(rng.choice([4, 64, 128])); ntr = min(n, max(ntr, nlist * 20))
+            g = ca.IVFPQIndex(ctx, d, metric, nlist, M, nbits); o = orc.IVFPQ(d, metric, nlist, M, nbits)
+            kw["nprobes"] = int(rng.choice([1, 2, max(1, nlist // 4), nlist])); tag += f" nlist={nlist} nprobe={kw['nprobes']}"
+        g.train(X[:ntr]); assert o.train(X[:ntr]) == 0
+        g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
+        tag += f" M={M} nbits={nbits}"
+    compare(g, o, Q, k, tag, **kw)
+    if rng.random() < 0.5:
+        compare(g, o, Q, max(1, k), tag + " filter", filter_ids=[int(i) for i in rng.choice(ids, size=max(1, n // 3), replace=False)], **kw)
+    if rng.random() < 0.5:
+        for i in rng.choice(ids, size=5, replace=False):
+            g.remove(int(i)); o.remove(int(i))
+        compare(g, o, Q, max(1, k), tag + " deletes", **kw)
+    if rng.random() < 0.4:
+        ref = (o.search(Q[0], 50, kw["nprobes"]) if "nprobes" in kw else o.search(Q[0], 50))[2]
+        if len(ref) > 6:
+            compare(g, o, Q, max(1, k), tag + " threshold", threshold=float(ref[5]), **kw)
+    g.close()
+    rounds += 1; kinds[kind] = kinds.get(kind, 0) + 1
+print(f"soak OK: {rounds} random configurations in {budget:.0f} s, all bit-identical to the oracle: {kinds}")
