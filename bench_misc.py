@@ -39,7 +39,9 @@ def main():
     ap.add_argument("--docs", type=int, default=100_000)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--skip", default="", help="comma list of hnsw,ivf,bm25")
+    ap.add_argument("--skip", default="", help="comma list of hnsw,ivf,bm25,segments")
+    ap.add_argument("--segments", type=int, default=16)
+    ap.add_argument("--segment-rows", type=int, default=62_500)
     args = ap.parse_args()
     import comet_amd as ca
     import oracle_lib as orc
@@ -149,6 +151,64 @@ def main():
         out["bm25"] = {"workload": f"BM25 over {nd} docs (zipf token ids, 20-120 tokens), batch={B} 4-token queries, K=10 (both indexes built in {build_s:.0f}s)",
                        "gpu_qps_host_buffers": B / el, "ms_per_batch": el * 1e3, "cpu_oracle_qps": nq / cel, "cpu_threads": nq,
                        "parity_checked": nq, "parity_mismatches": len(bad), "kernels_ms_per_batch": bm_prof}
+
+    # ---------------------------------------------------------------- segment layer: S Flat segments resident in HBM, one fused call
+    if "segments" not in skip:
+        import ctypes as C
+        from bench import add_rows
+        from comet_amd.hybrid import HybridSearchResult as R, merge_results, sort_results_by_score
+        S, m, d, K = args.segments, args.segment_rows, args.dim, 100
+        segs = []
+        for s_ in range(S):
+            f = ca.FlatIndex(ctx, d, ca.COSINE)
+            add_rows(ctx, f, s_ * m, (s_ + 1) * m, d, lambda buf, r0, mm: ctx.synth_fill(buf, 0xC0DE, r0 * d, mm * d))
+            segs.append(f)
+        whole = ca.FlatIndex(ctx, d, ca.COSINE)
+        add_rows(ctx, whole, 0, S * m, d, lambda buf, r0, mm: ctx.synth_fill(buf, 0xC0DE, r0 * d, mm * d))
+        ss = ca.SegmentSet(segs)
+        q_dev = ctx.alloc(B * d * 4); ctx.synth_fill(q_dev, 0xABCD, 0, B * d)
+        o_ids, o_sc, o_cn = ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)
+        p_ids, p_sc, p_cn = ctx.alloc(S * B * K * 4), ctx.alloc(S * B * K * 4), ctx.alloc(S * B * 4)
+
+        def fused():
+            ss.search_batch_dev(q_dev, B, K, o_ids, o_sc, o_cn, K)
+
+        def one_index():
+            whole.search_batch_dev(q_dev, B, K, o_ids, o_sc, o_cn, K)
+
+        def fan_out_host_merge():     # what a host-side port of storage.go:546-626 does: S searches, S result downloads, merge on the host
+            per = []
+            for i, f in enumerate(segs):
+                f.search_batch_dev(q_dev, B, K, p_ids + i * B * K * 4, p_sc + i * B * K * 4, p_cn + i * B * 4, K)
+            ctx.sync()
+            ids = ctx.download(p_ids, (S, B, K), np.uint32); sc = ctx.download(p_sc, (S, B, K), np.float32)
+            # vectorised mergeResults + sortResultsByScore + cut (ids are unique across these segments: no deduplication work)
+            allsc = sc.transpose(1, 0, 2).reshape(B, S * K); allid = ids.transpose(1, 0, 2).reshape(B, S * K)
+            order = np.lexsort((allid, -allsc), axis=1)[:, :K]
+            return np.take_along_axis(allid, order, 1), np.take_along_axis(allsc, order, 1)
+
+        def clock(fn, steps):
+            fn(); ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            ctx.sync()
+            return (time.perf_counter() - t0) / steps
+        t_fused, t_one, t_host = clock(fused, args.steps), clock(one_index, args.steps), clock(fan_out_host_merge, max(2, args.steps // 3))
+        ctx.profile(True); ctx.profile_reset()
+        for _ in range(args.steps):
+            fused()
+        ctx.sync()
+        seg_prof = {k: round(v[0] / args.steps, 4) for k, v in sorted(ctx.profile_dump().items())}; ctx.profile(False)
+        fused(); ctx.sync()
+        gi, gs, gc = ctx.download(o_ids, (B, K), np.uint32), ctx.download(o_sc, (B, K), np.float32), ctx.download(o_cn, (B,), np.int32)
+        hi_, hs = fan_out_host_merge()
+        bad = int(np.sum(np.any(gi != hi_, axis=1) | np.any(gs.view(np.uint32) != hs.view(np.uint32), axis=1) | (gc != K)))
+        out["segments"] = {"workload": f"{S} Flat cosine segments x {m} rows x {d} resident in HBM, batch={B}, K={K}: per-segment top-K, highest score per id, "
+                                       "score DESCENDING, cut to K (storage.go:489-626 + storage_merge.go:13-54)",
+                           "fused_call_ms_per_batch": t_fused * 1e3, "fused_qps": B / t_fused,
+                           "fan_out_with_host_merge_ms_per_batch": t_host * 1e3, "one_index_of_all_rows_ms_per_batch": t_one * 1e3,
+                           "parity_vs_host_merge": {"checked_queries": B, "mismatches": bad}, "kernels_ms_per_batch": seg_prof}
 
     if vec_res is not None and txt_res is not None:
         t0 = time.perf_counter()

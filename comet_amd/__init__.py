@@ -6,5 +6,5 @@ The compute lives in ``libcomet_hip.so`` (hand-written HIP kernels behind the C 
 from ._lib import CometError, ZeroVectorError, load, LIB_PATH  # noqa: F401
 from .index import (  # noqa: F401
     COSINE, EUCLIDEAN, L2_SQUARED, MAX_AGGREGATION, MEAN_AGGREGATION, SUM_AGGREGATION, Context, FlatIndex, IVFIndex,
-    IVFPQIndex, PQIndex, HNSWIndex, BM25SearchIndex, TextResult, TextSearch, UnknownDistanceKind, VectorIndex, VectorResult, VectorSearch, aggregate, autocut, sanitize_k,
+    IVFPQIndex, PQIndex, HNSWIndex, BM25SearchIndex, SegmentSet, TextResult, TextSearch, UnknownDistanceKind, VectorIndex, VectorResult, VectorSearch, aggregate, autocut, sanitize_k,
 )

@@ -119,6 +119,8 @@ def load() -> C.CDLL:
         "comet_index_search_wait": (i32, [p, u64]),
         "comet_merge_topk_dev": (i32, [p, p, p, p, i32, i32, i32, i32, p, p, p]),
         "comet_merge_topk_packed_dev": (i32, [p, p, i64, i32, i32, i32, i32, p, p, p]),
+        "comet_segments_search_dev": (i32, [pp, i32, p, i32, C.POINTER(SearchParams), p, p, p, i32]),
+        "comet_segments_search": (i32, [pp, i32, p, i32, C.POINTER(SearchParams), p, p, p, i32]),
         "comet_index_get_centroids": (i32, [p, p]),
         "comet_index_get_codebooks": (i32, [p, p]),
         "comet_index_list_size": (i32, [p, i32, C.POINTER(i64)]),

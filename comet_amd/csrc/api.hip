@@ -310,6 +310,70 @@ int comet_index_search_wait(comet_index* idx, uint64_t ticket) {
     });
 }
 
+// ---- segment layer: persistentHybridSearch.Execute storage.go:489-626, vector leg --------------------------------
+// One call searches every segment's index for the batch (all of them resident in HBM, searches enqueued back to back on the
+// context's stream, no host round trip between them) and merges on the device as mergeResults + sortResultsByScore + the cut do.
+static void segments_search(comet_index* const* segs, int S, const float* queries_dev, int B, const comet_search_params* p,
+                            uint32_t* out_ids, float* out_scores, int32_t* out_counts, int k_cap) {
+    Ctx* c = segs[0]->c;
+    const int k = p->k;
+    if (k == 0) {   // merged[:0] (storage.go:621-623)
+        HIP_CHECK(hipMemsetAsync(out_counts, 0, (size_t)B * 4, c->stream));
+        return;
+    }
+    uint32_t* ids = c->salloc<uint32_t>((size_t)S * B * k);
+    float* sc = c->salloc<float>((size_t)S * B * k);
+    int32_t* cn = c->salloc<int32_t>((size_t)S * B);
+    std::vector<uint64_t> tickets(S);
+    // newest first, as the reference walks memtables and segments (the order has no effect on the merged result)
+    for (int s = S - 1; s >= 0; s--)
+        tickets[s] = segs[s]->search_begin(queries_dev, B, *p, ids + (size_t)s * B * k, sc + (size_t)s * B * k, cn + (size_t)s * B, k);
+    for (int s = S - 1; s >= 0; s--) segs[s]->search_finish(tickets[s]);
+    launch_merge_segments(c, ids, sc, cn, S, B, k, k, out_ids, out_scores, out_counts, k_cap);
+}
+static void check_segments(comet_index* const* segs, int S, int B, const comet_search_params* p, int k_cap) {
+    if (!segs || S <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "no segments");
+    if (!p) COMET_FAIL(COMET_ERR_INVALID_ARG, "null search params");
+    if (B < 0 || k_cap <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "bad batch size / k_cap");
+    if (p->k < 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "k must not be negative (the reference slices merged[:k], storage.go:621-623)");
+    for (int s = 0; s < S; s++) {
+        if (!segs[s]) COMET_FAIL(COMET_ERR_INVALID_ARG, "null segment %d", s);
+        if (segs[s]->c != segs[0]->c) COMET_FAIL(COMET_ERR_INVALID_ARG, "segment %d lives on another context", s);
+        if (segs[s]->dim != segs[0]->dim) COMET_FAIL(COMET_ERR_DIM_MISMATCH, "segment %d: dimension %d, expected %d", s, segs[s]->dim, segs[0]->dim);
+    }
+}
+int comet_segments_search_dev(comet_index* const* segs, int32_t S, const float* queries_dev, int32_t B, const comet_search_params* p,
+                              uint32_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev, int32_t k_cap) {
+    return guarded([&] {
+        check_segments(segs, S, B, p, k_cap);
+        if (B == 0) return (int)COMET_OK;
+        CallGuard g(segs[0]->c);
+        segments_search(segs, S, queries_dev, B, p, out_ids_dev, out_scores_dev, out_counts_dev, k_cap);
+        return (int)COMET_OK;
+    });
+}
+int comet_segments_search(comet_index* const* segs, int32_t S, const float* queries, int32_t B, const comet_search_params* p,
+                          uint32_t* out_ids, float* out_scores, int32_t* out_counts, int32_t k_cap) {
+    return guarded([&] {
+        check_segments(segs, S, B, p, k_cap);
+        if (B == 0) return (int)COMET_OK;
+        Ctx* c = segs[0]->c; CallGuard g(c);
+        float* dq = c->salloc<float>((size_t)B * segs[0]->dim);
+        uint32_t* dids = c->salloc<uint32_t>((size_t)B * k_cap);
+        float* dsc = c->salloc<float>((size_t)B * k_cap);
+        int32_t* dcn = c->salloc<int32_t>(B);
+        c->h2d(dq, queries, (size_t)B * segs[0]->dim * sizeof(float));
+        segments_search(segs, S, dq, B, p, dids, dsc, dcn, k_cap);
+        c->d2h(out_ids, dids, (size_t)B * k_cap * 4);
+        c->d2h(out_scores, dsc, (size_t)B * k_cap * 4);
+        c->d2h(out_counts, dcn, (size_t)B * 4);
+        c->sync();
+        for (int i = 0; i < B; i++) if (out_counts[i] == -(int)COMET_ERR_ZERO_VECTOR)
+            COMET_FAIL(COMET_ERR_ZERO_VECTOR, "zero vector not allowed for this metric");   // the memtable search's error is returned (storage.go:537-540)
+        return (int)COMET_OK;
+    });
+}
+
 // lookupNodeVectors (flat_index_search.go:171-196 and siblings): stored vectors of the given node ids, in order
 int comet_index_fetch_vectors(comet_index* idx, const uint32_t* ids, int32_t n, float* out_vecs) {
     return guarded([&] {

@@ -51,6 +51,9 @@ int select_max_k();
 // merge R per-shard sorted top-k lists per query (ties: lower shard, then lower position). R*k_cap <= select_max_k().
 void launch_merge_topk(Ctx* c, const uint32_t* ids, const float* scores, const int32_t* counts, int R, int B, int k_cap, int k,
                        uint32_t* out_ids, float* out_scores, int32_t* out_counts, int64_t rank_stride = 0, int64_t rank_stride_counts = 0);
+// segment merge (storage_merge.go:13-54): S per-segment top-k lists per query -> distinct ids with their highest score, score descending, cut to k
+void launch_merge_segments(Ctx* c, const uint32_t* ids, const float* scores, const int32_t* counts, int S, int B, int k_cap, int k,
+                           uint32_t* out_ids, float* out_scores, int32_t* out_counts, int out_ld);
 // top-K of rows of (key << 32 | position) composites already filtered by a producer kernel (cursor[q] of them per row)
 void launch_select_composites(Ctx* c, const unsigned long long* comp, int64_t ld, const int32_t* cursor, int B, int K, uint32_t* out_pos, float* out_scores,
                               int32_t* out_counts, int k_cap);

@@ -1014,4 +1014,111 @@ void launch_merge_topk(Ctx* c, const uint32_t* ids, const float* scores, const i
     LAUNCH_CHECK();
 }
 
+// ---- segment merge (mergeResults storage_merge.go:13-46 + sortResultsByScore :50-54 + the cut to k, storage.go:618-623) -----------
+// in: S segments x B queries x k_cap (ids, scores), counts S x B — every segment's own top-k for the same query batch.
+// out: per query the distinct ids with their HIGHEST score, sorted by score DESCENDING (the reference sorts hybrid scores — for a vector-only
+// query those are distances — descending; restated as it is), cut to k. Equal scores: ascending id (the reference's order is Go map
+// iteration order there, i.e. unspecified). A negative count (a search-time error code, e.g. a zero query under cosine) is passed through.
+__device__ __forceinline__ unsigned long long seg_comp1(const unsigned* ids, const float* scores, const int* counts, int S, int B, int k_cap, int q, long i) {
+    const long s = i / k_cap; const int j = (int)(i - s * k_cap);
+    if (s >= S) return ~0ull;
+    int cnt = counts[s * B + q]; if (cnt > k_cap) cnt = k_cap;
+    if (j >= cnt) return ~0ull;
+    const long at = (s * B + q) * (long)k_cap + j;
+    unsigned b = __float_as_uint(scores[at]); if (b == 0x80000000u) b = 0u;       // -0 == +0
+    return ((unsigned long long)ids[at] << 32) | (unsigned)~f2key(b);              // by id, the id's highest score first
+}
+__device__ __forceinline__ int seg_error(const int* counts, int S, int B, int q) { for (int s = 0; s < S; s++) { const int c = counts[s * B + q]; if (c < 0) return c; } return 0; }
+
+__global__ __launch_bounds__(1024) void seg_merge_kernel(const unsigned* __restrict__ ids, const float* __restrict__ scores, const int* __restrict__ counts, int S, int B, int k_cap, int k,
+                                                         int n2, unsigned* __restrict__ out_ids, float* __restrict__ out_scores, int* __restrict__ out_counts, int out_ld) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
+    __shared__ int s_heads;
+    const int q = blockIdx.x;
+    if (threadIdx.x == 0) s_heads = 0;
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) sm[i] = seg_comp1(ids, scores, counts, S, B, k_cap, q, i);
+    __syncthreads();
+    bitonic_sort_lds(sm, n2);
+    // heads of the id groups -> (score descending, id ascending) composites; everything else sorts last
+    constexpr int EPT = 8;                                           // n2 <= 8192 = 1024 threads x 8
+    unsigned long long mine[EPT]; int nh = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const int i = threadIdx.x + e * blockDim.x;
+        mine[e] = ~0ull;
+        if (i < n2) {
+            const unsigned long long c = sm[i];
+            if (c != ~0ull && (i == 0 || (sm[i - 1] >> 32) != (c >> 32))) { mine[e] = ((c & 0xFFFFFFFFull) << 32) | (c >> 32); nh++; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; e++) { const int i = threadIdx.x + e * blockDim.x; if (i < n2) sm[i] = mine[e]; }
+    if (nh) atomicAdd(&s_heads, nh);
+    __syncthreads();
+    bitonic_sort_lds(sm, n2);
+    const int err = seg_error(counts, S, B, q);
+    const int heads = s_heads, kq = err ? 0 : (heads < k ? heads : k), nw = kq < out_ld ? kq : out_ld;
+    for (int i = threadIdx.x; i < out_ld; i += blockDim.x) {
+        unsigned id = 0xFFFFFFFFu; float sc = 0.0f;
+        if (i < nw) { const unsigned long long c = sm[i]; id = (unsigned)(c & 0xFFFFFFFFull); sc = __uint_as_float(key2f(~(unsigned)(c >> 32))); }
+        out_ids[(long)q * out_ld + i] = id; out_scores[(long)q * out_ld + i] = sc;
+    }
+    if (threadIdx.x == 0) out_counts[q] = err ? err : kq;
+}
+// the same beyond 8192 entries per query: composites in global memory, two global sorts
+__global__ __launch_bounds__(256) void seg_build_kernel(const unsigned* __restrict__ ids, const float* __restrict__ scores, const int* __restrict__ counts, int S, int B, int k_cap,
+                                                        unsigned long long* __restrict__ comp, long n2, int* __restrict__ heads) {
+    const int q = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) heads[q] = 0;
+    if (i < n2) comp[(long)q * n2 + i] = seg_comp1(ids, scores, counts, S, B, k_cap, q, i);
+}
+__global__ __launch_bounds__(256) void seg_heads_kernel(const unsigned long long* __restrict__ comp, unsigned long long* __restrict__ comp2, long n2, int* __restrict__ heads) {
+    const int q = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    bool head = false;
+    if (i < n2) {
+        const unsigned long long c = comp[(long)q * n2 + i];
+        head = c != ~0ull && (i == 0 || (comp[(long)q * n2 + i - 1] >> 32) != (c >> 32));
+        comp2[(long)q * n2 + i] = head ? ((c & 0xFFFFFFFFull) << 32) | (c >> 32) : ~0ull;
+    }
+    const unsigned long long m = __ballot(head);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&heads[q], __popcll(m));
+}
+__global__ __launch_bounds__(256) void seg_emit_kernel(const unsigned long long* __restrict__ comp2, long n2, const int* __restrict__ heads, const int* __restrict__ counts, int S, int B, int k,
+                                                       unsigned* __restrict__ out_ids, float* __restrict__ out_scores, int* __restrict__ out_counts, int out_ld) {
+    const int q = blockIdx.y;
+    const int err = seg_error(counts, S, B, q);
+    const int h = heads[q], kq = err ? 0 : (h < k ? h : k), nw = kq < out_ld ? kq : out_ld;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < out_ld) {
+        unsigned id = 0xFFFFFFFFu; float sc = 0.0f;
+        if (i < nw) { const unsigned long long c = comp2[(long)q * n2 + i]; id = (unsigned)(c & 0xFFFFFFFFull); sc = __uint_as_float(key2f(~(unsigned)(c >> 32))); }
+        out_ids[(long)q * out_ld + i] = id; out_scores[(long)q * out_ld + i] = sc;
+    }
+    if (i == 0) out_counts[q] = err ? err : kq;
+}
+void launch_merge_segments(Ctx* c, const uint32_t* ids, const float* scores, const int32_t* counts, int S, int B, int k_cap, int k,
+                           uint32_t* out_ids, float* out_scores, int32_t* out_counts, int out_ld) {
+    if (B <= 0) return;
+    int64_t n2 = 64; while (n2 < (int64_t)S * k_cap) n2 <<= 1;
+    if (n2 <= 8192) {
+        ProfScope ps(c, "segments_merge");
+        seg_merge_kernel<<<dim3(B), dim3(n2 >= 2048 ? 1024 : 256), sizeof(unsigned long long) * n2, c->stream>>>(ids, scores, counts, S, B, k_cap, k, (int)n2, out_ids, out_scores, out_counts, out_ld);
+        LAUNCH_CHECK();
+        return;
+    }
+    ScratchMark mark(c);
+    unsigned long long* comp = c->salloc<unsigned long long>((size_t)B * n2);
+    unsigned long long* comp2 = c->salloc<unsigned long long>((size_t)B * n2);
+    int* heads = c->salloc<int>(B);
+    const dim3 grid((unsigned)ceil_div(n2, 256), B);
+    { ProfScope ps(c, "segments_merge"); seg_build_kernel<<<grid, dim3(256), 0, c->stream>>>(ids, scores, counts, S, B, k_cap, comp, n2, heads); LAUNCH_CHECK(); }
+    sort_rows_u64(c, comp, n2, B);
+    { ProfScope ps(c, "segments_merge"); seg_heads_kernel<<<grid, dim3(256), 0, c->stream>>>(comp, comp2, n2, heads); LAUNCH_CHECK(); }
+    sort_rows_u64(c, comp2, n2, B);
+    { ProfScope ps(c, "segments_merge"); seg_emit_kernel<<<dim3((unsigned)ceil_div(out_ld, 256), B), dim3(256), 0, c->stream>>>(comp2, n2, heads, counts, S, B, k, out_ids, out_scores, out_counts, out_ld); LAUNCH_CHECK(); }
+}
+
 }  // namespace comet

@@ -123,14 +123,15 @@ class HybridSearch:
 # ---- segment layer (storage.go:489-626): one hybrid index per memtable / segment, results merged on the host -------------
 def merge_results(results: list[HybridSearchResult]) -> list[HybridSearchResult] | None:
     """mergeResults storage_merge.go:13-46: deduplicate by document id, keep the HIGHEST score; nil for no input.
-    (The reference's output order is Go map order — unspecified; this mirror keeps first-seen order.)"""
+    (The reference's output order is Go map order — unspecified; this mirror and the device merge return ascending ids, which the
+    stable descending sort below keeps among equal scores.)"""
     if not results:
         return None
     best: dict[int, float] = {}
     for r in results:
         if r.id not in best or r.score > best[r.id]:
             best[r.id] = r.score
-    return [HybridSearchResult(i, s) for i, s in best.items()]
+    return [HybridSearchResult(i, best[i]) for i in sorted(best)]
 
 
 def sort_results_by_score(results: list[HybridSearchResult]) -> None:
@@ -141,21 +142,53 @@ def sort_results_by_score(results: list[HybridSearchResult]) -> None:
 class SegmentedHybridSearch:
     """persistentHybridSearch.Execute storage.go:489-626 without the storage engine: the same query runs against every
     segment's (vector index, text index) pair — newest first, as the reference walks memtables then segments — and the
-    per-segment lists are merged (highest score per id), sorted and cut to k. Every per-segment search is a GPU search
-    through the C ABI; the merge is O(segments * k) on the host, exactly where the reference has it."""
+    per-segment lists are merged (highest score per id), sorted descending and cut to k.
+
+    Two forms. `with_query(fn)`: fn configures every per-segment HybridSearch (vector, text, fusion ...); every per-segment
+    search is a GPU search through the C ABI and the merge is O(segments * k) on the host, where the reference has it.
+    `with_vector(q)` (a vector-only query): ONE call into the library (`comet_segments_search`, index.SegmentSet) searches all
+    the segments' vector indexes, resident in HBM, and merges on the device."""
 
     def __init__(self, segments):
         self.segments = list(segments)          # [(vector_index | None, text_index | None), ...], oldest first
-        self.configure = lambda s: s            # applied to every per-segment HybridSearch (with_vector / with_text / ...)
+        self.configure = None                   # applied to every per-segment HybridSearch (with_vector / with_text / ...)
+        self.vector_query = None
         self.k = 10
+        self.n_probes, self.ef_search, self.threshold, self.document_ids = 1, 0, 0.0, []   # hybrid defaults (hybrid_search_index.go:236)
 
     def with_k(self, k): self.k = int(k); return self
     def with_query(self, fn): self.configure = fn; return self
+    def with_vector(self, q): self.vector_query = q; return self
+    def with_n_probes(self, n): self.n_probes = int(n); return self
+    def with_ef_search(self, ef): self.ef_search = int(ef); return self
+    def with_threshold(self, t): self.threshold = float(t); return self
+    def with_document_ids(self, *ids): self.document_ids = [int(i) for i in ids]; return self
 
-    def execute(self) -> list[HybridSearchResult]:
+    def _per_segment(self, h: HybridSearch) -> HybridSearch:
+        if self.configure is not None:
+            return self.configure(h)
+        h = h.with_vector(self.vector_query).with_n_probes(self.n_probes).with_ef_search(self.ef_search).with_threshold(self.threshold)
+        return h.with_document_ids(*self.document_ids) if self.document_ids else h
+
+    def execute_on_host(self) -> list[HybridSearchResult]:
+        if self.k < 0:
+            raise ValueError("k must not be negative")      # merged[:k] panics in the reference
         allr: list[HybridSearchResult] = []
         for vec, txt in reversed(self.segments):
-            allr.extend(self.configure(HybridSearch(vec, txt).with_k(self.k)).execute())
+            allr.extend(self._per_segment(HybridSearch(vec, txt).with_k(self.k)).execute())
         merged = merge_results(allr) or []
         sort_results_by_score(merged)
-        return merged[:self.k] if 0 < self.k < len(merged) else merged
+        return merged[:self.k] if len(merged) > self.k else merged      # storage.go:621-623
+
+    def execute(self) -> list[HybridSearchResult]:
+        if self.configure is not None or self.vector_query is None:
+            return self.execute_on_host()
+        import numpy as np
+        from .index import SegmentSet
+        vecs = [v for v, _ in self.segments if v is not None]
+        if len(vecs) != len(self.segments):
+            raise ValueError("vector query specified but no vector index configured")
+        ids, sc, cn = SegmentSet(vecs).search_batch(np.asarray(self.vector_query, dtype=np.float32)[None, :], self.k,
+                                                    threshold=self.threshold if self.threshold > 0 else 0.0, nprobes=max(self.n_probes, 0),
+                                                    ef_search=max(self.ef_search, 0), document_ids=self.document_ids)
+        return [HybridSearchResult(int(i), float(s)) for i, s in zip(ids[0, :cn[0]], sc[0, :cn[0]])]

@@ -542,6 +542,45 @@ class VectorIndex:
         return [out[i].copy() for i in range(len(ids))]
 
 
+class SegmentSet:
+    """The vector indexes of a persistent store's memtables / segments (storage.go:489-626), oldest first, all resident in HBM:
+    one call searches every one of them for a batch of queries and merges on the device (comet_segments_search: highest score per
+    id, scores DESCENDING, cut to k — mergeResults / sortResultsByScore storage_merge.go:13-54)."""
+
+    def __init__(self, indexes: Sequence["VectorIndex"]):
+        self.indexes = list(indexes)
+        if not self.indexes:
+            raise ValueError("no segments")
+        self.lib = self.indexes[0].lib
+        self.dim = self.indexes[0].dim
+        self._handles = (C.c_void_p * len(self.indexes))(*[ix.h for ix in self.indexes])
+
+    def _params(self, k, threshold, nprobes, ef_search, flt, mode):
+        return SearchParams(k=int(k), threshold=float(threshold), nprobes=int(nprobes), ef_search=int(ef_search),
+                            filter_ids=flt.ctypes.data_as(C.POINTER(C.c_uint32)) if flt is not None and flt.size else None,
+                            n_filter=int(flt.size) if flt is not None else 0, mode=int(mode))
+
+    def search_batch(self, queries, k: int, threshold: float = 0.0, nprobes: int = 0, ef_search: int = 0,
+                     document_ids: Iterable[int] = (), mode: int = 0):
+        q = _f32(queries)
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"query dimension mismatch: expected {self.dim}, got {q.shape[-1]}")
+        B, k_cap = q.shape[0], max(1, int(k))
+        flt = np.ascontiguousarray(list(document_ids), dtype=np.uint32)
+        p = self._params(k, threshold, nprobes, ef_search, flt, mode)
+        ids = np.zeros((B, k_cap), dtype=np.uint32); scores = np.zeros((B, k_cap), dtype=np.float32); counts = np.zeros(B, dtype=np.int32)
+        check(self.lib.comet_segments_search(self._handles, len(self.indexes), q.ctypes.data_as(C.c_void_p), B, C.byref(p),
+                                             ids.ctypes.data_as(C.c_void_p), scores.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), k_cap))
+        return ids, scores, counts
+
+    def search_batch_dev(self, q_dev: int, B: int, k: int, out_ids_dev: int, out_scores_dev: int, out_counts_dev: int, k_cap: int,
+                         threshold: float = 0.0, nprobes: int = 0, ef_search: int = 0, mode: int = 0) -> None:
+        """Device-resident queries and outputs; asynchronous on the context's stream apart from the per-segment finish."""
+        p = self._params(k, threshold, nprobes, ef_search, None, mode)
+        check(self.lib.comet_segments_search_dev(self._handles, len(self.indexes), C.c_void_p(q_dev), int(B), C.byref(p), C.c_void_p(out_ids_dev),
+                                                 C.c_void_p(out_scores_dev), C.c_void_p(out_counts_dev), int(k_cap)))
+
+
 class FlatIndex(VectorIndex):
     """comet.NewFlatIndex(dim, distanceKind) — flat_index.go:127."""
     kind_name = "flat"

@@ -228,6 +228,25 @@ COMET_API int comet_merge_topk_packed_dev(comet_ctx* ctx, const uint32_t* packed
                                           int32_t k_cap, int32_t k, uint32_t* out_ids_dev, float* out_scores_dev,
                                           int32_t* out_counts_dev);
 
+/* ---- segment layer: persistentHybridSearch.Execute storage.go:489-626, vector leg -----------
+ * The persistent store fans one query over a hybrid index per memtable / disk segment and merges on the host
+ * (mergeResults storage_merge.go:13-46: highest score per document id; sortResultsByScore :50-54: DESCENDING;
+ * merged[:k] storage.go:621-623). Here the segments' vector indexes stay resident in HBM and ONE call searches all of
+ * them for a batch of queries (the per-segment searches are enqueued back to back, each with the caller's parameters
+ * exactly as :503-533 / :568-597 pass them) and merges on the device. `segments[i]`: any vector index kinds of one
+ * dimension on one context, oldest first. Outputs as comet_index_search_dev: row q holds min(k, distinct ids) entries,
+ * counts[q] of them (or a negative status code, see comet_index_search_dev). Scores are the per-segment search scores
+ * (distances) — the reference sorts them descending at this layer, and so does this call. Equal scores: ascending id
+ * (Go map order in the reference, i.e. unspecified). k == 0 returns empty rows (merged[:0]); k < 0 is an error (a slice
+ * bounds panic in the reference). */
+COMET_API int comet_segments_search_dev(comet_index* const* segments, int32_t n_segments, const float* queries_dev, int32_t B,
+                                        const comet_search_params* p, uint32_t* out_ids_dev, float* out_scores_dev,
+                                        int32_t* out_counts_dev, int32_t k_cap);
+/* host buffers in and out (one H2D, one D2H per call) */
+COMET_API int comet_segments_search(comet_index* const* segments, int32_t n_segments, const float* queries, int32_t B,
+                                    const comet_search_params* p, uint32_t* out_ids, float* out_scores, int32_t* out_counts,
+                                    int32_t k_cap);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI inside the library --------------------------------
  * Every rank holds one shard of an index (Flat: a contiguous row block; IVF / PQ / IVFPQ: see comet_index_set_shard)
  * and searches it for the SAME query batch; the per-shard top-K blocks are exchanged with ONE ncclAllGather per batch on

@@ -173,8 +173,38 @@ int main(void) {
         free(img);
         OK(comet_index_destroy(h)); OK(comet_index_destroy(h2));
     }
+    /* segment layer (storage.go:489-626, vector leg): three Flat segments; id 5 re-written in the newest one. The fused call returns,
+     * per query, the highest score per id over the per-segment top-k's, scores DESCENDING, cut to k (storage_merge.go:13-54). */
+    {
+        enum { SK = 6 };
+        comet_index* sg[3]; const int lo[4] = {0, 700, 1500, N};
+        for (int s = 0; s < 3; s++) {
+            OK(comet_flat_create(ctx, DIM, COMET_L2SQ, &sg[s]));
+            static uint32_t sid[N]; for (int i = lo[s]; i < lo[s + 1]; i++) sid[i] = (uint32_t)(i + 1);
+            if (s == 2) sid[lo[2]] = 5u;                                   /* the row at lo[2] carries document id 5 again */
+            int64_t added = 0; OK(comet_index_add(sg[s], sid + lo[s], X[lo[s]], lo[s + 1] - lo[s], &added, NULL)); CHECK(added == lo[s + 1] - lo[s], "segment add");
+        }
+        comet_search_params sp; memset(&sp, 0, sizeof(sp)); sp.k = SK;
+        uint32_t g_ids[SK]; float g_sc[SK]; int32_t g_cnt = -1;
+        OK(comet_segments_search((comet_index* const*)sg, 3, Q[1], 1, &sp, g_ids, g_sc, &g_cnt, SK));
+        /* expectation from the per-segment searches through the single-index entry point */
+        uint32_t u_ids[3 * SK]; float u_sc[3 * SK]; int un = 0;
+        for (int s = 0; s < 3; s++) {
+            uint32_t t_ids[SK]; float t_sc[SK]; int32_t t_cnt = 0;
+            OK(comet_index_search(sg[s], Q[1], 1, &sp, t_ids, t_sc, &t_cnt, SK));
+            for (int i = 0; i < t_cnt; i++) {
+                int at = -1; for (int j = 0; j < un; j++) if (u_ids[j] == t_ids[i]) at = j;
+                if (at < 0) { u_ids[un] = t_ids[i]; u_sc[un] = t_sc[i]; un++; } else if (t_sc[i] > u_sc[at]) u_sc[at] = t_sc[i];
+            }
+        }
+        for (int i = 0; i < un; i++) for (int j = i + 1; j < un; j++)      /* score descending, equal scores: ascending id */
+            if (u_sc[j] > u_sc[i] || (u_sc[j] == u_sc[i] && u_ids[j] < u_ids[i])) { uint32_t ti = u_ids[i]; u_ids[i] = u_ids[j]; u_ids[j] = ti; float ts = u_sc[i]; u_sc[i] = u_sc[j]; u_sc[j] = ts; }
+        CHECK(g_cnt == SK && un >= SK && memcmp(g_ids, u_ids, sizeof(g_ids)) == 0 && memcmp(g_sc, u_sc, sizeof(g_sc)) == 0, "segments search differs from the merged per-segment searches (count %d)", g_cnt);
+        sp.k = -1; CHECK(comet_segments_search((comet_index* const*)sg, 3, Q[1], 1, &sp, g_ids, g_sc, &g_cnt, SK) == COMET_ERR_INVALID_ARG, "negative k accepted");
+        for (int s = 0; s < 3; s++) OK(comet_index_destroy(sg[s]));
+    }
     OK(comet_ctx_destroy(ctx));
     free(wb.p);
-    printf("abi_harness OK: create/add/search/filter/threshold/remove/errors/write_to/read_from/%d-thread concurrency/hnsw build+serialize through the C ABI\n", THREADS);
+    printf("abi_harness OK: create/add/search/filter/threshold/remove/errors/write_to/read_from/%d-thread concurrency/hnsw build+serialize/segment fan-out through the C ABI\n", THREADS);
     return 0;
 }

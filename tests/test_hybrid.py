@@ -111,3 +111,108 @@ def test_segmented_search_equals_one_index(ctx):
     one = HybridSearch(whole, None).with_vector(q).with_k(k).execute()
     many = SegmentedHybridSearch(segs).with_k(k).with_query(lambda s: s.with_vector(q)).execute()
     assert [(r.id, r.score) for r in one] == [(r.id, r.score) for r in many]
+
+
+def _host_merge(per_segment, k):
+    """storage.go:600-623 on plain (ids, scores) lists: highest score per id, descending (equal scores: ascending id), cut to k."""
+    from comet_amd.hybrid import HybridSearchResult as R, merge_results, sort_results_by_score
+    allr = [R(int(i), float(s)) for ids, sc in per_segment for i, s in zip(ids, sc)]
+    merged = merge_results(allr) or []
+    sort_results_by_score(merged)
+    merged = merged[:k] if len(merged) > k else merged
+    return [(r.id, np.float32(r.score)) for r in merged]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", ["l2_squared", "cosine", "l2"])
+def test_segments_fused_search_matches_oracle_segments(ctx, metric):
+    """comet_segments_search: per-segment top-k + mergeResults + sortResultsByScore + cut on the device equals the ORACLE's
+    per-segment Flat searches merged on the host — batch of queries, documents re-written in newer segments (the same id in several
+    segments), duplicated vectors under different ids (equal scores), a segment shorter than k, an empty segment."""
+    import oracle_lib as orc
+    from comet_amd import FlatIndex
+    from comet_amd.index import SegmentSet
+    d, B = 48, 9
+    X = orc.synth(301, 0, 2600 * d).reshape(2600, d); Q = orc.synth(302, 0, B * d).reshape(B, d)
+    X[1500:1520] = X[100:120]                                   # the same vectors under other ids, in another segment: equal scores
+    ids = np.arange(10, 2610, dtype=np.uint32)
+    ids[1200:1260] = ids[40:100]                                # documents re-written in a newer segment (other vectors)
+    bounds = [(0, 1000), (1000, 1000), (1000, 1007), (1007, 1800), (1800, 2600)]   # one empty, one of 7 rows
+    gsegs, osegs = [], []
+    for lo, hi in bounds:
+        g = FlatIndex(ctx, d, metric); o = orc.Flat(d, metric)
+        if hi > lo:
+            g.add_batch(ids[lo:hi], X[lo:hi]); assert o.add_batch(ids[lo:hi], X[lo:hi]) == 0
+        gsegs.append(g); osegs.append(o)
+    ss = SegmentSet(gsegs)
+    for k in (1, 10, 100, 1500, 3000):
+        gi, gs, gc = ss.search_batch(Q, k)
+        for qi in range(B):
+            per = []
+            for o in osegs:
+                n, oi, osc = o.search(Q[qi], k)
+                per.append((oi[:min(n, k)], osc[:min(n, k)]) if n > 0 else ([], []))
+            want = _host_merge(per, k)
+            got = list(zip(gi[qi, :gc[qi]].tolist(), gs[qi, :gc[qi]]))
+            assert gc[qi] == len(want), (metric, k, qi)
+            assert [g[0] for g in got] == [w[0] for w in want], (metric, k, qi)
+            assert [g[1].tobytes() for g in got] == [w[1].tobytes() for w in want], (metric, k, qi)
+
+
+@pytest.mark.gpu
+def test_segments_fused_search_equals_host_mirror(ctx):
+    """The device merge and the host mirror of storage.go:489-626 (per-segment GPU searches merged in Python) agree for mixed index kinds
+    (Flat + IVF + HNSW segments), with a threshold, a document filter, soft deletes, and beyond the LDS merge (segments x k > 8192)."""
+    import oracle_lib as orc
+    from comet_amd import FlatIndex, HNSWIndex, IVFIndex, L2_SQUARED
+    from comet_amd.hybrid import SegmentedHybridSearch
+    d = 32
+    X = orc.synth(311, 0, 9000 * d).reshape(9000, d)
+    ids = np.arange(1, 9001, dtype=np.uint32)
+    f1 = FlatIndex(ctx, d, L2_SQUARED); f1.add_batch(ids[:3000], X[:3000]); f1.remove(17); f1.remove(2999)
+    iv = IVFIndex(ctx, d, 16, L2_SQUARED); iv.train(X[3000:6000]); iv.add_batch(ids[3000:6000], X[3000:6000])
+    hn = HNSWIndex(ctx, d, L2_SQUARED, 8, 64, 64); hn.add_batch(ids[6000:6400], X[6000:6400])
+    f2 = FlatIndex(ctx, d, L2_SQUARED); f2.add_batch(ids[6400:], X[6400:])
+    segs = [(f1, None), (iv, None), (hn, None), (f2, None)]
+    for seed, (k, thr, docs, npb) in enumerate([(10, 0.0, (), 1), (50, 0.0, (), 4), (2500, 0.0, (), 16), (40, -1.0, (), 2),
+                                                 (30, 0.0, tuple(range(5, 9000, 7)), 3)]):
+        q = orc.synth(320 + seed, 0, d)
+        if thr < 0:     # a threshold that cuts the unthresholded result list in half
+            sc = sorted(r.score for r in SegmentedHybridSearch(segs).with_k(k).with_vector(q).with_n_probes(npb).with_ef_search(64).execute_on_host())
+            thr = float(np.float32(sc[len(sc) // 2]))
+        def build():
+            s = SegmentedHybridSearch(segs).with_k(k).with_vector(q).with_n_probes(npb).with_ef_search(64)
+            if thr: s = s.with_threshold(thr)
+            if docs: s = s.with_document_ids(*docs)
+            return s
+        fused = build().execute()
+        host = build().execute_on_host()
+        assert len(host) > 0
+        assert [(r.id, np.float32(r.score).tobytes()) for r in fused] == [(r.id, np.float32(r.score).tobytes()) for r in host], (k, thr, npb)
+
+
+@pytest.mark.gpu
+def test_segments_fused_search_edges(ctx):
+    """k == 0 is merged[:0] (storage.go:621-623), k < 0 a slice-bounds panic (an error here), a zero query under cosine is the
+    memtable search's error, mismatched dimensions are refused."""
+    import oracle_lib as orc
+    from comet_amd import COSINE, CometError, FlatIndex, ZeroVectorError
+    from comet_amd.index import SegmentSet
+    d = 16
+    X = orc.synth(331, 0, 300 * d).reshape(300, d)
+    a = FlatIndex(ctx, d, COSINE); a.add_batch(np.arange(300, dtype=np.uint32), X)
+    b = FlatIndex(ctx, d, COSINE); b.add_batch(np.arange(300, 600, dtype=np.uint32), X[::-1].copy())
+    ss = SegmentSet([a, b])
+    ids, sc, cn = ss.search_batch(X[:4], 0)
+    assert cn.tolist() == [0, 0, 0, 0]
+    with pytest.raises(CometError):
+        ss.search_batch(X[:1], -1)
+    with pytest.raises(ZeroVectorError):
+        ss.search_batch(np.zeros((1, d), np.float32), 5)
+    ids, sc, cn = ss.search_batch(X[:3], 5)
+    assert cn.tolist() == [5, 5, 5] and np.all(np.diff(sc, axis=1) <= 0)         # descending
+    c8 = FlatIndex(ctx, 8, COSINE)
+    with pytest.raises(CometError):
+        SegmentSet([a, c8]).search_batch(X[:1], 5)
+    with pytest.raises(ValueError):
+        SegmentSet([])
