@@ -198,7 +198,7 @@ struct FlatIndex : comet_index {
         // multi-GPU run live in this regime). The batch size does not matter: even ONE query is faster through the half-
         // precision shadow (1.5 GB streamed instead of 3 GB; 1M x 768: 0.61 ms vs 0.72; 100k rows: 0.14 vs 0.22).
         (void)B;
-        return ok && n >= (int64_t)flat_fast_unit_rows(256) * 4 * keff;
+        return ok && n >= (int64_t)128 * 4 * keff;
     }
 
     // MFMA fast path for up to 256 prepared queries; writes the final ids / scores / counts of the slice.
@@ -206,8 +206,9 @@ struct FlatIndex : comet_index {
     void search_fast(const float* Qp, int32_t* zflag, int bn, const comet_search_params& p, const uint8_t* elig, uint32_t* out_ids,
                      float* out_scores, int32_t* out_counts, int k_cap, Pending* pend, const float* raw_queries = nullptr) {
         ScratchMark sm(c);
-        // key units: the scan emits, per query, 2 keys + 1 bound for every 128-row unit (64-row unit on the narrow tile for <= 64 queries)
-        const int unit_rows = flat_fast_unit_rows(bn);
+        // key units: the scan emits, per query, 2 keys + 1 bound for every 128-row unit (64-row units on the narrow tile for <= 64 queries
+        // and where 128-row units would often be expanded: small indexes / large k)
+        const int unit_rows = flat_fast_unit_rows(bn, n, p.k, ldh);
         const int64_t n_tiles = ceil_div(n, flat_fast_tile_rows()) * (flat_fast_tile_rows() / unit_rows);
         const int64_t ldS = round_up(2 * n_tiles, 16), ldB = round_up(n_tiles, 16);
         const int NB = flat_fast_batch();
@@ -222,7 +223,7 @@ struct FlatIndex : comet_index {
         else launch_prep_queries_fast(c, Qp, bn, ld, dim, Qh, ldh, qn, err, fmode, xn2, st);
         float* S0 = c->salloc<float>((size_t)NB * ldS);
         float* bound = c->salloc<float>((size_t)NB * ldB);
-        launch_flat_scan_f16(c, fmode, Xh.p, n, ldh, Qh, bn, rn.as<float>(), qn, elig, S0, ldS, bound, ldB);
+        launch_flat_scan_f16(c, fmode, Xh.p, n, ldh, Qh, bn, rn.as<float>(), qn, elig, S0, ldS, bound, ldB, unit_rows);
         // kappa: exact K-th smallest emitted key per query
         const int64_t keff = (p.k <= 0 || p.k > n) ? n : p.k;
         const int Kq = (int)std::min<int64_t>(keff, 2 * n_tiles);

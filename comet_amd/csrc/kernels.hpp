@@ -93,7 +93,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
 
 // ---- kernels_fast.hip (MFMA fast path of the Flat scan) ------------------------------------------
 int flat_fast_tile_rows();
-int flat_fast_unit_rows(int nq);    // rows per key unit for a slice of nq queries (64-row units on the narrow tile)
+int flat_fast_unit_rows(int nq, int64_t n, int64_t k, int ldh);    // rows per key unit for a slice of nq queries over n rows (64-row units on the narrow tile and where 128-row units would be expanded often)
 int flat_fast_batch();
 // fp32 padded rows -> fp16 shadow in the TILED layout [256-row tile][64-half K step][row][64] (each (tile, K step)
 // slab is 32 KiB contiguous). X / rn point at the first new row whose global row index is row_base; the shadow
@@ -102,7 +102,7 @@ int flat_fast_batch();
 void launch_to_half_rows(Ctx* c, const float* X, int64_t n, int ld, void* Xh, int ldh, int64_t row_base, float* rn, uint32_t* stats);
 // mode 0 cosine / 1 L2 family. Qh: 256 x ldh fp16. S0: 256 x ldS (2 packed keys per 256-row tile), bound: 256 x ldB.
 void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, int nq_used, const float* rn, const float* qn,
-                          const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB);
+                          const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB, int unit_rows);
 void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const float* bound, int64_t ldB, int64_t n_tiles, int unit_rows, int64_t n, const uint8_t* elig,
                       const float* err_abs, int K, int kappa_rank, float thr, const float* X, int ld, const float* Qp, int B,
                       const uint32_t* ids_table, const int32_t* zflag, uint32_t* out_ids, float* out_scores, int32_t* out_counts, int k_cap,

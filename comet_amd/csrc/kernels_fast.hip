@@ -364,7 +364,9 @@ __device__ __forceinline__ void ins3max(float& t0, float& t1, float& t2, float v
 // Containment is unchanged: two emitted keys are real rows' approximate distances, the third is a lower bound of every
 // other row of the unit up to the packing perturbation (2^-15 relative to |s| resp. |t|, twice), which flat_post_kernel's
 // tau carries as an absolute slack (FAST_PACK_SLACK).
-template <int MODE, bool CHECK>
+// UR = rows per key unit: 128, or 64 where 128-row units would often hold three candidates (small indexes / large k: every such unit
+// is rescored whole by the post stage).
+template <int MODE, bool CHECK, int UR>
 __device__ __forceinline__ void scan_epilogue_q(f32x16 (&acc)[8], int wid, long tile, long row0, long n, const float* __restrict__ rn_lds /*256 floats, MODE 1*/,
                                                 const float* __restrict__ qn, const unsigned char* __restrict__ elig,
                                                 float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, unsigned long long* etr = nullptr) {
@@ -375,34 +377,35 @@ __device__ __forceinline__ void scan_epilogue_q(f32x16 (&acc)[8], int wid, long 
     const long nvalid = n - row0;
     float qnv = 0.0f;
     if constexpr (MODE == 1) qnv = qn[q];
+    constexpr int NU = 256 / UR, MBU = UR / 32;
 #pragma unroll
-    for (int u = 0; u < 2; u++) {                               // key unit = 128 rows (tiles mb = 4u .. 4u+3)
-        if (etr) etr[u * 2] = __builtin_amdgcn_s_memtime();
-        const int lane_rowbits = 4 * khalf + 128 * u;
+    for (int u = 0; u < NU; u++) {                              // key unit = UR rows (tiles mb = MBU*u .. MBU*u + MBU-1)
+        if (etr && u < 2) etr[u * 2] = __builtin_amdgcn_s_memtime();
+        const int lane_rowbits = 4 * khalf + UR * u;
         unsigned long long okmask = ~0ull;                      // CHECK: last tile / soft deletes / filters (a separate instantiation: the
         if constexpr (CHECK) okmask = unit_okmask(lane_rowbits, nvalid, elig, row0);   // per-element selects cost more than the network itself)
         // selection on v: cosine v = score (largest wins), L2 v = -(rn - 2 s) (largest wins as well: one network for both)
         float t0 = -INF, t1 = -INF, t2 = -INF;
 #pragma unroll
-        for (int mb = 0; mb < 4; mb++) {
+        for (int mb = 0; mb < MBU; mb++) {
 #pragma unroll
             for (int e4 = 0; e4 < 4; e4++) {
                 f32x4v rnv;
-                if constexpr (MODE == 1) rnv = *reinterpret_cast<const f32x4v*>(rn_lds + u * 128 + mb * 32 + 8 * e4 + 4 * khalf);   // rows e&3 = 0..3 are consecutive
+                if constexpr (MODE == 1) rnv = *reinterpret_cast<const f32x4v*>(rn_lds + u * UR + mb * 32 + 8 * e4 + 4 * khalf);   // rows e&3 = 0..3 are consecutive
 #pragma unroll
                 for (int e1 = 0; e1 < 4; e1++) {
                     const int e = e4 * 4 + e1;
                     const int rconst = mb * 32 + e1 + 8 * e4;              // compile-time part of the row-in-unit (bit 2 = lane >> 5 is added to the survivors)
                     float v;
-                    if constexpr (MODE == 0) v = acc[4 * u + mb][e];
-                    else v = __builtin_fmaf(2.0f, acc[4 * u + mb][e], -rnv[e1]);
+                    if constexpr (MODE == 0) v = acc[MBU * u + mb][e];
+                    else v = __builtin_fmaf(2.0f, acc[MBU * u + mb][e], -rnv[e1]);
                     v = __uint_as_float((__float_as_uint(v) & 0xFFFFFF00u) | (unsigned)rconst);
                     if constexpr (CHECK) v = ((okmask >> (mb * 16 + e)) & 1ull) ? v : -INF;
                     ins3max(t0, t1, t2, v);
                 }
             }
         }
-        if (etr) etr[u * 2 + 1] = __builtin_amdgcn_s_memtime();
+        if (etr && u < 2) etr[u * 2 + 1] = __builtin_amdgcn_s_memtime();
         const float o0 = __shfl_xor(t0, 32, 64), o1 = __shfl_xor(t1, 32, 64), o2 = __shfl_xor(t2, 32, 64);
         const unsigned mybit = (unsigned)(4 * khalf), otherbit = (unsigned)(4 * (khalf ^ 1));
         auto tag = [&](float v, unsigned bit) { return v == -INF ? v : __uint_as_float(__float_as_uint(v) | bit); };
@@ -418,7 +421,7 @@ __device__ __forceinline__ void scan_epilogue_q(f32x16 (&acc)[8], int wid, long 
                 a = fmaxf(a, 0.0f);
                 return __uint_as_float((__float_as_uint(a) & 0xFFFFFF00u) | row);
             };
-            const long un = tile * 2 + u;
+            const long un = tile * NU + u;
             S0[(long)q * ldS + 2 * un] = to_key(t0);
             S0[(long)q * ldS + 2 * un + 1] = to_key(t1);
             bound[(long)q * ldB + un] = to_key(t2);
@@ -430,7 +433,7 @@ __device__ __forceinline__ void scan_epilogue_q(f32x16 (&acc)[8], int wid, long 
 // pairs — the slab ring and the counted waits run straight across tile boundaries, so the first slabs of tile T+1 are in flight
 // while the waves run tile T's last K steps and its epilogue (a one-shot tile exposes ~4000 cycles of HBM latency before its
 // first MFMA: s_memtime trace in profiles/r02_flat_scan_investigation.txt).
-template <int MODE>
+template <int MODE, int UR>
 __global__ __launch_bounds__(FB_THREADS) void flat_scan_q8_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
                                                                   const _Float16* __restrict__ QF /*fragment-ordered queries*/,
                                                                   const float* __restrict__ rn, const float* __restrict__ qn,
@@ -561,8 +564,8 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_q8_kernel(const _Float16
                 __syncthreads_lds_only();
             }
             unsigned long long* etr = (tr && g < 2 * nk + 2) ? trace + 8 * 32 * 4 + wid * 8 : nullptr;
-            if ((n - row0 < FB_M) || elig != nullptr) scan_epilogue_q<MODE, true>(acc, wid, tile, row0, n, rn_lds, qn, elig, S0, ldS, bound, ldB, etr);   // workgroup-uniform
-            else scan_epilogue_q<MODE, false>(acc, wid, tile, row0, n, rn_lds, qn, elig, S0, ldS, bound, ldB, etr);
+            if ((n - row0 < FB_M) || elig != nullptr) scan_epilogue_q<MODE, true, UR>(acc, wid, tile, row0, n, rn_lds, qn, elig, S0, ldS, bound, ldB, etr);   // workgroup-uniform
+            else scan_epilogue_q<MODE, false, UR>(acc, wid, tile, row0, n, rn_lds, qn, elig, S0, ldS, bound, ldB, etr);
             stamp(g, 3);
         }
     };
@@ -592,8 +595,14 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_q8_kernel(const _Float16
 // persistent tiles, wave priorities and classic register staging (global_load -> ds_write_b128, no LDS-DMA: 0.59 ms) were all
 // built and measured in round 1: 0.51-0.63 ms against 0.51-0.55 for this one.
 unsigned long long* g_scan_trace = nullptr;   // set by tools/scan_check.hip only
+static bool scan_uses_q8(int ldh) {           // the query-stationary tile takes even K-step counts; the few odd ones (and COMET_SCAN_VARIANT=1) keep the 2 x 4 tile
+    static const int variant0 = [] { const char* e = getenv("COMET_SCAN_VARIANT"); return e ? atoi(e) : 0; }();
+    const char* rt = getenv("COMET_SCAN_VARIANT_RT");           // tools/scan_check.hip switches variants inside one process
+    const int variant = rt ? atoi(rt) : variant0;
+    return variant == 0 && ((ldh / FB_K) & 1) == 0;
+}
 void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, const void* Qh, int nq_used, const float* rn, const float* qn,
-                          const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB) {
+                          const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB, int unit_rows) {
     const long n_tiles = ceil_div(n, FB_M);
     ProfScope ps(c, nq_used <= FN_N ? "flat_scan_f16_n64" : "flat_scan_f16");
     if (nq_used <= FN_N) {      // S0 / bound are laid out for 64-row units in this case (flat_fast_unit_rows(nq))
@@ -609,23 +618,20 @@ void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, 
         LAUNCH_CHECK();
         return;
     }
-    static const int variant0 = [] { const char* e = getenv("COMET_SCAN_VARIANT"); return e ? atoi(e) : 0; }();
-    const char* rt = getenv("COMET_SCAN_VARIANT_RT");           // tools/scan_check.hip switches variants inside one process
-    const int variant = rt ? atoi(rt) : variant0;
-    if (variant == 0 && ((ldh / FB_K) & 1) == 0) {          // query-stationary tile (even K-step counts; the few odd ones keep the 2 x 4 tile): rows through a 4-stage LDS ring, query fragments straight from L2
+    if (scan_uses_q8(ldh)) {          // query-stationary tile: rows through a 4-stage LDS ring, query fragments straight from L2
         const size_t ldsq = (size_t)FQ_STAGES * FQ_STAGE_BYTES + 1024;
         const long gridq = std::min<long>(round_up(n_tiles, 8), (long)round_up(c->prop.multiProcessorCount, 8));   // persistent: one workgroup per CU
         const _Float16* QF = (const _Float16*)Qh + (size_t)FB_N * ldh;
-        if (mode == 0) {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_q8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
-            flat_scan_q8_kernel<0><<<dim3((unsigned)gridq), dim3(FB_THREADS), ldsq, c->stream>>>((const _Float16*)Xh, n, ldh, QF, rn, qn, elig, S0, ldS, bound, ldB, n_tiles, g_scan_trace);
-        } else {
-            HIP_CHECK(hipFuncSetAttribute((const void*)flat_scan_q8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
-            flat_scan_q8_kernel<1><<<dim3((unsigned)gridq), dim3(FB_THREADS), ldsq, c->stream>>>((const _Float16*)Xh, n, ldh, QF, rn, qn, elig, S0, ldS, bound, ldB, n_tiles, g_scan_trace);
-        }
+        auto go = [&](auto kernel) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
+            kernel<<<dim3((unsigned)gridq), dim3(FB_THREADS), ldsq, c->stream>>>((const _Float16*)Xh, n, ldh, QF, rn, qn, elig, S0, ldS, bound, ldB, n_tiles, g_scan_trace);
+        };
+        if (unit_rows == 64) { if (mode == 0) go(flat_scan_q8_kernel<0, 64>); else go(flat_scan_q8_kernel<1, 64>); }
+        else { if (mode == 0) go(flat_scan_q8_kernel<0, 128>); else go(flat_scan_q8_kernel<1, 128>); }
         LAUNCH_CHECK();
         return;
     }
+    if (unit_rows != FB_UNIT) COMET_FAIL(COMET_ERR_INVALID_ARG, "the 2 x 4 scan tile emits 128-row key units");
     const size_t lds = 2 * 65536;
     const long grid = round_up(n_tiles, 8);
     if (mode == 0) {
@@ -638,7 +644,21 @@ void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, 
     LAUNCH_CHECK();
 }
 int flat_fast_tile_rows() { return FB_M; }
-int flat_fast_unit_rows(int nq) { return nq <= FN_N ? FN_UNIT : FB_UNIT; }
+// Rows per key unit of a search: the narrow tile (<= 64 queries) always emits 64-row units; the wide tile emits 128-row units unless
+// those would often hold three candidates — a unit whose third-smallest key passes tau is rescored whole by the post stage. With
+// c ~ 1.5 k + 16 candidates per query spread over n rows a unit of 128 rows holds Poisson(lambda = 128 c / n) of them, so a query
+// expands about (n / 128) * lambda^3 / 6 units: 0.01 at 1M rows and k = 100, 0.2 at 250k, 3 at 62.5k (measured 0.004, 0.12 and 1.3) —
+// beyond 0.1 the scan switches to 64-row units (an eighth of the expansion work: a quarter of the expansions, half the rows each;
+// twice the keys for the post stage to select from). Measured step, B = 256, K = 100, 128- vs 64-row units: 62.5k rows 0.172 vs
+// 0.114 ms, 250k 0.211 vs 0.203, 500k 0.312 vs 0.319, 1M 0.543 vs 0.579.
+int flat_fast_unit_rows(int nq, int64_t n, int64_t k, int ldh) {
+    if (nq <= FN_N) return FN_UNIT;
+    static const int forced = [] { const char* e = getenv("COMET_FLAT_UNIT"); return e ? atoi(e) : 0; }();
+    if (!scan_uses_q8(ldh)) return FB_UNIT;                     // the 2 x 4 tile knows 128-row units only
+    if (forced == 64 || forced == 128) return forced;
+    const double keff = (k <= 0 || k > n) ? (double)n : (double)k, cand = 1.5 * keff + 16.0, lambda = 128.0 * cand / (double)std::max<int64_t>(n, 1);
+    return ((double)n / 128.0) * lambda * lambda * lambda / 6.0 > 0.1 ? 64 : FB_UNIT;
+}
 int flat_fast_batch() { return FB_N; }
 
 // ------------------------------------------------------------------------------------------------

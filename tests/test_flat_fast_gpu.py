@@ -49,8 +49,9 @@ def test_fast_equals_strict(ctx, metric, n, d, B, k):
 
 
 @pytest.mark.parametrize("metric", METRICS)
-def test_fast_with_filter_delete_threshold(ctx, metric):
-    n, d, B, k = 12000, 64, 64, 20
+@pytest.mark.parametrize("d,B", [(64, 64), (128, 200)])     # the narrow tile; the wide tile with 64-row key units (small index: kernels_fast.hip flat_fast_unit_rows)
+def test_fast_with_filter_delete_threshold(ctx, metric, d, B):
+    n, k = 12000, 20
     X = synth(5, n, d); Q = synth(6, B, d)
     g = FlatIndex(ctx, d, metric)
     g.add_batch(np.arange(1, n + 1, dtype=np.uint32), X)

@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < B; i++) { double s = 0; for (int j = 0; j < dim; j++) { Q[i * ld + j] = U(rng); s += Q[i * ld + j] * Q[i * ld + j]; } for (int j = 0; j < dim; j++) Q[i * ld + j] /= (float)std::sqrt(s); }
     if (argc > 5) { const float sc = (float)atof(argv[5]); for (auto& v : X) v *= sc; }      // argv[5] = 0: zero corpus (clock / power experiment)
     float *dX, *dQ, *rn, *qn, *err; void *Xh, *Qh; uint32_t* stats; int32_t* st4;
-    const int unit = B <= 64 ? 64 : 128;          // the narrow tiles (<= 64 queries) emit per 64-row unit
+    const int unit = (B <= 64 || (getenv("SCAN_UNIT") && atoi(getenv("SCAN_UNIT")) == 64)) ? 64 : 128;          // the narrow tiles (<= 64 queries) emit per 64-row unit; SCAN_UNIT=64: the wide tile with 64-row units (variant 0 only)
     const long tiles = ceil_div(n, 256), units = tiles * (256 / unit), ldS = round_up(2 * units, 16), ldB = round_up(units, 16);
     HIP_CHECK(hipMalloc(&dX, X.size() * 4)); HIP_CHECK(hipMalloc(&dQ, Q.size() * 4)); HIP_CHECK(hipMalloc(&rn, n * 4)); HIP_CHECK(hipMalloc(&qn, 1024)); HIP_CHECK(hipMalloc(&err, 1024));
     HIP_CHECK(hipMalloc(&Xh, (size_t)tiles * 256 * ldh * 2)); HIP_CHECK(hipMalloc(&Qh, (size_t)256 * ldh * 2 * 2)); HIP_CHECK(hipMalloc(&stats, 8)); HIP_CHECK(hipMalloc(&st4, 16));
@@ -41,9 +41,10 @@ int main(int argc, char** argv) {
     unsigned long long* dtrace = nullptr;
     if (getenv("SCAN_TRACE")) { HIP_CHECK(hipMalloc(&dtrace, (8 * 32 * 4 + 64) * 8)); HIP_CHECK(hipMemset(dtrace, 0, (8 * 32 * 4 + 64) * 8)); g_scan_trace = dtrace; }
     for (int variant : {0, 1}) {
+        if (variant == 1 && unit == 64 && B > 64) continue;
         setenv("COMET_SCAN_VARIANT_RT", variant ? "1" : "0", 1);
         HIP_CHECK(hipMemset(S0, 0xFF, (size_t)256 * ldS * 4)); HIP_CHECK(hipMemset(bound, 0xFF, (size_t)256 * ldB * 4));
-        launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, B, rn, qn, nullptr, S0, ldS, bound, ldB);
+        launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, B, rn, qn, nullptr, S0, ldS, bound, ldB, unit);
         HIP_CHECK(hipStreamSynchronize(c.stream));
         std::vector<float> hS((size_t)256 * ldS), hB((size_t)256 * ldB);
         HIP_CHECK(hipMemcpy(hS.data(), S0, hS.size() * 4, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(hB.data(), bound, hB.size() * 4, hipMemcpyDeviceToHost));
@@ -78,9 +79,9 @@ int main(int argc, char** argv) {
         bad_total += bad;
         if (iters > 0) {
             hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-            for (int i = 0; i < 3; i++) launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, B, rn, qn, nullptr, S0, ldS, bound, ldB);
+            for (int i = 0; i < 3; i++) launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, B, rn, qn, nullptr, S0, ldS, bound, ldB, unit);
             HIP_CHECK(hipEventRecord(a, c.stream));
-            for (int i = 0; i < iters; i++) launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, B, rn, qn, nullptr, S0, ldS, bound, ldB);
+            for (int i = 0; i < iters; i++) launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, B, rn, qn, nullptr, S0, ldS, bound, ldB, unit);
             HIP_CHECK(hipEventRecord(b, c.stream)); HIP_CHECK(hipEventSynchronize(b));
             float ms; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
             printf("variant %d: %.4f ms per launch (%ld rows x %d, %d queries)\n", variant, ms / iters, n, dim, B);
