@@ -629,12 +629,12 @@ __device__ __forceinline__ void adc_chains2(const f32x2q* __restrict__ lut, int 
                 }
             }
         }
-        if (ngroups == 0) {                            // the first group was never consumed: `cur` must still become the next call's
+    }
+    if (ngroups == 0) {                                // the first group was never consumed (a phase of < G words, or the zero-width phase of a pruned wave): `cur` must still become the next call's
 #pragma unroll
-            for (int c = 0; c < ADC_CHAINS; c++)
+        for (int c = 0; c < ADC_CHAINS; c++)
 #pragma unroll
-                for (int i = 0; i < G; i++) cur[c][i] = adc_ldw(nrs, voff, nxw[i] + c * stride16b);
-        }
+            for (int i = 0; i < G; i++) cur[c][i] = adc_ldw(nrs, voff, nxw[i] + c * stride16b);
     }
 }
 
@@ -645,6 +645,7 @@ struct AdcArgs {
     // fused top-K filter (cand != nullptr; K in [1, 64]): no distance matrix — survivors of the per-query running bound tq[] go to
     // cand[q * ldD + cursor[q]++] as (order-preserving key << 32 | position in the query's candidate row)
     unsigned long long* cand; int* cursor; unsigned* tq; int K; float thr;
+    int prune;                  // fused filter: waves skip the remaining phases of an item once all their partial sums exceed the bounds
 };
 __device__ __forceinline__ unsigned adc_f2key(unsigned u) { return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) {
@@ -720,8 +721,33 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
 #pragma unroll
             for (int c = 0; c < ADC_CHAINS; c++) { acc[ps][c][0] = 0.0f; acc[ps][c][1] = 0.0f; }
         const int na0 = chains_of(cur, 0), na1 = chains_of(cur, 1);
+        // Fused filter: the terms of a sum are squares, so a candidate's partial sum over the first phases never exceeds its sum
+        // (float32 addition of non-negative terms is monotone). A wave whose candidates are ALL above their query's bound after a
+        // phase cannot deliver a survivor: it skips the gathers of the item's remaining phases (the far lists of a query, mostly).
+        // The bounds are read once per item, before the first phase (a stale bound is only looser).
+        unsigned pTa = 0xFFFFFFFFu, pTb = 0xFFFFFFFFu;
+        bool dead = false;                                          // wave-uniform
+        if (a.prune && na0 > 0) {                                   // (with the 4 ulp of slack of the epilogue's test; kept in SGPRs)
+            auto slack = [](unsigned t) { return t >= 0x7F800000u ? 0xFFFFFFFFu : __float_as_uint(__uint_as_float(t) * 1.0000005f); };
+            pTa = (unsigned)RFL((int)slack(__builtin_nontemporal_load(&a.tq[cur.qA])));
+            pTb = cur.qB >= 0 ? (unsigned)RFL((int)slack(__builtin_nontemporal_load(&a.tq[cur.qB]))) : 0u;
+        }
         for (int ph = 0; ph < P; ph++, stage++) {
             __syncthreads();        // table (cur, ph) has landed (the barrier drains vmcnt); nobody still reads the other buffer; ticket visible
+            if (a.prune && ph > 0 && !dead && na0 > 0) {
+                const unsigned sa = pTa, sb = pTb;
+                bool alive = false;
+#pragma unroll
+                for (int ps = 0; ps < ADC_SEG_PASSES; ps++) {
+                    const int na = ps == 0 ? na0 : na1;
+#pragma unroll
+                    for (int c = 0; c < ADC_CHAINS; c++) {
+                        if (c >= na) continue;           // (lanes past the segment's end hold sums of foreign codes: they can only keep the wave alive)
+                        alive = alive || __float_as_uint(acc[ps][c][0]) <= sa || __float_as_uint(acc[ps][c][1]) <= sb;
+                    }
+                }
+                dead = __ballot(alive) == 0ull;
+            }
             if (ph == 0) { nxt = decode(s_ticket[parity ^ 1][0], s_ticket[parity ^ 1][1]); if (nxt.live) rs_nxt = rsrc_of(nxt); }
             const bool last_ph = ph + 1 == P;
             if (!last_ph) issue_table(cur, ph + 1, (stage + 1) & 1);
@@ -734,7 +760,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
                     for (int i = 0; i < ADC_G; i++) cw_cur[c][i] = adc_ldw(rs_nxt, voff, off_of(0) + c * stride16b + min(i, M4 - 1) * 256);
             }
             const f32x2q* lut = reinterpret_cast<const f32x2q*>(lds + (long)(stage & 1) * (ADC_BUF_BYTES / 4));
-            const int w_lo = (ph * mp) >> 2, m_hi = min(M, (ph + 1) * mp);
+            const int w_lo = (ph * mp) >> 2, m_hi = dead ? (w_lo << 2) : min(M, (ph + 1) * mp);   // a dead wave runs zero-width phases: no gathers, only the code words of its next call
             const int w_next = last_ph ? 0 : ((ph + 1) * mp) >> 2;   // first word of the wave's next call after this phase's last pass
 #pragma unroll
             for (int ps = 0; ps < ADC_SEG_PASSES; ps++) {
@@ -926,8 +952,9 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
             const long n_items = (long)(n_slots / 2) * segs;
             long g = std::min<long>(n_items, (long)c->prop.multiProcessorCount);
             g = std::max<long>(8, (g + 7) / 8 * 8);          // a multiple of the XCD count so that blockIdx % 8 is the XCD of every slot
+            static const bool prune_on = getenv("COMET_ADC_NO_PRUNE") == nullptr;
             AdcArgs a{lut, codes, (const long*)list_base, list_len, so, elig, order, slist, qitems, qcount, queues, D ? D + (size_t)b0 * ldD : nullptr, (long)ldD, M, KL, mp, M4, np, (int)qcap,
-                      flt ? flt->cand + (size_t)b0 * ldD : nullptr, flt ? flt->cursor + b0 : nullptr, flt ? flt->tq + b0 : nullptr, flt ? flt->K : 0, flt ? flt->thr : 0.0f};
+                      flt ? flt->cand + (size_t)b0 * ldD : nullptr, flt ? flt->cursor + b0 : nullptr, flt ? flt->tq + b0 : nullptr, flt ? flt->K : 0, flt ? flt->thr : 0.0f, (flt && prune_on) ? 1 : 0};
             adc_scan_kernel<<<dim3((unsigned)g), dim3(ADC_THREADS), lds, c->stream>>>(a);
             LAUNCH_CHECK();
         }
