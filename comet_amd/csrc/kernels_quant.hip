@@ -776,13 +776,22 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
     const int P = (M + mp - 1) / mp;
     const int stride16b = ADC_WAVES * M4 * 256;                     // bytes between a wave's chains (16 blocks)
     // Eight queues, one per XCD (workgroup b runs on XCD b % 8); a drained workgroup steals from the next queue.
-    auto take = [&](int& xq, int& tried) -> int {   // thread 0 only
-        while (tried < 8) {
-            const int t = atomicAdd(&a.queues[xq], 1);
-            if (t < a.qcount[xq]) return t;
-            xq = (xq + 1) & 7; tried++;
+    // (wave 0, all lanes) lanes 0..7 look at the eight queues at once, so that a drained launch costs one round trip instead of eight
+    // dependent atomics; the atomic goes to the first queue with work at or behind the workgroup's own.
+    auto take = [&](int& xq) -> int {
+        while (true) {
+            bool has = false;
+            if (lane < 8u) has = __hip_atomic_load(&a.queues[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.qcount[lane];
+            const unsigned m = (unsigned)__ballot(has) & 0xFFu;
+            if (!m) return -1;
+            const unsigned rot = ((m >> xq) | (m << (8 - xq))) & 0xFFu;
+            const int pick = (xq + __builtin_ctz(rot)) & 7;
+            int t = 0;
+            if (lane == 0u) t = atomicAdd(&a.queues[pick], 1);
+            t = __shfl(t, 0, 64);
+            xq = pick;
+            if (t < a.qcount[pick]) return t;
         }
-        return -1;
     };
     auto decode = [&](int xq, int ticket) -> AdcItem {
         AdcItem it; it.live = 0; it.start = it.seg_end = 0; it.qA = it.soA = it.soB = 0; it.qB = -1; it.base_blk = 0; it.duo = 0;
@@ -816,8 +825,8 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
                                                  (__attribute__((address_space(3))) void*)(dst + e), 16, 0, 0);
         }
     };
-    int my_q = blockIdx.x & 7, tried = 0, parity = 0;
-    if (threadIdx.x == 0) { const int t = take(my_q, tried); s_ticket[0][0] = my_q; s_ticket[0][1] = t; }
+    int my_q = blockIdx.x & 7, parity = 0;
+    if (wid == 0) { const int t = take(my_q); if (lane == 0u) { s_ticket[0][0] = my_q; s_ticket[0][1] = t; } }
     __syncthreads();
     AdcItem cur = decode(s_ticket[0][0], s_ticket[0][1]);
     if (!cur.live) return;
@@ -830,7 +839,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
         for (int i = 0; i < ADC_G; i++) cw_cur[c][i] = adc_ldw(rs_cur, voff, off_of(0) + c * stride16b + min(i, M4 - 1) * 256);
     int stage = 0;
     while (true) {
-        if (threadIdx.x == 0) { const int t = take(my_q, tried); s_ticket[parity ^ 1][0] = my_q; s_ticket[parity ^ 1][1] = t; }   // next item's ticket
+        if (wid == 0) { const int t = take(my_q); if (lane == 0u) { s_ticket[parity ^ 1][0] = my_q; s_ticket[parity ^ 1][1] = t; } }   // next item's ticket
         AdcItem nxt = decode(0, -1);
         adc_rsrc_t rs_nxt = rs_cur;
         f32x2q acc[ADC_SEG_PASSES][ADC_CHAINS];
@@ -1107,7 +1116,12 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
         {
             ProfScope ps(c, "pq_lb");
             if (64 * (M + 1) * 4 > 64 * 1024) COMET_FAIL(COMET_ERR_UNSUPPORTED, "too many PQ subspaces for the lower-bound kernel (%d)", M);
-            pq_lb_kernel<<<dim3((unsigned)ceil_div(n_pairs, 64)), dim3(256), (size_t)64 * (M + 1) * 4, c->stream>>>(rowmin, M, n_pairs, np, so, flt->tq + b0, dead, nullptr);
+            static const bool lb_stats = getenv("COMET_ADC_STATS") != nullptr;      // debugging: pairs left alive by the lower bound, per sub-batch (synchronises)
+            int32_t* st = lb_stats ? c->salloc<int32_t>(1) : nullptr;
+            if (st) HIP_CHECK(hipMemsetAsync(st, 0, 4, c->stream));
+            pq_lb_kernel<<<dim3((unsigned)ceil_div(n_pairs, 64)), dim3(256), (size_t)64 * (M + 1) * 4, c->stream>>>(rowmin, M, n_pairs, np, so, flt->tq + b0, dead, st);
+            if (st) { int32_t h = 0; HIP_CHECK(hipMemcpyAsync(&h, st, 4, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream));
+                      fprintf(stderr, "[comet] adc two-stage: %d of %d pairs behind the nearest lists alive after the lower bound\n", h, n_pairs - bn); }
             LAUNCH_CHECK();
         }
         run_stage(2);

@@ -42,6 +42,7 @@ def main():
     probed = np.argsort(d2, axis=1, kind="stable")[:, :nprobe]
     cb_n2 = (cb ** 2).sum(2)                                                # [M][256]
     tot = np.zeros(4); cand = 0
+    death_hist = np.zeros(13, dtype=np.int64)
     by_rank = np.zeros((nprobe, 4)); cand_rank = np.zeros(nprobe)
     for b in range(B):
         r = q64[b][None, :] - cent[probed[b]]                               # [np][d]
@@ -52,6 +53,10 @@ def main():
         suffix = np.stack([mins[:, s:].sum(1) for s in (0, 32, 64)], 1)     # lower bound of what phases >= s add
         typical = np.stack([np.median(lut[:, :s, :], axis=2).sum(1) for s in (32, 64)], 1)   # a typical candidate's partial sum after 1 / 2 phases
         w = list_len[probed[b]].astype(np.float64)
+        csum = np.cumsum(mins, axis=1)                                      # partial lower bound after m + 1 subspaces
+        first = np.where(csum > kth_sum[b], np.arange(M)[None, :], M).min(1)   # subspaces needed until the pair is provably dead (M: never)
+        for p_ in range(1, nprobe):
+            death_hist[min(int(first[p_]) // 8, 12)] += 1
         dead0 = suffix[:, 0] > kth_sum[b]                                   # the whole item can be skipped for this query
         dead1 = typical[:, 0] + suffix[:, 1] > kth_sum[b]                   # typical candidate dead after phase 1 with the rest's lower bound
         dead2 = typical[:, 1] + suffix[:, 2] > kth_sum[b]
@@ -65,6 +70,7 @@ def main():
                       "frac_typical_dead_after_phase1_with_min_rest": tot[1] / cand,
                       "frac_typical_dead_after_phase2_with_min_rest": tot[2] / cand,
                       "frac_typical_dead_after_phase2_plain_partial_sum": tot[3] / cand,
+                      "pairs_behind_probe0_by_subspaces_until_dead (bins of 8; last = never)": death_hist.tolist(),
                       "dead_before_any_gather_by_probe_rank": [round(x, 3) for x in (by_rank[:, 0] / np.maximum(cand_rank, 1)).tolist()]}))
 
 
