@@ -450,6 +450,7 @@ struct PQFamilyIndex : comet_index {
     DevBuf codebooks;   // M x Ksub x dsub dense fp32 (pq_index.go:99-101 layout)
     DevBuf codes_arr;   // arrival-order codes, n x M4 words (byte m of a row = code[m])
     DevBuf codes_il;    // compiled, block-interleaved
+    DevBuf adc_stats;   // two-stage search counters (AdcFilter::stats), read by get_stat
     bool il_dirty = true;
     ListLayout lay;
 
@@ -599,7 +600,12 @@ struct PQFamilyIndex : comet_index {
             const int qb = (int)std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(budget / ((size_t)ldD * (fuse ? 8 : 4)))));
             float* D = fuse ? nullptr : c->salloc<float>((size_t)qb * ldD);
             AdcFilter afl{};
-            if (fuse) { afl.cand = c->salloc<unsigned long long>((size_t)qb * ldD); afl.cursor = c->salloc<int32_t>(qb); afl.tq = c->salloc<uint32_t>(qb); afl.K = p.k; afl.thr = p.threshold; }
+            if (fuse) {
+                afl.cand = c->salloc<unsigned long long>((size_t)qb * ldD); afl.cursor = c->salloc<int32_t>(qb); afl.tq = c->salloc<uint32_t>(qb); afl.K = p.k; afl.thr = p.threshold;
+                if (!adc_stats.p) { adc_stats.reserve(16, c->stream, 0); HIP_CHECK(hipMemsetAsync(adc_stats.p, 0, 16, c->stream)); }
+                afl.stats = adc_stats.as<int32_t>();
+                afl.one_stage = p.mode == 1 ? 1 : 0;      // mode 1 ("strict"): the reference's literal work — every candidate of every probed list is scored
+            }
             for (int b0 = 0; b0 < B; b0 += qb) {
                 const int bn = std::min(qb, B - b0);
                 launch_adc_scan(c, Qp + (size_t)b0 * ld, ld, dim, ivf ? centroids.as<float>() : nullptr, codebooks.as<float>(), M, Ksub, dsub,
@@ -738,6 +744,12 @@ struct PQFamilyIndex : comet_index {
     bool get_stat(const char* name, double* out) const override {
         std::string k(name);
         if (k == "max_list_len") { const_cast<ListLayout&>(lay).compile(c); *out = (double)lay.max_len; return true; }
+        if (k == "adc_pairs_alive" || k == "adc_pairs_behind_nearest") {      // two-stage search: (query, list) pairs the lower bound left / all pairs behind the nearest lists
+            int32_t h[2] = {0, 0};
+            if (adc_stats.p) { c->d2h(h, adc_stats.p, 8); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+            *out = (double)h[k == "adc_pairs_alive" ? 0 : 1];
+            return true;
+        }
         return false;
     }
     int64_t list_size(int l) const override { const_cast<ListLayout&>(lay).compile(c); return (l >= 0 && l < nlist) ? lay.len_h[l] : 0; }

@@ -86,7 +86,10 @@ size_t adc_lds_bytes(int M, int Ksub, int dim);
 int64_t adc_codes_pad();    // code slots the ADC scan may read (never use) past the last list
 // fused top-K filter of the ADC scan (K in [1, ADC_FILTER_MAX_K]): survivors as composites in cand[q * ldD ..], cursor[q] of them
 constexpr int ADC_FILTER_MAX_K = 64;
-struct AdcFilter { unsigned long long* cand; int32_t* cursor; uint32_t* tq; int K; float thr; };
+struct AdcFilter { unsigned long long* cand; int32_t* cursor; uint32_t* tq; int K; float thr;
+                   int one_stage;    // 1: scan every probed candidate in one pass (search mode 1), no lower-bound pruning
+                   int32_t* stats;   // nullable: [0] += pairs behind the nearest lists the lower bound left alive, [1] += pairs behind the nearest lists (two-stage search)
+};
 void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* centroids, const float* codebooks, int M, int Ksub, int dsub,
                      const uint32_t* codes, int M4, const int64_t* list_base, const int32_t* list_len, const uint32_t* probe_list, int ldp,
                      int np, const int32_t* seg_off, const uint8_t* elig, int B, int nlist, int max_list_len, float* D, int64_t ldD, const AdcFilter* flt = nullptr);

@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void pq_lb_kernel(const float* __restrict__ ro
         dd = __float_as_uint(lb) > Ts ? 1 : 0;
     }
     dead[i] = dd;
-    if (stats && !dd) atomicAdd(&stats[0], 1);
+    if (stats) { if (!dd) atomicAdd(&stats[0], 1); if (pi != 0) atomicAdd(&stats[1], 1); }
 }
 
 // order[] = the pair indices grouped by probed list (counting sort in LDS; pairs with nothing to scan go last; the
@@ -1054,7 +1054,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
     // Exact: a removed candidate's sum is above a bound that only ever tightens. On clustered data almost everything behind the
     // nearest lists goes (bench corpus: 98.6 % of the candidates); on unclustered data the cost is the row-minima kernel.
     static const bool two_stage_on = getenv("COMET_ADC_ONE_STAGE") == nullptr;
-    const bool two_stage = flt != nullptr && np >= 2 && !identity && two_stage_on;
+    const bool two_stage = flt != nullptr && np >= 2 && !identity && two_stage_on && !flt->one_stage;
     int32_t* used = c->salloc<int32_t>(4);
     float* rowmin = two_stage ? c->salloc<float>((size_t)qc * np * M) : nullptr;
     uint8_t* dead = two_stage ? c->salloc<uint8_t>((size_t)qc * np) : nullptr;
@@ -1116,12 +1116,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
         {
             ProfScope ps(c, "pq_lb");
             if (64 * (M + 1) * 4 > 64 * 1024) COMET_FAIL(COMET_ERR_UNSUPPORTED, "too many PQ subspaces for the lower-bound kernel (%d)", M);
-            static const bool lb_stats = getenv("COMET_ADC_STATS") != nullptr;      // debugging: pairs left alive by the lower bound, per sub-batch (synchronises)
-            int32_t* st = lb_stats ? c->salloc<int32_t>(1) : nullptr;
-            if (st) HIP_CHECK(hipMemsetAsync(st, 0, 4, c->stream));
-            pq_lb_kernel<<<dim3((unsigned)ceil_div(n_pairs, 64)), dim3(256), (size_t)64 * (M + 1) * 4, c->stream>>>(rowmin, M, n_pairs, np, so, flt->tq + b0, dead, st);
-            if (st) { int32_t h = 0; HIP_CHECK(hipMemcpyAsync(&h, st, 4, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream));
-                      fprintf(stderr, "[comet] adc two-stage: %d of %d pairs behind the nearest lists alive after the lower bound\n", h, n_pairs - bn); }
+            pq_lb_kernel<<<dim3((unsigned)ceil_div(n_pairs, 64)), dim3(256), (size_t)64 * (M + 1) * 4, c->stream>>>(rowmin, M, n_pairs, np, so, flt->tq + b0, dead, flt->stats);
             LAUNCH_CHECK();
         }
         run_stage(2);

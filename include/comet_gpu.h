@@ -188,7 +188,9 @@ typedef struct {
     int32_t ef_search;          /* WithEfSearch; <=0 => index default (hnsw_index_search.go:302-305) */
     const uint32_t* filter_ids; /* WithDocumentIDs; NULL/0 => no filter (document_filter.go:27-30). HOST pointer. */
     int32_t n_filter;
-    int32_t mode;               /* 0 = auto, 1 = strict exact-arithmetic kernels only, 2 = force fast path */
+    int32_t mode;               /* 0 = auto, 1 = strict: the reference's literal work (Flat: exact-arithmetic kernels only; IVFPQ: every
+                                 * candidate of every probed list is scored, no lower-bound pruning), 2 = force the fast path. The
+                                 * results are identical in every mode. */
 } comet_search_params;
 
 /* B queries (B x dim, host) -> out_ids / out_scores (B x k_cap, host), out_counts[B] = number of

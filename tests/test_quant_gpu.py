@@ -414,3 +414,36 @@ def test_merge_topk_packed_blocks(ctx):
         assert np.array_equal(mi[b, :ec[b]], ei[b, :ec[b]]) and np.array_equal(bits(ms[b, :ec[b]]), bits(es[b, :ec[b]]))
     for p in (pk, o_ids, o_sc, o_cn):
         ctx.free(p)
+
+
+def test_ivfpq_two_stage_lower_bound_pruning(ctx):
+    """The two-stage IVFPQ search (nearest lists first, then an exact lower bound per (query, list) pair — the serial float32 sum of the
+    pair's table row minima — removes pairs whose candidates cannot pass the query's bound) returns the oracle's ids and scores, and
+    the same as the every-candidate search (mode 1), on a clustered corpus where most pairs are removed and on an unclustered one
+    where hardly any is; with thresholds, document filters, soft deletes (removed candidates never count towards a bound), a K
+    above the nearest list's size (the bound stays +inf), queries whose nearest list is not where their neighbours are."""
+    d, M, nbits, nlist = 64, 8, 8, 24
+    for tag, X in (("clustered", clustered(71, 16000, d, 24, 0.05)), ("uniform", synth(72, 6000, d))):
+        n = len(X)
+        ids = np.arange(1, n + 1, dtype=np.uint32)
+        g = IVFPQIndex(ctx, d, L2_SQUARED, nlist, M, nbits); o = orc.IVFPQ(d, L2_SQUARED, nlist, M, nbits)
+        g.train(X[:4000]); assert o.train(X[:4000]) == 0
+        g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
+        Q = np.vstack([X[5:25] + np.float32(0.003), synth(73, 7, d) * np.float32(0.6), clustered(71, 9, d, 24, 0.4)])   # near corpus points, far from everything, between clusters
+        a0, b0 = g.stat("adc_pairs_alive"), g.stat("adc_pairs_behind_nearest")
+        for k, npb in ((1, 2), (5, 8), (10, 24), (64, 6)):
+            check_search(g, o, Q, k, npb)
+            m0 = g.search_batch(Q, k, nprobes=npb)
+            m1 = g.search_batch(Q, k, nprobes=npb, mode=1)
+            assert np.array_equal(m0[2], m1[2]) and np.array_equal(m0[0], m1[0]) and np.array_equal(bits(m0[1]), bits(m1[1])), (tag, k, npb)
+        alive, behind = g.stat("adc_pairs_alive") - a0, g.stat("adc_pairs_behind_nearest") - b0
+        assert behind > 0 and alive <= behind
+        if tag == "clustered":
+            assert alive < 0.5 * behind, (alive, behind)          # the bound does remove most of the far lists here
+        ref = o.search(Q[0], 50, 8)[2]
+        check_search(g, o, Q, 10, 8, threshold=float(ref[5]))
+        check_search(g, o, Q, 10, 8, filter_ids=list(range(3, n, 5)))
+        for i in range(6, 26, 2):
+            g.remove(i); assert o.remove(i) == 0
+        check_search(g, o, Q, 10, 8)
+        check_search(g, o, Q, 64, 24)

@@ -35,14 +35,20 @@ def main():
     cent = idx.centroids(nlist).astype(np.float64)
     dsub = d // M
     cb = idx.codebooks(M, 256, dsub).astype(np.float64)                     # [M][256][dsub]
-    _, e_lists, _ = idx.export()
+    _, e_lists, e_codes = idx.export(codes_width=M)
     list_len = np.bincount(e_lists, minlength=nlist)
+    # geometric bound: a candidate of list L is c_L + rho with |rho|^2 = sum_m |cb[m][code_m]|^2 (orthogonal subspaces), so its ADC distance
+    # to q is |(q - c_L) - rho| >= |q - c_L| - R_L with R_L = the largest |rho| among the list's codes — known at add time, free at query time
+    cbn2 = (idx.codebooks(M, 256, d // M).astype(np.float64) ** 2).sum(2)   # [M][256]
+    rho2 = cbn2[np.arange(M)[None, :], e_codes.astype(np.int64)].sum(1)
+    R = np.zeros(nlist); np.maximum.at(R, e_lists, np.sqrt(rho2))
     q64 = Q.astype(np.float64)
     d2 = (q64 ** 2).sum(1)[:, None] + (cent ** 2).sum(1)[None, :] - 2.0 * (q64 @ cent.T)
     probed = np.argsort(d2, axis=1, kind="stable")[:, :nprobe]
     cb_n2 = (cb ** 2).sum(2)                                                # [M][256]
     tot = np.zeros(4); cand = 0
     death_hist = np.zeros(13, dtype=np.int64)
+    geo_dead = 0; geo_or_lb = 0
     by_rank = np.zeros((nprobe, 4)); cand_rank = np.zeros(nprobe)
     for b in range(B):
         r = q64[b][None, :] - cent[probed[b]]                               # [np][d]
@@ -53,6 +59,9 @@ def main():
         suffix = np.stack([mins[:, s:].sum(1) for s in (0, 32, 64)], 1)     # lower bound of what phases >= s add
         typical = np.stack([np.median(lut[:, :s, :], axis=2).sum(1) for s in (32, 64)], 1)   # a typical candidate's partial sum after 1 / 2 phases
         w = list_len[probed[b]].astype(np.float64)
+        dco = np.sqrt(np.maximum(d2[b, probed[b]], 0.0))
+        geo = np.maximum(dco - R[probed[b]], 0.0) ** 2 * (1.0 - 1e-4)
+        geo_dead += int(((geo > kth_sum[b]) & (np.arange(nprobe) > 0)).sum())
         csum = np.cumsum(mins, axis=1)                                      # partial lower bound after m + 1 subspaces
         first = np.where(csum > kth_sum[b], np.arange(M)[None, :], M).min(1)   # subspaces needed until the pair is provably dead (M: never)
         for p_ in range(1, nprobe):
@@ -71,6 +80,7 @@ def main():
                       "frac_typical_dead_after_phase2_with_min_rest": tot[2] / cand,
                       "frac_typical_dead_after_phase2_plain_partial_sum": tot[3] / cand,
                       "pairs_behind_probe0_by_subspaces_until_dead (bins of 8; last = never)": death_hist.tolist(),
+                      "pairs_behind_probe0_dead_by_the_geometric_bound": [geo_dead, B * (nprobe - 1)],
                       "dead_before_any_gather_by_probe_rank": [round(x, 3) for x in (by_rank[:, 0] / np.maximum(cand_rank, 1)).tolist()]}))
 
 
