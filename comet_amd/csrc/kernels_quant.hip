@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void pq_rowmin_kernel(const float* __restrict_
         const int pl = e / wcols, col = e - pl * wcols;
         const int pr = p0 + pl, q = pr / np, pi = pr - q * np;
         const int* so = seg_off + (long)q * (np + 1) + pi;
-        const bool lv = pi != 0 && so[1] != so[0];               // probe 0 was scanned in stage 1; empty lists have nothing to bound
+        const bool lv = so[1] != so[0] && so[0] != so[-pi];      // the query's first non-empty list was scanned in stage 1; empty lists have nothing to bound
         float r = 0.0f;
         if (lv) {
             const float qv = Qp[(long)q * ld + m_base * d + col];
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void pq_rowmin_kernel(const float* __restrict_
     }
 }
 // dead[pair] = 1 when no candidate of the pair's list can pass the query's bound: the serial float32 sum (the scan's order, m = 0 ..
-// M-1) of the row minima is above it (with the 4 ulp of slack of the scan's own test). Probe-0 pairs and empty lists are "dead" for stage 2.
+// M-1) of the row minima is above it (with the 4 ulp of slack of the scan's own test). Stage-1 pairs and empty lists are "dead" for stage 2.
 __global__ __launch_bounds__(256) void pq_lb_kernel(const float* __restrict__ rowmin, int M, int n_pairs, int np, const int* __restrict__ seg_off,
                                                     const unsigned* __restrict__ tq, unsigned char* __restrict__ dead, int* __restrict__ stats /*nullable: [pairs alive]*/) {
     extern __shared__ __attribute__((aligned(16))) float rml[];     // [64][M + 1]: the row minima of this workgroup's 64 pairs (coalesced loads; the sum itself is serial)
@@ -503,7 +503,8 @@ __global__ __launch_bounds__(256) void pq_lb_kernel(const float* __restrict__ ro
     const int q = i / np, pi = i - q * np;
     const int* so = seg_off + (long)q * (np + 1) + pi;
     unsigned char dd = 1;
-    if (pi != 0 && so[1] != so[0]) {
+    const bool behind = so[1] != so[0] && so[0] != so[-pi];      // a non-empty list behind the query's first non-empty one
+    if (behind) {
         const float* r = rml + threadIdx.x * (M + 1);
         float lb = 0.0f;
         for (int m = 0; m < M; m++) lb = lb + r[m];
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(256) void pq_lb_kernel(const float* __restrict__ ro
         dd = __float_as_uint(lb) > Ts ? 1 : 0;
     }
     dead[i] = dd;
-    if (stats) { if (!dd) atomicAdd(&stats[0], 1); if (pi != 0) atomicAdd(&stats[1], 1); }
+    if (stats) { if (!dd) atomicAdd(&stats[0], 1); if (behind) atomicAdd(&stats[1], 1); }
 }
 
 // order[] = the pair indices grouped by probed list (counting sort in LDS; pairs with nothing to scan go last; the
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
                                                          unsigned* __restrict__ order, unsigned* __restrict__ slist, AdcRec* __restrict__ qitems, int qcap,
                                                          int* __restrict__ qcount, int* __restrict__ queues, unsigned* __restrict__ tq, int* __restrict__ cursor, int n_q, int lead,
                                                          const long* __restrict__ list_base, int stage, const unsigned char* __restrict__ dead, int* __restrict__ used) {
-    // stage (two-stage fused search, see launch_adc_scan): 0 = every pair; 1 = only every query's nearest list (probe 0), which seeds the
+    // stage (two-stage fused search, see launch_adc_scan): 0 = every pair; 1 = only every query's nearest non-empty list, which seeds the
     // bounds; 2 = the other pairs that the lower-bound test (pq_lb_kernel) left alive. Pairs outside the stage take no slot at all.
     // lead (fused filter, np >= 2): every query's NEAREST list (probe 0) gets a duo of its own in the first 2 * n_q slots, so that
     // those pairs are scanned first and seed the per-query bound before the bulk of the candidates is tested against it.
@@ -576,7 +577,10 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
     auto key_of = [&](int i) {
         const int q = i / np, pi = i - q * np;
         const int* so = seg_off + (long)q * (np + 1) + pi;
-        if ((stage == 1 && pi != 0) || (stage == 2 && (pi == 0 || dead[i]))) return nlist;
+        if (stage) {     // "first": the query's nearest list that holds anything here (probe 0, or — on a rank that does not own it — the nearest owned list)
+            const bool first = so[0] == so[-pi] && so[1] != so[0];
+            if ((stage == 1 && !first) || (stage == 2 && (first || dead[i]))) return nlist;
+        }
         return (so[1] == so[0]) ? nlist : (int)min(probe_list[(long)q * ldp + pi], (unsigned)(nlist - 1));
     };
     for (int i = t; i < n_slots; i += 1024) { order[i] = ADC_HOLE; slist[i] = (unsigned)nlist; }
