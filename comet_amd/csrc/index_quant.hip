@@ -604,7 +604,11 @@ struct PQFamilyIndex : comet_index {
                 afl.cand = c->salloc<unsigned long long>((size_t)qb * ldD); afl.cursor = c->salloc<int32_t>(qb); afl.tq = c->salloc<uint32_t>(qb); afl.K = p.k; afl.thr = p.threshold;
                 if (!adc_stats.p) { adc_stats.reserve(16, c->stream, 0); HIP_CHECK(hipMemsetAsync(adc_stats.p, 0, 16, c->stream)); }
                 afl.stats = adc_stats.as<int32_t>();
-                afl.one_stage = p.mode == 1 ? 1 : 0;      // mode 1 ("strict"): the reference's literal work — every candidate of every probed list is scored
+                // mode 1 ("strict"): the reference's literal work — every candidate of every probed list is scored. On a list shard of more
+                // than two ranks the single pass is used as well: a rank owns the nearest list of only 1 / world of the queries, the bounds of
+                // the others are seeded by a farther list and remove little, and the second set of launches costs more than it saves
+                // (tools/shard_probe.py, 1M rows, B = 256: 4 ranks 0.69 ms two-stage vs 0.60 single pass; 2 ranks 0.75 vs 0.80)
+                afl.one_stage = (p.mode == 1 || shard_world > 2) ? 1 : 0;
             }
             for (int b0 = 0; b0 < B; b0 += qb) {
                 const int bn = std::min(qb, B - b0);
