@@ -138,7 +138,10 @@ def pmc_traffic(kernel, rows_local):
         try:
             pm = json.loads(f.read_text())
             for kname, kv in pm.get("kernels", {}).items():
-                if kname.split("<")[0].strip() == kernel or kernel + "_kernel" in kname:
+                # profile scope -> kernel symbols: the scope "flat_scan_f16" is the query-stationary tile flat_scan_q8_kernel since round 2
+                # (the cosine instantiation <0, ...> is the headline's; the 2 x 4 tile flat_scan_f16_kernel serves odd K-step counts)
+                names = {"flat_scan_f16": ("flat_scan_q8_kernelILi0E", "flat_scan_f16_kernel")}.get(kernel, (kernel + "_kernel",))
+                if kname.split("<")[0].strip() == kernel or any(nm in kname for nm in names):
                     per = kv.get("hbm_read_bytes_per_launch_corrected", 0) + kv.get("hbm_write_bytes_per_launch_uncalibrated", 0)
                     rows_ref = pm.get("rows", 1_000_000)
                     best = (per * rows_local / rows_ref, f"profiles/{f.name} (separate rocprofv3 --pmc pass: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, "
