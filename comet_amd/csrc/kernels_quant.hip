@@ -516,6 +516,109 @@ __global__ __launch_bounds__(256) void pq_lb_kernel(const float* __restrict__ ro
     if (stats) { if (!dd) atomicAdd(&stats[0], 1); if (behind) atomicAdd(&stats[1], 1); }
 }
 
+// The lower bound in one kernel, for 8-bit codebooks (KL = 256) and DSUB known at compile time: ONE WAVE per group of BND_GP pairs of
+// a query walks the subspaces IN ORDER, keeps every pair's running serial sum of row minima, and stops computing for a pair the
+// moment that sum passes the query's bound — on the bench corpus a pair dies after 37 of 96 subspaces on average (tools/prune_probe.py),
+// so 60 % of the entry arithmetic that bounds pq_rowmin_kernel is never done, and neither the M floats per pair nor a second
+// kernel are needed. A lane holds four codewords (k = lane + 64 j); an entry is formed exactly as pq_lut_kernel forms it; the
+// minimum over the wave is a reduce-scatter butterfly over the pairs; no LDS traffic besides the residual slices, no barrier.
+// A group takes every ng-th pair of its query (ng groups per query), so every wave holds a nearer and a farther list.
+// Group size (same box, 1M x 768, nprobe 32, B = 256; the two-kernel form takes 0.137 ms): 8 pairs 0.180 ms, 4 pairs 0.136,
+// 2 pairs 0.106, 1 pair 0.148 — a wave's subspace step is short, so few large groups (one wave per SIMD) cannot hide the latency
+// of the next subspace's codewords, while many small ones re-read the 8 KB codebook slice of every subspace from L2 once per wave
+// (2 pairs: ~1.8 GB per batch). Sharing the slice between the waves of a workgroup through an LDS ring is the next step.
+constexpr int BND_GP = 2;
+template <bool HAS_CENTROID, int DSUB>
+__global__ __launch_bounds__(64) void pq_bound_kernel(const float* __restrict__ Qp, int ld, const float* __restrict__ centroids,
+                                                      const float* __restrict__ codebooks, int M, int Ksub,
+                                                      const unsigned* __restrict__ probe_list, int ldp, int np, const int* __restrict__ seg_off, int n_q,
+                                                      const unsigned* __restrict__ tq, unsigned char* __restrict__ dead, int* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float res[];     // [BND_GP][M * DSUB] residuals of the group's pairs
+    const int ng = (np + BND_GP - 1) / BND_GP;                       // groups per query
+    const int q = blockIdx.x / ng, j0 = blockIdx.x - q * ng;
+    if (q >= n_q) return;
+    const int lane = threadIdx.x, dimc = M * DSUB;
+    const int* sor = seg_off + (long)q * (np + 1);
+    // pair t of the group: probe pi = j0 + t * ng; "behind" = a non-empty list behind the query's first non-empty one
+    unsigned mask = 0u;
+#pragma unroll
+    for (int t = 0; t < BND_GP; t++) {
+        const int pi = j0 + t * ng;
+        if (pi < np && sor[pi + 1] != sor[pi] && sor[pi] != sor[0]) mask |= 1u << t;
+    }
+    const unsigned behind = mask;
+    for (int t = 0; t < BND_GP; t++) {
+        if (!((mask >> t) & 1u)) continue;
+        const int pi = j0 + t * ng;
+        const float* cen = HAS_CENTROID ? centroids + (long)probe_list[(long)q * ldp + pi] * ld : nullptr;
+        for (int col = lane; col < dimc; col += 64) {
+            const float qv = Qp[(long)q * ld + col];
+            res[t * dimc + col] = HAS_CENTROID ? qv - cen[col] : qv;
+        }
+    }
+    const unsigned T = tq[q];
+    const unsigned Ts = T >= 0x7F800000u ? 0xFFFFFFFFu : __float_as_uint(__uint_as_float(T) * 1.0000005f);
+    float lb = 0.0f;                                                 // lanes 0 .. BND_GP-1: the running sum of pair `lane`
+    float cb[4][DSUB], cbn[4][DSUB];
+    auto load_cb = [&](int m, float (&dst)[4][DSUB]) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float* p = codebooks + ((long)m * Ksub + lane + 64 * j) * DSUB;
+#pragma unroll
+            for (int i = 0; i < DSUB; i++) dst[j][i] = p[i];
+        }
+    };
+    load_cb(0, cb);
+    __syncthreads();
+    for (int m = 0; m < M && mask; m++) {
+        if (m + 1 < M) load_cb(m + 1, cbn);
+        float v[BND_GP];
+#pragma unroll
+        for (int t = 0; t < BND_GP; t++) {
+            v[t] = __builtin_inff();
+            if (!((mask >> t) & 1u)) continue;                       // wave-uniform
+            const float* r = res + t * dimc + m * DSUB;
+            float rr[DSUB];
+#pragma unroll
+            for (int i = 0; i < DSUB; i++) rr[i] = r[i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float dsum = 0.0f;
+#pragma unroll
+                for (int i = 0; i < DSUB; i++) { const float diff = rr[i] - cb[j][i]; const float sq = diff * diff; dsum = dsum + sq; }
+                v[t] = fminf(v[t], dsum);
+            }
+        }
+#define BND_STEP(O) { const bool up = (lane & O) != 0; _Pragma("unroll") for (int t = 0; t < O; t++) { \
+            const float send = up ? v[t] : v[t + O], keep = up ? v[t + O] : v[t]; v[t] = fminf(keep, __shfl_xor(send, O, 64)); } }
+        if constexpr (BND_GP >= 8) BND_STEP(4)
+        if constexpr (BND_GP >= 4) BND_STEP(2)
+        if constexpr (BND_GP >= 2) BND_STEP(1)
+#undef BND_STEP
+        float mn = v[0];                                             // pair (lane & (BND_GP - 1)), minimum over this lane's group of BND_GP lanes
+#pragma unroll
+        for (int o = BND_GP; o < 64; o <<= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
+        bool alive = false;
+        if (lane < BND_GP && ((mask >> lane) & 1u)) { lb = lb + mn; alive = __float_as_uint(lb) <= Ts; }
+        mask = (unsigned)__ballot(alive) & ((1u << BND_GP) - 1u);
+        if (m + 1 < M) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < DSUB; i++) cb[j][i] = cbn[j][i];
+        }
+    }
+    // pairs still in the mask passed every subspace: their lower bound is within the query's bound — alive
+    if (lane < BND_GP) {
+        const int pi = j0 + lane * ng;
+        if (pi < np) {
+            const bool al = (mask >> lane) & 1u;
+            dead[(long)q * np + pi] = al ? 0 : 1;
+            if (stats) { if (al) atomicAdd(&stats[0], 1); if ((behind >> lane) & 1u) atomicAdd(&stats[1], 1); }
+        }
+    }
+}
+
 // order[] = the pair indices grouped by probed list (counting sort in LDS; pairs with nothing to scan go last; the
 // order inside a list is whatever the atomics give — results do not depend on it). One workgroup, nlist + 1 bins in LDS.
 __global__ __launch_bounds__(1024) void order_pairs_kernel(const unsigned* __restrict__ probe_list, int ldp, int np, const int* __restrict__ seg_off,
@@ -1105,6 +1208,22 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
         };
         if (!two_stage) { run_stage(0); continue; }
         run_stage(1);
+        static const bool bound_off = getenv("COMET_ADC_ROWMIN") != nullptr;      // the two-kernel form (row minima of every subspace, then the sums)
+        const size_t bnd_lds = (size_t)BND_GP * M * dsub * 4;
+        if (!bound_off && KL == 256 && Ksub == 256 && (dsub == 4 || dsub == 8 || dsub == 16) && bnd_lds <= 64 * 1024) {
+            {
+            ProfScope ps(c, "pq_bound");
+            const unsigned groups = (unsigned)(bn * ceil_div(np, BND_GP));
+#define BND_LAUNCH(HC, DS) pq_bound_kernel<HC, DS><<<dim3(groups), dim3(64), bnd_lds, c->stream>>>(Qb, ld, centroids, codebooks, M, Ksub, pl, ldp, np, so, bn, flt->tq + b0, dead, flt->stats)
+#define BND_DS(HC) do { switch (dsub) { case 4: BND_LAUNCH(HC, 4); break; case 8: BND_LAUNCH(HC, 8); break; default: BND_LAUNCH(HC, 16); break; } } while (0)
+            if (centroids) BND_DS(true); else BND_DS(false);
+#undef BND_DS
+#undef BND_LAUNCH
+            LAUNCH_CHECK();
+            }
+            run_stage(2);
+            continue;
+        }
         {
             ProfScope ps(c, "pq_rowmin");
             dim3 grid((unsigned)ceil_div(M, mw), (unsigned)ceil_div(n_pairs, ppw)), blk(256);
