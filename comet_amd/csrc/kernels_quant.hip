@@ -526,7 +526,9 @@ __global__ __launch_bounds__(256) void pq_lb_kernel(const float* __restrict__ ro
 // Group size (same box, 1M x 768, nprobe 32, B = 256; the two-kernel form takes 0.137 ms): 8 pairs 0.180 ms, 4 pairs 0.136,
 // 2 pairs 0.106, 1 pair 0.148 — a wave's subspace step is short, so few large groups (one wave per SIMD) cannot hide the latency
 // of the next subspace's codewords, while many small ones re-read the 8 KB codebook slice of every subspace from L2 once per wave
-// (2 pairs: ~1.8 GB per batch). Sharing the slice between the waves of a workgroup through an LDS ring is the next step.
+// (2 pairs: ~1.8 GB per batch). Built and measured as well: four such waves per workgroup sharing the slice through a three-stage
+// LDS-DMA ring two subspaces ahead, one voting barrier per subspace — 0.194 ms: a subspace step (~0.3 us) is far shorter than the
+// DMA's round trip, the ring would have to be six or more slices deep, and the workgroup lives as long as its slowest pair.
 constexpr int BND_GP = 2;
 template <bool HAS_CENTROID, int DSUB>
 __global__ __launch_bounds__(64) void pq_bound_kernel(const float* __restrict__ Qp, int ld, const float* __restrict__ centroids,
