@@ -245,20 +245,26 @@ void launch_interleave_codes(Ctx* c, const uint32_t* src_words, int M4, const ui
 __global__ __launch_bounds__(64) void probe_segments_kernel(const unsigned* __restrict__ probe_list, int ldp, const int* __restrict__ probe_cnt,
                                                             const int* __restrict__ list_len, int B, int np, int* __restrict__ seg_off,
                                                             int* __restrict__ cnts) {
-    int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= B) return;
-    int run = 0;
+    // one wave per query: lane p fetches the length of probe p (two dependent loads for the whole row instead of 2 * np in a chain), wave prefix sum
+    const int q = blockIdx.x, lane = threadIdx.x;
     const int npq = probe_cnt ? probe_cnt[q] : np;
-    for (int p = 0; p < np; p++) {
-        seg_off[(long)q * (np + 1) + p] = run;
-        if (p < npq) run += list_len[probe_list[(long)q * ldp + p]];
+    int run = 0;
+    for (int p0 = 0; p0 < np; p0 += 64) {
+        const int p = p0 + lane;
+        int len = 0;
+        if (p < np && p < npq) len = list_len[probe_list[(long)q * ldp + p]];
+        int inc = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+        if (p < np) seg_off[(long)q * (np + 1) + p] = run + inc - len;
+        run += __shfl(inc, 63, 64);
     }
-    seg_off[(long)q * (np + 1) + np] = run;
-    cnts[q] = run;
+    if (lane == 0) { seg_off[(long)q * (np + 1) + np] = run; cnts[q] = run; }
 }
 void launch_probe_segments(Ctx* c, const uint32_t* probe_list, int ldp, const int32_t* probe_cnt, const int32_t* list_len, int B, int np,
                            int32_t* seg_off, int32_t* cnts) {
-    probe_segments_kernel<<<dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, c->stream>>>(probe_list, ldp, probe_cnt, list_len, B, np, seg_off, cnts);
+    if (B <= 0) return;
+    probe_segments_kernel<<<dim3((unsigned)B), dim3(64), 0, c->stream>>>(probe_list, ldp, probe_cnt, list_len, B, np, seg_off, cnts);
     LAUNCH_CHECK();
 }
 __device__ __forceinline__ int find_probe(const int* __restrict__ so, int np, int pos) {
