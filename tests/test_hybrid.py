@@ -216,3 +216,28 @@ def test_segments_fused_search_edges(ctx):
         SegmentSet([a, c8]).search_batch(X[:1], 5)
     with pytest.raises(ValueError):
         SegmentSet([])
+
+
+@pytest.mark.gpu
+def test_segments_search_device_buffers(ctx):
+    """comet_segments_search_dev (queries and results resident in HBM, what a batched host loop uses) returns what the host-buffer
+    entry point returns, for IVFPQ segments too (their two-stage search runs inside the fused call)."""
+    import oracle_lib as orc
+    from comet_amd import FlatIndex, IVFPQIndex, L2_SQUARED
+    from comet_amd.index import SegmentSet
+    d, B, k = 32, 12, 7
+    X = orc.synth(341, 0, 5000 * d).reshape(5000, d); Q = orc.synth(342, 0, B * d).reshape(B, d)
+    ids = np.arange(1, 5001, dtype=np.uint32)
+    a = FlatIndex(ctx, d, L2_SQUARED); a.add_batch(ids[:2000], X[:2000])
+    b = IVFPQIndex(ctx, d, L2_SQUARED, 8, 8, 8); b.train(X[2000:4000]); b.add_batch(ids[2000:5000], X[2000:5000])
+    ss = SegmentSet([a, b])
+    hi, hs, hc = ss.search_batch(Q, k, nprobes=4)
+    q_dev = ctx.alloc(Q.nbytes); ctx.upload(q_dev, Q)
+    o_ids, o_sc, o_cn = ctx.alloc(B * k * 4), ctx.alloc(B * k * 4), ctx.alloc(B * 4)
+    ss.search_batch_dev(q_dev, B, k, o_ids, o_sc, o_cn, k, nprobes=4)
+    ctx.sync()
+    di, ds, dc = ctx.download(o_ids, (B, k), np.uint32), ctx.download(o_sc, (B, k), np.float32), ctx.download(o_cn, (B,), np.int32)
+    assert np.array_equal(dc, hc) and np.all(dc == k)
+    assert np.array_equal(di, hi) and np.array_equal(ds.view(np.uint32), hs.view(np.uint32))
+    for p in (q_dev, o_ids, o_sc, o_cn):
+        ctx.free(p)
