@@ -173,6 +173,55 @@ int main(void) {
         free(img);
         OK(comet_index_destroy(h)); OK(comet_index_destroy(h2));
     }
+    /* IVFPQ (ivfpq_index.go:113 New, :180 Train, :279 Add, :544 WriteTo; ivfpq_index_search.go:231 search): trained and filled on the GPU;
+     * the pruned (default) search and the every-candidate search (mode 1) return the same rows; the IVPQ image round-trips. */
+    {
+        enum { PN = 3000, PK = 8 };
+        comet_index* pq = NULL;
+        OK(comet_ivfpq_create(ctx, DIM, COMET_L2SQ, 8, 4, 8, &pq));
+        CHECK(comet_index_trained(pq) == 0, "untrained index reports trained");
+        { comet_search_params sp0; memset(&sp0, 0, sizeof(sp0)); sp0.k = 3; uint32_t i3[3]; float s3[3]; int32_t c3;
+          CHECK(comet_index_search(pq, Q[0], 1, &sp0, i3, s3, &c3, 3) == COMET_ERR_NOT_TRAINED, "search before Train accepted"); }
+        OK(comet_index_train(pq, &X[0][0], 2000));
+        static uint32_t pid[PN]; for (int i = 0; i < PN; i++) pid[i] = (uint32_t)(i + 1);
+        int64_t added = 0; OK(comet_index_add(pq, pid, &X[0][0], PN, &added, NULL)); CHECK(added == PN && comet_index_size(pq) == PN, "ivfpq add: %lld", (long long)added);
+        comet_search_params sp; memset(&sp, 0, sizeof(sp)); sp.k = PK; sp.nprobes = 4;
+        static uint32_t a_ids[NQ * PK], b_ids[NQ * PK]; static float a_sc[NQ * PK], b_sc[NQ * PK]; int32_t a_cn[NQ], b_cn[NQ];
+        OK(comet_index_search(pq, &Q[0][0], NQ, &sp, a_ids, a_sc, a_cn, PK));
+        sp.mode = 1; OK(comet_index_search(pq, &Q[0][0], NQ, &sp, b_ids, b_sc, b_cn, PK)); sp.mode = 0;
+        for (int q = 0; q < NQ; q++) {
+            CHECK(a_cn[q] == PK && b_cn[q] == PK, "ivfpq counts %d / %d", a_cn[q], b_cn[q]);
+            CHECK(memcmp(a_ids + q * PK, b_ids + q * PK, PK * 4) == 0 && memcmp(a_sc + q * PK, b_sc + q * PK, PK * 4) == 0, "ivfpq: pruned and every-candidate search differ (query %d)", q);
+            for (int i = 1; i < PK; i++) CHECK(a_sc[q * PK + i - 1] <= a_sc[q * PK + i], "ivfpq scores not ascending");
+        }
+        size_t need = 0, used = 0;
+        OK(comet_index_serialize(pq, NULL, 0, &need));
+        unsigned char* img = malloc(need);
+        OK(comet_index_serialize(pq, img, need, &used)); CHECK(used == need && memcmp(img, "IVPQ", 4) == 0, "ivfpq image");
+        comet_index* pq2 = NULL; OK(comet_ivfpq_create(ctx, DIM, COMET_L2SQ, 8, 4, 8, &pq2));
+        OK(comet_index_deserialize(pq2, img, need, &used)); CHECK(used == need && comet_index_size(pq2) == PN && comet_index_trained(pq2) == 1, "ivfpq image consumed %zu of %zu", used, need);
+        OK(comet_index_search(pq2, &Q[0][0], NQ, &sp, b_ids, b_sc, b_cn, PK));
+        CHECK(memcmp(a_ids, b_ids, sizeof(a_ids)) == 0 && memcmp(a_sc, b_sc, sizeof(a_sc)) == 0, "reloaded ivfpq index answers differently");
+        free(img);
+        OK(comet_index_destroy(pq)); OK(comet_index_destroy(pq2));
+    }
+    /* BM25 (bm25_index.go:143 New, :188 Add, :253 Remove; bm25_index_search.go:143 Execute): token ids in, scores descending, a removed
+     * document disappears, a document holding the query token twice outranks one holding it once (same length). */
+    {
+        comet_text_index* tx = NULL;
+        OK(comet_bm25_create(ctx, &tx));
+        const uint32_t d1[4] = {7, 7, 3, 4}, d2[4] = {7, 5, 3, 4}, d3[4] = {9, 5, 3, 4}, d4[2] = {1, 2};
+        OK(comet_bm25_add(tx, 11, d1, 4)); OK(comet_bm25_add(tx, 12, d2, 4)); OK(comet_bm25_add(tx, 13, d3, 4)); OK(comet_bm25_add(tx, 14, d4, 2));
+        CHECK(comet_bm25_num_docs(tx) == 4 && fabs(comet_bm25_avg_doc_len(tx) - 3.5) < 1e-12, "bm25 stats");
+        const uint32_t qt[1] = {7}; const int32_t qo[2] = {0, 1};
+        uint32_t t_ids[4]; float t_sc[4]; double t_sc64[4]; int32_t t_cn = -1;
+        OK(comet_bm25_search(tx, qt, qo, 1, 10, NULL, 0, t_ids, t_sc, t_sc64, &t_cn, 4));
+        CHECK(t_cn == 2 && t_ids[0] == 11 && t_ids[1] == 12 && t_sc64[0] > t_sc64[1] && t_sc64[1] > 0.0, "bm25 ranking: %d results, first %u", t_cn, t_ids[0]);
+        OK(comet_bm25_remove(tx, 11));
+        OK(comet_bm25_search(tx, qt, qo, 1, 10, NULL, 0, t_ids, t_sc, t_sc64, &t_cn, 4));
+        CHECK(t_cn == 1 && t_ids[0] == 12, "bm25 after remove: %d results", t_cn);
+        OK(comet_bm25_destroy(tx));
+    }
     /* segment layer (storage.go:489-626, vector leg): three Flat segments; id 5 re-written in the newest one. The fused call returns,
      * per query, the highest score per id over the per-segment top-k's, scores DESCENDING, cut to k (storage_merge.go:13-54). */
     {
@@ -205,6 +254,6 @@ int main(void) {
     }
     OK(comet_ctx_destroy(ctx));
     free(wb.p);
-    printf("abi_harness OK: create/add/search/filter/threshold/remove/errors/write_to/read_from/%d-thread concurrency/hnsw build+serialize/segment fan-out through the C ABI\n", THREADS);
+    printf("abi_harness OK: create/add/search/filter/threshold/remove/errors/write_to/read_from/%d-thread concurrency/hnsw build+serialize/ivfpq train+search+serialize/bm25/segment fan-out through the C ABI\n", THREADS);
     return 0;
 }
