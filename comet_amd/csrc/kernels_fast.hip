@@ -71,6 +71,9 @@ void launch_to_half_rows(Ctx* c, const float* X, int64_t n, int ld, void* Xh, in
 // the scan kernel
 // ------------------------------------------------------------------------------------------------
 constexpr int FB_M = 256;     // corpus rows per workgroup tile
+#ifndef FAST_ROW_AUX
+#define FAST_ROW_AUX 2    // cache policy of the streamed row pieces (LDS-DMA aux immediate): 2 = nt (non-temporal) — the shadow is read once per scan and should not displace the query slab and the keys in L2; narrow tile 0.287 -> 0.270 ms (71 % of 8 TB/s), wide tile unchanged (0 / 1 = sc0 / 3: 0.287 / 0.292 / 0.27, tools/scan_check)
+#endif
 constexpr int FB_UNIT = 128;  // rows per key unit (a wave row group): 2 emitted keys + 1 bound per (query, unit)
 constexpr int FB_N = 256;     // queries per tile (the whole batch)
 constexpr int FB_K = 64;      // halves per K step (128 bytes per row)
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_n64_kernel(const _Fl
 #pragma unroll
         for (int i = 0; i < 4; i++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + (long)kt * (256 * 128)),
-                                             (__attribute__((address_space(3))) void*)(sb + xdst[i]), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sb + xdst[i]), 16, 0, FAST_ROW_AUX);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc + (long)kt * 128),
                                          (__attribute__((address_space(3))) void*)(sb + qdst), 16, 0, 0);
     };
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_q8_kernel(const _Float16
     auto pre_advance = [&]() { pre_ptr += 256 * 128; if (++pre_kt == nk) { pre_kt = 0; pre_ptr += tile_jump; } };
     auto stage_piece = [&](long g, int i) {
         unsigned char* xb = smem + (g & (FQ_STAGES - 1)) * FQ_STAGE_BYTES;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre_ptr + poff[i]), (__attribute__((address_space(3))) void*)(xb + ldsoff[i]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre_ptr + poff[i]), (__attribute__((address_space(3))) void*)(xb + ldsoff[i]), 16, 0, FAST_ROW_AUX);
     };
     // ---- query fragments: [wave][K step][ks][lane] 16-byte pieces, 4 KiB contiguous per (wave, K step); the same for every tile ----
     const char* qbase = reinterpret_cast<const char*>(QF) + ((long)wid * nk) * 4096 + lane * 16;
