@@ -697,7 +697,8 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
         return (so[1] == so[0]) ? nlist : (int)min(probe_list[(long)q * ldp + pi], (unsigned)(nlist - 1));
     };
     for (int i = t; i < n_slots; i += 1024) { order[i] = ADC_HOLE; slist[i] = (unsigned)nlist; }
-    if (used && t == 0) used[0] = n_slots;
+    __shared__ int s_used;                                          // slots actually in use (the queue builder below walks only those)
+    if (t == 0) { s_used = n_slots; if (used) used[0] = n_slots; }
     const int lead0 = (lead && !identity) ? 2 * n_q : 0;            // slots of the leading region
     auto in_bulk = [&](int i) { return lead0 == 0 || (i % np) != 0; };
     if (identity) {
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
         int run = lead0 + wbase + inc - s;                          // exclusive prefix of this thread's bins (behind the leading region)
         for (int i = lo; i < hi; i++) {
             const int cnt = obin[i]; obin[i] = run; run += (i < nlist) ? ((cnt + 1) & ~1) : cnt;
-            if (i == nlist && used) used[0] = obin[i];              // slots in use: everything behind holds pairs with nothing to scan
+            if (i == nlist) { s_used = obin[i]; if (used) used[0] = obin[i]; }   // slots in use: everything behind holds pairs with nothing to scan
         }
         __syncthreads();
         // (pairs with nothing to scan — empty lists, pairs outside the stage — keep their slots as holes: no table is built for them)
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
     __syncthreads();
     // work queues: waves x and x + 8 build queue x (first and second half of its duos), two passes (count, then write)
     const int lane = t & 63, w = t >> 6, x = w & 7, h = w >> 3;
-    const int n_duos = n_slots >> 1, n_chunks = (n_duos + ADC_XCD_CHUNK - 1) / ADC_XCD_CHUNK;
+    const int n_duos = min(n_slots, (s_used + 1) & ~1) >> 1, n_chunks = (n_duos + ADC_XCD_CHUNK - 1) / ADC_XCD_CHUNK;
     const int nu = ((n_chunks - x + 7) >> 3) * ADC_XCD_CHUNK;       // duo positions of queue x
     const int umid = ((nu / 2 + 63) / 64) * 64, u0 = h ? min(umid, nu) : 0, u1 = h ? nu : min(umid, nu);
     auto segs_of = [&](int u, int& duo) -> int {
