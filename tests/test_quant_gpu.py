@@ -416,7 +416,8 @@ def test_merge_topk_packed_blocks(ctx):
         ctx.free(p)
 
 
-def test_ivfpq_two_stage_lower_bound_pruning(ctx):
+@pytest.mark.parametrize("metric", METRICS)
+def test_ivfpq_two_stage_lower_bound_pruning(ctx, metric):
     """The two-stage IVFPQ search (nearest lists first, then an exact lower bound per (query, list) pair — the serial float32 sum of the
     pair's table row minima — removes pairs whose candidates cannot pass the query's bound) returns the oracle's ids and scores, and
     the same as the every-candidate search (mode 1), on a clustered corpus where most pairs are removed and on an unclustered one
@@ -426,7 +427,7 @@ def test_ivfpq_two_stage_lower_bound_pruning(ctx):
     for tag, X in (("clustered", clustered(71, 16000, d, 24, 0.05)), ("uniform", synth(72, 6000, d))):
         n = len(X)
         ids = np.arange(1, n + 1, dtype=np.uint32)
-        g = IVFPQIndex(ctx, d, L2_SQUARED, nlist, M, nbits); o = orc.IVFPQ(d, L2_SQUARED, nlist, M, nbits)
+        g = IVFPQIndex(ctx, d, metric, nlist, M, nbits); o = orc.IVFPQ(d, metric, nlist, M, nbits)
         g.train(X[:4000]); assert o.train(X[:4000]) == 0
         g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
         Q = np.vstack([X[5:25] + np.float32(0.003), synth(73, 7, d) * np.float32(0.6), clustered(71, 9, d, 24, 0.4)])   # near corpus points, far from everything, between clusters
