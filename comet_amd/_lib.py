@@ -89,6 +89,9 @@ def load() -> C.CDLL:
         "comet_distance": (i32, [p, i32, p, p, i32, p]),
         "comet_distance_batch": (i32, [p, i32, p, i32, p, i32, p]),
         "comet_preprocess": (i32, [p, i32, p, i32, p]),
+        "comet_norm_batch": (i32, [p, p, i64, i32, p]),
+        "comet_normalize_batch": (i32, [p, p, i64, i32, p]),
+        "comet_scale_batch": (i32, [p, p, i64, i32, f32, p]),
         "comet_kmeans": (i32, [p, p, i64, i32, i32, i32, i32, p, p, C.POINTER(i32)]),
         "comet_nearest_centroid": (i32, [p, p, i64, i32, p, i32, i32, p]),
         "comet_flat_create": (i32, [p, i32, i32, pp]),

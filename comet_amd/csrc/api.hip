@@ -123,6 +123,28 @@ int comet_distance_batch(comet_ctx* c, int metric, const float* queries, int nq,
 int comet_distance(comet_ctx* c, int metric, const float* a, const float* b, int d, float* out) {
     return comet_distance_batch(c, metric, a, 1, b, d, out);
 }
+// Norm / Normalize / Scale distance.go:312-428 (host buffers; one upload, one download)
+static int vec_op(comet_ctx* c, const float* x, int64_t n, int32_t d, int op, float scalar, float* out) {
+    return guarded([&] {
+        if (n < 0 || d < 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "negative size");
+        if (n == 0 || (d == 0 && op != 0)) return (int)COMET_OK;
+        CallGuard g(c);
+        float* dx = c->salloc<float>((size_t)std::max<int64_t>(1, n * d));
+        float* dn = c->salloc<float>((size_t)n);
+        if (d > 0) c->h2d(dx, x, (size_t)n * d * sizeof(float));
+        if (op == 0 || op == 1) launch_vec_norm(c, dx, n, d, dn);
+        if (op == 0) { c->d2h(out, dn, (size_t)n * sizeof(float)); c->sync(); return (int)COMET_OK; }
+        float* dout = c->salloc<float>((size_t)n * d);
+        launch_vec_scale(c, dx, n, d, op == 1 ? dn : nullptr, scalar, dout);
+        c->d2h(out, dout, (size_t)n * d * sizeof(float));
+        c->sync();
+        return (int)COMET_OK;
+    });
+}
+int comet_norm_batch(comet_ctx* c, const float* x, int64_t n, int32_t d, float* out_norms) { return vec_op(c, x, n, d, 0, 0.0f, out_norms); }
+int comet_normalize_batch(comet_ctx* c, const float* x, int64_t n, int32_t d, float* out) { return vec_op(c, x, n, d, 1, 0.0f, out); }
+int comet_scale_batch(comet_ctx* c, const float* x, int64_t n, int32_t d, float scalar, float* out) { return vec_op(c, x, n, d, 2, scalar, out); }
+
 int comet_preprocess(comet_ctx* c, int metric, const float* x, int d, float* out) {
     return guarded([&] {
         check_metric(metric);

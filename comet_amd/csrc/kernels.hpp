@@ -17,6 +17,9 @@ inline int padded_dim(int d) { return (int)round_up(d, ROW_PAD); }
 void launch_ingest_rows(Ctx* c, int metric, const float* src, int64_t n, int d, float* dst, int ld, int32_t* zero_flag);
 // dst (n x d dense) <- src (n x ld padded): strip padding (for read-back)
 void launch_unpad_rows(Ctx* c, const float* src, int64_t n, int ld, float* dst, int d);
+// Norm / Normalize / Scale (distance.go:312-428) over dense rows; vec_scale with norms != nullptr normalises (zero rows unchanged)
+void launch_vec_norm(Ctx* c, const float* x, int64_t n, int d, float* norms);
+void launch_vec_scale(Ctx* c, const float* x, int64_t n, int d, const float* norms, float scalar, float* out);
 // Exact-arithmetic distances: D[q][row] = Calculate(Q[q], X[row]) with the reference's float32
 // evaluation order (sequential over the dimension, no FMA). X: n x ld, Q: B x ld, D: B x ldD.
 // elig (nullable): per-row eligibility bytes; ineligible rows get the EXCLUDED sentinel in D.

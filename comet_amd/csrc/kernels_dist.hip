@@ -269,6 +269,40 @@ void launch_dist_exact(Ctx* c, int metric, const float* X, int64_t n, int ld, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Norm / Normalize / Scale (distance.go:312-428) over dense rows. The norm is the reference's serial float32 sum (one thread per row: a
+// chain by definition), float32(sqrt(float64)); Normalize multiplies by 1 / norm (a zero row stays as it is); Scale is elementwise.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vec_norm_kernel(const float* __restrict__ x, long n, int d, float* __restrict__ norms) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const float* v = x + r * d;
+    float sum = 0.0f;
+    for (int i = 0; i < d; i++) { const float p = v[i] * v[i]; sum = sum + p; }
+    norms[r] = (float)__builtin_sqrt((double)sum);
+}
+// out[r][i] = x[r][i] * (norms ? (norms[r] == 0 ? 1 (unchanged) : 1 / norms[r]) : scalar)
+__global__ __launch_bounds__(256) void vec_scale_kernel(const float* __restrict__ x, long n, int d, const float* __restrict__ norms, float scalar, float* __restrict__ out) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * d) return;
+    if (norms) {
+        const float nv = norms[e / d];
+        if (nv == 0.0f) { out[e] = x[e]; return; }
+        const float sc = 1.0f / nv;
+        out[e] = x[e] * sc;
+    } else out[e] = x[e] * scalar;
+}
+void launch_vec_norm(Ctx* c, const float* x, int64_t n, int d, float* norms) {
+    if (n <= 0) return;
+    vec_norm_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, c->stream>>>(x, n, d, norms);
+    LAUNCH_CHECK();
+}
+void launch_vec_scale(Ctx* c, const float* x, int64_t n, int d, const float* norms, float scalar, float* out) {
+    if (n <= 0 || d <= 0) return;
+    vec_scale_kernel<<<dim3((unsigned)ceil_div(n * d, 256)), dim3(256), 0, c->stream>>>(x, n, d, norms, scalar, out);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Coarse quantiser, fast form (ivf_index_search.go:246-261: distances to ALL centroids, full sort, first nprobes).
 // Ranking nlist centroids exactly costs B * nlist serial 768-term chains for the sake of the nprobes nearest. Here:
 //   coarse_dot_kernel   S = Q . C^T in plain float32 FMAs (any order), plus ||q||^2 and ||c||^2

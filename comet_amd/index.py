@@ -143,6 +143,29 @@ class Context:
                                         out.ctypes.data_as(C.c_void_p)))
         return out
 
+    # Norm / Normalize / Scale (distance.go:312-428): one vector or a batch of rows
+    def _rows(self, x):
+        x = _f32(x)
+        return (x[None, :], True) if x.ndim == 1 else (x, False)
+
+    def norm(self, x):
+        X, one = self._rows(x)
+        out = np.empty(X.shape[0], np.float32)
+        check(self.lib.comet_norm_batch(self.h, X.ctypes.data_as(C.c_void_p), X.shape[0], X.shape[1], out.ctypes.data_as(C.c_void_p)))
+        return out[0] if one else out
+
+    def normalize(self, x) -> np.ndarray:
+        X, one = self._rows(x)
+        out = np.empty_like(X)
+        check(self.lib.comet_normalize_batch(self.h, X.ctypes.data_as(C.c_void_p), X.shape[0], X.shape[1], out.ctypes.data_as(C.c_void_p)))
+        return out[0] if one else out
+
+    def scale(self, x, scalar: float) -> np.ndarray:
+        X, one = self._rows(x)
+        out = np.empty_like(X)
+        check(self.lib.comet_scale_batch(self.h, X.ctypes.data_as(C.c_void_p), X.shape[0], X.shape[1], C.c_float(float(scalar)), out.ctypes.data_as(C.c_void_p)))
+        return out[0] if one else out
+
     def kmeans(self, vectors, k: int, kind: str = L2_SQUARED, max_iter: int = 20):
         """KMeans / KMeansSubspace (clustering.go:60,112). Returns (centroids, assignments) or (None, None)."""
         v = _f32(vectors)

@@ -100,6 +100,14 @@ COMET_API int comet_distance_batch(comet_ctx* ctx, int metric, const float* quer
                                    int d, float* out);
 /* Preprocess / PreprocessInPlace (out may alias x): distance.go:138-147,182-191,244-290 */
 COMET_API int comet_preprocess(comet_ctx* ctx, int metric, const float* x, int d, float* out);
+/* Norm distance.go:312-318 for n vectors of d floats (dense rows): out_norms[i] = float32(sqrt(float64(sum))), the sum formed serially in
+ * float32 as the Go loop does. */
+COMET_API int comet_norm_batch(comet_ctx* ctx, const float* x, int64_t n, int32_t d, float* out_norms);
+/* Normalize distance.go:374-399 / NormalizeInPlace :403-428 (out may alias x): every row times 1 / Norm(row); a zero row is returned
+ * unchanged (no error, unlike the cosine Preprocess). */
+COMET_API int comet_normalize_batch(comet_ctx* ctx, const float* x, int64_t n, int32_t d, float* out);
+/* Scale distance.go:341-347: out[i] = x[i] * scalar (out may alias x). */
+COMET_API int comet_scale_batch(comet_ctx* ctx, const float* x, int64_t n, int32_t d, float scalar, float* out);
 
 /* ---- k-means (clustering.go:60,112,259) ---------------------------------------------------- */
 /* KMeans / KMeansSubspace. out_centroids: min(k,n) x d; out_assign: n int32; *out_k = effective k */

@@ -268,3 +268,38 @@ def test_long_rows_sample_bound_and_its_generic_fallback(ctx):
     g3, o3 = build_pair(ctx, L2_SQUARED, X3)
     ids, sc, cnt = g3.search_batch(Z[:1], 10, mode=1)
     assert ids[0, :10].tolist() == list(range(1, 11)) == o3.search(Z[0], 10)[1].tolist()
+
+
+def test_norm_normalize_scale_bit_exact(ctx):
+    """Norm / Normalize / Scale (distance.go:312-428) through comet_norm_batch / comet_normalize_batch / comet_scale_batch: bit-identical to
+    the oracle's restatement — serial float32 sum, float32(sqrt(float64)), multiplication by 1 / norm; a zero vector comes back unchanged
+    from Normalize; the reference's documented examples (Norm([3, 4]) = 5; Scale([1, 2, 3], 2) = [2, 4, 6])."""
+    import json
+    from pathlib import Path
+    bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+    kats = json.loads((Path(__file__).parent / "golden" / "reference_kats.json").read_text())
+    for cse in kats["norm"]["cases"]:                  # distance_test.go:533-575 (TestNorm)
+        assert abs(float(ctx.norm(np.array(cse["v"], np.float32))) - cse["expected"]) <= 1e-6
+    for cse in kats["normalize"]["cases"]:             # distance_test.go:640-690 (TestNormalize)
+        assert np.allclose(ctx.normalize(np.array(cse["v"], np.float32)), np.array(cse["expected"], np.float32), atol=1e-6)
+    for cse in kats["scale"]["cases"]:                 # distance_test.go:577-600 (TestScale)
+        assert ctx.scale(np.array(cse["v"], np.float32), cse["s"]).tolist() == cse["expected"]
+    rng = np.random.default_rng(15)
+    assert ctx.norm(np.array([3, 4], np.float32)) == np.float32(5.0)
+    assert ctx.scale(np.array([1, 2, 3], np.float32), 2.0).tolist() == [2.0, 4.0, 6.0]
+    assert ctx.scale(np.array([1, 2, 3], np.float32), -1.0).tolist() == [-1.0, -2.0, -3.0]
+    z = np.zeros(7, np.float32)
+    assert ctx.norm(z) == 0.0 and np.array_equal(ctx.normalize(z), z)
+    for d in (1, 2, 3, 31, 128, 769):
+        X = (rng.standard_normal((37, d)) * rng.choice([1e-20, 1e-3, 1.0, 1e6, 1e18], (37, 1))).astype(np.float32)
+        X[5] = 0.0
+        gn, gz = ctx.norm(X), ctx.normalize(X)
+        for i in range(len(X)):
+            assert bits(gn[i]) == bits(orc.norm(X[i])), (d, i)
+            assert np.array_equal(bits(gz[i]), bits(orc.normalize(X[i]))), (d, i)
+        for sc in (0.0, -1.0, 0.3333333, 1e30, float("inf")):
+            with np.errstate(all="ignore"):
+                gs = ctx.scale(X, sc)
+            for i in (0, 5, 36):
+                assert np.array_equal(bits(gs[i]), bits(orc.scale(X[i], sc))), (d, i, sc)
+    assert np.array_equal(bits(ctx.normalize(X[3])), bits(orc.normalize(X[3])))       # single-vector form
