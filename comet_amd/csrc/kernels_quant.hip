@@ -1205,15 +1205,14 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
 #undef LUT_LAUNCH
                 LAUNCH_CHECK();
             }
-            {
-                ProfScope ps(c, "adc_scan");
+            {   // (timed through Ctx::launch_timed: no event-record packets around the kernel when a bench times this scope)
                 const long n_items = (long)(n_slots / 2) * segs;
                 long g = std::min<long>(n_items, (long)c->prop.multiProcessorCount);
                 g = std::max<long>(8, (g + 7) / 8 * 8);          // a multiple of the XCD count so that blockIdx % 8 is the XCD of every slot
                 static const bool prune_on = getenv("COMET_ADC_NO_PRUNE") == nullptr;
                 AdcArgs a{lut, codes, (const long*)list_base, list_len, so, elig, order, slist, qitems, qcount, queues, D ? D + (size_t)b0 * ldD : nullptr, (long)ldD, M, KL, mp, M4, np, (int)qcap,
                           flt ? flt->cand + (size_t)b0 * ldD : nullptr, flt ? flt->cursor + b0 : nullptr, flt ? flt->tq + b0 : nullptr, flt ? flt->K : 0, flt ? flt->thr : 0.0f, (flt && prune_on) ? 1 : 0};
-                adc_scan_kernel<<<dim3((unsigned)g), dim3(ADC_THREADS), lds, c->stream>>>(a);
+                c->launch_timed("adc_scan", adc_scan_kernel, dim3((unsigned)g), dim3(ADC_THREADS), lds, a);
                 LAUNCH_CHECK();
             }
         };
