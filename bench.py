@@ -475,7 +475,7 @@ def main():
             "recall_at_10": {"flat": 1.0},
             "scaling_note": None if world == 1 else "strong scaling of the named config: the 1M-row corpus is split over the ranks and every rank searches its shard for the "
                             "same 256 queries; per batch a rank keeps ~0.15 ms that does not shrink with its shard (post stage per shard, query preparation, "
-                            "exchange + merge, launch gaps), so the measured single-GPU shard timings predict 1.6x / 2.4x / 3.0x at 2 / 4 / 8 GPUs (DESIGN.md 3.9)",
+                            "exchange + merge, launch gaps), so the measured single-GPU shard timings predict 1.7x / 2.4x / 3.1x at 2 / 4 / 8 GPUs (DESIGN.md 3.9)",
         }
         if world == 1 and not args.no_cpu_baseline:
             last = ptrs[(args.steps - 1) % 3]
