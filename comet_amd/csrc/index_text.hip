@@ -101,13 +101,65 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(const double* __r
     const int* tl = touched + (long)q * tcap;
     unsigned long long* tk = tkeys + (long)q * tcap;
     const int total = (int)min((long)tcount[q * BM_TCOUNT_STRIDE], tcap);
-    // pass 0: keys of the touched documents
-    for (int i = t; i < total; i += BM_THREADS) tk[i] = d2key_desc(row[tl[i]]);
-    __syncthreads();
     const int kq_all = (K <= 0 || K >= total) ? total : K;          // `k <= 0 || k >= len(scores)` -> all (:330)
     const int kq = kq_all < k_cap ? kq_all : k_cap;                 // what the caller's rows can hold
     KP* sel = (kq > BM_KMAX) ? slab + (long)q * slab_ld : sel_lds;
-    if (kq > 0) {
+    // Dense form, for a query that touched a good part of the collection and wants few results (a frequent token touches most
+    // documents: 99 of 100 k in the bench): the touched list, its gather of 8-byte accumulators and the 64-bit keys written to and
+    // re-read from HBM by every radix pass below (256 queries x 100 k x 12 bytes do not fit in any cache: ~0.08 ms per pass, five
+    // passes) are replaced by two coalesced walks over the accumulator row itself — untouched documents hold exactly 0.0, touched
+    // ones a score > 0. Walk 1: every thread's smallest composite (key, document index); the kq-th smallest of the 1024 minima —
+    // distinct documents — bounds the kq-th smallest composite of the row. Walk 2: the composites at or under the bound (a few dozen)
+    // are collected, sorted, and the first kq are the result. More than BM_SMALL of them (mass ties): the radix form below.
+    bool done = false;
+    if (kq > 0 && kq <= 64 && (long)total * 16 >= nd && nd >= BM_THREADS) {
+        KP mine; mine.key = ~0ull; mine.pos = 0xFFFFFFFFu; mine.pad = 0;
+        for (long i = t; i < nd; i += BM_THREADS) { const double v = row[i]; if (v != 0.0) { const unsigned long long k = d2key_desc(v); if (k < mine.key) { mine.key = k; mine.pos = (unsigned)i; } } }
+        sel_lds[t] = mine;                                           // (ascending i: of equal keys the lowest document index stays)
+        if (t == 0) s_n = 0;
+        __syncthreads();
+        auto sort_lds = [&](KP* a, int n2) {                        // bitonic, ascending by (key, pos)
+            for (int k2 = 2; k2 <= n2; k2 <<= 1)
+                for (int j = k2 >> 1; j > 0; j >>= 1) {
+                    for (int i = t; i < n2; i += BM_THREADS) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            KP x = a[i], y = a[ixj];
+                            const bool gt = (x.key > y.key) || (x.key == y.key && x.pos > y.pos);
+                            if (gt == ((i & k2) == 0)) { a[i] = y; a[ixj] = x; }
+                        }
+                    }
+                    __syncthreads();
+                }
+        };
+        sort_lds(sel_lds, BM_THREADS);
+        const KP bnd = sel_lds[kq - 1];                              // (an unused thread's ~0 minimum here: everything passes, the count below decides)
+        __syncthreads();
+        KP* col = sel_lds + BM_THREADS;                              // BM_KMAX - BM_THREADS = BM_SMALL slots
+        for (long i = t; i < nd; i += BM_THREADS) {
+            const double v = row[i];
+            if (v != 0.0) {
+                const unsigned long long k = d2key_desc(v);
+                if (k < bnd.key || (k == bnd.key && (unsigned)i <= bnd.pos)) { const int sl = atomicAdd(&s_n, 1); if (sl < BM_SMALL) { col[sl].key = k; col[sl].pos = (unsigned)i; col[sl].pad = 0; } }
+            }
+        }
+        __syncthreads();
+        const int members = s_n;
+        if (members <= BM_SMALL) {                                   // (>= kq: the kq smallest minima are among them)
+            int n2 = 1; while (n2 < members) n2 <<= 1;
+            for (int i = members + t; i < n2; i += BM_THREADS) { col[i].key = ~0ull; col[i].pos = 0xFFFFFFFFu; }
+            __syncthreads();
+            sort_lds(col, n2);
+            if (t < kq) { const KP x = col[t]; sel_lds[t] = x; }     // kq <= 64 < BM_THREADS: no overlap between source and destination
+            __syncthreads();
+            done = true;
+        }
+        __syncthreads();
+    }
+    if (kq > 0 && !done) {
+    // pass 0: keys of the touched documents
+    for (int i = t; i < total; i += BM_THREADS) tk[i] = d2key_desc(row[tl[i]]);
+    __syncthreads();
         // Byte-wise radix select on the keys; as soon as the bin that holds the kq-th composite has <= BM_SMALL members they are
         // ranked directly in LDS as (key, doc index) composites — usually after two or three passes instead of 8 + 4.
         unsigned long long prefix = 0, mask = 0; int remaining = kq;
