@@ -446,6 +446,21 @@ __global__ __launch_bounds__(256) void coarse_dot_mfma_kernel(const float* __res
     }
 }
 
+template <int KR>
+__device__ __forceinline__ unsigned cq_kappa_wave(const unsigned* keys, int nlist, int np, int lane) {
+    unsigned kr[KR];
+#pragma unroll
+    for (int j = 0; j < KR; j++) kr[j] = (j * 64 + lane < nlist) ? keys[j * 64 + lane] : 0xFFFFFFFFu;
+    unsigned kth = 0u;
+    for (int bit = 31; bit >= 0; bit--) {
+        const unsigned tv = kth | ((1u << bit) - 1u);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < KR; j++) cnt += (int)__builtin_popcountll(__ballot(j * 64 + lane < nlist && kr[j] <= tv));
+        if (cnt < np) kth |= 1u << bit;
+    }
+    return kth;
+}
 template <int METRIC>
 __global__ __launch_bounds__(256) void coarse_pick_kernel(const float* __restrict__ S, long ldS, const float* __restrict__ qn, const float* __restrict__ cn,
                                                           const float* __restrict__ C, int nlist, int ld, int dim, const float* __restrict__ Qp, int np,
@@ -482,9 +497,19 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(const float* __restric
     float E;
     if constexpr (METRIC == COMET_COSINE) E = 4.0f * ((float)dim + 2.0f) * u * nq * nc + 2.0e-7f;
     else E = 4.0f * ((float)dim + 3.0f) * u * (nq + nc) * (nq + nc);
-    // kappa: the np-th smallest key, bit by bit from the top (one barrier per bit: the wave counts alternate between two slots;
-    // a nibble per step with 16 ballot counters was measured and is slower: 0.041 vs 0.037 ms)
+    // kappa: the np-th smallest key, bit by bit from the top. Up to 4096 lists ONE wave does it alone with the keys in registers
+    // (16 or 64 per lane): a step is a ballot and a scalar popcount per register — no LDS traffic, no barrier (an s_memtime trace put
+    // the four-wave form below, one barrier and two LDS round trips per bit, at 39 k of the kernel's 87 k clocks).
     unsigned kth = 0u;
+    __shared__ unsigned s_kth;
+    if (nlist <= 4096) {
+        if (w == 0) kth = nlist <= 1024 ? cq_kappa_wave<16>(keys, nlist, np, lane) : cq_kappa_wave<64>(keys, nlist, np, lane);
+        if (t == 0) s_kth = kth;
+        __syncthreads();
+        kth = s_kth;
+    } else
+    // (one barrier per bit: the wave counts alternate between two slots; a nibble per step with 16 ballot counters was measured and
+    // is slower: 0.041 vs 0.037 ms)
     for (int bit = 31; bit >= 0; bit--) {
         const unsigned tv = kth | ((1u << bit) - 1u);
         int cnt = 0;
