@@ -533,11 +533,23 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(const float* __restric
         const unsigned l = list[ci];
         const float* __restrict__ cr = C + (long)l * ld;
         float acc = 0.0f;
-        for (int i = 0; i < ld; i += 4) {
-            const f32x4 cv = *reinterpret_cast<const f32x4*>(cr + i);
-            const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + i);
-            acc = acc_step<METRIC>(acc, qv[0], cv[0]); acc = acc_step<METRIC>(acc, qv[1], cv[1]);
-            acc = acc_step<METRIC>(acc, qv[2], cv[2]); acc = acc_step<METRIC>(acc, qv[3], cv[3]);
+        // the chain is serial, its operands are not: 32 elements of the centroid row are requested two blocks ahead (ld is a multiple of 32),
+        // so the thread — one of ~40 at work in the workgroup — waits for the first block only
+        f32x4 cur[8], nxt[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) cur[j] = *reinterpret_cast<const f32x4*>(cr + j * 4);
+        for (int i0 = 0; i0 < ld; i0 += 32) {
+            const int in = min(i0 + 32, ld - 32);
+#pragma unroll
+            for (int j = 0; j < 8; j++) nxt[j] = *reinterpret_cast<const f32x4*>(cr + in + j * 4);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + i0 + j * 4);
+                acc = acc_step<METRIC>(acc, qv[0], cur[j][0]); acc = acc_step<METRIC>(acc, qv[1], cur[j][1]);
+                acc = acc_step<METRIC>(acc, qv[2], cur[j][2]); acc = acc_step<METRIC>(acc, qv[3], cur[j][3]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) cur[j] = nxt[j];
         }
         const float d = acc_finish<METRIC>(acc);
         comp[ci] = ((unsigned long long)cq_f2key(__float_as_uint(d)) << 32) | l;
