@@ -497,13 +497,14 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(const float* __restric
     float E;
     if constexpr (METRIC == COMET_COSINE) E = 4.0f * ((float)dim + 2.0f) * u * nq * nc + 2.0e-7f;
     else E = 4.0f * ((float)dim + 3.0f) * u * (nq + nc) * (nq + nc);
-    // kappa: the np-th smallest key, bit by bit from the top. Up to 4096 lists ONE wave does it alone with the keys in registers
-    // (16 or 64 per lane): a step is a ballot and a scalar popcount per register — no LDS traffic, no barrier (an s_memtime trace put
-    // the four-wave form below, one barrier and two LDS round trips per bit, at 39 k of the kernel's 87 k clocks).
+    // kappa: the np-th smallest key, bit by bit from the top. Up to 1024 lists ONE wave does it alone with the keys in registers
+    // (16 per lane): a step is a ballot and a scalar popcount per register — no LDS traffic, no barrier (an s_memtime trace put
+    // the four-wave form below, one barrier and two LDS round trips per bit, at 39 k of the kernel's 87 k clocks). With 64 registers
+    // per lane (4096 lists) the one wave is slower than the four (0.082 vs 0.053 ms): 2048 dependent ballot / popcount pairs.
     unsigned kth = 0u;
     __shared__ unsigned s_kth;
-    if (nlist <= 4096) {
-        if (w == 0) kth = nlist <= 1024 ? cq_kappa_wave<16>(keys, nlist, np, lane) : cq_kappa_wave<64>(keys, nlist, np, lane);
+    if (nlist <= 1024) {
+        if (w == 0) kth = cq_kappa_wave<16>(keys, nlist, np, lane);
         if (t == 0) s_kth = kth;
         __syncthreads();
         kth = s_kth;
