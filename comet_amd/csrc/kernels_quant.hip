@@ -690,11 +690,14 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
     auto key_of = [&](int i) {
         const int q = i / np, pi = i - q * np;
         const int* so = seg_off + (long)q * (np + 1) + pi;
-        if (stage) {     // "first": the query's nearest list that holds anything here (probe 0, or — on a rank that does not own it — the nearest owned list)
-            const bool first = so[0] == so[-pi] && so[1] != so[0];
-            if ((stage == 1 && !first) || (stage == 2 && (first || dead[i]))) return nlist;
-        }
-        return (so[1] == so[0]) ? nlist : (int)min(probe_list[(long)q * ldp + pi], (unsigned)(nlist - 1));
+        // every operand is fetched before anything is decided (no early return): a thread's keys are sixteen independent load groups in
+        // flight instead of a chain of dependent round trips
+        const int s0 = so[0], s1 = so[1], sr = so[-pi];
+        const unsigned pl = probe_list[(long)q * ldp + pi];
+        const unsigned char dd = stage == 2 ? dead[i] : (unsigned char)0;
+        const bool first = s0 == sr && s1 != s0;     // the query's nearest list that holds anything here (probe 0, or — on a rank that does not own it — the nearest owned list)
+        const bool out = (stage == 1 && !first) || (stage == 2 && (first || dd)) || s1 == s0;
+        return out ? nlist : (int)min(pl, (unsigned)(nlist - 1));
     };
     for (int i = t; i < n_slots; i += 1024) { order[i] = ADC_HOLE; slist[i] = (unsigned)nlist; }
     __shared__ int s_used;                                          // slots actually in use (the queue builder below walks only those)
