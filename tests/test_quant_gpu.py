@@ -448,3 +448,22 @@ def test_ivfpq_two_stage_lower_bound_pruning(ctx, metric):
             g.remove(i); assert o.remove(i) == 0
         check_search(g, o, Q, 10, 8)
         check_search(g, o, Q, 64, 24)
+
+
+@pytest.mark.parametrize("d,M", [(32, 8), (128, 8), (96, 8), (48, 24)])      # dsub 4, 16: the one-kernel lower bound; 12, 2: the two-kernel form
+def test_ivfpq_two_stage_subspace_widths(ctx, d, M):
+    """The lower-bound kernels of the two-stage search are instantiated per subspace width (pq_bound_kernel for dsub 4 / 8 / 16 with 8-bit
+    codebooks, pq_rowmin_kernel + pq_lb_kernel otherwise): every width returns the oracle's rows, and the pruned search the every-candidate one's."""
+    nlist, nbits = 16, 8
+    X = clustered(81 + d, 9000, d, 16, 0.05)
+    ids = np.arange(1, len(X) + 1, dtype=np.uint32)
+    g = IVFPQIndex(ctx, d, L2_SQUARED, nlist, M, nbits); o = orc.IVFPQ(d, L2_SQUARED, nlist, M, nbits)
+    g.train(X[:3000]); assert o.train(X[:3000]) == 0
+    g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
+    Q = np.vstack([X[7:19] + np.float32(0.002), clustered(82 + d, 5, d, 16, 0.3)])
+    a0, b0 = g.stat("adc_pairs_alive"), g.stat("adc_pairs_behind_nearest")
+    for k, npb in ((3, 4), (10, 16)):
+        check_search(g, o, Q, k, npb)
+        m0 = g.search_batch(Q, k, nprobes=npb); m1 = g.search_batch(Q, k, nprobes=npb, mode=1)
+        assert np.array_equal(m0[2], m1[2]) and np.array_equal(m0[0], m1[0]) and np.array_equal(bits(m0[1]), bits(m1[1]))
+    assert g.stat("adc_pairs_behind_nearest") > b0 and g.stat("adc_pairs_alive") - a0 < g.stat("adc_pairs_behind_nearest") - b0
