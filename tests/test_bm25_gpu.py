@@ -71,3 +71,23 @@ def test_bm25_empty_and_flush(ctx):
     assert g.num_docs() == 1
     ids, sc, sc64, cnt = g.search_batch([[6]], 5)
     assert cnt[0] == 1 and ids[0, 0] == 2
+
+
+def test_bm25_dense_topk_form(ctx):
+    """Queries that touch most of the collection and want few results go through the dense form of the top-K (two walks over the
+    accumulator row, bm25_topk_kernel): frequent tokens, duplicated documents (equal scores: lowest document index first), soft
+    deletes, a document filter, k from 1 to 64 and beyond (65: the list form again) — float64 bit patterns as always."""
+    docs = make_docs(6000, 300, 7)
+    keys = sorted(docs)
+    for j in range(0, 400, 4):                       # copies of earlier documents: exact score ties
+        docs[keys[2000 + j]] = docs[keys[j]].copy()
+    g, o = build(ctx, docs)
+    frequent = [[0], [0, 1], [1, 2, 0, 3], [0, 0, 1], [2, 7, 0]]            # token 0 is in nearly every document
+    for k in (1, 10, 64, 65):
+        check(g, o, frequent, k)
+    for d in keys[:300:3]:
+        g.remove(d); o.remove(d)
+    check(g, o, frequent, 10)
+    check(g, o, frequent, 10, filter_ids=keys[1::2])
+    g.flush(); o.flush()
+    check(g, o, frequent, 25)
