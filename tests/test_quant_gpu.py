@@ -115,6 +115,18 @@ def test_ivf_coarse_fast_ranking_matches_exact(ctx, metric):
     check_search(g, o, Q, 0, 3)
 
 
+@pytest.mark.parametrize("d", [256, 288, 800])
+def test_ivf_coarse_product_k_splits(ctx, d):
+    """The coarse product runs on MFMA with K split over up to four workgroups per tile when there are at least eight 32-wide K chunks
+    (coarse_dot_mfma_kernel; planes added by coarse_pick_kernel): 8 chunks (4 x 2), 9 (3 x 3, uneven tail), 25 (4 splits of 7, 7, 7, 4)."""
+    n, nlist = 5000, 64
+    X = clustered(91 + d, n, d, 40, 0.3)
+    g, o = build_ivf(ctx, L2_SQUARED, X, X[:2000], nlist)
+    Q = np.vstack([clustered(92 + d, 10, d, 40, 0.3), X[:3], g.centroids(nlist)[2:4]])
+    for nprobes in (1, 5, 16):
+        check_search(g, o, Q, 10, nprobes)
+
+
 @pytest.mark.parametrize("metric", METRICS)
 def test_ivf_matches_oracle(ctx, metric):
     n, d, nlist = 3000, 48, 24
