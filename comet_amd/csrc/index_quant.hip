@@ -84,6 +84,9 @@ struct ListLayout {
     // compiled (host)
     std::vector<int32_t> len_h; std::vector<int64_t> base_h; std::vector<uint32_t> row_of_slot_h;
     int64_t nslots = 0; int max_len = 0;
+    uint64_t version = 0;                  // bumped by every compile (derived device state, e.g. the IVF fp16 shadow, follows it)
+    int64_t total_tiles256 = 0;            // sum over lists of ceil(len / 256)
+    std::map<int, std::pair<int64_t, int64_t>> bound_cache;   // np -> (max candidates, max 64-row units) of one query
     // compiled (device)
     DevBuf row_of_slot, ids_slot, list_base, list_len;
     std::unordered_map<uint32_t, int> id_count;
@@ -101,8 +104,9 @@ struct ListLayout {
         for (int64_t i = 0; i < n; i++) len_h[list_of[i]]++;
         base_h.assign(nlist, 0);
         int64_t run = 0; max_len = 0;
-        for (int l = 0; l < nlist; l++) { base_h[l] = run; run += round_up(len_h[l], align); max_len = std::max(max_len, len_h[l]); }
-        nslots = run;
+        total_tiles256 = 0;
+        for (int l = 0; l < nlist; l++) { base_h[l] = run; run += round_up(len_h[l], align); max_len = std::max(max_len, len_h[l]); total_tiles256 += ceil_div(len_h[l], 256); }
+        nslots = run; version++; bound_cache.clear();
         row_of_slot_h.assign(std::max<int64_t>(nslots, 1), 0xFFFFFFFFu);
         std::vector<uint32_t> ids_slot_h(std::max<int64_t>(nslots, 1), 0);
         std::vector<int64_t> cur(base_h);
@@ -119,12 +123,17 @@ struct ListLayout {
         dirty = false;
     }
     // upper bound on the candidates of one query probing `np` lists: the np longest lists
-    int64_t max_candidates(int np) const {
+    int64_t max_candidates(int np) { return bounds(np).first; }
+    // upper bound on the 64-row units of one query probing `np` lists
+    int64_t max_units(int np) { return bounds(np).second; }
+    const std::pair<int64_t, int64_t>& bounds(int np) {
+        auto it = bound_cache.find(np);
+        if (it != bound_cache.end()) return it->second;
         std::vector<int32_t> l(len_h);
-        if (np >= nlist) { int64_t s = 0; for (auto x : l) s += x; return s; }
-        std::partial_sort(l.begin(), l.begin() + np, l.end(), std::greater<int32_t>());
-        int64_t s = 0; for (int i = 0; i < np; i++) s += l[i];
-        return s;
+        const int m = std::min(np, nlist);
+        if (m < nlist) std::partial_sort(l.begin(), l.begin() + m, l.end(), std::greater<int32_t>());
+        int64_t s = 0, u = 0; for (int i = 0; i < m; i++) { s += l[i]; u += ceil_div(l[i], 64); }
+        return bound_cache[np] = std::make_pair(s, u);
     }
     // rows (arrival indices) surviving a flush, in arrival order
     std::vector<int64_t> survivors(const std::unordered_set<uint32_t>& deleted) const {
@@ -192,6 +201,32 @@ struct IVFIndex : comet_index {
     DevBuf centroids;   // nlist x ld
     DevBuf V;           // arrival-order rows, n x ld
     ListLayout lay;
+    // fp16 shadow for the MFMA fast path (kernels_ivf.hip): slot-ordered rows, squared norms per slot, magnitude statistics;
+    // rebuilt lazily when the slot layout was recompiled (shadow_version != lay.version)
+    int ldh = 0;
+    DevBuf Vh, rn_slot, stats_dev, scan_counts;
+    uint64_t shadow_version = 0;
+    float xmax_abs = 0.0f, xmax_norm2 = 0.0f;
+    int64_t st_candidates = 0, st_overflows = 0, st_expansions = 0, st_fast_queries = 0, st_strict_queries = 0;
+    // deferred verification of fast-path searches, as FlatIndex does it: the post stage leaves per-query overflow flags (candidate
+    // list beyond its LDS capacity: adversarial clustering / mass ties) which travel to pinned memory on a second stream;
+    // search_finish() waits for the search's event and re-runs the flagged queries on the exact kernels
+    struct Pending {
+        bool active = false; uint64_t ticket = 0; hipEvent_t ev = nullptr, ev_post = nullptr;
+        int B = 0, k_cap = 0, nfast_slices = 0, slice = 256;
+        const float* queries = nullptr; comet_search_params p{}; std::vector<uint32_t> flt;
+        uint32_t* out_ids = nullptr; float* out_scores = nullptr; int32_t* out_counts = nullptr;
+        int32_t* flags = nullptr;   // pinned: per fast slice [256 overflow flags | 4 stats]
+        int32_t* dflags = nullptr;  // the same slices in HBM
+    };
+    hipStream_t copy_stream = nullptr;
+    static constexpr int kRing = 8, kSliceInts = 260, kMaxSlices = 64, kFastBatch = 256;
+    Pending ring[kRing];
+    uint64_t next_ticket = 1;
+    ~IVFIndex() override {
+        for (auto& r : ring) { if (r.ev) (void)hipEventDestroy(r.ev); if (r.ev_post) (void)hipEventDestroy(r.ev_post); if (r.flags) (void)hipHostFree(r.flags); if (r.dflags) (void)hipFree(r.dflags); }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    }
 
     int64_t size() const override { return lay.n; }
     int default_nprobes() const override { return (int)std::sqrt((double)nlist); }   // ivf_index.go:406-413
@@ -362,11 +397,175 @@ struct IVFIndex : comet_index {
         lay.keep_rows(keep);
         deleted.clear(); deleted_dirty = true;
     }
-    // ivfIndexSearch.searchSingleQuery ivf_index_search.go:217-322
-    void search_dev(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
-                    int32_t* out_counts, int k_cap) override {
+    // ---- MFMA fast path (kernels_ivf.hip) ----
+    void build_shadow() {
+        lay.compile(c);
+        if (shadow_version == lay.version) return;
+        const int64_t ns = std::max<int64_t>(lay.nslots, 64);
+        Vh.reserve((size_t)ns * ldh * 2, c->stream, 0);
+        rn_slot.reserve((size_t)ns * 4, c->stream, 0);
+        stats_dev.reserve(8, c->stream, 0);
+        c->zero(stats_dev.p, 8);
+        launch_ivf_shadow(c, V.as<float>(), ld, lay.row_of_slot.as<uint32_t>(), lay.nslots, Vh.p, ldh, rn_slot.as<float>(), stats_dev.as<uint32_t>());
+        uint32_t hs[2] = {0, 0};
+        c->d2h(hs, stats_dev.p, 8);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        std::memcpy(&xmax_abs, &hs[0], 4); std::memcpy(&xmax_norm2, &hs[1], 4);
+        shadow_version = lay.version;
+    }
+    bool fast_usable(int B, const comet_search_params& p) {
+        if (p.mode == 1 || lay.n < 1 || B < 1) return false;
+        static const bool off = getenv("COMET_IVF_STRICT") != nullptr;
+        if (off && p.mode != 2) return false;
+        if (nlist > ivf_fast_max_lists() || p.k < 1 || p.k > 1024) return false;
+        build_shadow();
+        return std::isfinite(xmax_abs) && xmax_abs <= 60000.0f && std::isfinite(xmax_norm2);
+    }
+    // up to 256 raw queries through the fast path; writes the final ids / scores / counts of the slice
+    void search_fast(const float* queries_dev, int bn, const comet_search_params& p, const uint8_t* elig, uint32_t* out_ids, float* out_scores,
+                     int32_t* out_counts, int k_cap, Pending* pend) {
+        ScratchMark sm(c);
+        const int np = sanitize_nprobes(p.nprobes, nlist);
+        const int NB = kFastBatch;
+        float* Qp = c->salloc<float>((size_t)bn * ld);
+        int32_t* zflag = c->salloc<int32_t>(bn);
+        void* Qh = c->scratch_alloc((size_t)NB * ldh * 2 * 2);      // row-major copy (the scan gathers its query rows from it) + the fragment-ordered copy of the Flat scan
+        float* qn = c->salloc<float>(NB);
+        float* err = c->salloc<float>(NB);
+        int32_t* flags = pend->dflags + (size_t)pend->nfast_slices * kSliceInts;
+        int32_t* ovf = flags; int32_t* st = flags + 256;
+        const int fmode = metric == COMET_COSINE ? 0 : 1;
+        const float xn2 = metric == COMET_COSINE ? 1.0002f : xmax_norm2;
+        if (prep_queries_fused_ok(dim)) launch_prep_queries_fused(c, metric, queries_dev, bn, dim, Qp, ld, zflag, Qh, ldh, qn, err, fmode, xn2, st);
+        else { launch_ingest_rows(c, metric, queries_dev, bn, dim, Qp, ld, zflag); launch_prep_queries_fast(c, Qp, bn, ld, dim, Qh, ldh, qn, err, fmode, xn2, st); }
+        uint32_t* probe_list = c->salloc<uint32_t>((size_t)bn * np);
+        coarse_probe(c, metric, centroids.as<float>(), nlist, ld, dim, Qp, bn, np, probe_list);
+        int32_t* seg_off = c->salloc<int32_t>((size_t)bn * (np + 1));
+        int32_t* uoff = c->salloc<int32_t>((size_t)bn * (np + 1));
+        launch_ivf_probe_units(c, probe_list, np, lay.list_len.as<int32_t>(), bn, np, seg_off, uoff);
+        const int64_t umax = std::max<int64_t>(lay.max_units(np), 1);
+        const int64_t ldD = umax * ivf_fast_unit_rows();             // score row of a query: its probed lists' 64-row units in probe order
+        const int64_t P = (int64_t)bn * np;
+        const int64_t gmax = P / 64 + std::min<int64_t>(nlist, P) + 1;
+        const int64_t imax = ceil_div(P, 64) * ceil_div(std::max(lay.max_len, 1), 256) + lay.total_tiles256 + 1;
+        void* groups = c->scratch_alloc((size_t)gmax * ivf_group_bytes());
+        void* items = c->scratch_alloc((size_t)imax * ivf_item_bytes());
+        scan_counts.reserve(16, c->stream, 0);
+        int32_t* counts = scan_counts.as<int32_t>();       // persistent: get_stat reads the last launch's figures
+        launch_ivf_items(c, probe_list, np, np, uoff, (int)P, nlist, lay.list_len.as<int32_t>(), lay.list_base.as<int64_t>(), groups, items, counts);
+        float* D = c->salloc<float>((size_t)bn * ldD);
+        launch_ivf_scan_f16(c, fmode, Vh.p, ldh, Qh, rn_slot.as<float>(), qn, elig, groups, items, counts, D, ldD);
+        launch_ivf_post(c, metric, D, ldD, uoff, np, probe_list, np, lay.list_base.as<int64_t>(), lay.list_len.as<int32_t>(), lay.row_of_slot.as<uint32_t>(),
+                        lay.ids_slot.as<uint32_t>(), elig, err, p.k, p.threshold, V.as<float>(), ld, Qp, bn, zflag, out_ids, out_scores, out_counts, k_cap, ovf, st);
+        pend->nfast_slices++;
+    }
+    void search_core(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores, int32_t* out_counts, int k_cap, Pending* pend) {
         if (!trained) COMET_FAIL(COMET_ERR_NOT_TRAINED, "index must be trained before searching");
         lay.compile(c);
+        // queries per slice: the score rows of a slice (slice x max units of a query x 64 floats) stay under 4 GiB
+        int slice = kFastBatch;
+        bool fast = pend && fast_usable(B, p);
+        if (fast) {
+            const int64_t row_bytes = std::max<int64_t>(lay.max_units(sanitize_nprobes(p.nprobes, nlist)), 1) * ivf_fast_unit_rows() * 4;
+            slice = (int)std::min<int64_t>(kFastBatch, ((int64_t)4 << 30) / row_bytes);
+            fast = slice >= 1 && ceil_div(B, slice) <= kMaxSlices;
+        }
+        if (p.mode == 2 && !fast) COMET_FAIL(COMET_ERR_UNSUPPORTED, "fast path unavailable for this index / k (values beyond fp16 range, k < 1 or k > 1024, too many lists)");
+        if (!fast) { search_strict(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap); st_strict_queries += B; return; }
+        const uint8_t* elig = nullptr;
+        int nf = 0;
+        const uint32_t* flt = filter_sorted_scratch(p, &nf);
+        const uint32_t* del = deleted.empty() ? nullptr : deleted_sorted_dev();
+        const int nd = deleted.empty() ? 0 : n_deleted_dev;
+        if (nd > 0 || nf > 0) {
+            uint8_t* e = c->salloc<uint8_t>(lay.nslots);
+            launch_build_elig(c, lay.ids_slot.as<uint32_t>(), lay.nslots, del, nd, flt, nf, e);
+            elig = e;
+        }
+        pend->slice = slice;
+        for (int b0 = 0; b0 < B; b0 += slice) {
+            const int bn = std::min(slice, B - b0);
+            search_fast(queries_dev + (size_t)b0 * dim, bn, p, elig, out_ids + (size_t)b0 * k_cap, out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap, pend);
+        }
+    }
+    uint64_t search_begin(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
+                          int32_t* out_counts, int k_cap) override {
+        Pending* slot = nullptr;
+        for (auto& r : ring) if (!r.active) { slot = &r; break; }
+        if (!slot) {
+            Pending* oldest = &ring[0];
+            for (auto& r : ring) if (r.ticket < oldest->ticket) oldest = &r;
+            search_finish(oldest->ticket);
+            slot = oldest;
+        }
+        if (!slot->ev) HIP_CHECK(hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
+        if (!slot->ev_post) HIP_CHECK(hipEventCreateWithFlags(&slot->ev_post, hipEventDisableTiming));
+        if (!slot->flags) HIP_CHECK(hipHostMalloc((void**)&slot->flags, sizeof(int32_t) * kSliceInts * kMaxSlices, hipHostMallocDefault));
+        if (!slot->dflags) HIP_CHECK(hipMalloc((void**)&slot->dflags, sizeof(int32_t) * kSliceInts * kMaxSlices));
+        if (!copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        slot->ticket = next_ticket++; slot->B = B; slot->k_cap = k_cap; slot->nfast_slices = 0; slot->queries = queries_dev;
+        slot->p = p; slot->flt.clear();
+        if (p.filter_ids && p.n_filter > 0) { slot->flt.assign(p.filter_ids, p.filter_ids + p.n_filter); slot->p.filter_ids = slot->flt.data(); }
+        slot->out_ids = out_ids; slot->out_scores = out_scores; slot->out_counts = out_counts;
+        st_candidates = st_overflows = st_expansions = st_fast_queries = st_strict_queries = 0;
+        search_core(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap, slot);
+        if (slot->nfast_slices > 0) {
+            HIP_CHECK(hipEventRecord(slot->ev_post, c->stream));
+            HIP_CHECK(hipStreamWaitEvent(copy_stream, slot->ev_post, 0));
+            HIP_CHECK(hipMemcpyAsync(slot->flags, slot->dflags, sizeof(int32_t) * kSliceInts * slot->nfast_slices, hipMemcpyDeviceToHost, copy_stream));
+            HIP_CHECK(hipEventRecord(slot->ev, copy_stream));
+        } else HIP_CHECK(hipEventRecord(slot->ev, c->stream));
+        slot->active = true;
+        return slot->ticket;
+    }
+    bool search_finish(uint64_t ticket) override {
+        Pending* slot = nullptr;
+        for (auto& r : ring) if (r.active && r.ticket == ticket) { slot = &r; break; }
+        if (!slot) return false;
+        HIP_CHECK(hipEventSynchronize(slot->ev));
+        slot->active = false;
+        std::vector<int> redo;
+        for (int sl = 0; sl < slot->nfast_slices; sl++) {
+            const int32_t* hf = slot->flags + (size_t)sl * kSliceInts;
+            const int bn = std::min(slot->slice, slot->B - sl * slot->slice);
+            st_candidates += hf[256]; st_overflows += hf[257]; st_expansions += hf[258];
+            int nfast = bn;
+            for (int q = 0; q < bn; q++) if (hf[q]) { redo.push_back(sl * slot->slice + q); nfast--; }
+            st_fast_queries += nfast;
+        }
+        comet_search_params sp = slot->p; sp.mode = 1;
+        for (int q : redo) {
+            ScratchMark sm(c);
+            search_core(slot->queries + (size_t)q * dim, 1, sp, slot->out_ids + (size_t)q * slot->k_cap, slot->out_scores + (size_t)q * slot->k_cap,
+                        slot->out_counts + q, slot->k_cap, nullptr);
+        }
+        if (!redo.empty()) HIP_CHECK(hipStreamSynchronize(c->stream));
+        return !redo.empty();
+    }
+    void search_dev(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
+                    int32_t* out_counts, int k_cap) override {
+        search_finish(search_begin(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap));
+    }
+    bool get_stat(const char* name, double* out) const override {
+        std::string k(name);
+        if (k == "fast_candidates") *out = (double)st_candidates;
+        else if (k == "fast_overflows") *out = (double)st_overflows;
+        else if (k == "fast_expansions") *out = (double)st_expansions;
+        else if (k == "fast_queries") *out = (double)st_fast_queries;
+        else if (k == "strict_queries") *out = (double)st_strict_queries;
+        else if (k == "max_list_len") { const_cast<ListLayout&>(lay).compile(c); *out = (double)lay.max_len; }
+        else if (k == "ivf_scan_rows" || k == "ivf_scan_items") {       // rows the last fast slice's scan streamed (x ldh x 2 = its algorithmic bytes) / its work items
+            int32_t h[4] = {0, 0, 0, 0};
+            if (scan_counts.p) { c->d2h(h, scan_counts.p, 16); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+            *out = k == "ivf_scan_rows" ? (double)h[2] * 64.0 : (double)h[0];
+        }
+        else return false;
+        return true;
+    }
+
+    // ivfIndexSearch.searchSingleQuery ivf_index_search.go:217-322 — the exact kernels (search mode 1, and whatever the fast path does not take)
+    void search_strict(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
+                       int32_t* out_counts, int k_cap) {
         float* Qp; int32_t* zflag;
         prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag, true);
         const int np = sanitize_nprobes(p.nprobes, nlist);
@@ -436,7 +635,8 @@ struct IVFIndex : comet_index {
 comet_index* make_ivf(Ctx* c, int dim, int metric, int nlist) {
     auto* f = new IVFIndex();
     f->c = c; f->kind = COMET_KIND_IVF; f->dim = dim; f->ld = padded_dim(dim); f->metric = metric; f->nlist = nlist;
-    f->lay.nlist = nlist; f->lay.align = 1;
+    f->ldh = (int)round_up(dim, 64);
+    f->lay.nlist = nlist; f->lay.align = ivf_fast_unit_rows();   // every list starts on a 64-slot key unit of the fast path's shadow
     return f;
 }
 

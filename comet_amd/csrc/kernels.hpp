@@ -119,4 +119,26 @@ void launch_prep_queries_fused(Ctx* c, int metric, const float* src, int B, int 
 void launch_prep_queries_fast(Ctx* c, const float* Qp, int B, int ld, int dim, void* Qh, int ldh, float* qn, float* err_abs, int mode, float xmax_norm2,
                               int32_t* stats4);
 
+// the same post stage over the key rows of the IVF fast path
+void launch_ivf_post(Ctx* c, int metric, const float* D, int64_t ldD, const int32_t* uoff, int np, const uint32_t* probe_list, int ldp,
+                     const int64_t* list_base, const int32_t* list_len, const uint32_t* row_of_slot, const uint32_t* ids_slot, const uint8_t* elig,
+                     const float* err_abs, int K, float thr, const float* X, int ld, const float* Qp, int B, const int32_t* zflag,
+                     uint32_t* out_ids, float* out_scores, int32_t* out_counts, int k_cap, int32_t* overflow, int32_t* stats);
+
+// ---- kernels_ivf.hip (MFMA fast path of the IVF list scan) ------------------------------------------
+int ivf_fast_unit_rows();      // rows per key unit = the list alignment the slot layout must have (64)
+int ivf_fast_max_lists();      // list counts the item builder takes
+size_t ivf_group_bytes();
+size_t ivf_item_bytes();
+// slot-ordered fp16 shadow [unit of 64 slots][K step of 64 halves][row][64 halves] of the rows V[row_of_slot[slot]] (padding slots: zeros),
+// rn[slot] = sum x^2, stats[0] = max |x| bits, stats[1] = max row norm^2 bits (atomicMax; caller zero-initialises)
+void launch_ivf_shadow(Ctx* c, const float* V, int ld, const uint32_t* row_of_slot, int64_t nslots, void* Vh, int ldh, float* rn, uint32_t* stats);
+// seg_off[q][0..np] = prefix of the probed lists' lengths, uoff[q][0..np] = prefix of their 64-row unit counts
+void launch_ivf_probe_units(Ctx* c, const uint32_t* probe_list, int ldp, const int32_t* list_len, int B, int np, int32_t* seg_off, int32_t* uoff);
+// (query, list) pairs -> groups of <= 64 queries per list -> (group, 256-row tile) items; counts[0] = items, counts[1] = groups
+void launch_ivf_items(Ctx* c, const uint32_t* probe_list, int ldp, int np, const int32_t* uoff, int n_pairs, int nlist, const int32_t* list_len,
+                      const int64_t* list_base, void* groups, void* items, int32_t* counts);
+void launch_ivf_scan_f16(Ctx* c, int mode, const void* Vh, int ldh, const void* Qh, const float* rn, const float* qn, const uint8_t* elig,
+                         const void* groups, const void* items, const int32_t* counts, float* D, int64_t ldD);
+
 }  // namespace comet

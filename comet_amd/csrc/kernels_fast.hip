@@ -882,44 +882,122 @@ __device__ __forceinline__ void post_append(bool want, unsigned v, unsigned* lis
     if (want) { const int s = base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull)); if (s < cap) list[s] = v; }
 }
 
-template <int METRIC>
-__global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __restrict__ S0, long ldS, const float* __restrict__ bound, long ldB,
-                                                                 long n_tiles, int unit_rows, long n, const unsigned char* __restrict__ elig,
+// Geometry of the key rows the post stage reads: which rows a key unit stands for, where a candidate's vector and id live.
+// A candidate is named by its POSITION = unit * unit_rows + row-in-unit inside the query's key row; ascending position is the
+// canonical tie order of the strict path for both geometries.
+//   FlatGeom: unit u = rows u * unit_rows .. of the index, the same for every query; position = row.
+//   IvfGeom : the key row of query q holds the 64-row units of its probed lists in probe order (uoff[q][j] = first unit of probe j);
+//             position -> probe j (binary search over uoff[q]) -> slot = list_base[list] + offset -> arrival row / id of the slot.
+struct FlatGeom {
+    long n_units; int unit_rows; long n; const unsigned char* elig; const unsigned* ids_table;
+    static constexpr bool kSlots = false, kDense = false;
+    struct Unit { long row0; long nvalid; };
+    __device__ __forceinline__ void bind(int) {}
+    __device__ __forceinline__ long units() const { return n_units; }
+    __device__ __forceinline__ int urows() const { return unit_rows; }
+    __device__ __forceinline__ Unit unit(long u) const { return Unit{u * unit_rows, n - u * unit_rows}; }
+    __device__ __forceinline__ bool ok(const Unit& U, int r) const { return r < U.nvalid && (!elig || elig[U.row0 + r]); }
+    __device__ __forceinline__ long slot_of(unsigned pos) const { return (long)pos; }
+    __device__ __forceinline__ long xrow(long slot) const { return slot; }
+    __device__ __forceinline__ unsigned id_of(long slot) const { return ids_table[slot]; }
+};
+struct IvfGeom {
+    const int* uoff; int np; const unsigned* probe_list; int ldp; const long* list_base; const int* list_len;
+    const unsigned* row_of_slot; const unsigned* ids_slot; const unsigned char* elig;      // elig per slot
+    const int* uo = nullptr; const unsigned* pl = nullptr;                                  // this query's rows (bind)
+    static constexpr bool kSlots = true, kDense = true;                                      // dense: the key row holds one approximate distance per position (+inf: no candidate)
+    struct Unit { long row0; long nvalid; };                                                // row0 = first slot of the unit
+    __device__ __forceinline__ void bind(int q) { uo = uoff + (long)q * (np + 1); pl = probe_list + (long)q * ldp; }
+    __device__ __forceinline__ long units() const { return uo[np]; }
+    __device__ __forceinline__ int urows() const { return 64; }
+    __device__ __forceinline__ int probe_of(long u) const {      // largest j with uo[j] <= u (uo non-decreasing: skips lists without units)
+        int lo = 0, hi = np;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (uo[mid] <= u) lo = mid; else hi = mid; }
+        return lo;
+    }
+    __device__ __forceinline__ Unit unit(long u) const {
+        const int j = probe_of(u); const unsigned l = pl[j]; const long off = (u - uo[j]) * 64;
+        return Unit{list_base[l] + off, (long)list_len[l] - off};
+    }
+    __device__ __forceinline__ bool ok(const Unit& U, int r) const { return r < U.nvalid && (!elig || elig[U.row0 + r]); }
+    __device__ __forceinline__ long slot_of(unsigned pos) const { const Unit U = unit((long)(pos >> 6)); return U.row0 + (pos & 63u); }
+    __device__ __forceinline__ long xrow(long slot) const { return (long)row_of_slot[slot]; }
+    __device__ __forceinline__ unsigned id_of(long slot) const { return ids_slot[slot]; }
+};
+
+template <int METRIC, class GEOM>
+__global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, const float* __restrict__ S0, long ldS, const float* __restrict__ bound, long ldB,
                                                                  const float* __restrict__ err_abs, int K /*requested, sanitised against n*/, int kappa_rank /*0: tau = inf*/,
                                                                  float thr, const float* __restrict__ X, int ld, const float* __restrict__ Qp,
-                                                                 const unsigned* __restrict__ ids_table, const int* __restrict__ zflag,
+                                                                 const int* __restrict__ zflag,
                                                                  unsigned* __restrict__ out_ids, float* __restrict__ out_scores, int* __restrict__ out_counts,
                                                                  int k_cap, int* __restrict__ overflow, int* __restrict__ stats, unsigned long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    geom.bind(blockIdx.x);
+    const long n_tiles = geom.units();
+    const int unit_rows = geom.urows();
     unsigned long long tr_prev = trace ? __builtin_amdgcn_s_memtime() : 0ull;
     auto TR = [&](int ph) { if (trace && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); atomicAdd(&trace[ph], now - tr_prev); tr_prev = now; } };
     unsigned* hist = reinterpret_cast<unsigned*>(psm) + POST_MAXKEYS;       // [4096]; the 64 KiB in front: rescoring slices, then the sort buffer
     unsigned* lst = hist + 4096;                                             // [POST_CAP] candidate rows
     float* sc = reinterpret_cast<float*>(lst + POST_CAP);                    // [POST_CAP] exact scores
+    unsigned* slotv = reinterpret_cast<unsigned*>(sc + POST_CAP);            // [POST_CAP] slot of every candidate (GEOM::kSlots only: the launcher adds the 16 KiB)
     __shared__ unsigned wsum[16];
     __shared__ int s_bin, s_before, s_cnt, s_exp, s_valid;
     const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const int nkeys = (int)(2 * n_tiles);
+    constexpr bool DENSE = GEOM::kDense;
+    const int nkeys = DENSE ? (int)(n_tiles * unit_rows) : (int)(2 * n_tiles);
     const float* s0 = S0 + (long)q * ldS;
-    const float* bd = bound + (long)q * ldB;
+    const float* bd = DENSE ? nullptr : bound + (long)q * ldB;
     const float INF = __builtin_inff();
     if (t == 0) { s_cnt = 0; s_exp = 0; s_valid = 0; }
     // The query's unit keys (two per unit) and unit bounds are read ONCE, into registers, when they fit (<= POST_RU units per
     // thread: 1M rows at 128-row units); every pass below then runs out of registers. Longer rows are streamed from L2 per pass.
-    constexpr int POST_RU = 8;
-    const bool reg = n_tiles <= (long)POST_RU * POST_THREADS;
-    f32x2v kreg[POST_RU]; float breg[POST_RU];
+    // Dense rows (one approximate distance per position): POST_RD values per thread, value j of thread t = position j * 1024 + t.
+    // (16-byte loads: value e of vector j of thread t = position (j * 1024 + t) * 4 + e; a dense row is a multiple of 64 values long)
+    constexpr int POST_RU = DENSE ? 1 : 8, POST_RD = DENSE ? 10 : 1;
+    const bool reg = DENSE ? nkeys <= POST_RD * POST_THREADS * 4 : n_tiles <= (long)POST_RU * POST_THREADS;
+    f32x2v kreg[POST_RU]; float breg[POST_RU]; f32x4v dreg[POST_RD];
+    const f32x4v INF4 = {INF, INF, INF, INF};
     if (reg) {
+        if constexpr (DENSE) {
 #pragma unroll
-        for (int j = 0; j < POST_RU; j++) {
-            const long tl = (long)j * POST_THREADS + t;
-            const bool lv = tl < n_tiles;
-            kreg[j] = lv ? *reinterpret_cast<const f32x2v*>(s0 + 2 * tl) : f32x2v{INF, INF};
-            breg[j] = lv ? bd[tl] : INF;
+            for (int j = 0; j < POST_RD; j++) { const int i = (j * POST_THREADS + t) * 4; dreg[j] = i < nkeys ? *reinterpret_cast<const f32x4v*>(s0 + i) : INF4; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < POST_RU; j++) {
+                const long tl = (long)j * POST_THREADS + t;
+                const bool lv = tl < n_tiles;
+                kreg[j] = lv ? *reinterpret_cast<const f32x2v*>(s0 + 2 * tl) : f32x2v{INF, INF};
+                breg[j] = lv ? bd[tl] : INF;
+            }
         }
     }
-    auto for_keys = [&](auto&& f) {                 // f(key) over every unit key of the query, in no particular order
+    // dense rows beyond the registers: streamed per pass, 4 x 16 bytes per thread in flight (a one-load-per-iteration loop pays the
+    // L2 / HBM latency once per value: ~300 iterations for a query that probes a 40 k-row list); every thread makes the same
+    // number of calls (absent values arrive as +inf), so f may use wave-wide ballots
+    auto for_keys_idx = [&](auto&& f) {             // dense rows: f(value, position)
         if (reg) {
+#pragma unroll
+            for (int j = 0; j < POST_RD; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) f(dreg[j][e], (j * POST_THREADS + t) * 4 + e);
+        } else {
+            for (int i0 = 0; i0 < nkeys; i0 += 16 * POST_THREADS) {
+                f32x4v b[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int i = i0 + (k * POST_THREADS + t) * 4; b[k] = i < nkeys ? *reinterpret_cast<const f32x4v*>(s0 + i) : INF4; }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) f(b[k][e], i0 + (k * POST_THREADS + t) * 4 + e);
+            }
+        }
+    };
+    auto for_keys = [&](auto&& f) {                 // f(key) over every key of the query, in no particular order
+        if constexpr (DENSE) {
+            for_keys_idx([&](float v, int) { f(v); });
+        } else if (reg) {
 #pragma unroll
             for (int j = 0; j < POST_RU; j++) { f(kreg[j][0]); f(kreg[j][1]); }
         } else {
@@ -934,6 +1012,7 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
         // are), locate the bin of the K-th smallest, and rank the handful of keys inside it directly.
         int mine = 0; float lo = INF, hi = 0.0f;
         for_keys([&](float v) { if (v != INF) { mine++; lo = fminf(lo, v); hi = fmaxf(hi, v); } });
+        const float mn_thread = lo;                  // this thread's smallest value (dense rows: the sample of the bound below)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); mine += __shfl_xor(mine, off, 64); }
         float* wlo = reinterpret_cast<float*>(hist); float* whi = wlo + 16; int* wct = reinterpret_cast<int*>(whi + 16);
@@ -942,7 +1021,57 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
         int valid = 0;
         for (int w = 0; w < POST_WAVES; w++) { lo = fminf(lo, wlo[w]); hi = fmaxf(hi, whi[w]); valid += wct[w]; }
         __syncthreads();
-        if (valid >= kappa_rank) {
+        unsigned kap = 0; bool have_kap = false;
+        if constexpr (DENSE) {
+            // Dense rows hold tens of thousands of values for the sake of the K smallest, and most of them share a few histogram bins
+            // (the far lists' distances): binning all of them costs ~30 k contended LDS atomics per query. Instead: every thread's
+            // MINIMUM over its (strided, i.e. spread over the whole row) values — 1024 distinct positions, K <= 1024 — is binned; the
+            // bin of the K-th smallest minimum bounds the K-th smallest of the row from above; the few values at or below that bin
+            // are collected and ranked exactly.
+            if (valid >= kappa_rank) {
+                const float mn = mn_thread;
+                float mlo = mn, mhi = mn == INF ? 0.0f : mn;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { mlo = fminf(mlo, __shfl_xor(mlo, off, 64)); mhi = fmaxf(mhi, __shfl_xor(mhi, off, 64)); }
+                if (lane == 0) { wlo[wid] = mlo; whi[wid] = mhi; }
+                __syncthreads();
+                for (int w = 0; w < POST_WAVES; w++) { mlo = fminf(mlo, wlo[w]); mhi = fmaxf(mhi, whi[w]); }
+                __syncthreads();
+                const float mscale = mhi > mlo ? 4095.0f / (mhi - mlo) : 0.0f;
+                auto mbin = [&](float v) { const int bq = (int)((v - mlo) * mscale); return bq < 0 ? 0 : (bq > 4095 ? 4095 : bq); };   // monotone; values beyond the largest minimum land in the last bin
+                for (int i = t; i < 4096; i += POST_THREADS) hist[i] = 0;
+                if (t == 0) { s_bin = 4095; s_cnt = 0; }
+                __syncthreads();
+                if (mn != INF) atomicAdd(&hist[mbin(mn)], 1u);
+                const int nfin = __syncthreads_count(mn != INF);           // finite minima
+                if (nfin >= kappa_rank) post_find_bin(hist, kappa_rank, wsum, &s_bin, &s_before);
+                const int bbin = s_bin;
+                // the largest minimum at or below that bin: at least K positions hold a value <= it
+                float bmax = (mn != INF && mbin(mn) <= bbin) ? mn : 0.0f;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, off, 64));
+                if (lane == 0) whi[wid] = bmax;
+                __syncthreads();
+                for (int w = 0; w < POST_WAVES; w++) bmax = fmaxf(bmax, whi[w]);
+                if (nfin < kappa_rank) bmax = 3.0e38f;                     // fewer than K finite minima: every finite value survives
+                for_keys([&](float v) { post_append(v <= bmax, __float_as_uint(v), lst, &s_cnt, POST_CAP); });
+                __syncthreads();
+                const int m = s_cnt;
+                if (m <= 1024) {                                          // (m >= K: the K smallest minima are among them)
+                    if (t < m) {
+                        const unsigned me = lst[t]; int less = 0;
+                        for (int j = 0; j < m; j++) { const unsigned o = lst[j]; less += (o < me || (o == me && j < t)) ? 1 : 0; }
+                        if (less == kappa_rank - 1) hist[0] = me;         // exactly one thread
+                    }
+                    __syncthreads();
+                    kap = hist[0]; have_kap = true;
+                }
+                __syncthreads();
+                if (t == 0) s_cnt = 0;
+                __syncthreads();
+            }
+        }
+        if (valid >= kappa_rank && !have_kap) {
             const float scale = hi > lo ? 4095.0f / (hi - lo) : 0.0f;
             auto bin_of = [&](unsigned k) { const int bq = (int)((__uint_as_float(k) - lo) * scale); return bq < 0 ? 0 : (bq > 4095 ? 4095 : bq); };
             for (int i = t; i < 4096; i += POST_THREADS) hist[i] = 0;
@@ -952,7 +1081,6 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
             post_find_bin(hist, kappa_rank, wsum, &s_bin, &s_before);
             const int kbin = s_bin, rank_in = kappa_rank - s_before, members = (int)hist[kbin];
             __syncthreads();
-            unsigned kap = 0;
             if (members <= 1024) {
                 unsigned* mem = lst;                      // the candidate list is not in use yet
                 if (t == 0) s_cnt = 0;
@@ -987,6 +1115,9 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
                 }
                 kap = prefix;
             }
+            have_kap = true;
+        }
+        if (have_kap) {
             const float kappa = __uint_as_float(kap);
             tau = kappa + 2.0f * err_abs[q] + 1.0e-4f * fabsf(kappa) + 1e-30f;   // 1e-4 ~ 3 * 2^-15: key packing slack, both sides
         }
@@ -1004,10 +1135,9 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
             const int src = __builtin_ctzll(em); em &= em - 1ull;
             const long te = t0 + (t & ~63) + src;      // tile of lane `src`
             if (lane == src) atomicAdd(&s_exp, 1);
-            for (int j = lane; j < unit_rows; j += 64) {
-                const long r = te * unit_rows + j;
-                post_append(r < n && (!elig || elig[r]), (unsigned)r, lst, &s_cnt, POST_CAP);
-            }
+            const typename GEOM::Unit U = geom.unit(te);
+            for (int j = lane; j < unit_rows; j += 64)
+                post_append(geom.ok(U, j), (unsigned)(te * unit_rows + j), lst, &s_cnt, POST_CAP);
         }
 #pragma unroll
         for (int e = 0; e < 2; e++) {
@@ -1015,7 +1145,9 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
             post_append(key <= tau && key != INF, (unsigned)(tl * unit_rows + (__float_as_uint(key) & (unsigned)(unit_rows - 1))), lst, &s_cnt, POST_CAP);
         }
     };
-    if (reg) {
+    if constexpr (DENSE) {                               // every position whose approximate distance is within tau
+        for_keys_idx([&](float v, int i) { post_append(v <= tau && v != INF, (unsigned)i, lst, &s_cnt, POST_CAP); });
+    } else if (reg) {
 #pragma unroll
         for (int j = 0; j < POST_RU; j++) if ((long)j * POST_THREADS < n_tiles) candidates_of((long)j * POST_THREADS, breg[j], kreg[j][0], kreg[j][1]);
     } else {
@@ -1037,6 +1169,10 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
     for (int i = cnt + t; i < n2; i += POST_THREADS) lst[i] = 0xFFFFFFFFu;
     __syncthreads();
     post_sort(lst, cnt, n2, hist);                     // ascending row = canonical tie order of the strict path (hist: 16 KiB scratch)
+    if constexpr (GEOM::kSlots) {                      // position -> slot, once per candidate
+        for (int i = t; i < cnt; i += POST_THREADS) slotv[i] = (unsigned)geom.slot_of(lst[i]);
+        __syncthreads();
+    }
     TR(2);
     // ---- 3. exact distances ----
     float* terms = reinterpret_cast<float*>(psm) + wid * (POST_CPW * POST_CHUNK);   // 4 KiB per wave over the key area
@@ -1059,7 +1195,12 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
     for (int c0 = wid * CPW; c0 < cnt; c0 += POST_WAVES * CPW) {
         const float* xr[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; j++) { const int ci = c0 + j * POST_CPI + sub; xr[j] = X + (long)lst[ci < cnt ? ci : c0] * ld + lp * 4; }
+        for (int j = 0; j < NJ; j++) {
+            const int ci = c0 + j * POST_CPI + sub, cj = ci < cnt ? ci : c0;
+            long row;
+            if constexpr (GEOM::kSlots) row = geom.xrow((long)slotv[cj]); else row = (long)lst[cj];
+            xr[j] = X + row * ld + lp * 4;
+        }
         float acc = 0.0f;
         // A block of POST_DEPTH slices per candidate is requested at once and consumed in order (counted waits: only the block's
         // first slice pays the random-read latency). A register ring refilled slot by slot compiles to vmcnt(0) in every
@@ -1147,7 +1288,10 @@ __global__ __launch_bounds__(POST_THREADS) void flat_post_kernel(const float* __
     for (int i = t; i < k_cap; i += POST_THREADS) {
         if (i < nw) {
             const unsigned long long cc = comp[i];
-            out_ids[(long)q * k_cap + i] = ids_table[lst[(unsigned)(cc & 0xFFFFFFFFull)]];     // VectorResult.Node.ID()
+            const unsigned ci = (unsigned)(cc & 0xFFFFFFFFull);
+            long slot;
+            if constexpr (GEOM::kSlots) slot = (long)slotv[ci]; else slot = (long)lst[ci];
+            out_ids[(long)q * k_cap + i] = geom.id_of(slot);     // VectorResult.Node.ID()
             out_scores[(long)q * k_cap + i] = __uint_as_float(pkey2f((unsigned)(cc >> 32)));
         } else {
             out_ids[(long)q * k_cap + i] = 0u;
@@ -1169,9 +1313,10 @@ void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const fl
     if (B <= 0) return;
     static unsigned long long* trace = [] { unsigned long long* p = nullptr; if (getenv("COMET_POST_TRACE")) { HIP_CHECK(hipMalloc(&p, 64)); HIP_CHECK(hipMemset(p, 0, 64)); } return p; }();
     ProfScope ps(c, "flat_post");
-#define POST(M) do { HIP_CHECK(hipFuncSetAttribute((const void*)flat_post_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POST_LDS)); \
-        flat_post_kernel<M><<<dim3(B), dim3(POST_THREADS), POST_LDS, c->stream>>>(S0, ldS, bound, ldB, n_tiles, unit_rows, n, elig, err_abs, K, kappa_rank, thr, X, ld, Qp, \
-                                                                                 ids_table, zflag, out_ids, out_scores, out_counts, k_cap, overflow, stats, trace); } while (0)
+    const FlatGeom geom{(long)n_tiles, unit_rows, (long)n, (const unsigned char*)elig, ids_table};
+#define POST(M) do { HIP_CHECK(hipFuncSetAttribute((const void*)fast_post_kernel<M, FlatGeom>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POST_LDS)); \
+        fast_post_kernel<M, FlatGeom><<<dim3(B), dim3(POST_THREADS), POST_LDS, c->stream>>>(geom, S0, ldS, bound, ldB, err_abs, K, kappa_rank, thr, X, ld, Qp, \
+                                                                                 zflag, out_ids, out_scores, out_counts, k_cap, overflow, stats, trace); } while (0)
     switch (metric) { case COMET_L2: POST(COMET_L2); break; case COMET_L2SQ: POST(COMET_L2SQ); break; default: POST(COMET_COSINE); break; }
 #undef POST
     LAUNCH_CHECK();
@@ -1182,6 +1327,35 @@ void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const fl
             const double wg = (double)h[6];
             fprintf(stderr, "[post trace] per query, us: kappa %.1f  candidates %.1f  sort %.1f  rescoring %.1f  final %.1f   (%.0f candidates)\n", h[0] / wg / 100.0, h[1] / wg / 100.0,
                     h[2] / wg / 100.0, h[3] / wg / 100.0, h[4] / wg / 100.0, h[5] / wg);
+        }
+    }
+}
+
+// the same post stage over the key rows of the IVF fast path (kernels_ivf.hip): units of the probed lists in probe order
+void launch_ivf_post(Ctx* c, int metric, const float* D, int64_t ldD, const int32_t* uoff, int np, const uint32_t* probe_list, int ldp,
+                     const int64_t* list_base, const int32_t* list_len, const uint32_t* row_of_slot, const uint32_t* ids_slot, const uint8_t* elig,
+                     const float* err_abs, int K, float thr, const float* X, int ld, const float* Qp, int B, const int32_t* zflag,
+                     uint32_t* out_ids, float* out_scores, int32_t* out_counts, int k_cap, int32_t* overflow, int32_t* stats) {
+    if (B <= 0) return;
+    static unsigned long long* trace = [] { unsigned long long* p = nullptr; if (getenv("COMET_POST_TRACE")) { HIP_CHECK(hipMalloc(&p, 64)); HIP_CHECK(hipMemset(p, 0, 64)); } return p; }();
+    ProfScope ps(c, "ivf_post");
+    const IvfGeom geom{uoff, np, probe_list, ldp, (const long*)list_base, list_len, row_of_slot, ids_slot, (const unsigned char*)elig};
+    const size_t lds = POST_LDS + (size_t)POST_CAP * 4;
+    const int kr = K >= 1 ? K : 0;       // fewer valid keys than K (or K <= 0 = all): tau = inf inside the kernel, every unit is expanded
+#define POST(M) do { HIP_CHECK(hipFuncSetAttribute((const void*)fast_post_kernel<M, IvfGeom>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        fast_post_kernel<M, IvfGeom><<<dim3(B), dim3(POST_THREADS), lds, c->stream>>>(geom, D, ldD, nullptr, 0, err_abs, K, kr, thr, X, ld, Qp, \
+                                                                                 zflag, out_ids, out_scores, out_counts, k_cap, overflow, stats, trace); } while (0)
+    switch (metric) { case COMET_L2: POST(COMET_L2); break; case COMET_L2SQ: POST(COMET_L2SQ); break; default: POST(COMET_COSINE); break; }
+#undef POST
+    LAUNCH_CHECK();
+    if (trace) {          // COMET_POST_TRACE: cumulative s_memtime ticks (100 MHz) per phase, printed every 16 launches
+        static int calls = 0;
+        if ((++calls & 15) == 0) {
+            unsigned long long h[8]; HIP_CHECK(hipStreamSynchronize(c->stream)); HIP_CHECK(hipMemcpy(h, trace, 64, hipMemcpyDeviceToHost));
+            const double wg = (double)h[6];
+            fprintf(stderr, "[ivf post trace] per query, us: kappa %.1f  candidates %.1f  sort+slots %.1f  rescoring %.1f  final %.1f   (%.0f candidates)\n", h[0] / wg / 100.0, h[1] / wg / 100.0,
+                    h[2] / wg / 100.0, h[3] / wg / 100.0, h[4] / wg / 100.0, h[5] / wg);
+            HIP_CHECK(hipMemset(trace, 0, 64));
         }
     }
 }

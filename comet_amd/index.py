@@ -389,6 +389,23 @@ class VectorIndex:
             raise ValueError(f"vector dimension mismatch: expected {self.dim}, got {v.shape[-1] if v.size else 0}")
         check(self.lib.comet_index_train(self.h, v.ctypes.data_as(C.c_void_p), v.shape[0]))
 
+    def train_dev(self, vecs_dev: int, n: int) -> None:
+        """Train on n dense rows that already sit in device memory."""
+        check(self.lib.comet_index_train_dev(self.h, C.c_void_p(vecs_dev), int(n)))
+
+    def add_batch_dev(self, ids, vecs_dev: int, n: int) -> int:
+        """Add n dense rows that already sit in device memory (ids from the host); returns the rows added."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        idbuf = self.ctx.alloc(max(4, ids.nbytes))
+        try:
+            self.ctx.upload(idbuf, ids)
+            added = C.c_int64()
+            check(self.lib.comet_index_add_dev(self.h, C.c_void_p(idbuf), C.c_void_p(vecs_dev), int(n), C.byref(added)))
+        finally:
+            self.ctx.free(idbuf)
+        self.last_added = added.value
+        return added.value
+
     def add(self, node_id: int, vector, write_back: bool = True) -> None:
         """VectorIndex.Add. Like the reference (flat_index.go:182) a cosine index normalises the caller's
         float32 array in place when `vector` is a writable float32 ndarray."""

@@ -7,6 +7,7 @@ import "C"
 
 import (
 	"fmt"
+	"runtime"
 
 	comet "github.com/wizenheimer/comet"
 )
@@ -97,7 +98,13 @@ func (s *vectorSearch) Execute() ([]comet.VectorResult, error) {
 	scores := make([]float32, B*kCap)
 	counts := make([]int32, B)
 	p := C.comet_search_params{k: C.int32_t(s.k), threshold: C.float(s.threshold), nprobes: C.int32_t(s.nProbes), ef_search: C.int32_t(s.efSearch)}
+	// p lives in Go memory and p.filter_ids would be a Go pointer stored inside it: cgo's pointer-passing rules (and the
+	// default cgocheck) forbid handing C a Go pointer to memory that holds an UNPINNED Go pointer, so the id slice is pinned
+	// for the duration of the call (the library copies the ids before it returns and never retains the pointer).
+	var pin runtime.Pinner
+	defer pin.Unpin()
 	if len(s.documentIDs) > 0 {
+		pin.Pin(&s.documentIDs[0])
 		p.filter_ids = (*C.uint32_t)(&s.documentIDs[0])
 		p.n_filter = C.int32_t(len(s.documentIDs))
 	}

@@ -7,6 +7,7 @@ import "C"
 
 import (
 	"fmt"
+	"runtime"
 
 	comet "github.com/wizenheimer/comet"
 )
@@ -64,7 +65,10 @@ func (s *SegmentSet) Search(query []float32, k, nProbes, efSearch int, threshold
 	if threshold > 0 {
 		p.threshold = C.float(threshold)
 	}
+	var pin runtime.Pinner // see vectorSearch.Execute: a Go pointer stored in the parameter block must be pinned
+	defer pin.Unpin()
 	if len(documentIDs) > 0 {
+		pin.Pin(&documentIDs[0])
 		p.filter_ids = (*C.uint32_t)(&documentIDs[0])
 		p.n_filter = C.int32_t(len(documentIDs))
 	}
