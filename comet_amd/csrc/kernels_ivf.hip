@@ -151,16 +151,25 @@ __global__ __launch_bounds__(1024) void ivf_items_kernel(const unsigned* __restr
     }
     int rg = part_g[t] - sg, ri = part_i[t] - si;
     for (int l = lo; l < hi; l++) {
-        const int c0 = cnt[l], ng = (c0 + IV_NQ - 1) / IV_NQ, nt = (list_len[l] + IV_TILE - 1) / IV_TILE;
+        const int ng = (cnt[l] + IV_NQ - 1) / IV_NQ, nt = (list_len[l] + IV_TILE - 1) / IV_TILE;
         gbase[l] = rg; ibase[l] = ri;
-        // group headers and the list's items: tile-major, the groups of one tile adjacent
-        for (int g = 0; g < ng; g++) {
-            IvfGroup* G = groups + rg + g;
-            G->list = l; G->nq = min(IV_NQ, c0 - g * IV_NQ); G->unit0 = (int)(list_base[l] >> 6); G->len = list_len[l];
-        }
-        for (int tl = 0; tl < nt; tl++)
-            for (int g = 0; g < ng; g++) items[ri + tl * ng + g] = IvfItem{rg + g, tl};
         rg += ng; ri += ng * nt;
+    }
+    __syncthreads();
+    // group headers and items, one per thread and round (a thread per LIST would leave the one that owns a 40 k-row list writing
+    // hundreds of items alone): the list of group / item i is the last l with base[l] <= i — lists without groups share their
+    // successor's base, so the last of a run of equal bases is the one that owns the index
+    const int n_groups = part_g[1023], n_items_all = part_i[1023];
+    auto owner = [&](const int* base, int i) { int a = 0, b = nlist; while (b - a > 1) { const int m = (a + b) >> 1; if (base[m] <= i) a = m; else b = m; } return a; };
+    for (int gi = t; gi < n_groups; gi += 1024) {
+        const int l = owner(gbase, gi), g = gi - gbase[l];
+        IvfGroup* G = groups + gi;
+        G->list = l; G->nq = min(IV_NQ, cnt[l] - g * IV_NQ); G->unit0 = (int)(list_base[l] >> 6); G->len = list_len[l];
+    }
+    for (int ii = t; ii < n_items_all; ii += 1024) {      // tile-major inside a list, the groups of one tile adjacent
+        const int l = owner(ibase, ii), loc = ii - ibase[l];
+        const int ng = (cnt[l] + IV_NQ - 1) / IV_NQ;
+        items[ii] = IvfItem{gbase[l] + loc % ng, loc / ng};
     }
     __syncthreads();
     for (int i = t; i < nlist; i += 1024) cnt[i] = 0;     // now the scatter cursors
