@@ -1,37 +1,43 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json's metric: queries/sec + recall@10, 1M x 768 Flat & IVFPQ, on N MI355X.
+"""bench.py — BASELINE.json's metric: queries/sec + recall@10, 1M x 768 Flat & IVFPQ, on N MI355X — and every other BASELINE config
+inside the same driver-run line.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
-torch.distributed.run, one rank per GPU. Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under torch.distributed.run, one rank
+per GPU. Rank 0 prints ONE JSON line.
 
-Legs (all inside the one line):
-  * headline = BASELINE configs[1]: Flat cosine 1M x 768, batch = 256 queries, K = 100 (uniform SplitMix64 data,
-    SURVEY.md §8d). A "step" = one batch through the whole search path (preprocess -> scan -> top-K -> ids) with
-    queries and results resident in HBM. `value` = queries/s of this leg. N > 1: the SAME 1M rows sharded by
-    contiguous row blocks ("scaling": "strong"), per-shard top-K exchanged with one RCCL all-gather and merged;
-  * "flat_l2" (N = 1): Flat L2^2 over a clustered 1M x 768 corpus at batches where HBM binds (B = 1 and B = 64,
-    the narrow scan tile) and at B = 256, each with its own roofline — the north star's ">= 70 % of HBM roofline on
-    the Flat L2 scan" is read off the B <= 64 lines;
-  * "ivfpq" (N = 1): IVFPQ over the same clustered corpus, nlist 1024, nprobe 32, M 96, nbits 8, K 10, B 256:
-    queries/s, roofline of adc_scan (algorithmic bytes = sum over probed lists of len * M),
-    recall@10 against the exact Flat L2^2 search on the same corpus and against the CPU oracle's IVFPQ search of the
-    same index (handed over in the reference's IVPQ on-disk format), its own cpu_baseline.
-Timing: W warm-up steps, then R (= --regions, default 5) timed regions of EXACTLY K steps each, every region
-bracketed by barrier + sync on both sides and max-reduced over ranks; the MEDIAN region is reported (all R are listed).
-`roofline`: algorithmic bytes of the dominant kernel / its mean launch duration, measured with HIP events recorded on
-the library's own stream around every launch of the timed regions (comet_profile_*), against the 8 TB/s HBM peak;
-`traffic` comes from a separate `rocprofv3 --pmc` pass committed under profiles/ (its file is named in the line).
-`cpu_baseline`: the CPU oracle (C++ restatement of the reference's Go loops — no Go toolchain in this image) timed on
-this box's host cores on a bounded sample of the same workload, rank 0, N = 1, with a bit-exact parity check.
-The product path never touches the oracle: it is imported only inside cpu_baseline_*().
+Legs (all inside the one line; `--legs` selects):
+  * headline `flat` = BASELINE configs[1]: Flat cosine 1M x 768, batch 256, K 100 (uniform SplitMix64 data). A "step"
+    = one batch through the whole search path (preprocess -> scan -> top-K -> ids) with queries and results resident in HBM.
+    `value` = queries/s of this leg. N > 1: the SAME 1M rows sharded by contiguous row blocks ("scaling": "strong"), per-shard
+    top-K exchanged with one RCCL all-gather inside the library and merged;
+  * `flat_l2` (N = 1): Flat L2^2 over a clustered 1M x 768 corpus at B = 1, 64 (HBM binds: the north star's ">= 70 % of the HBM
+    roofline on the Flat L2 scan" is read off these) and B = 256;
+  * `ivfpq`: IVFPQ 1M x 768, nlist 1024, nprobe 32, M 96, nbits 8, K 10 — the other half of the metric, with recall@10 against exact
+    Flat search and against the CPU oracle on the same index; N > 1: inverted lists sharded over the ranks;
+  * `ivfpq10m` = configs[3]'s shape on the GPUs present: IVFPQ 10M x 768, nlist 4096, nprobe 32, M 96, nbits 8, K 10, built on the
+    GPU inside the run (N > 1: list shards, the sharded form the config names);
+  * `hnsw` (N = 1) = configs[2]: HNSW L2 d 384, M 16, efConstruction 200, efSearch 128, K 10, graph built on the GPU inside the run
+    (`--hnsw-rows`, default 100k: the reference's insertion is sequential — a 1M-node build is minutes on any hardware; the 1M line is
+    in profiles/), recall@10 against exact Flat search, batch sweep;
+  * `hybrid` (N = 1) = configs[4]: IVF 1M x 768 (nlist 1024; nprobe 32 and the hybrid default 1) + BM25 over 100k documents +
+    Reciprocal Rank Fusion.
+Every leg rotates 8 distinct query batches (no step replays the previous step's queries), reports the median of R timed regions of
+EXACTLY K steps (barrier + sync on both sides, max over ranks), a `sustained` figure (>= 2 s of back-to-back steps: the Flat scan is
+power-governed, a 10 ms region cannot show the settled clock), a `host_buffers` figure (queries uploaded and results downloaded
+inside every call — what the reference's Execute([]float32) shape costs; never `value`), `roofline` of its dominant kernel from HIP
+events attached to that kernel's dispatches in the timed regions, and `cpu_baseline` + a bit-for-bit parity count against the CPU
+oracle (C++ restatement of the reference's Go loops — no Go toolchain in this image) on a bounded sample of the same workload.
+The product path never touches the oracle: it is imported only inside the cpu_baseline / parity helpers.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import statistics
+import subprocess
 import sys
 import threading
 import time
@@ -44,10 +50,13 @@ sys.path.insert(0, str(ROOT))
 
 N_ROWS, DIM, BATCH, TOPK = 1_000_000, 768, 256, 100
 CORPUS_SEED, QUERY_SEED = 0xC0FFEE + 2, 0xBEEF + 2
-# clustered corpus of the L2 / IVFPQ legs: 2048 centres, 65536 sub-centres at 0.15 around them (~15 rows each at 1M rows), 0.02 noise:
+# clustered corpus of the L2 / IVFPQ / IVF legs: 2048 centres, 65536 sub-centres at 0.15 around them (~15 rows each at 1M rows), 0.02 noise:
 # a query's true neighbours are the rows of its own sub-centre
 MIX_SEED, MIX_CENTERS, MIX_SIGMA, MIX_SUB, MIX_NOISE = 0xC0FFEE + 4, 2048, 0.15, 65536, 0.02
 HBM_PEAK_GBS = 8000.0
+NQB = 8               # distinct query batches a leg rotates through
+DTYPE = ("f32 results: every returned score is the reference's serial float32 sum (bit-identical to the CPU path); candidates are "
+         "screened on fp16 MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate) with a rigorous error bound, PQ tables / BM25 in f32 / f64")
 
 
 def parse():
@@ -56,26 +65,32 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--sustain-s", type=float, default=2.0, help="length of the sustained (back-to-back) measurement of every leg")
     ap.add_argument("--rows", type=int, default=N_ROWS)
     ap.add_argument("--dim", type=int, default=DIM)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--k", type=int, default=TOPK)
     ap.add_argument("--metric", default="cosine")
     ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 strict exact kernels, 2 fast path")
-    ap.add_argument("--legs", default="flat,flat_l2,ivfpq", help="comma list; flat is always run (it is the headline)")
+    ap.add_argument("--legs", default="flat,flat_l2,ivfpq,ivfpq10m,hnsw,hybrid", help="comma list; flat is always run (it is the headline)")
     ap.add_argument("--nlist", type=int, default=1024)
     ap.add_argument("--nprobe", type=int, default=32)
     ap.add_argument("--M", type=int, default=96)
     ap.add_argument("--nbits", type=int, default=8)
     ap.add_argument("--ivfpq-k", type=int, default=10)
+    ap.add_argument("--big-rows", type=int, default=10_000_000, help="rows of the ivfpq10m leg (configs[3])")
+    ap.add_argument("--big-nlist", type=int, default=4096)
+    ap.add_argument("--hnsw-rows", type=int, default=100_000)
+    ap.add_argument("--hnsw-dim", type=int, default=384)
+    ap.add_argument("--docs", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
 # ------------------------------------------------------------------------------------------------ helpers
-def add_rows(ctx, idx, row_lo, row_hi, dim, fill):
-    """Generate rows [row_lo, row_hi) on the device with fill(buf, lo, m) and add them (ids = row + 1)."""
+def add_rows(ctx, idx, row_lo, row_hi, dim, fill, also=()):
+    """Generate rows [row_lo, row_hi) on the device with fill(buf, lo, m) and add them (ids = row + 1) to idx (and to every index in `also`)."""
     from comet_amd._lib import check
     chunk = 65536
     buf = ctx.alloc(chunk * dim * 4)
@@ -84,9 +99,10 @@ def add_rows(ctx, idx, row_lo, row_hi, dim, fill):
         m = min(chunk, row_hi - lo)
         fill(buf, lo, m)
         ctx.upload(idbuf, np.arange(lo + 1, lo + m + 1, dtype=np.uint32))
-        added = C.c_int64()
-        check(ctx.lib.comet_index_add_dev(idx.h, C.c_void_p(idbuf), C.c_void_p(buf), m, C.byref(added)))
-        assert added.value == m
+        for ix in (idx,) + tuple(also):
+            added = C.c_int64()
+            check(ctx.lib.comet_index_add_dev(ix.h, C.c_void_p(idbuf), C.c_void_p(buf), m, C.byref(added)))
+            assert added.value == m
     ctx.free(buf)
     ctx.free(idbuf)
 
@@ -108,6 +124,16 @@ class Timer:
             times.append(self.reduce_max(time.perf_counter() - t0))
         return statistics.median(times), times
 
+    def sustained(self, step_fn, steps, med_region_s, seconds):
+        """Back-to-back steps for >= `seconds` (the step count is derived from the max-reduced region time: the same on every rank)."""
+        n = max(steps, int(np.ceil(seconds / max(med_region_s / steps, 1e-7) / steps)) * steps)
+        self.barrier()
+        t0 = time.perf_counter()
+        step_fn(n)
+        self.barrier()
+        el = self.reduce_max(time.perf_counter() - t0)
+        return n, el
+
 
 def timed(ctx, timer, step, args, dominant):
     """Timed regions with HIP events around the DOMINANT kernel only (every timed scope is two event records — barrier packets —
@@ -121,46 +147,78 @@ def timed(ctx, timer, step, args, dominant):
     step(args.steps)
     ctx.sync()
     allk = ctx.profile_dump(); ctx.profile(False)
-    # (the chip is power-limited in the Flat scan: with idle gaps between the kernels — which the extra event records add — the scan
-    # itself runs a few percent faster, so the same kernel reads shorter in this region than in the timed ones)
     return med, times, prof, {k: round(v[0] / args.steps, 4) for k, v in sorted(allk.items())}
 
 
-def kernel_stats(prof, name, launches_hint):
+def measure(ctx, timer, args, step, dominant, B):
+    """The common part of every leg's record: median region, regions, sustained run, dominant-kernel profile, kernel breakdown."""
+    med, times, prof, allk = timed(ctx, timer, step, args, dominant)
+    n_sus, el_sus = timer.sustained(step, args.steps, med, args.sustain_s)
+    rec = {"qps": B * args.steps / med, "ms_per_step": med / args.steps * 1e3, "region_ms": [round(t * 1e3, 3) for t in times],
+           "sustained": {"seconds": round(el_sus, 3), "steps": n_sus, "qps": B * n_sus / el_sus, "ms_per_step": el_sus / n_sus * 1e3},
+           "kernels_ms_per_step": allk}
+    return rec, prof, med, times
+
+
+def host_buffers_qps(fn, B, reps=5):
+    """queries/s with the queries uploaded and the results downloaded inside every call (blocking host API)"""
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    el = time.perf_counter() - t0
+    return {"qps": B * reps / el, "ms_per_call": el / reps * 1e3, "what": "host numpy queries in, host numpy results out, one blocking call per batch (H2D + search + D2H + sync)"}
+
+
+def kernel_stats(prof, name):
     ms, n = prof.get(name, (0.0, 0))
     return (ms / n if n else 0.0), n
 
 
+def source_sha():
+    """fingerprint of the kernel sources: a committed PMC profile is only quoted when it was collected from the same code"""
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "comet_amd" / "csrc").glob("*.h*")):
+        h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel, rows_local):
-    """HBM bytes per launch from the committed rocprofv3 --pmc pass (newest profiles/r*_pmc*.json naming the kernel)."""
-    best = None
+    """HBM bytes per launch from the committed rocprofv3 --pmc pass (newest profiles/r*_pmc*.json naming the kernel). The file carries
+    the fingerprint of the kernel sources it was measured on (tools/pmc_collect.py); a file measured on other code is NOT quoted."""
+    best, stale = None, None
+    sha = source_sha()
     for f in sorted((ROOT / "profiles").glob("r*pmc*.json")):
         try:
             pm = json.loads(f.read_text())
             for kname, kv in pm.get("kernels", {}).items():
-                # profile scope -> kernel symbols: the scope "flat_scan_f16" is the query-stationary tile flat_scan_q8_kernel since round 2
-                # (the cosine instantiation <0, ...> is the headline's; the 2 x 4 tile flat_scan_f16_kernel serves odd K-step counts)
                 names = {"flat_scan_f16": ("flat_scan_q8_kernelILi0E", "flat_scan_f16_kernel")}.get(kernel, (kernel + "_kernel",))
                 if kname.split("<")[0].strip() == kernel or any(nm in kname for nm in names):
+                    if pm.get("source_sha") != sha:
+                        stale = f.name
+                        continue
                     per = kv.get("hbm_read_bytes_per_launch_corrected", 0) + kv.get("hbm_write_bytes_per_launch_uncalibrated", 0)
                     rows_ref = pm.get("rows", 1_000_000)
-                    best = (per * rows_local / rows_ref, f"profiles/{f.name} (separate rocprofv3 --pmc pass: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, "
-                                                         f"measured at {rows_ref} rows, scaled to {rows_local})")
+                    best = (per * rows_local / rows_ref, f"profiles/{f.name} (separate rocprofv3 --pmc pass on these kernel sources [{sha}]: FETCH_SIZE x2 gfx950 "
+                                                         f"correction + WRITE_SIZE, measured at {rows_ref} rows, scaled to {rows_local})")
         except Exception:
             continue
-    return best if best else (None, "not measured in this run (PMC needs its own rocprofv3 pass)")
+    if best:
+        return best
+    return (None, f"not quoted: the newest committed PMC pass naming this kernel ({stale}) was measured on other kernel sources" if stale
+            else "not measured in this run (PMC needs its own rocprofv3 pass: tools/pmc_bench.sh)")
 
 
-def flat_roofline(prof, steps_total, rows_local, dim, nq):
+def flat_roofline(prof, rows_local, dim, nq):
     ldh = (dim + 63) // 64 * 64
     name = "flat_scan_f16_n64" if (nq <= 64 and "flat_scan_f16_n64" in prof) else ("flat_scan_f16" if "flat_scan_f16" in prof else "dist_exact")
-    avg_ms, n = kernel_stats(prof, name, steps_total)
+    avg_ms, n = kernel_stats(prof, name)
     if name.startswith("flat_scan_f16"):
         qtile = 64 if name.endswith("n64") else 256
         alg = rows_local * ldh * 2 + qtile * ldh * 2          # the fp16 shadow once + the staged query tile
         flops = 2.0 * qtile * rows_local * ldh
     else:
-        alg = rows_local * dim * 4                            # exact-arithmetic scan: every fp32 row once (SURVEY §8d N*d*4)
+        alg = rows_local * dim * 4                            # exact-arithmetic scan: every fp32 row once (SURVEY 8d N*d*4)
         flops = 0.0
     ach = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic, src = pmc_traffic(name, rows_local)
@@ -179,12 +237,70 @@ def threads_map(fn, n_items, T):
     return time.time() - t0
 
 
+def same_rows(g_ids, g_sc, g_cn, b, cnt, oi, os_):
+    return bool(g_cn[b] == cnt and np.array_equal(g_ids[b, :cnt], oi) and np.array_equal(g_sc[b, :cnt].view(np.uint32), np.asarray(os_, np.float32).view(np.uint32)))
+
+
+class Pipe:
+    """Two batches in flight on device-resident buffers, rotating NQB query batches: batch i+1 is enqueued before batch i is waited for."""
+
+    def __init__(self, ctx, idx, q_ptrs, B, K, comm=None, **params):
+        self.ctx, self.idx, self.q, self.B, self.K, self.comm, self.params = ctx, idx, q_ptrs, B, K, comm, params
+        self.bufs = [(ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)) for _ in range(3)]
+        self.i = 0
+
+    def step(self, nsteps):
+        prev = None
+        for _ in range(nsteps):
+            w = self.i % 3; q = self.q[self.i % len(self.q)]; self.i += 1
+            if self.comm is not None:
+                t = self.comm.search_async(self.idx, q, self.B, self.K, *self.bufs[w], self.K, **self.params)
+            else:
+                t = self.idx.search_batch_dev_async(q, self.B, self.K, *self.bufs[w], self.K, **self.params)
+            if prev is not None:
+                self.comm.search_wait(self.idx, prev, block=False) if self.comm is not None else self.idx.search_wait(prev)
+            prev = t
+        if prev is not None:
+            self.comm.search_wait(self.idx, prev, block=True) if self.comm is not None else self.idx.search_wait(prev)
+
+    def results_of(self, qi, **override):
+        """one blocking search of query batch qi; host copies of (ids, scores, counts)"""
+        p = dict(self.params); p.update(override)
+        b = self.bufs[0]
+        if self.comm is not None:
+            self.comm.search_wait(self.idx, self.comm.search_async(self.idx, self.q[qi], self.B, self.K, *b, self.K, **p), block=True); self.comm.sync()
+        else:
+            self.idx.search_batch_dev(self.q[qi], self.B, self.K, *b, self.K, **p)
+        self.ctx.sync()
+        return self.ctx.download(b[0], (self.B, self.K), np.uint32), self.ctx.download(b[1], (self.B, self.K), np.float32), self.ctx.download(b[2], (self.B,), np.int32)
+
+    def free(self):
+        for b in self.bufs:
+            for p in b:
+                self.ctx.free(p)
+
+
+def query_batches(ctx, B, d, fill):
+    """NQB device-resident query batches: fill(ptr, batch_index)"""
+    base = ctx.alloc(NQB * B * d * 4)
+    ptrs = [base + i * B * d * 4 for i in range(NQB)]
+    for i, p in enumerate(ptrs):
+        fill(p, i)
+    ctx.sync()
+    return ptrs
+
+
 # ------------------------------------------------------------------------------------------------ CPU baselines (the only users of the oracle)
-def cpu_baseline_flat(args, ids_gpu, scores_gpu, counts_gpu):
-    """Oracle Flat search on a bounded sample of the batch vs the full corpus: single-thread latency of one query, then as many
-    queries as fit in ~cpu_seconds with one query per host thread; every sampled query is compared bit for bit with the GPU's."""
+def oracle():
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib as orc
+    return orc
+
+
+def cpu_baseline_flat(args, ids_gpu, scores_gpu, counts_gpu):
+    """Oracle Flat search on a bounded sample of query batch 0 vs the full corpus: single-thread latency of one query, then as many
+    queries as fit in ~cpu_seconds with one query per host thread; every sampled query is compared bit for bit with the GPU's."""
+    orc = oracle()
     cores = os.cpu_count() or 1
     X = orc.synth(CORPUS_SEED, 0, args.rows * args.dim).reshape(args.rows, args.dim)
     Q = orc.synth(QUERY_SEED, 0, args.batch * args.dim).reshape(args.batch, args.dim)
@@ -210,194 +326,347 @@ def cpu_baseline_flat(args, ids_gpu, scores_gpu, counts_gpu):
             n, oi, os_ = o.search(Q[qi], args.k)
             with lock:
                 done.append(qi)
-                ok = counts_gpu[qi] == n and np.array_equal(ids_gpu[qi, :n], oi) and np.array_equal(scores_gpu[qi, :n].view(np.uint32), os_.view(np.uint32))
-                if not ok:
+                if not same_rows(ids_gpu, scores_gpu, counts_gpu, qi, n, oi, os_):
                     mismatches.append(qi)
     el = threads_map(worker, cores, cores)
     return {"value": len(done) / el, "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"{len(done)} of the batch's {args.batch} queries vs the full {args.rows}x{args.dim} corpus, {cores} threads (one query each), "
+            "sample": f"{len(done)} of query batch 0's {args.batch} queries vs the full {args.rows}x{args.dim} corpus, {cores} threads (one query each), "
                       f"{el:.1f}s; oracle index build {build_s:.1f}s not timed",
             "single_thread_latency_s": single_s, "single_thread_qps": 1.0 / single_s if single_s > 0 else None,
             "parity_checked_queries": len(done), "parity_mismatches": len(mismatches)}
 
 
-def cpu_baseline_ivfpq(args, blob, Q, K, g_ids, g_sc, g_cn, flat_ids):
-    """The oracle loads the GPU-built index from the reference's IVPQ on-disk bytes and searches a bounded query sample
-    (one query per thread); parity + the oracle's own recall vs the exact Flat results."""
-    sys.path.insert(0, str(ROOT / "tests"))
-    import oracle_lib as orc
+def cpu_baseline_from_bytes(make_oracle, blob, search, Q, K, g, what, flat_ids=None, max_q=None):
+    """The oracle loads the GPU-built index from the reference's on-disk bytes and searches a bounded query sample (one query per
+    thread); parity + (flat_ids given) the oracle's own recall vs the exact Flat results."""
     cores = os.cpu_count() or 1
-    o = orc.IVFPQ(args.dim, "l2_squared", args.nlist, args.M, args.nbits)
+    o = make_oracle()
     t0 = time.time()
     assert o.from_bytes(blob) == len(blob)
     load_s = time.time() - t0
     t0 = time.time()
-    o.search(Q[0], K, args.nprobe, cap=K)
+    search(o, Q[0])
     single_s = time.time() - t0
-    nq = min(len(Q), max(cores, 64))
+    nq = min(len(Q), max_q or max(cores, 64))
     bad, lock, orecall = [], threading.Lock(), []
 
     def work(lo, hi):
         for b in range(lo, hi):
-            cnt, ci, cs = o.search(Q[b], K, args.nprobe, cap=K)
-            ok = g_cn[b] == cnt and np.array_equal(g_ids[b, :cnt], ci) and np.array_equal(g_sc[b, :cnt].view(np.uint32), cs.view(np.uint32))
+            cnt, ci, cs = search(o, Q[b])
+            ok = same_rows(g[0], g[1], g[2], b, cnt, ci, cs)
             with lock:
                 if not ok:
                     bad.append(b)
-                orecall.append(len(set(flat_ids[b].tolist()) & set(ci.tolist())) / K)
+                if flat_ids is not None:
+                    orecall.append(len(set(flat_ids[b].tolist()) & set(ci.tolist())) / K)
     T = min(cores, nq)
     el = threads_map(work, nq, T)
-    return {"value": nq / el, "unit": "queries/s", "cores": T, "kind": "port",
-            "sample": f"{nq} of the batch's queries on the GPU-built index (loaded from its IVPQ bytes in {load_s:.1f}s), {T} threads, {el:.2f}s",
-            "single_thread_latency_s": single_s, "parity_checked_queries": nq, "parity_mismatches": len(bad),
-            "oracle_recall_at_k_vs_exact_flat": float(np.mean(orecall))}
+    out = {"value": nq / el, "unit": "queries/s", "cores": T, "kind": "port",
+           "sample": f"{nq} of query batch 0's queries on the GPU-built index ({what}, loaded from its on-disk bytes in {load_s:.1f}s), {T} threads, {el:.2f}s",
+           "single_thread_latency_s": single_s, "parity_checked_queries": nq, "parity_mismatches": len(bad)}
+    if flat_ids is not None:
+        out["oracle_recall_at_k_vs_exact_flat"] = float(np.mean(orecall))
+    return out
+
+
+def recall_of(f_ids, g_ids, g_cn, K):
+    return float(np.mean([len(set(f_ids[b, :K].tolist()) & set(g_ids[b, :g_cn[b]].tolist())) / K for b in range(len(g_cn))]))
+
+
+def mix_fill(ctx, d, nsub=MIX_SUB):
+    return lambda buf, lo, m: ctx.synth_mixture(buf, MIX_SEED, MIX_CENTERS, MIX_SIGMA, nsub, MIX_NOISE, lo, m, d)
 
 
 # ------------------------------------------------------------------------------------------------ legs
-def leg_flat_l2(ctx, ca, args, timer, flat2, q_dev):
+def leg_flat_l2(ctx, ca, args, timer, flat2, q_ptrs):
     """Flat L2^2 at B = 1, 64, 256 on the clustered corpus."""
     out = {"workload": f"Flat l2_squared {args.rows}x{args.dim} (clustered corpus: {MIX_CENTERS} centres, {MIX_SUB} sub-centres at {MIX_SIGMA}, noise {MIX_NOISE}), K={args.ivfpq_k}"}
     K = args.ivfpq_k
     for B in (1, 64, 256):
-        bufs = [(ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)) for _ in range(2)]
-
-        def step(nsteps, B=B, bufs=bufs):
-            prev = None
-            for i in range(nsteps):
-                w = i & 1
-                t = flat2.search_batch_dev_async(q_dev, B, K, bufs[w][0], bufs[w][1], bufs[w][2], K)
-                if prev is not None:
-                    flat2.search_wait(prev)
-                prev = t
-            if prev is not None:
-                flat2.search_wait(prev)
-        step(2)
-        med, times, prof, allk = timed(ctx, timer, step, args, "flat_scan_f16_n64" if B <= 64 else "flat_scan_f16")
-        out[f"batch{B}"] = {"qps": B * args.steps / med, "ms_per_step": med / args.steps * 1e3, "region_ms": [round(t * 1e3, 3) for t in times],
-                            "roofline": flat_roofline(prof, args.steps * len(times), args.rows, args.dim, B),
-                            "kernels_ms_per_step": allk}
-        for b in bufs:
-            for p in b:
-                ctx.free(p)
+        pipe = Pipe(ctx, flat2, q_ptrs, B, K)
+        pipe.step(2)
+        rec, prof, _med, _t = measure(ctx, timer, args, pipe.step, "flat_scan_f16_n64" if B <= 64 else "flat_scan_f16", B)
+        rec["roofline"] = flat_roofline(prof, args.rows, args.dim, B)
+        out[f"batch{B}"] = rec
+        pipe.free()
     return out
 
 
-def leg_ivfpq(ctx, ca, args, timer, flat2, q_dev, Q_host, comm=None, rank=0, world=1):
+def adc_lookups_ceiling():
+    """random 8-byte LDS gather rate of this GPU, measured by tools/lds_gather_probe (built by __graft_entry__.build())"""
+    exe = ROOT / "tools" / "lds_gather_probe"
+    try:
+        r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:          # the ceiling is context, not a result: the line says why it is missing
+        return {"error": f"tools/lds_gather_probe did not run: {e}"}
+
+
+def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, comm=None, rank=0, world=1, every_candidate=True, nsub=MIX_SUB):
     """world > 1: every rank trains on the same vectors (deterministic GPU k-means: replicated quantisers), owns the inverted lists
     l % world == rank (comet_index_set_shard) and adds every row (foreign members are dropped); searches go through the in-library
     RCCL exchange, so every rank ends up with the merged global top-K."""
-    B, K, d, n = args.batch, args.ivfpq_k, args.dim, args.rows
-    idx = ca.IVFPQIndex(ctx, d, ca.L2_SQUARED, args.nlist, args.M, args.nbits)
-    ntrain = min(n, args.nlist * 100)
+    B, K, d, n = args.batch, args.ivfpq_k, args.dim, rows
+    idx = ca.IVFPQIndex(ctx, d, ca.L2_SQUARED, nlist, args.M, args.nbits)
+    ntrain = min(n, nlist * 100)
     tbuf = ctx.alloc(ntrain * d * 4)
-    ctx.synth_mixture(tbuf, MIX_SEED, MIX_CENTERS, MIX_SIGMA, MIX_SUB, MIX_NOISE, 0, ntrain, d)
-    from comet_amd._lib import check
+    mix_fill(ctx, d, nsub)(tbuf, 0, ntrain)
     t0 = time.time()
-    check(ctx.lib.comet_index_train_dev(idx.h, C.c_void_p(tbuf), ntrain))
+    idx.train_dev(tbuf, ntrain)
     train_s = time.time() - t0
     ctx.free(tbuf)
     if world > 1:
         idx.set_shard(rank, world)
     t0 = time.time()
-    add_rows(ctx, idx, 0, n, d, lambda buf, lo, m: ctx.synth_mixture(buf, MIX_SEED, MIX_CENTERS, MIX_SIGMA, MIX_SUB, MIX_NOISE, lo, m, d))
+    add_rows(ctx, idx, 0, n, d, mix_fill(ctx, d, nsub))
     ctx.sync()
     add_s = time.time() - t0
-    bufs = [(ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)) for _ in range(2)]
-    oi, os_, oc = bufs[0]
-
-    def step(nsteps):       # batch i+1 is enqueued before batch i is waited for, as in the Flat leg
-        prev = None
-        for i in range(nsteps):
-            w = i & 1
-            if comm is not None:
-                t = comm.search_async(idx, q_dev, B, K, bufs[w][0], bufs[w][1], bufs[w][2], K, nprobes=args.nprobe)
-            else:
-                t = idx.search_batch_dev_async(q_dev, B, K, bufs[w][0], bufs[w][1], bufs[w][2], K, nprobes=args.nprobe)
-            if prev is not None:
-                comm.search_wait(idx, prev, block=False) if comm is not None else idx.search_wait(prev)
-            prev = t
-        if prev is not None:
-            comm.search_wait(idx, prev, block=True) if comm is not None else idx.search_wait(prev)
-    step(2)
+    pipe = Pipe(ctx, idx, q_ptrs, B, K, comm, nprobes=args.nprobe)
+    pipe.step(2)
     stat0 = (idx.stat("adc_pairs_alive"), idx.stat("adc_pairs_behind_nearest"))
-    med, times, prof, allk = timed(ctx, timer, step, args, "adc_scan")
+    i0 = pipe.i
+    rec, prof, med, times = measure(ctx, timer, args, pipe.step, "adc_scan", B)
+    searches = pipe.i - i0
     stat1 = (idx.stat("adc_pairs_alive"), idx.stat("adc_pairs_behind_nearest"))
-    # the same search with every candidate scored (mode 1: no lower-bound pruning): what the ADC kernel itself sustains
-    searches_two_stage = args.steps * len(times) + max(1, args.warmup) + args.steps
-    ex_prof = ex_med = None
-    if comm is None:
-        def step_all(nsteps):
-            for i in range(nsteps):
-                idx.search_batch_dev(q_dev, B, K, bufs[i & 1][0], bufs[i & 1][1], bufs[i & 1][2], K, nprobes=args.nprobe, mode=1)
-        step_all(2)
-        ex_steps = max(3, args.steps // 2)
-        ctx.profile_only("adc_scan"); ctx.profile(True); ctx.profile_reset()
-        ctx.sync(); t0 = time.perf_counter(); step_all(ex_steps); ctx.sync(); ex_med = (time.perf_counter() - t0) / ex_steps
-        ex_prof = ctx.profile_dump(); ctx.profile_only(None); ctx.profile(False)
-        idx.search_batch_dev(q_dev, B, K, bufs[1][0], bufs[1][1], bufs[1][2], K, nprobes=args.nprobe, mode=1); ctx.sync()
-        x_ids = ctx.download(bufs[1][0], (B, K), np.uint32); x_sc = ctx.download(bufs[1][1], (B, K), np.float32); x_cn = ctx.download(bufs[1][2], (B,), np.int32)
-    if comm is not None:
-        comm.search_wait(idx, comm.search_async(idx, q_dev, B, K, oi, os_, oc, K, nprobes=args.nprobe), block=True); comm.sync()
-    else:
-        idx.search_batch_dev(q_dev, B, K, oi, os_, oc, K, nprobes=args.nprobe)
-    ctx.sync()
-    g_ids = ctx.download(oi, (B, K), np.uint32); g_sc = ctx.download(os_, (B, K), np.float32); g_cn = ctx.download(oc, (B,), np.int32)
-    # exact Flat L2^2 top-K on the same corpus (strict kernels): the recall reference
-    f_ids = flat2.search_batch(Q_host, K, mode=1)[0]
-    recall = float(np.mean([len(set(f_ids[b].tolist()) & set(g_ids[b, :g_cn[b]].tolist())) / K for b in range(B)]))
-    # algorithmic bytes of one adc_scan launch: sum over the batch's probed lists of len * M (SURVEY §8d; +4 id bytes beside it)
-    e_ids, e_lists, _ = idx.export()
-    list_len = np.bincount(e_lists, minlength=args.nlist)
-    cent = idx.centroids(args.nlist).astype(np.float64)
-    q64 = Q_host.astype(np.float64)
-    d2 = (q64 ** 2).sum(1)[:, None] + (cent ** 2).sum(1)[None, :] - 2.0 * (q64 @ cent.T)       # fp64 ranking: enough for a byte count
-    probed = np.argsort(d2, axis=1, kind="stable")[:, :args.nprobe]
-    cand = int(list_len[probed].sum())
-    total_steps = args.steps * len(times) + max(1, args.warmup)
-    # roofline of the ADC kernel: from the every-candidate search (mode 1) when it ran — in the pruned search the kernel only sees what
-    # the lower bound left, and the algorithmic-bytes convention (one code byte per probed candidate and subspace) stops measuring it
-    if ex_prof is not None:
-        adc_ms, adc_n = ex_prof.get("adc_scan", (0.0, 0)); adc_per_step = adc_ms / ex_steps
-    else:
-        adc_ms, adc_n = prof.get("adc_scan", (0.0, 0)); adc_per_step = adc_ms / total_steps
-    ach = cand * args.M / (adc_per_step * 1e-3) / 1e9 if adc_per_step > 0 else 0.0
-    traffic, src = pmc_traffic("adc_scan", n)
-    out = {"workload": f"IVFPQ l2_squared {n}x{d} (clustered corpus), nlist={args.nlist} nprobe={args.nprobe} M={args.M} nbits={args.nbits}, batch={B}, K={K}"
-                       + (f"; inverted lists sharded over {world} ranks (roofline block: rank 0's lists)" if world > 1 else ""),
-           "qps": B * args.steps / med, "ms_per_step": med / args.steps * 1e3, "region_ms": [round(t * 1e3, 3) for t in times],
-           "recall_at_10_vs_exact_flat": recall, "train_vectors": ntrain, "train_s": round(train_s, 2), "add_s": round(add_s, 2),
-           "max_list_len": int(list_len.max()), "mean_list_len": float(list_len.mean()), "candidates_per_query": cand / B,
-           "roofline": {"bound": "hbm", "kernel": "adc_scan", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                        "traffic": traffic, "traffic_source": src, "avg_kernel_ms": adc_per_step, "launches": adc_n,
-                        "algorithmic_bytes_per_launch": cand * args.M, "algorithmic_bytes_per_launch_with_ids": cand * (args.M + 4),
-                        "lds_lookups_per_s": cand * args.M / (adc_per_step * 1e-3) if adc_per_step > 0 else 0.0,
-                        "note": "SURVEY 8(d) convention: one code byte per (query, candidate, subspace). The kernel is bound by LDS gathers, not HBM: "
-                                "queries probing the same list are scanned two at a time (one ds_read_b64 of the interleaved table serves both), so "
-                                "a list's codes are physically read once per pair and mostly from L2 — the counter traffic beside this figure is "
-                                "far below the algorithmic bytes and the fraction can exceed 1. Gather ceiling (random 8-byte reads, 32 lanes on 32 "
-                                "bank pairs, ~3.5 deep): 256 CUs x 2.4 GHz x 128 values / 7 cycles = 11.2e12 lookups/s. Even this every-candidate pass "
-                                "skips gathers: a wave whose partial sums are all above the running bounds after a table phase stops (exact), so "
-                                "the lookups/s figure counts lookups the reference would do, not lookups issued.",
-                        "lds_gather_frac_of_model_ceiling": (cand * args.M / (adc_per_step * 1e-3) / 11.2e12) if adc_per_step > 0 else 0.0},
-           "kernels_ms_per_step": allk}
-    out["roofline"]["measured_on"] = ("the every-candidate search (mode 1), see `every_candidate_search`" if ex_prof is not None
-                                      else "the pruned search (sharded run): only the candidates the lower bound left were read, the fraction is not a bandwidth")
+    g = pipe.results_of(0)
+    out = {"workload": f"IVFPQ l2_squared {n}x{d} (clustered corpus), nlist={nlist} nprobe={args.nprobe} M={args.M} nbits={args.nbits}, batch={B}, K={K}"
+                       + (f"; inverted lists sharded over {world} ranks" if world > 1 else ""), **rec,
+           "train_vectors": ntrain, "train_s": round(train_s, 2), "add_s": round(add_s, 2)}
     alive, behind = stat1[0] - stat0[0], stat1[1] - stat0[1]
     out["two_stage"] = {"what": "stage 1 scans every query's nearest list and seeds the per-query K-th-best bounds; an exact lower bound per remaining (query, list) pair — "
                                 "the serial float32 sum of the pair's table row minima — removes the pairs none of whose candidates can pass; stage 2 scans the rest. "
                                 "Results are bit-identical to the every-candidate search.",
-                        "pairs_behind_nearest_lists_per_batch": behind / searches_two_stage,
-                        "pairs_left_alive_fraction": (alive / behind) if behind else None}
-    if ex_med is not None:
-        same = bool(np.array_equal(x_cn, g_cn) and all(np.array_equal(x_ids[b, :g_cn[b]], g_ids[b, :g_cn[b]]) and
-                                                     np.array_equal(x_sc[b, :g_cn[b]].view(np.uint32), g_sc[b, :g_cn[b]].view(np.uint32)) for b in range(B)))
-        out["every_candidate_search"] = {"qps": B / ex_med, "ms_per_step": ex_med * 1e3, "steps": ex_steps, "adc_scan_ms": adc_per_step,
-                                         "identical_to_pruned_search": same}
-    if not args.no_cpu_baseline and world == 1:
-        blob = idx.to_bytes()                                 # the reference's IVPQ on-disk layout (flushes; nothing is soft-deleted)
-        cb = cpu_baseline_ivfpq(args, blob, Q_host, K, g_ids, g_sc, g_cn, f_ids)
-        out["cpu_baseline"] = cb
-        out["recall_at_10_vs_oracle_ivfpq"] = 1.0 - cb["parity_mismatches"] / max(1, cb["parity_checked_queries"])   # identical lists on every sampled query -> 1.0
+                        "pairs_behind_nearest_lists_per_batch": behind / max(1, searches), "pairs_left_alive_fraction": (alive / behind) if behind else None}
+    if rank == 0 and flat_exact is not None:
+        f_ids = flat_exact.search_batch(Q0, K)[0]
+        out["recall_at_10_vs_exact_flat"] = recall_of(f_ids, g[0], g[2], K)
+    else:
+        f_ids = None
+    if world == 1:
+        # what the ADC kernel itself sustains: the same search with every candidate scored (mode 1: no lower-bound pruning)
+        e_ids, e_lists, _ = idx.export()
+        list_len = np.bincount(e_lists, minlength=nlist)
+        out.update({"max_list_len": int(list_len.max()), "mean_list_len": float(list_len.mean())})
+        if every_candidate:
+            p1 = Pipe(ctx, idx, q_ptrs, B, K, None, nprobes=args.nprobe, mode=1)
+            p1.step(2)
+            ex_steps = max(3, args.steps // 2)
+            idx.stat("adc_stats_reset")
+            ctx.profile_only("adc_scan"); ctx.profile(True); ctx.profile_reset()
+            ctx.sync(); t0 = time.perf_counter(); p1.step(ex_steps); ctx.sync(); ex_el = (time.perf_counter() - t0) / ex_steps
+            ex_prof = ctx.profile_dump(); ctx.profile_only(None); ctx.profile(False)
+            ns = max(1.0, idx.stat("adc_searches"))              # per search (= per adc_scan launch here: one stage, one sub-batch)
+            cand = idx.stat("adc_candidates") / ns / B
+            code_bytes, table_bytes = idx.stat("adc_code_bytes") / ns, idx.stat("adc_table_bytes") / ns
+            x = p1.results_of(0)
+            p1.free()
+            adc_ms = ex_prof.get("adc_scan", (0.0, 0))[0] / ex_steps
+            phys = code_bytes + table_bytes
+            same = bool(np.array_equal(x[2], g[2]) and all(np.array_equal(x[0][b, :g[2][b]], g[0][b, :g[2][b]]) and
+                                                         np.array_equal(x[1][b, :g[2][b]].view(np.uint32), g[1][b, :g[2][b]].view(np.uint32)) for b in range(B)))
+            ceil_ = adc_lookups_ceiling()
+            lookups = cand * B * args.M
+            # what has to come from HBM at least: the code words of every DISTINCT probed list once (the duos of a list share them through L2 / the
+            # Infinity Cache) + the lookup tables of the scanned pairs once (built by pq_lut into HBM, streamed back by the scan)
+            cent = idx.centroids(nlist).astype(np.float64); q64 = Q0.astype(np.float64)
+            d2 = (q64 ** 2).sum(1)[:, None] + (cent ** 2).sum(1)[None, :] - 2.0 * (q64 @ cent.T)       # fp64 ranking: enough for a byte count
+            probed = np.unique(np.argsort(d2, axis=1, kind="stable")[:, :args.nprobe])
+            uniq_code_bytes = float(list_len[probed].sum()) * ((args.M + 3) // 4 * 4)
+            pair_tables = float((list_len[np.argsort(d2, axis=1, kind="stable")[:, :args.nprobe]] > 0).sum()) * args.M * min(1 << args.nbits, 256) * 4
+            must = uniq_code_bytes + pair_tables
+            ach = must / (adc_ms * 1e-3) / 1e9 if adc_ms > 0 else 0.0
+            traffic, src = pmc_traffic("adc_scan", n)
+            out["every_candidate_search"] = {"qps": B / ex_el, "ms_per_step": ex_el * 1e3, "steps": ex_steps, "adc_scan_ms": adc_ms, "identical_to_pruned_search": same,
+                                             "candidates_per_query": cand}
+            out["roofline"] = {"bound": "hbm", "kernel": "adc_scan", "measured_on": "the every-candidate search (mode 1): the pruned search's launches see only what the lower bound left",
+                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                               "avg_kernel_ms": adc_ms,
+                               "algorithmic_bytes_per_launch": must,
+                               "algorithmic_bytes_are": "what must come from HBM: the code words of every distinct probed list once + one lookup table per scanned (query, list) pair "
+                                                        "(the tables are built into HBM by pq_lut and streamed back once)",
+                               "unique_code_bytes": uniq_code_bytes, "pair_table_bytes": pair_tables,
+                               "requested_bytes_per_launch": phys,
+                               "requested_bytes_are": "what the launch's work items ask the memory system for: every item's code words (a list's codes once per PAIR of queries sharing it) "
+                                                      "+ its duo's table per 8192-code item — counted by the kernel that lays out the work (get_stat adc_code_bytes / adc_table_bytes); "
+                                                      "the difference to the HBM bytes is served by L2 and the 256 MB Infinity Cache (the 1M index's codes are 96 MB)",
+                               "requested_code_bytes": code_bytes, "requested_table_bytes": table_bytes,
+                               "requested_GBps": phys / (adc_ms * 1e-3) / 1e9 if adc_ms > 0 else 0.0,
+                               "binding_resource": "LDS gathers: see lds_frac_of_measured_ceiling",
+                               "lds_lookups_per_s": lookups / (adc_ms * 1e-3) if adc_ms > 0 else 0.0,
+                               "lds_gather_ceiling": ceil_,
+                               "lds_frac_of_measured_ceiling": (lookups / (adc_ms * 1e-3) / ceil_["lookups_per_s_two_queries_per_gather"])
+                               if adc_ms > 0 and isinstance(ceil_, dict) and ceil_.get("lookups_per_s_two_queries_per_gather") else None,
+                               "note": "the scan is bound by LDS gathers (one ds_read_b64 of the interleaved table serves the two queries of a duo), not by HBM: the HBM fraction says how "
+                                       "little of the memory system the gathers leave used; the LDS fraction is lookups the reference would do per second over the measured random-gather "
+                                       "rate of this chip (lookups of candidates pruned inside the scan are counted although never issued, so it can exceed the issue-rate ceiling)"}
+        if not args.no_cpu_baseline:
+            orc = oracle()
+            blob = idx.to_bytes()                                 # the reference's IVPQ on-disk layout (flushes; nothing is soft-deleted)
+            cb = cpu_baseline_from_bytes(lambda: orc.IVFPQ(d, "l2_squared", nlist, args.M, args.nbits), blob,
+                                         lambda o, q: o.search(q, K, args.nprobe, cap=K), Q0, K, g, "IVPQ", f_ids)
+            out["cpu_baseline"] = cb
+            out["recall_at_10_vs_oracle_ivfpq"] = 1.0 - cb["parity_mismatches"] / max(1, cb["parity_checked_queries"])   # identical lists on every sampled query -> 1.0
+    pipe.free()
+    return out
+
+
+def leg_hnsw(ctx, ca, args, timer):
+    """configs[2]: HNSW L2, M 16, efConstruction 200, efSearch 128, K 10; graph built by the GPU insert kernel (the reference's sequential
+    semantics: one insertion at a time), searched at B = 256 and in a batch sweep; recall@10 vs exact Flat; oracle on the same graph."""
+    n, d, K, B = args.hnsw_rows, args.hnsw_dim, 10, args.batch
+    M, efc, efs = 16, 200, 128
+    g = ca.HNSWIndex(ctx, d, ca.EUCLIDEAN, M, efc, efs)
+    flat = ca.FlatIndex(ctx, d, ca.EUCLIDEAN)
+    g.set_level_seed(7)
+    # clustered rows (the mixture of the other legs at this dimension, ~15 rows per sub-centre): on i.i.d. uniform 384-d data every row is nearly
+    # equidistant from every query and recall measures nothing
+    nsub = max(64, n // 15)
+    fill = lambda buf, lo, m: ctx.synth_mixture(buf, MIX_SEED + 1, MIX_CENTERS, MIX_SIGMA, nsub, MIX_NOISE, lo, m, d)
+    t0 = time.time()
+    add_rows(ctx, g, 0, n, d, fill, also=(flat,))
+    ctx.sync()
+    build_s = time.time() - t0
+    q_ptrs = query_batches(ctx, 8192, d, lambda p, i: ctx.synth_mixture(p, MIX_SEED + 1, MIX_CENTERS, MIX_SIGMA, nsub, MIX_NOISE, n + 7 + i * 8192, 8192, d))   # 8 x 8192 fresh draws (the sweep's largest batch)
+    Q0 = ctx.download(q_ptrs[0], (B, d), np.float32)
+    params = dict(ef_search=efs)
+    pipe = Pipe(ctx, g, q_ptrs, B, K, None, **params)
+    pipe.step(2)
+    rec, prof, med, times = measure(ctx, timer, args, pipe.step, "hnsw_search", B)
+    gr = pipe.results_of(0)
+    evals, exps = g.stat("hnsw_distance_evals"), g.stat("hnsw_expansions")          # counted by the kernel, per search (here: query batch 0)
+    pipe.free()
+    avg_ms, nl = kernel_stats(prof, "hnsw_search")
+    alg = evals * d * 4 + exps * 2 * M * 4            # distance evaluations read a row each; every expansion reads one (layer-0: 2M slots) edge list
+    ach = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    f_ids = flat.search_batch(Q0, K)[0]
+    out = {"workload": f"HNSW l2 {n}x{d}, M={M} efConstruction={efc} efSearch={efs}, batch={B}, K={K} (BASELINE configs[2] at {n} rows: the graph is built inside the run by "
+                       f"the GPU insert kernel, one insertion at a time as the reference's semantics demand — {build_s:.0f}s; a 1M-node build is minutes, its line is in profiles/)",
+           **rec, "build_s": round(build_s, 1), "inserts_per_s": n / build_s,
+           "distance_evals_per_query": evals / B, "expansions_per_query": exps / B,
+           "recall_at_10_vs_exact_flat": recall_of(f_ids, gr[0], gr[2], K),
+           "recall_note": "the reference's insertNode never promotes the entry point and prunes before the new node is linked (DESIGN.md 1), so its graphs recall poorly by "
+                          "construction; parity means identical results on the identical graph",
+           "roofline": {"bound": "hbm", "kernel": "hnsw_search", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "avg_kernel_ms": avg_ms, "launches": nl, "algorithmic_bytes_per_launch": alg,
+                        "algorithmic_bytes_are": "distance evaluations x d x 4 + expansions x 2M x 4, both counted by the kernel (random 1.5 KB row reads: latency-bound, one wave per query)"}}
+    sweep = {}
+    for Bs in (1024, 4096, 8192):
+        p2 = Pipe(ctx, g, q_ptrs, Bs, K, None, **params)
+        p2.step(2)
+        ctx.sync(); t0 = time.perf_counter(); p2.step(6); ctx.sync(); el = (time.perf_counter() - t0) / 6
+        sweep[f"batch{Bs}"] = {"qps": Bs / el, "ms_per_step": el * 1e3}
+        p2.free()
+    out["batch_sweep"] = sweep
+    out["host_buffers"] = host_buffers_qps(lambda: g.search_batch(Q0, K, ef_search=efs), B)
+    if not args.no_cpu_baseline:
+        orc = oracle()
+        blob = g.to_bytes()
+        out["cpu_baseline"] = cpu_baseline_from_bytes(lambda: orc.HNSW(d, "l2", M, efc, efs), blob, lambda o, q: o.search(q, K, efs), Q0, K, gr, "HNSW")
+    ctx.free(q_ptrs[0])
+    return out
+
+
+def leg_hybrid(ctx, ca, args, timer, q_ptrs, Q0):
+    """configs[4]: IVF 1M x 768 + BM25 over 100k documents + Reciprocal Rank Fusion (K = 60), k = 10."""
+    from comet_amd.hybrid import reciprocal_rank_fusion
+    B, K, d, n, nlist = args.batch, 10, args.dim, args.rows, args.nlist
+    ivf = ca.IVFIndex(ctx, d, nlist, ca.COSINE)
+    ntrain = min(n, nlist * 100)
+    tbuf = ctx.alloc(ntrain * d * 4)
+    mix_fill(ctx, d)(tbuf, 0, ntrain)
+    t0 = time.time(); ivf.train_dev(tbuf, ntrain); train_s = time.time() - t0
+    ctx.free(tbuf)
+    t0 = time.time(); add_rows(ctx, ivf, 0, n, d, mix_fill(ctx, d)); ctx.sync(); add_s = time.time() - t0
+    out = {"workload": f"Hybrid (BASELINE configs[4]): IVF cosine {n}x{d} nlist={nlist} (clustered corpus; GPU train {train_s:.1f}s, add {add_s:.1f}s) + BM25 over {args.docs} documents "
+                       f"+ Reciprocal Rank Fusion (K=60), batch={B}, k={K}"}
+    ldh = (d + 63) // 64 * 64
+    vec_last = None
+    for npb in (args.nprobe, 1):
+        pipe = Pipe(ctx, ivf, q_ptrs, B, K, None, nprobes=npb)
+        pipe.step(2)
+        rec, prof, med, times = measure(ctx, timer, args, pipe.step, "ivf_scan_f16", B)
+        g = pipe.results_of(0)
+        scan_rows = ivf.stat("ivf_scan_rows")
+        avg_ms, nl = kernel_stats(prof, "ivf_scan_f16")
+        alg = scan_rows * ldh * 2
+        ach = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, src = pmc_traffic("ivf_scan_f16", n)
+        rec["roofline"] = {"bound": "hbm", "kernel": "ivf_scan_f16", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": traffic, "traffic_source": src, "avg_kernel_ms": avg_ms, "launches": nl, "algorithmic_bytes_per_launch": alg,
+                           "algorithmic_bytes_are": "fp16 shadow rows of every probed list, once per group of <= 64 of its queries (counted by the kernel that lays out the "
+                                                    f"work: {int(scan_rows)} rows of query batch 0) x {ldh} x 2 bytes"}
+        rec["fast_path"] = {k: ivf.stat(k) for k in ("fast_queries", "strict_queries", "fast_candidates", "fast_overflows")}
+        x = pipe.results_of(0, mode=1)                                                     # the exact kernels (search mode 1) on the same batch
+        rec["identical_to_exact_kernels"] = bool(np.array_equal(x[2], g[2]) and np.array_equal(x[0], g[0]) and np.array_equal(x[1].view(np.uint32), g[1].view(np.uint32)))
+        p1 = Pipe(ctx, ivf, q_ptrs, B, K, None, nprobes=npb, mode=1)
+        p1.step(1); ctx.sync(); t0 = time.perf_counter(); p1.step(4); ctx.sync()
+        rec["exact_kernels_ms_per_step"] = (time.perf_counter() - t0) / 4 * 1e3
+        p1.free()
+        rec["host_buffers"] = host_buffers_qps(lambda npb=npb: ivf.search_batch(Q0, K, nprobes=npb), B)
+        out[f"ivf_nprobe{npb}"] = rec
+        vec_last = g if npb == 1 else vec_last
+        if npb == args.nprobe:
+            vec32 = g
+        pipe.free()
+    # ---- BM25: 100k documents of Zipf(1.1) token ids over a 50k vocabulary, 64-256 tokens, 3-term queries (SURVEY 8d) ----
+    orc = oracle() if not args.no_cpu_baseline else None
+    rng = np.random.default_rng(3)
+    vocab, nd = 50_000, args.docs
+    zipf = lambda size: np.minimum(vocab - 1, (rng.pareto(1.1, size) * 20).astype(np.int64)).astype(np.uint32)
+    lens = rng.integers(64, 257, nd)
+    gt = ca.BM25SearchIndex(ctx)
+    ot = orc.BM25() if orc else None
+    t0 = time.time()
+    for i, l in enumerate(lens):
+        t = zipf(int(l))
+        gt.add(i + 1, t)
+        if ot:
+            ot.add(i + 1, t)
+    tbuild = time.time() - t0
+    qsets = [[zipf(3).tolist() for _ in range(B)] for _ in range(NQB)]
+    gt.search_batch(qsets[0], K)
+    it = [0]
+
+    def tstep(nsteps):
+        for _ in range(nsteps):
+            gt.search_batch(qsets[it[0] % NQB], K); it[0] += 1
+    trec, tprof, tmed, _t = measure(ctx, timer, args, tstep, "bm25_score", B)
+    tr = gt.search_batch(qsets[0], K)
+    trec["roofline"] = {"bound": "hbm", "kernel": "bm25 (per-token scoring launches + top-K)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                        "note": "SURVEY 8d: sum over terms of df x 12 bytes + n_docs x 8 is microseconds of traffic at 100k documents — the leg is launch- and latency-bound, a "
+                                "roofline fraction is not meaningful and is not reported"}
+    if ot:
+        nq = min(B, os.cpu_count() or 1)
+        bad = []
+
+        def work(lo, hi):
+            for b in range(lo, hi):
+                c, oi, _, os64 = ot.search(qsets[0][b], K)
+                if not (tr[3][b] == c and np.array_equal(tr[0][b, :c], oi) and np.array_equal(tr[2][b, :c].view(np.uint64), np.asarray(os64, np.float64).view(np.uint64))):
+                    bad.append(b)
+        cel = threads_map(work, nq, nq)
+        trec["cpu_baseline"] = {"value": nq / cel, "unit": "queries/s", "cores": nq, "kind": "port", "sample": f"{nq} of query set 0's 3-term queries over the {nd} documents, {nq} threads, {cel:.2f}s",
+                                "parity_checked_queries": nq, "parity_mismatches": len(bad), "parity_is": "ids and float64 score bit patterns"}
+    trec["workload"] = f"BM25 over {nd} documents (Zipf(1.1) token ids, vocabulary {vocab}, 64-256 tokens), batch={B} 3-term queries, K={K} (host-side token lists in, host results out; both indexes built in {tbuild:.0f}s)"
+    out["bm25"] = trec
+    # ---- fusion: the reference cuts both legs to k before fusing (hybrid_search_index.go:518,555), ranks on the host ----
+    t0 = time.perf_counter()
+    fused = []
+    for b in range(B):
+        v = {int(i): float(s) for i, s in zip(vec_last[0][b, :vec_last[2][b]], vec_last[1][b, :vec_last[2][b]])}
+        t = {int(i): float(s) for i, s in zip(tr[0][b, :tr[3][b]], tr[2][b, :tr[3][b]])}
+        f = reciprocal_rank_fusion(v, t)
+        fused.append(sorted(f.items(), key=lambda kv: (-kv[1], kv[0]))[:K])
+    fuse_ms = (time.perf_counter() - t0) * 1e3
+    v1 = out["ivf_nprobe1"]
+    e2e_ms = v1["ms_per_step"] + trec["ms_per_step"] + fuse_ms
+    out["rrf"] = {"host_ms_per_batch": fuse_ms, "what": "reciprocalRankFusion.Combine + sort + cut (fusion.go:174-243) on the host for 256 queries, as in the reference (O(k) per query); "
+                                                        "this is the Python mirror's time (dict arithmetic), the Go host's is microseconds"}
+    out["end_to_end"] = {"qps": B / (e2e_ms * 1e-3), "ms_per_batch": e2e_ms, "what": "vector leg (nprobe 1, the hybrid default) + text leg + fusion, run one after the other"}
+    if orc:
+        blob = ivf.to_bytes()
+        out["cpu_baseline"] = cpu_baseline_from_bytes(lambda: orc.IVF(d, "cosine", nlist), blob, lambda o, q: o.search(q, K, args.nprobe, cap=K), Q0, K, vec32, "IVFX", None)
+        out["cpu_baseline"]["covers"] = f"the IVF leg at nprobe {args.nprobe}; the BM25 leg's baseline is in `bm25`"
     return out
 
 
@@ -424,6 +693,7 @@ def main():
     def reduce_max(x):
         return comm.allreduce_max(x) if comm is not None else x
     timer = Timer(barrier, reduce_max)
+    t_start = time.time()
 
     # ---------------------------------------------------------------- headline: Flat (configs[1])
     idx = ca.FlatIndex(ctx, args.dim, args.metric)
@@ -434,81 +704,108 @@ def main():
     ctx.sync()
     build_s = time.time() - t0
     B, K = args.batch, args.k
-    q_dev = ctx.alloc(B * args.dim * 4)
-    ctx.synth_fill(q_dev, QUERY_SEED, 0, B * args.dim)
-    # result-buffer sets: batch i+1 is enqueued before batch i is finalised / exchanged (software pipeline)
-    ptrs = [(ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)) for _ in range(3)]
-
-    def run(nsteps):
-        prev = None
-        for i in range(nsteps):
-            w = i % 3
-            if comm is not None:    # shard search now; all-gather + merge of the previous batch follow it on the exchange stream
-                t = comm.search_async(idx, q_dev, B, K, ptrs[w][0], ptrs[w][1], ptrs[w][2], K, mode=args.mode)
-            else:
-                t = idx.search_batch_dev_async(q_dev, B, K, ptrs[w][0], ptrs[w][1], ptrs[w][2], K, mode=args.mode)
-            if prev is not None:
-                comm.search_wait(idx, prev, block=False) if comm is not None else idx.search_wait(prev)
-            prev = t
-        if prev is not None:
-            comm.search_wait(idx, prev, block=True) if comm is not None else idx.search_wait(prev)
-
-    run(1)
-    med, times, prof, allk = timed(ctx, timer, run, args, "flat_scan_f16" if B > 64 else "flat_scan_f16_n64")
+    # query batch 0 is the stream the CPU baseline regenerates (QUERY_SEED from offset 0); batches 1.. continue it
+    q_ptrs = query_batches(ctx, B, args.dim, lambda p, i: ctx.synth_fill(p, QUERY_SEED, i * B * args.dim, B * args.dim))
+    pipe = Pipe(ctx, idx, q_ptrs, B, K, comm, mode=args.mode)
+    pipe.step(1)
+    dominant = "flat_scan_f16" if B > 64 else "flat_scan_f16_n64"
+    rec, prof, med, times = measure(ctx, timer, args, pipe.step, dominant, B)
+    g0 = pipe.results_of(0)
 
     line = None
     if rank == 0:
-        total_steps = args.steps * len(times) + max(1, args.warmup)
         line = {
             "metric": "queries/sec + recall@10, 1M x 768 Flat & IVFPQ (value = the Flat leg: exact search, recall@K = 1.0 by construction, ids bit-identical "
-                      "to the CPU reference path; the IVFPQ leg with its recall@10 is in `ivfpq`)",
-            "value": B * args.steps / med, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": med / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "timing": {"regions": len(times), "reported": "median region", "region_ms": [round(t * 1e3, 3) for t in times]},
+                      "to the CPU reference path; the IVFPQ leg with its recall@10 is in `ivfpq`; the other BASELINE configs are in `ivfpq10m`, `hnsw`, `hybrid`)",
+            "value": rec["qps"], "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": DTYPE, "data": "synthetic",
+            "timing": {"regions": len(times), "reported": "median region", "region_ms": rec["region_ms"], "query_batches_rotated": NQB},
+            "sustained": rec["sustained"],
             "config": {"workload": f"Flat {args.metric} {args.rows}x{args.dim}, batch={B} queries, K={K} (BASELINE configs[1])",
                        "rows": args.rows, "dim": args.dim, "batch": B, "k": K, "metric": args.metric,
                        "mode": {0: "auto", 1: "strict", 2: "fast"}[args.mode], "sharding": f"rows/{world}", "build_s": round(build_s, 2)},
-            "roofline": flat_roofline(prof, total_steps, hi - lo, args.dim, B),
-            "kernels_ms_per_step": allk,
+            "roofline": flat_roofline(prof, hi - lo, args.dim, B),
+            "kernels_ms_per_step": rec["kernels_ms_per_step"],
             "fast_path": {k: idx.stat(k) for k in ("fast_queries", "strict_queries", "fast_candidates", "fast_expansions", "fast_overflows")},
             "recall_at_10": {"flat": 1.0},
             "scaling_note": None if world == 1 else "strong scaling of the named config: the 1M-row corpus is split over the ranks and every rank searches its shard for the "
-                            "same 256 queries; per batch a rank keeps ~0.15 ms that does not shrink with its shard (post stage per shard, query preparation, "
-                            "exchange + merge, launch gaps), so the measured single-GPU shard timings predict 1.7x / 2.4x / 3.1x at 2 / 4 / 8 GPUs (DESIGN.md 3.9)",
+                            "same 256 queries; per batch a rank keeps a fixed cost that does not shrink with its shard (post stage per shard, query preparation, "
+                            "exchange + merge, launch gaps), see DESIGN.md 3.9; no multi-GPU box was available to the builder: the exchange ran at world size > 1 only "
+                            "as processes sharing one GPU (tests/test_comm_gpu.py)",
         }
-        if world == 1 and not args.no_cpu_baseline:
-            last = ptrs[(args.steps - 1) % 3]
-            ids = ctx.download(last[0], (B, K), np.uint32)
-            sc = ctx.download(last[1], (B, K), np.float32)
-            cn = ctx.download(last[2], (B,), np.int32)
-            line["cpu_baseline"] = cpu_baseline_flat(args, ids, sc, cn)
-        else:
-            line["cpu_baseline"] = None
+        if world == 1:
+            Qh = ctx.download(q_ptrs[0], (B, args.dim), np.float32)
+            line["host_buffers"] = host_buffers_qps(lambda: idx.search_batch(Qh, K, mode=args.mode), B)
+        line["cpu_baseline"] = cpu_baseline_flat(args, *g0) if (world == 1 and not args.no_cpu_baseline) else None
+    pipe.free()
 
-    # ---------------------------------------------------------------- Flat L2^2 at HBM-binding batches (N = 1) + IVFPQ (any N: list shards)
-    if legs & ({"flat_l2", "ivfpq"} if world == 1 else {"ivfpq"}):
-        flat2 = ca.FlatIndex(ctx, args.dim, ca.L2_SQUARED)
-        add_rows(ctx, flat2, 0, args.rows, args.dim, lambda buf, r0, m: ctx.synth_mixture(buf, MIX_SEED, MIX_CENTERS, MIX_SIGMA, MIX_SUB, MIX_NOISE, r0, m, args.dim))
+    def guarded(name, fn):
+        """a leg that fails leaves its error in the line instead of taking the headline with it"""
+        try:
+            return fn()
+        except Exception as e:        # noqa: BLE001
+            import traceback
+            return {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc(limit=4)}
+
+    # ---------------------------------------------------------------- clustered 1M corpus: Flat L2^2 (N = 1), IVFPQ (any N), hybrid (N = 1)
+    need_mix = legs & ({"flat_l2", "ivfpq", "hybrid"} if world == 1 else {"ivfpq"})
+    if need_mix:
+        flat2 = None
+        if rank == 0 or world == 1:
+            flat2 = ca.FlatIndex(ctx, args.dim, ca.L2_SQUARED)
+            add_rows(ctx, flat2, 0, args.rows, args.dim, mix_fill(ctx, args.dim))
         # queries: fresh draws from the same mixture (rows past the corpus)
-        q2_dev = ctx.alloc(B * args.dim * 4)
-        ctx.synth_mixture(q2_dev, MIX_SEED, MIX_CENTERS, MIX_SIGMA, MIX_SUB, MIX_NOISE, args.rows + 7, B, args.dim)
-        ctx.sync()
-        Q2 = ctx.download(q2_dev, (B, args.dim), np.float32)
+        q2 = query_batches(ctx, B, args.dim, lambda p, i: ctx.synth_mixture(p, MIX_SEED, MIX_CENTERS, MIX_SIGMA, MIX_SUB, MIX_NOISE, args.rows + 7 + i * B, B, args.dim))
+        Q2 = ctx.download(q2[0], (B, args.dim), np.float32)
         if "flat_l2" in legs and world == 1:
-            line["flat_l2"] = leg_flat_l2(ctx, ca, args, timer, flat2, q2_dev)
+            r = guarded("flat_l2", lambda: leg_flat_l2(ctx, ca, args, timer, flat2, q2))
+            line["flat_l2"] = r
         if "ivfpq" in legs:
-            iv = leg_ivfpq(ctx, ca, args, timer, flat2, q2_dev, Q2, comm, rank, world)
-        if "ivfpq" in legs and rank == 0:
-            line["ivfpq"] = iv
-            line["recall_at_10"]["ivfpq_vs_exact_flat"] = line["ivfpq"]["recall_at_10_vs_exact_flat"]
-            if "recall_at_10_vs_oracle_ivfpq" in line["ivfpq"]:
-                line["recall_at_10"]["ivfpq_vs_oracle_ivfpq"] = line["ivfpq"]["recall_at_10_vs_oracle_ivfpq"]
+            iv = guarded("ivfpq", lambda: leg_ivfpq(ctx, ca, args, timer, flat2, q2, Q2, args.rows, args.nlist, "ivfpq", comm, rank, world))
+            if rank == 0:
+                line["ivfpq"] = iv
+                if "recall_at_10_vs_exact_flat" in iv:
+                    line["recall_at_10"]["ivfpq_vs_exact_flat"] = iv["recall_at_10_vs_exact_flat"]
+                if "recall_at_10_vs_oracle_ivfpq" in iv:
+                    line["recall_at_10"]["ivfpq_vs_oracle_ivfpq"] = iv["recall_at_10_vs_oracle_ivfpq"]
+        if "hybrid" in legs and world == 1:
+            line["hybrid"] = guarded("hybrid", lambda: leg_hybrid(ctx, ca, args, timer, q2, Q2))
+        if flat2 is not None:
+            flat2.close()
+        ctx.free(q2[0])
+    # ---------------------------------------------------------------- configs[3]: IVFPQ 10M (single GPU: the whole index; N > 1: list shards)
+    if "ivfpq10m" in legs:
+        def big():
+            nb = args.big_rows
+            nsub = max(MIX_SUB, nb * MIX_SUB // N_ROWS)         # the same ~15 rows per sub-centre as the 1M corpus (with 65536 sub-centres a 10M corpus has 150 near-duplicates per query)
+            qb = query_batches(ctx, B, args.dim, lambda p, i: ctx.synth_mixture(p, MIX_SEED, MIX_CENTERS, MIX_SIGMA, nsub, MIX_NOISE, nb + 7 + i * B, B, args.dim))
+            Qb = ctx.download(qb[0], (B, args.dim), np.float32)
+            fx = None
+            if rank == 0:         # exact ground truth at 10M rows: a Flat index of the same rows (30 GB + 15 GB of fp16 shadow: nothing on a 288 GB part)
+                fx = ca.FlatIndex(ctx, args.dim, ca.L2_SQUARED)
+                add_rows(ctx, fx, 0, nb, args.dim, mix_fill(ctx, args.dim, nsub))
+            r = leg_ivfpq(ctx, ca, args, timer, fx, qb, Qb, nb, args.big_nlist, "ivfpq10m", comm, rank, world, every_candidate=False, nsub=nsub)
+            r["corpus"] = f"{MIX_CENTERS} centres, {nsub} sub-centres at {MIX_SIGMA}, noise {MIX_NOISE}"
+            if fx is not None:
+                fx.close()
+            ctx.free(qb[0])
+            return r
+        r = guarded("ivfpq10m", big)
+        if rank == 0:
+            line["ivfpq10m"] = r
+            if "recall_at_10_vs_exact_flat" in r:
+                line["recall_at_10"]["ivfpq10m_vs_exact_flat"] = r["recall_at_10_vs_exact_flat"]
+    if "hnsw" in legs and world == 1:
+        line["hnsw"] = guarded("hnsw", lambda: leg_hnsw(ctx, ca, args, timer))
+        if "recall_at_10_vs_exact_flat" in line["hnsw"]:
+            line["recall_at_10"]["hnsw_vs_exact_flat"] = line["hnsw"]["recall_at_10_vs_exact_flat"]
 
     if comm is not None:
         comm.barrier()
         comm.close()
     if rank == 0:
+        line["wall_s"] = round(time.time() - t_start, 1)
         # RCCL writes its version banner through C stdio: flush that first so that the JSON line is the LAST line of stdout
         try:
             C.CDLL(None).fflush(None)

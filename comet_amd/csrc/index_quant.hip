@@ -802,7 +802,7 @@ struct PQFamilyIndex : comet_index {
             AdcFilter afl{};
             if (fuse) {
                 afl.cand = c->salloc<unsigned long long>((size_t)qb * ldD); afl.cursor = c->salloc<int32_t>(qb); afl.tq = c->salloc<uint32_t>(qb); afl.K = p.k; afl.thr = p.threshold;
-                if (!adc_stats.p) { adc_stats.reserve(16, c->stream, 0); HIP_CHECK(hipMemsetAsync(adc_stats.p, 0, 16, c->stream)); }
+                if (!adc_stats.p) { adc_stats.reserve(32, c->stream, 0); HIP_CHECK(hipMemsetAsync(adc_stats.p, 0, 32, c->stream)); }
                 afl.stats = adc_stats.as<int32_t>();
                 // mode 1 ("strict"): the reference's literal work — every candidate of every probed list is scored. On a list shard of more
                 // than two ranks the single pass is used as well: a rank owns the nearest list of only 1 / world of the queries, the bounds of
@@ -948,10 +948,21 @@ struct PQFamilyIndex : comet_index {
     bool get_stat(const char* name, double* out) const override {
         std::string k(name);
         if (k == "max_list_len") { const_cast<ListLayout&>(lay).compile(c); *out = (double)lay.max_len; return true; }
-        if (k == "adc_pairs_alive" || k == "adc_pairs_behind_nearest") {      // two-stage search: (query, list) pairs the lower bound left / all pairs behind the nearest lists
-            int32_t h[2] = {0, 0};
-            if (adc_stats.p) { c->d2h(h, adc_stats.p, 8); HIP_CHECK(hipStreamSynchronize(c->stream)); }
-            *out = (double)h[k == "adc_pairs_alive" ? 0 : 1];
+        if (k.rfind("adc_", 0) == 0) {
+            // cumulative counters of the fused ADC search. Two-stage search: (query, list) pairs the lower bound left / all pairs behind the nearest
+            // lists. What the scan launches were given to move and score: code bytes (every item's blocks, once per duo), table bytes (every item
+            // streams its duo's table), candidates (per query), searches. adc_stats_reset zeroes them.
+            int32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (adc_stats.p) { c->d2h(h, adc_stats.p, 32); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+            const int KL = std::min(Ksub, 256);
+            if (k == "adc_pairs_alive") *out = (double)h[0];
+            else if (k == "adc_pairs_behind_nearest") *out = (double)h[1];
+            else if (k == "adc_code_bytes") *out = (double)h[2] * 64.0 * M4 * 4.0;
+            else if (k == "adc_table_bytes") *out = (double)h[3] * 2.0 * M * KL * 4.0;
+            else if (k == "adc_candidates") *out = (double)h[4] * 64.0;
+            else if (k == "adc_searches") *out = (double)h[5];
+            else if (k == "adc_stats_reset") { if (adc_stats.p) { HIP_CHECK(hipMemsetAsync(adc_stats.p, 0, 32, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); } *out = 0.0; }
+            else return false;
             return true;
         }
         return false;

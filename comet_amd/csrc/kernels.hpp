@@ -91,7 +91,8 @@ int64_t adc_codes_pad();    // code slots the ADC scan may read (never use) past
 constexpr int ADC_FILTER_MAX_K = 64;
 struct AdcFilter { unsigned long long* cand; int32_t* cursor; uint32_t* tq; int K; float thr;
                    int one_stage;    // 1: scan every probed candidate in one pass (search mode 1), no lower-bound pruning
-                   int32_t* stats;   // nullable: [0] += pairs behind the nearest lists the lower bound left alive, [1] += pairs behind the nearest lists (two-stage search)
+                   int32_t* stats;   // nullable, 8 ints: [0] += pairs behind the nearest lists the lower bound left alive, [1] += pairs behind the nearest lists (two-stage search),
+                                     // [2] += 64-code blocks the scan's items cover, [3] += items (each streams one duo table), [4] += (query, block) pairs, [5] += searches
 };
 void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* centroids, const float* codebooks, int M, int Ksub, int dsub,
                      const uint32_t* codes, int M4, const int64_t* list_base, const int32_t* list_len, const uint32_t* probe_list, int ldp,

@@ -126,7 +126,18 @@ __global__ __launch_bounds__(256) void km_update_kernel(const float* __restrict_
     if (cnt <= 0) return;
     const int* __restrict__ mem = members + offs[cidx];
     float sum = 0.0f;
-    for (int i = 0; i < cnt; i++) sum = sum + V[(long)mem[i] * ld + col];       // clusterSums[c][dim] += v[dim]
+    // the sum is one serial chain in member order, its operands are not: eight member rows are requested at once (a load per
+    // iteration pays the index -> row round trip, ~0.5 us, once per member: 220 us for a 400-member cluster of a PQ subspace)
+    constexpr int KU = 8;
+    for (int i = 0; i < cnt; i += KU) {
+        int m[KU]; float v[KU];
+#pragma unroll
+        for (int j = 0; j < KU; j++) m[j] = mem[min(i + j, cnt - 1)];
+#pragma unroll
+        for (int j = 0; j < KU; j++) v[j] = V[(long)m[j] * ld + col];
+#pragma unroll
+        for (int j = 0; j < KU; j++) if (i + j < cnt) sum = sum + v[j];          // clusterSums[c][dim] += v[dim]
+    }
     centroids[(long)cidx * ld + col] = sum / (float)cnt;                         // sum / float32(clusterSize)
 }
 void launch_kmeans_update(Ctx* c, const float* V, int64_t n, int ld, const int32_t* assign, int k, float* centroids) {
@@ -141,7 +152,8 @@ void launch_kmeans_update(Ctx* c, const float* V, int64_t n, int ld, const int32
     km_chunk_prefix_kernel<<<dim3((unsigned)ceil_div(k, 256)), dim3(256), 0, c->stream>>>(chunkcnt, nchunks, k, counts); LAUNCH_CHECK();
     km_offsets_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(counts, k, offs); LAUNCH_CHECK();
     km_place_kernel<<<dim3(nchunks), dim3(KM_CHUNK), 0, c->stream>>>(assign, n, k, chunkcnt, offs, members); LAUNCH_CHECK();
-    km_update_kernel<<<dim3((unsigned)ceil_div(ld, 256), k), dim3(256), 0, c->stream>>>(V, ld, members, offs, counts, k, centroids); LAUNCH_CHECK();
+    const int ub = ld <= 64 ? 64 : 256;       // PQ subspaces are 32 floats wide: one wave per cluster, not four of which three idle
+    km_update_kernel<<<dim3((unsigned)ceil_div(ld, ub), k), dim3(ub), 0, c->stream>>>(V, ld, members, offs, counts, k, centroids); LAUNCH_CHECK();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -678,7 +690,8 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
                                                          int n_pairs, int nlist, int identity, const int* __restrict__ list_len, int n_slots,
                                                          unsigned* __restrict__ order, unsigned* __restrict__ slist, AdcRec* __restrict__ qitems, int qcap,
                                                          int* __restrict__ qcount, int* __restrict__ queues, unsigned* __restrict__ tq, int* __restrict__ cursor, int n_q, int lead,
-                                                         const long* __restrict__ list_base, int stage, const unsigned char* __restrict__ dead, int* __restrict__ used) {
+                                                         const long* __restrict__ list_base, int stage, const unsigned char* __restrict__ dead, int* __restrict__ used,
+                                                         int* __restrict__ gstats /*nullable: [2] += 64-code blocks the items cover, [3] += items, [4] += (query, block) pairs, [5] += searches*/) {
     // stage (two-stage fused search, see launch_adc_scan): 0 = every pair; 1 = only every query's nearest non-empty list, which seeds the
     // bounds; 2 = the other pairs that the lower-bound test (pq_lb_kernel) left alive. Pairs outside the stage take no slot at all.
     // lead (fused filter, np >= 2): every query's NEAREST list (probe 0) gets a duo of its own in the first 2 * n_q slots, so that
@@ -764,6 +777,7 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
     if (lane == 0) wtot[w] = tot;
     __syncthreads();
     int base = h ? wtot[x] : 0;
+    int st_blocks = 0, st_items = 0, st_qblocks = 0;                // what the scan will move / score (bench roofline)
     constexpr int NBK = 4;                                          // 64-duo blocks gathered together: their (dependent) loads overlap
     for (int ub0 = u0; ub0 < u1; ub0 += 64 * NBK) {
         AdcRec r[NBK]; int ns[NBK], len[NBK];
@@ -779,6 +793,8 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
                 r[b].qB = -1; r[b].soB = 0;
                 if (pb != ADC_HOLE) { r[b].qB = (int)pb / np; r[b].soB = seg_off[(long)r[b].qB * (np + 1) + ((int)pb - r[b].qB * np)]; }
                 r[b].base_lo = (unsigned)(bb & 0xFFFFFFFFl); r[b].base_hi = (unsigned)(bb >> 32); r[b].pad0 = r[b].pad1 = r[b].pad2 = 0;
+                const int nblk = (len[b] + 63) >> 6;
+                st_blocks += nblk; st_items += ns[b]; st_qblocks += nblk * (r[b].qB >= 0 ? 2 : 1);
             }
         }
 #pragma unroll
@@ -794,6 +810,11 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
         }
     }
     if (h && lane == 0) { qcount[x] = min(wtot[x] + wtot[x + 8], qcap); queues[x] = 0; }
+    if (gstats) {
+        for (int o = 32; o > 0; o >>= 1) { st_blocks += __shfl_xor(st_blocks, o); st_items += __shfl_xor(st_items, o); st_qblocks += __shfl_xor(st_qblocks, o); }
+        if (lane == 0 && st_items) { atomicAdd(&gstats[2], st_blocks); atomicAdd(&gstats[3], st_items); atomicAdd(&gstats[4], st_qblocks); }
+        if (t == 0 && stage <= 1) atomicAdd(&gstats[5], 1);
+    }
 }
 
 // One wave, C blocks of a pass (chains), one PHASE of the duo's table: subspaces [4*w_lo, m_hi), table rows relative to 4*w_lo.
@@ -1195,7 +1216,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
                 adc_order_kernel<<<dim3(1), dim3(1024), identity ? 0 : (size_t)(nlist + 1) * 4, c->stream>>>(pl, ldp, np, so, n_pairs, nlist, identity ? 1 : 0, list_len,
                                                                                                            n_slots, order, slist, qitems, (int)qcap, qcount, queues,
                                                                                                            flt ? flt->tq + b0 : nullptr, flt ? flt->cursor + b0 : nullptr, bn, (lead && stage == 0) ? 1 : 0, (const long*)list_base,
-                                                                                                           stage, dead, used);
+                                                                                                           stage, dead, used, flt ? flt->stats : nullptr);
                 LAUNCH_CHECK();
             }
             {

@@ -44,7 +44,13 @@ for name, ctrs in acc.items():
     key = name if name not in kern else name + "#2"
     kern[key] = e
     e["short"] = short(name)
-json.dump({"what": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | LDS | TCC, one pass each) over `bench.py --no-cpu-baseline --regions 1 --steps 3 --warmup 1`",
+import hashlib
+import pathlib
+_h = hashlib.sha256()
+for _f in sorted((pathlib.Path(__file__).resolve().parent.parent / "comet_amd" / "csrc").glob("*.h*")):
+    _h.update(_f.name.encode()); _h.update(_f.read_bytes())
+json.dump({"source_sha": _h.hexdigest()[:16],       # fingerprint of the kernel sources (bench.py quotes this file only while it matches)
+           "what": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | LDS | TCC, one pass each) over `bench.py --no-cpu-baseline --regions 1 --steps 3 --warmup 1`",
            "correction": "gfx950: read bytes = 2 * FETCH_SIZE(KB) * 1024 (MI355X_MICROARCH.md §HBM); WRITE_SIZE uncalibrated",
            "rows": 1000000, "kernels": kern}, open(out, "w"), indent=1)
 print(f"wrote {out}: {len(kern)} kernels")
