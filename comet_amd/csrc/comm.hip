@@ -32,9 +32,16 @@ constexpr int NCCL_INT32 = 2, NCCL_FLOAT64 = 8, NCCL_MAX = 2, NCCL_SUM = 0;
 static Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
+    static std::string why;
     std::call_once(once, [] {
-        const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
-        for (const char* n : names) { r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+        // COMET_RCCL_LIB: another library with the same five entry points (tests/shm_rccl.cpp runs the ranks of a communicator as
+        // processes sharing one GPU over POSIX shared memory — real RCCL refuses several ranks on one device)
+        const char* env = getenv("COMET_RCCL_LIB");
+        const char* names[] = {env && *env ? env : "librccl.so.1", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+        for (int i = 0; i < (env && *env ? 1 : 4) && !r.h; i++) {
+            r.h = dlopen(names[i], RTLD_NOW | (env && *env ? RTLD_LOCAL : RTLD_GLOBAL));
+            if (!r.h) { const char* e = dlerror(); why = e ? e : "dlopen failed"; }     // dlerror() clears the state: read it once
+        }
         if (!r.h) return;
         r.GetUniqueId = (int (*)(void*))dlsym(r.h, "ncclGetUniqueId");
         r.CommDestroy = (int (*)(void*))dlsym(r.h, "ncclCommDestroy");
@@ -42,7 +49,7 @@ static Rccl& rccl() {
         r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(r.h, "ncclAllReduce");
         r.GetErrorString = (const char* (*)(int))dlsym(r.h, "ncclGetErrorString");
     });
-    if (!r.h || !r.GetUniqueId || !r.AllGather || !r.AllReduce) COMET_FAIL(COMET_ERR_UNSUPPORTED, "RCCL (librccl.so.1) is not available: %s", dlerror() ? dlerror() : "missing symbols");
+    if (!r.h || !r.GetUniqueId || !r.AllGather || !r.AllReduce) COMET_FAIL(COMET_ERR_UNSUPPORTED, "RCCL (librccl.so.1) is not available: %s", r.h ? "missing symbols" : why.c_str());
     return r;
 }
 #define RCCL_CHECK(expr) do { int _r = (expr); if (_r != 0) COMET_FAIL(COMET_ERR_HIP, "RCCL error %d (%s) in %s", _r, rccl().GetErrorString ? rccl().GetErrorString(_r) : "?", #expr); } while (0)
@@ -67,6 +74,8 @@ struct comet_comm {
         bool active = false; uint64_t ticket = 0, search_ticket = 0;
         comet_index* idx = nullptr; int B = 0, k_cap = 0, k = 0;
         DevBuf pack, gathered;           // this rank's block [B*k_cap ids | B*k_cap scores | B counts], and the R gathered blocks
+        DevBuf mergews;                  // the merge's own workspace (beyond 8192 candidates per query it sorts in global memory): the merge runs on the
+                                         // exchange stream while the context's stream is already recycling the scratch arena for the next search
         uint32_t* out_ids = nullptr; float* out_scores = nullptr; int32_t* out_counts = nullptr;
         hipEvent_t searched = nullptr, merged = nullptr;
     };
@@ -154,6 +163,7 @@ int comet_index_search_sharded_async(comet_index* idx, comet_comm* cm, const flo
         // the merge of the previous user of this slot must be done before its buffers are overwritten
         HIP_CHECK(hipEventSynchronize(s->merged));
         s->pack.reserve(words * 4, c->stream, 0); s->gathered.reserve(words * 4 * cm->world, c->stream, 0);
+        if (const size_t wsb = merge_topk_workspace_bytes(cm->world, B, k_cap)) s->mergews.reserve(wsb, c->stream, 0);
         uint32_t* pids = s->pack.as<uint32_t>(); float* psc = reinterpret_cast<float*>(pids + (size_t)B * k_cap); int32_t* pcn = reinterpret_cast<int32_t*>(pids + (size_t)2 * B * k_cap);
         s->search_ticket = idx->search_begin(queries_dev, B, *p, pids, psc, pcn, k_cap);
         s->idx = idx; s->B = B; s->k_cap = k_cap; s->k = p->k; s->out_ids = out_ids_dev; s->out_scores = out_scores_dev; s->out_counts = out_counts_dev;
@@ -183,7 +193,8 @@ int comet_index_search_sharded_wait(comet_index* idx, comet_comm* cm, uint64_t t
             { ProfScope ps(c, "shard_allgather"); RCCL_CHECK(rccl().AllGather(s->pack.p, s->gathered.p, words, NCCL_INT32, cm->comm, cm->xstream)); }
             const uint32_t* g = s->gathered.as<uint32_t>();
             launch_merge_topk(c, g, reinterpret_cast<const float*>(g + (size_t)s->B * s->k_cap), reinterpret_cast<const int32_t*>(g + (size_t)2 * s->B * s->k_cap),
-                              cm->world, s->B, s->k_cap, s->k, s->out_ids, s->out_scores, s->out_counts, (int64_t)words, (int64_t)words);
+                              cm->world, s->B, s->k_cap, s->k, s->out_ids, s->out_scores, s->out_counts, (int64_t)words, (int64_t)words,
+                              merge_topk_workspace_bytes(cm->world, s->B, s->k_cap) ? s->mergews.p : nullptr);
         }
         HIP_CHECK(hipEventRecord(s->merged, cm->xstream));
         s->active = false;

@@ -53,7 +53,8 @@ void launch_gather_indirect(Ctx* c, const uint32_t* table, int64_t ldt, const ui
 int select_max_k();
 // merge R per-shard sorted top-k lists per query (ties: lower shard, then lower position). R*k_cap <= select_max_k().
 void launch_merge_topk(Ctx* c, const uint32_t* ids, const float* scores, const int32_t* counts, int R, int B, int k_cap, int k,
-                       uint32_t* out_ids, float* out_scores, int32_t* out_counts, int64_t rank_stride = 0, int64_t rank_stride_counts = 0);
+                       uint32_t* out_ids, float* out_scores, int32_t* out_counts, int64_t rank_stride = 0, int64_t rank_stride_counts = 0, void* workspace = nullptr);
+size_t merge_topk_workspace_bytes(int R, int B, int k_cap);      // global-memory workspace of the merge (0: it runs in LDS); see launch_merge_topk
 // segment merge (storage_merge.go:13-54): S per-segment top-k lists per query -> distinct ids with their highest score, score descending, cut to k
 void launch_merge_segments(Ctx* c, const uint32_t* ids, const float* scores, const int32_t* counts, int S, int B, int k_cap, int k,
                            uint32_t* out_ids, float* out_scores, int32_t* out_counts, int out_ld);

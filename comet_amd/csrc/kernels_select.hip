@@ -993,14 +993,21 @@ __global__ __launch_bounds__(256) void merge_emit_kernel(const unsigned* __restr
     }
     if (i == 0) out_counts[q] = total < 0 ? total : kq;
 }
+// bytes of workspace the merge needs in global memory (0: it runs in LDS)
+size_t merge_topk_workspace_bytes(int R, int B, int k_cap) {
+    int64_t n2 = 1; while (n2 < (int64_t)R * k_cap) n2 <<= 1;
+    return n2 > 2 * SORT_MAX ? (size_t)B * n2 * sizeof(unsigned long long) : 0;
+}
 void launch_merge_topk(Ctx* c, const uint32_t* ids, const float* scores, const int32_t* counts, int R, int B, int k_cap, int k,
-                       uint32_t* out_ids, float* out_scores, int32_t* out_counts, int64_t rank_stride, int64_t rank_stride_counts) {
+                       uint32_t* out_ids, float* out_scores, int32_t* out_counts, int64_t rank_stride, int64_t rank_stride_counts, void* workspace) {
     if (B <= 0) return;
     const long rs = rank_stride > 0 ? rank_stride : (long)B * k_cap, rsc = rank_stride_counts > 0 ? rank_stride_counts : B;
     int64_t n2 = 1; while (n2 < (int64_t)R * k_cap) n2 <<= 1;
     if (n2 > 2 * SORT_MAX) {            // does not fit in LDS: composites to global memory, global sort, emit
+        // `workspace` (merge_topk_workspace_bytes): a caller that runs the merge on ANOTHER stream than the context's (the exchange stream of
+        // comm.hip) must own the buffer — the context's scratch arena is recycled by whatever the context's own stream runs next
         ScratchMark mark(c);
-        unsigned long long* comp = c->salloc<unsigned long long>((size_t)B * n2);
+        unsigned long long* comp = workspace ? static_cast<unsigned long long*>(workspace) : c->salloc<unsigned long long>((size_t)B * n2);
         { ProfScope ps(c, "merge_topk");
           merge_build_kernel<<<dim3((unsigned)ceil_div(n2, 256), B), dim3(256), 0, c->stream>>>(scores, counts, R, k_cap, comp, n2, rs, rsc); LAUNCH_CHECK(); }
         sort_rows_u64(c, comp, n2, B);
