@@ -27,7 +27,7 @@ struct Rccl {
     const char* (*GetErrorString)(int) = nullptr;
 };
 struct UniqueId { char internal[128]; };   // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed BY VALUE to ncclCommInitRank
-constexpr int NCCL_INT32 = 2, NCCL_FLOAT64 = 8, NCCL_MAX = 2, NCCL_SUM = 0;
+constexpr int NCCL_INT32 = 2, NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8, NCCL_MAX = 2, NCCL_MIN = 3, NCCL_SUM = 0;
 
 static Rccl& rccl() {
     static Rccl r;
@@ -165,6 +165,17 @@ int comet_index_search_sharded_async(comet_index* idx, comet_comm* cm, const flo
         s->pack.reserve(words * 4, c->stream, 0); s->gathered.reserve(words * 4 * cm->world, c->stream, 0);
         if (const size_t wsb = merge_topk_workspace_bytes(cm->world, B, k_cap)) s->mergews.reserve(wsb, c->stream, 0);
         uint32_t* pids = s->pack.as<uint32_t>(); float* psc = reinterpret_cast<float*>(pids + (size_t)B * k_cap); int32_t* pcn = reinterpret_cast<int32_t*>(pids + (size_t)2 * B * k_cap);
+        // list-sharded two-stage IVFPQ search: the ranks' stage-1 bounds are reduced to their minimum on the search stream (in place, B floats;
+        // every rank runs the same sub-batching, so the calls pair up)
+        struct Guard { comet_index* i; ~Guard() { i->bound_exchange = nullptr; i->bound_exchange_user = nullptr; } } guard{idx};
+        if (cm->world > 1) {
+            idx->bound_exchange_user = cm;
+            idx->bound_exchange = [](void* user, uint32_t* tq, int n) {
+                comet_comm* m = static_cast<comet_comm*>(user);
+                ProfScope ps(m->c, "shard_bound_allreduce");
+                RCCL_CHECK(rccl().AllReduce(tq, tq, (size_t)n, NCCL_FLOAT32, NCCL_MIN, m->comm, m->c->stream));
+            };
+        }
         s->search_ticket = idx->search_begin(queries_dev, B, *p, pids, psc, pcn, k_cap);
         s->idx = idx; s->B = B; s->k_cap = k_cap; s->k = p->k; s->out_ids = out_ids_dev; s->out_scores = out_scores_dev; s->out_counts = out_counts_dev;
         HIP_CHECK(hipEventRecord(s->searched, c->stream));          // the exchange of this batch depends on THIS search only, not on later ones

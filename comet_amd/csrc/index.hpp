@@ -25,6 +25,9 @@ struct comet_index {
     // centroids / codebooks stay replicated, every rank ranks ALL centroids and probes the same lists, and the lists it does
     // not own are simply empty here — table build, scan and selection all shrink with the rank count.
     int shard_rank = 0, shard_world = 1;
+    // set by comet_index_search_sharded_async for the duration of the call: all-reduce(min) of n floats on the context's stream across the
+    // ranks of the communicator (the stage-1 bound exchange of the sharded two-stage IVFPQ search); null outside a sharded search
+    void (*bound_exchange)(void* user, uint32_t* tq, int n) = nullptr; void* bound_exchange_user = nullptr;
 
     virtual ~comet_index() {}
     virtual int64_t size() const = 0;

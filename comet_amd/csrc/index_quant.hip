@@ -808,7 +808,10 @@ struct PQFamilyIndex : comet_index {
                 // than two ranks the single pass is used as well: a rank owns the nearest list of only 1 / world of the queries, the bounds of
                 // the others are seeded by a farther list and remove little, and the second set of launches costs more than it saves
                 // (tools/shard_probe.py, 1M rows, B = 256: 4 ranks 0.69 ms two-stage vs 0.60 single pass; 2 ranks 0.75 vs 0.80)
-                afl.one_stage = (p.mode == 1 || shard_world > 2) ? 1 : 0;
+                // — unless the ranks exchange their stage-1 bounds (a sharded search through comet_index_search_sharded_async): then every rank
+                // prunes with the global bound and the two-stage search pays on every world size
+                afl.exchange = shard_world > 1 ? bound_exchange : nullptr; afl.exchange_user = bound_exchange_user;
+                afl.one_stage = (p.mode == 1 || (shard_world > 2 && !afl.exchange)) ? 1 : 0;
             }
             for (int b0 = 0; b0 < B; b0 += qb) {
                 const int bn = std::min(qb, B - b0);

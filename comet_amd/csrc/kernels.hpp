@@ -92,6 +92,10 @@ int64_t adc_codes_pad();    // code slots the ADC scan may read (never use) past
 constexpr int ADC_FILTER_MAX_K = 64;
 struct AdcFilter { unsigned long long* cand; int32_t* cursor; uint32_t* tq; int K; float thr;
                    int one_stage;    // 1: scan every probed candidate in one pass (search mode 1), no lower-bound pruning
+                   // multi-GPU list shards: called between stage 1 and the lower-bound test with the sub-batch's bounds (float bits of sums, +inf where
+                   // this rank scanned nothing for the query) — an all-reduce(min) over the ranks makes every rank prune with the tightest bound. A rank's
+                   // bound is the K-th smallest sum of SOME candidates, i.e. an upper bound on the global K-th smallest, and so is the minimum.
+                   void (*exchange)(void* user, uint32_t* tq, int n); void* exchange_user;
                    int32_t* stats;   // nullable, 8 ints: [0] += pairs behind the nearest lists the lower bound left alive, [1] += pairs behind the nearest lists (two-stage search),
                                      // [2] += 64-code blocks the scan's items cover, [3] += items (each streams one duo table), [4] += (query, block) pairs, [5] += searches
 };

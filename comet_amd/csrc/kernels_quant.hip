@@ -1244,6 +1244,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
         };
         if (!two_stage) { run_stage(0); continue; }
         run_stage(1);
+        if (flt->exchange) flt->exchange(flt->exchange_user, flt->tq + b0, bn);     // list shards: the global bound (one small all-reduce per sub-batch)
         static const bool bound_off = getenv("COMET_ADC_ROWMIN") != nullptr;      // the two-kernel form (row minima of every subspace, then the sums)
         const size_t bnd_lds = (size_t)BND_GP * M * dsub * 4;
         if (!bound_off && KL == 256 && Ksub == 256 && (dsub == 4 || dsub == 8 || dsub == 16) && bnd_lds <= 64 * 1024) {

@@ -5,12 +5,13 @@
 // and real RCCL refuses several ranks on one device). comm.hip loads it instead of librccl when COMET_RCCL_LIB names it; nothing
 // else in the library knows.
 //
-// Semantics kept from NCCL: collectives are enqueued on the caller's stream and are asynchronous to the host; every rank issues
-// the same sequence of collectives on a communicator. Transport: a POSIX shared-memory segment named by the unique id. One
-// collective = [host function: wait until the slot's previous use was read by every rank] -> device-to-host copy of this rank's
-// block into the slot -> [host function: arrive, wait for all ranks] -> host-to-device copy of the gathered blocks (all-reduce:
-// reduced on the host first) -> [host function: depart]. NSLOT slots are used round-robin by sequence number, so up to NSLOT
-// collectives can be in flight.
+// Semantics: every rank issues the same sequence of collectives on a communicator, as with NCCL; unlike NCCL a collective here
+// BLOCKS THE CALLING HOST THREAD until it is complete (stream drained -> this rank's block copied into the shared segment -> all
+// ranks arrived -> gathered / reduced blocks copied back). Blocking inside stream callbacks instead (the asynchronous form) deadlocks:
+// HIP runs the host functions of all streams of a process on one thread, the library issues collectives on two streams (bounds on the
+// search stream, result blocks on the exchange stream), and two ranks can then each sit in the callback the other one needs next.
+// What still runs asynchronously is everything the library enqueues around the collectives (searches, the merge on the exchange stream).
+// Transport: a POSIX shared-memory segment named by the unique id, NSLOT slots used round-robin by sequence number.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -39,57 +40,41 @@ struct Comm {
     long seq = 0;
     void* stage = nullptr;                  // pinned staging for all-reduce results
 };
-struct Op { Comm* c; int slot; long use; int phase; size_t bytes; int dtype, op; size_t count; };   // phase 0: wait depart, 1: arrive + wait, 2: depart, 3: arrive + wait + reduce
-
 void spin_until(std::atomic<long>& a, long target) {
     const time_t t0 = time(nullptr);
     while (a.load(std::memory_order_acquire) < target) {
-        usleep(20);
+        usleep(10);
         if (time(nullptr) - t0 > 120) { fprintf(stderr, "[shm_rccl] a rank did not arrive within 120 s — aborting\n"); abort(); }
     }
 }
 size_t dtype_size(int dt) { switch (dt) { case 0: case 1: return 1; case 2: case 3: case 7: return 4; case 4: case 5: case 8: return 8; case 6: return 2; default: return 4; } }
 
-void host_fn(void* p) {
-    Op* o = static_cast<Op*>(p);
-    Header* h = o->c->hdr;
-    const int w = o->c->world;
-    if (o->phase == 0) spin_until(h->depart[o->slot], (long)w * o->use);
-    else if (o->phase == 1 || o->phase == 3) {
-        h->arrive[o->slot].fetch_add(1, std::memory_order_acq_rel);
-        spin_until(h->arrive[o->slot], (long)w * (o->use + 1));
-        if (o->phase == 3) {                 // reduce the world blocks of the slot into the pinned stage
-            unsigned char* base = o->c->data + (size_t)o->slot * SLOT_BYTES;
-            for (size_t i = 0; i < o->count; i++) {
-                if (o->dtype == 8) {         // ncclFloat64
-                    double acc = reinterpret_cast<double*>(base)[i];
-                    for (int r = 1; r < w; r++) { const double v = reinterpret_cast<double*>(base + (size_t)r * o->bytes)[i]; acc = o->op == 0 ? acc + v : (o->op == 2 ? (v > acc ? v : acc) : (v < acc ? v : acc)); }
-                    static_cast<double*>(o->c->stage)[i] = acc;
-                } else if (o->dtype == 7) {  // ncclFloat32
-                    float acc = reinterpret_cast<float*>(base)[i];
-                    for (int r = 1; r < w; r++) { const float v = reinterpret_cast<float*>(base + (size_t)r * o->bytes)[i]; acc = o->op == 0 ? acc + v : (o->op == 2 ? (v > acc ? v : acc) : (v < acc ? v : acc)); }
-                    static_cast<float*>(o->c->stage)[i] = acc;
-                } else {                     // ncclInt32 / ncclUint32
-                    int acc = reinterpret_cast<int*>(base)[i];
-                    for (int r = 1; r < w; r++) { const int v = reinterpret_cast<int*>(base + (size_t)r * o->bytes)[i]; acc = o->op == 0 ? acc + v : (o->op == 2 ? (v > acc ? v : acc) : (v < acc ? v : acc)); }
-                    static_cast<int*>(o->c->stage)[i] = acc;
-                }
-            }
-        }
-    } else h->depart[o->slot].fetch_add(1, std::memory_order_acq_rel);
-    delete o;
+template <class T> void reduce_into(T* out, const unsigned char* base, size_t block_bytes, size_t count, int world, int op) {
+    for (size_t i = 0; i < count; i++) {
+        T acc = reinterpret_cast<const T*>(base)[i];
+        for (int r = 1; r < world; r++) { const T v = reinterpret_cast<const T*>(base + (size_t)r * block_bytes)[i]; acc = op == 0 ? acc + v : (op == 2 ? (v > acc ? v : acc) : (v < acc ? v : acc)); }
+        out[i] = acc;
+    }
 }
-int enqueue(Comm* c, const void* send, void* recv, size_t bytes, bool reduce, int dtype, int op, size_t count, hipStream_t s) {
+int collective(Comm* c, const void* send, void* recv, size_t bytes, bool reduce, int dtype, int op, size_t count, hipStream_t s) {
     if (bytes * c->world > SLOT_BYTES) { fprintf(stderr, "[shm_rccl] collective of %zu bytes x %d ranks exceeds the slot\n", bytes, c->world); return 2; }
     const long q = c->seq++;
     const int slot = (int)(q % NSLOT); const long use = q / NSLOT;
     unsigned char* base = c->data + (size_t)slot * SLOT_BYTES;
-    if (hipLaunchHostFunc(s, host_fn, new Op{c, slot, use, 0, bytes, dtype, op, count}) != hipSuccess) return 1;
+    Header* h = c->hdr;
+    spin_until(h->depart[slot], (long)c->world * use);                 // the slot's previous use has been read by every rank
     if (hipMemcpyAsync(base + (size_t)c->rank * bytes, send, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
-    if (hipLaunchHostFunc(s, host_fn, new Op{c, slot, use, reduce ? 3 : 1, bytes, dtype, op, count}) != hipSuccess) return 1;
-    if (reduce) { if (hipMemcpyAsync(recv, c->stage, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return 1; }
-    else if (hipMemcpyAsync(recv, base, bytes * c->world, hipMemcpyHostToDevice, s) != hipSuccess) return 1;
-    if (hipLaunchHostFunc(s, host_fn, new Op{c, slot, use, 2, bytes, dtype, op, count}) != hipSuccess) return 1;
+    if (hipStreamSynchronize(s) != hipSuccess) return 1;               // everything enqueued before the collective + the copy
+    h->arrive[slot].fetch_add(1, std::memory_order_acq_rel);
+    spin_until(h->arrive[slot], (long)c->world * (use + 1));
+    if (reduce) {
+        if (dtype == 8) reduce_into(static_cast<double*>(c->stage), base, bytes, count, c->world, op);
+        else if (dtype == 7) reduce_into(static_cast<float*>(c->stage), base, bytes, count, c->world, op);
+        else reduce_into(static_cast<int*>(c->stage), base, bytes, count, c->world, op);
+        if (hipMemcpyAsync(recv, c->stage, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return 1;
+    } else if (hipMemcpyAsync(recv, base, bytes * c->world, hipMemcpyHostToDevice, s) != hipSuccess) return 1;
+    if (hipStreamSynchronize(s) != hipSuccess) return 1;               // the slot (and the stage) may be reused after this
+    h->depart[slot].fetch_add(1, std::memory_order_acq_rel);
     return 0;
 }
 }  // namespace
@@ -147,12 +132,12 @@ __attribute__((visibility("default"))) int ncclCommDestroy(void* comm) {
     return 0;
 }
 __attribute__((visibility("default"))) int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t s) {
-    return enqueue(static_cast<Comm*>(comm), send, recv, count * dtype_size(dtype), false, dtype, 0, count, s);
+    return collective(static_cast<Comm*>(comm), send, recv, count * dtype_size(dtype), false, dtype, 0, count, s);
 }
 // ncclRedOp_t: 0 sum, 1 prod, 2 max, 3 min
 __attribute__((visibility("default"))) int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t s) {
     if (count * dtype_size(dtype) > (1 << 20) || op == 1) return 4;
-    return enqueue(static_cast<Comm*>(comm), send, recv, count * dtype_size(dtype), true, dtype, op, count, s);
+    return collective(static_cast<Comm*>(comm), send, recv, count * dtype_size(dtype), true, dtype, op, count, s);
 }
 __attribute__((visibility("default"))) const char* ncclGetErrorString(int r) {
     switch (r) { case 0: return "success"; case 1: return "HIP call failed"; case 2: return "shared-memory transport failed"; case 4: return "invalid argument"; default: return "error"; }
