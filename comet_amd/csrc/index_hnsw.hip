@@ -265,16 +265,20 @@ __device__ __forceinline__ int hn_search_layer(const HnswGraph& g, const float* 
     return overflow;
 }
 
-__device__ __forceinline__ HnswLds hn_carve(unsigned char* smem, unsigned* s_cur, int* s_flag, float* s_dist) {
+// LDS of one wave: candidate heap [cand_cap] | result heap [res_cap] | staging tile | rows | distances. The search kernel sizes the heaps
+// for its efSearch (the 59 KiB of the full-size layout admit two waves per CU: a search at efSearch 128 needs 1 KiB of results and
+// rarely more than a few hundred live candidates); the insert kernel keeps the full-size layout.
+__device__ __forceinline__ HnswLds hn_carve(unsigned char* smem, unsigned* s_cur, int* s_flag, float* s_dist, int cand_cap = HN_CAND_CAP, int res_cap = HN_EF_MAX + 1) {
     HnswLds L;
-    L.cand = reinterpret_cast<HC*>(smem);                                    // HN_CAND_CAP
-    L.res = L.cand + HN_CAND_CAP;                                            // ef + 1
-    L.tile = reinterpret_cast<float*>(L.res + (HN_EF_MAX + 1));              // 64 x HN_LD
+    L.cand = reinterpret_cast<HC*>(smem);                                    // cand_cap
+    L.res = L.cand + cand_cap;                                               // ef + 1 <= res_cap
+    L.tile = reinterpret_cast<float*>(L.res + res_cap);                      // 64 x HN_LD
     L.rows = reinterpret_cast<unsigned*>(L.tile + 64 * HN_LD);               // 64
     L.dd = reinterpret_cast<float*>(L.rows + 64);                            // 64
-    L.s_cur = s_cur; L.s_flag = s_flag; L.s_dist = s_dist; L.cand_cap = HN_CAND_CAP;
+    L.s_cur = s_cur; L.s_flag = s_flag; L.s_dist = s_dist; L.cand_cap = cand_cap;
     return L;
 }
+static size_t hn_lds_bytes(int cand_cap, int res_cap) { return sizeof(HC) * ((size_t)cand_cap + res_cap) + sizeof(float) * 64 * HN_LD + 64 * 4 + 64 * 4 + 64; }
 // The result max-heap drained into ascending order (hnsw_index.go:623-626: pop everything, fill from the back). Popping is a
 // chain of dependent LDS round trips on one lane (~800 cycles per pop); when all distances are distinct the popped order is
 // simply the sorted order, which the whole wave finds by counting ranks. Equal distances (duplicated vectors) keep the serial
@@ -306,10 +310,11 @@ template <int METRIC>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswGraph g, const float* __restrict__ Qp, int ef, unsigned* __restrict__ visited /*[B][vwords]*/,
                                                          long vwords, unsigned* __restrict__ res_idx, float* __restrict__ res_dist,
                                                          int* __restrict__ res_cnt, int* __restrict__ status, unsigned long long* __restrict__ stats,
-                                                         HC* __restrict__ spill /*nullable: heaps in HBM*/, long spill_cand, long spill_res, int ef_ld) {
+                                                         HC* __restrict__ spill /*nullable: heaps in HBM*/, long spill_cand, long spill_res, int ef_ld,
+                                                         int cand_cap, int res_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned s_cur; __shared__ int s_flag; __shared__ float s_dist;
-    HnswLds L = hn_carve(smem, &s_cur, &s_flag, &s_dist);
+    HnswLds L = hn_carve(smem, &s_cur, &s_flag, &s_dist, cand_cap, res_cap);
     const int q = blockIdx.x, lane = threadIdx.x;
     if (spill) {        // ef beyond the LDS heaps (or a candidate heap that outgrew them): same code, heaps in HBM, one slab per query
         L.cand = spill + (long)q * (spill_cand + spill_res); L.res = L.cand + spill_cand;
@@ -779,9 +784,13 @@ struct HNSWIndex : comet_index {
         unsigned long long* st = c->salloc<unsigned long long>(2);
         c->zero(st, 16);
         HnswGraph g{V.as<float>(), ld, n, level.as<int>(), (const long*)slot_base.p, (const long*)edge_off.p, deg_dev.as<int>(), edges.as<uint32_t>(), entry, max_level, deleted_bitmap()};
-        const size_t lds = HN_LDS_BYTES;
-        // heaps in LDS (ef <= 1024, <= 4096 live candidates) or, beyond that, in HBM: one slab per query, queries in sub-batches of <= 2 GiB
+        // heaps in LDS (ef <= 1024, <= 4096 live candidates) or, beyond that, in HBM: one slab per query, queries in sub-batches of <= 2 GiB.
+        // The LDS heaps are sized for this search: result heap ef + 1, candidate heap 16 ef (>= 1024) first — 35 KiB per wave at ef 128,
+        // four waves per CU instead of two — and the full 4096 only if a query's live candidates outgrow that (the batch is re-run).
+        const int res_cap = (int)std::min<int64_t>(HN_EF_MAX, ef_ld) + 1;
+        int cand_cap = (int)std::min<int64_t>(HN_CAND_CAP, std::max<int64_t>(1024, 16 * (int64_t)ef));
         auto run = [&](bool spill) {
+            const size_t lds = spill ? hn_lds_bytes(64, 64) : hn_lds_bytes(cand_cap, res_cap);
             c->zero(vis, (size_t)B * vwords * 4); c->zero(status, 4);
             ScratchMark mark(c);
             const int64_t s_cand = n, s_res = (int64_t)ef_ld + 1;
@@ -792,7 +801,7 @@ struct HNSWIndex : comet_index {
                 const int bn = std::min(bs, B - b0);
 #define HS(MT) do { HIP_CHECK(hipFuncSetAttribute((const void*)hnsw_search_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                     hnsw_search_kernel<MT><<<dim3(bn), dim3(64), lds, c->stream>>>(g, Qp + (size_t)b0 * ld, ef, vis + (size_t)b0 * vwords, vwords, res_idx + (size_t)b0 * ef_ld, \
-                        res_dist + (size_t)b0 * ef_ld, res_cnt + b0, status, st, slab, s_cand, s_res, ef_ld); } while (0)
+                        res_dist + (size_t)b0 * ef_ld, res_cnt + b0, status, st, slab, s_cand, s_res, ef_ld, spill ? 64 : cand_cap, spill ? 64 : res_cap); } while (0)
                 switch (metric) { case COMET_L2: HS(COMET_L2); break; case COMET_L2SQ: HS(COMET_L2SQ); break; default: HS(COMET_COSINE); break; }
 #undef HS
                 LAUNCH_CHECK();
@@ -800,11 +809,14 @@ struct HNSWIndex : comet_index {
         };
         bool spill = ef > HN_EF_MAX;
         run(spill);
-        if (!spill) {         // more than HN_CAND_CAP live candidates: the same search again with the heaps in HBM
+        while (!spill) {      // more live candidates than the LDS heap holds: the same search again with the full-size heap, then with the heaps in HBM
             int32_t hs = 0;
             c->d2h(&hs, status, 4);
             HIP_CHECK(hipStreamSynchronize(c->stream));
-            if (hs) { c->zero(st, 16); run(true); }
+            if (!hs) break;
+            c->zero(st, 16);
+            if (cand_cap < HN_CAND_CAP) cand_cap = HN_CAND_CAP; else spill = true;
+            run(spill);
         }
         // phase 3: document filter + threshold applied AFTER the search (can return < k), sort, top-k (:321-351)
         const uint8_t* elig = nullptr;
