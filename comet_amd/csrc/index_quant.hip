@@ -236,13 +236,16 @@ struct IVFIndex : comet_index {
         if (olists) std::copy(lay.list_of.begin(), lay.list_of.end(), olists);
     }
     // first match in the reference's order: list by list, append order inside a list (ivf_index_search.go:183-198)
+    std::unordered_map<uint32_t, int64_t> first_row; uint64_t first_row_version = 0;     // id -> row of its first slot, rebuilt when the layout was recompiled
     int64_t row_of_id(uint32_t id) override {
         lay.compile(c);
-        int64_t best_slot = -1, best_row = -1;
-        if (!lay.id_count.count(id)) return -1;
-        for (int64_t s = 0; s < lay.nslots; s++) { const uint32_t r = lay.row_of_slot_h[s]; if (r != 0xFFFFFFFFu && lay.ids[r] == id) { best_slot = s; best_row = r; break; } }
-        (void)best_slot;
-        return best_row;
+        if (first_row_version != lay.version) {
+            first_row.clear(); first_row.reserve((size_t)lay.n);
+            for (int64_t s = 0; s < lay.nslots; s++) { const uint32_t r = lay.row_of_slot_h[s]; if (r != 0xFFFFFFFFu) first_row.emplace(lay.ids[r], (int64_t)r); }   // emplace keeps the first
+            first_row_version = lay.version;
+        }
+        auto it = first_row.find(id);
+        return it == first_row.end() ? -1 : it->second;
     }
     const float* rows_dev() const override { return V.as<float>(); }
 
@@ -651,6 +654,7 @@ struct PQFamilyIndex : comet_index {
     DevBuf codes_arr;   // arrival-order codes, n x M4 words (byte m of a row = code[m])
     DevBuf codes_il;    // compiled, block-interleaved
     DevBuf adc_stats;   // two-stage search counters (AdcFilter::stats), read by get_stat
+    DevBuf list_rmax;   // per list: upper bound on the norm of its members' decoded residuals (IVFPQ; rebuilt with the interleaved codes)
     bool il_dirty = true;
     ListLayout lay;
 
@@ -762,6 +766,11 @@ struct PQFamilyIndex : comet_index {
         il_dirty = false;
         codes_il.reserve((size_t)(lay.nslots + adc_codes_pad()) * M4 * 4 + 4, c->stream, 0);   // + the scan's read-ahead past the last block
         launch_interleave_codes(c, codes_arr.as<uint32_t>(), M4, lay.row_of_slot.as<uint32_t>(), lay.nslots, codes_il.as<uint32_t>());
+        if (ivf) {      // R(list) for the table-free lower bound of the two-stage search
+            list_rmax.reserve((size_t)nlist * 4, c->stream, 0);
+            launch_pq_list_rmax(c, codebooks.as<float>(), M, Ksub, dsub, codes_arr.as<uint32_t>(), M4, lay.row_of_slot.as<uint32_t>(), lay.list_base.as<int64_t>(),
+                                lay.list_len.as<int32_t>(), nlist, list_rmax.as<float>());
+        }
         HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     // pqIndexSearch.searchSingleQuery pq_index_search.go:218-325 / ivfpqIndexSearch.searchSingleQuery ivfpq_index_search.go:231-341
@@ -811,6 +820,8 @@ struct PQFamilyIndex : comet_index {
                 // — unless the ranks exchange their stage-1 bounds (a sharded search through comet_index_search_sharded_async): then every rank
                 // prunes with the global bound and the two-stage search pays on every world size
                 afl.exchange = shard_world > 1 ? bound_exchange : nullptr; afl.exchange_user = bound_exchange_user;
+                static const bool norm_bound_off = getenv("COMET_ADC_NO_NORM_BOUND") != nullptr;
+                afl.list_rmax = (ivf && !norm_bound_off && list_rmax.p) ? list_rmax.as<float>() : nullptr;
                 afl.one_stage = (p.mode == 1 || (shard_world > 2 && !afl.exchange)) ? 1 : 0;
             }
             for (int b0 = 0; b0 < B; b0 += qb) {

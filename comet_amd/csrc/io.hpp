@@ -88,7 +88,8 @@ inline std::vector<uint32_t> read_bitmap(Source& s) {
     std::vector<uint8_t> b(size);
     s.get(b.data(), size, "bitmap data");
     std::vector<uint32_t> out;
-    if (size == 0) return out;      // roaring.UnmarshalBinary of zero bytes fails in the reference; an absent tail is treated as empty here
+    // roaring.UnmarshalBinary of zero bytes fails in the reference (no cookie to read: flat_index.go:605-607 returns the wrapped error)
+    if (size == 0) COMET_FAIL(COMET_ERR_FORMAT, "failed to deserialize deleted nodes bitmap: empty");
     size_t off = 0;
     auto need = [&](size_t n) { if (off + n > b.size()) COMET_FAIL(COMET_ERR_FORMAT, "failed to deserialize deleted nodes bitmap: truncated"); };
     auto rd32 = [&]() { need(4); uint32_t v; std::memcpy(&v, &b[off], 4); off += 4; return v; };

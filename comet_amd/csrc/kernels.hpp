@@ -76,6 +76,8 @@ void launch_extract_sub(Ctx* c, const float* src, int ld_src, int64_t n, int col
 void launch_residual_rows(Ctx* c, const float* V, int ld, int64_t n, const float* C, const int32_t* assign, float* R);
 void launch_pq_encode(Ctx* c, const float* R, int ld, int64_t n, const float* codebooks, int M, int Ksub, int dsub,
                       uint8_t* codes, int code_stride);
+void launch_pq_list_rmax(Ctx* c, const float* codebooks, int M, int Ksub, int dsub, const uint32_t* codes_arr, int M4, const uint32_t* row_of_slot,
+                         const int64_t* list_base, const int32_t* list_len, int nlist, float* rmax);
 void launch_interleave_codes(Ctx* c, const uint32_t* src_words, int M4, const uint32_t* row_of_slot, int64_t nslots, uint32_t* dst);
 void launch_probe_segments(Ctx* c, const uint32_t* probe_list, int ldp, const int32_t* probe_cnt, const int32_t* list_len, int B, int np,
                            int32_t* seg_off, int32_t* cnts);
@@ -96,6 +98,7 @@ struct AdcFilter { unsigned long long* cand; int32_t* cursor; uint32_t* tq; int 
                    // this rank scanned nothing for the query) — an all-reduce(min) over the ranks makes every rank prune with the tightest bound. A rank's
                    // bound is the K-th smallest sum of SOME candidates, i.e. an upper bound on the global K-th smallest, and so is the minimum.
                    void (*exchange)(void* user, uint32_t* tq, int n); void* exchange_user;
+                   const float* list_rmax;   // nullable: per list an upper bound on the norm of its members' decoded residuals (launch_pq_list_rmax): the table-free lower bound
                    int32_t* stats;   // nullable, 8 ints: [0] += pairs behind the nearest lists the lower bound left alive, [1] += pairs behind the nearest lists (two-stage search),
                                      // [2] += 64-code blocks the scan's items cover, [3] += items (each streams one duo table), [4] += (query, block) pairs, [5] += searches
 };

@@ -251,6 +251,52 @@ void launch_interleave_codes(Ctx* c, const uint32_t* src_words, int M4, const ui
 }
 
 // ------------------------------------------------------------------------------------------------
+// R(list) = an upper bound on the Euclidean norm of the decoded residuals (concatenated codewords) of a list's members: feeds the
+// table-free lower bound of pq_bound_kernel. cbn2[m][k] = |codeword|^2 in float64, rounded up; per list the maximum over its members of
+// sqrt(sum_m cbn2[m][code_m]) with a 1e-5 margin (the float32 sum of M non-negative terms is within M 2^-24 of the real one).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pq_cb_norms_kernel(const float* __restrict__ codebooks, int M, int Ksub, int dsub, float* __restrict__ cbn2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * Ksub) return;
+    const float* p = codebooks + (long)i * dsub;
+    double s = 0.0;
+    for (int j = 0; j < dsub; j++) s += (double)p[j] * (double)p[j];
+    cbn2[i] = (float)(s * 1.000001);
+}
+__global__ __launch_bounds__(256) void pq_list_rmax_kernel(const unsigned* __restrict__ codes_arr, int M4, const unsigned* __restrict__ row_of_slot,
+                                                           const long* __restrict__ list_base, const int* __restrict__ list_len, const float* __restrict__ cbn2,
+                                                           int M, int Ksub, float* __restrict__ rmax) {
+    __shared__ float part[4];
+    const int l = blockIdx.x, len = list_len[l];
+    const long base = list_base[l];
+    float mx = 0.0f;
+    for (int j = threadIdx.x; j < len; j += 256) {
+        const unsigned row = row_of_slot[base + j];
+        const unsigned* cw = codes_arr + (long)row * M4;
+        float s = 0.0f;
+        for (int w = 0; w < M4; w++) {
+            const unsigned word = cw[w];
+#pragma unroll
+            for (int b = 0; b < 4; b++) { const int m = w * 4 + b; if (m < M) s += cbn2[(long)m * Ksub + min((int)((word >> (8 * b)) & 0xFFu), Ksub - 1)]; }
+        }
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) rmax[l] = (float)(sqrt((double)fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))) * 1.00002);
+}
+void launch_pq_list_rmax(Ctx* c, const float* codebooks, int M, int Ksub, int dsub, const uint32_t* codes_arr, int M4, const uint32_t* row_of_slot,
+                         const int64_t* list_base, const int32_t* list_len, int nlist, float* rmax) {
+    ScratchMark mark(c);
+    float* cbn2 = c->salloc<float>((size_t)M * Ksub);
+    pq_cb_norms_kernel<<<dim3((unsigned)ceil_div((int64_t)M * Ksub, 256)), dim3(256), 0, c->stream>>>(codebooks, M, Ksub, dsub, cbn2);
+    pq_list_rmax_kernel<<<dim3((unsigned)nlist), dim3(256), 0, c->stream>>>(codes_arr, M4, row_of_slot, (const long*)list_base, list_len, cbn2, M, Ksub, rmax);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
 // probe bookkeeping shared by IVF and IVFPQ
 // ------------------------------------------------------------------------------------------------
 // seg_off[q][0..np] = prefix of list_len over the probed lists; cnts[q] = total candidates
@@ -554,7 +600,8 @@ template <bool HAS_CENTROID, int DSUB>
 __global__ __launch_bounds__(64) void pq_bound_kernel(const float* __restrict__ Qp, int ld, const float* __restrict__ centroids,
                                                       const float* __restrict__ codebooks, int M, int Ksub,
                                                       const unsigned* __restrict__ probe_list, int ldp, int np, const int* __restrict__ seg_off, int n_q,
-                                                      const unsigned* __restrict__ tq, unsigned char* __restrict__ dead, int* __restrict__ stats) {
+                                                      const unsigned* __restrict__ tq, unsigned char* __restrict__ dead, int* __restrict__ stats,
+                                                      const float* __restrict__ list_rmax /*nullable: per list, an upper bound on the norm of its members' decoded residuals*/) {
     extern __shared__ __attribute__((aligned(16))) float res[];     // [BND_GP][M * DSUB] residuals of the group's pairs
     const int ng = (np + BND_GP - 1) / BND_GP;                       // groups per query
     const int q = blockIdx.x / ng, j0 = blockIdx.x - q * ng;
@@ -569,16 +616,32 @@ __global__ __launch_bounds__(64) void pq_bound_kernel(const float* __restrict__ 
         if (pi < np && sor[pi + 1] != sor[pi] && sor[pi] != sor[0]) mask |= 1u << t;
     }
     const unsigned behind = mask;
+    const unsigned T = tq[q];
     for (int t = 0; t < BND_GP; t++) {
         if (!((mask >> t) & 1u)) continue;
         const int pi = j0 + t * ng;
-        const float* cen = HAS_CENTROID ? centroids + (long)probe_list[(long)q * ldp + pi] * ld : nullptr;
+        const unsigned L = probe_list[(long)q * ldp + pi];
+        const float* cen = HAS_CENTROID ? centroids + (long)L * ld : nullptr;
+        float rn2 = 0.0f;
         for (int col = lane; col < dimc; col += 64) {
             const float qv = Qp[(long)q * ld + col];
-            res[t * dimc + col] = HAS_CENTROID ? qv - cen[col] : qv;
+            const float r = HAS_CENTROID ? qv - cen[col] : qv;
+            res[t * dimc + col] = r;
+            rn2 += r * r;
+        }
+        // A bound that needs no table entry: a candidate's sum is the float32 value of |r - x|^2 for its decoded residual x, and
+        // |r - x| >= |r| - |x| >= |r| - R(list). Float32 against real arithmetic: every term (fl(fl(r_i - x_i)^2)) and every addition of the
+        // non-negative terms loses at most one rounding, so the computed sum is >= (1 - (d + M + 3) 2^-24) times the real one (< 1 - 1e-4 for
+        // d <= 1500); the norm below is a float32 sum in another order (same relative bound) and R carries its own margin. The test is made
+        // with 1e-4 margins on every factor, so a pair it removes cannot hold a candidate at or under the query's bound — exactly the pairs the
+        // walk over the subspaces would remove later, found after one pass over the residual instead of ~40 % of the table arithmetic.
+        if (list_rmax && T < 0x7F800000u && dimc <= 1400) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rn2 += __shfl_xor(rn2, o, 64);
+            const float gap = sqrtf(rn2 * 0.9999f) * 0.9999f - list_rmax[L] * 1.0001f;
+            if (gap > 0.0f && gap * gap * 0.9998f > __uint_as_float(T) * 1.0001f) mask &= ~(1u << t);      // wave-uniform
         }
     }
-    const unsigned T = tq[q];
     const unsigned Ts = T >= 0x7F800000u ? 0xFFFFFFFFu : __float_as_uint(__uint_as_float(T) * 1.0000005f);
     float lb = 0.0f;                                                 // lanes 0 .. BND_GP-1: the running sum of pair `lane`
     float cb[4][DSUB], cbn[4][DSUB];
@@ -1251,7 +1314,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
             {
             ProfScope ps(c, "pq_bound");
             const unsigned groups = (unsigned)(bn * ceil_div(np, BND_GP));
-#define BND_LAUNCH(HC, DS) pq_bound_kernel<HC, DS><<<dim3(groups), dim3(64), bnd_lds, c->stream>>>(Qb, ld, centroids, codebooks, M, Ksub, pl, ldp, np, so, bn, flt->tq + b0, dead, flt->stats)
+#define BND_LAUNCH(HC, DS) pq_bound_kernel<HC, DS><<<dim3(groups), dim3(64), bnd_lds, c->stream>>>(Qb, ld, centroids, codebooks, M, Ksub, pl, ldp, np, so, bn, flt->tq + b0, dead, flt->stats, flt->list_rmax)
 #define BND_DS(HC) do { switch (dsub) { case 4: BND_LAUNCH(HC, 4); break; case 8: BND_LAUNCH(HC, 8); break; default: BND_LAUNCH(HC, 16); break; } } while (0)
             if (centroids) BND_DS(true); else BND_DS(false);
 #undef BND_DS

@@ -630,25 +630,7 @@ class FlatIndex(VectorIndex):
             raise ValueError("dimension must be positive")
         super().__init__(ctx, dim, distance_kind)
         check(self.lib.comet_flat_create(ctx.h, dim, _metric_code(distance_kind), C.byref(self.h)))
-        self._deleted: set[int] = set()
-
-    def remove(self, node_id: int) -> None:
-        super().remove(node_id)
-        self._deleted.add(int(node_id))
-
-    def flush(self) -> None:
-        super().flush()
-        self._deleted.clear()
-
-    def write_to(self, w) -> int:
-        n = super().write_to(w)       # WriteTo flushes (flat_index.go:368)
-        self._deleted.clear()
-        return n
-
-    def read_from(self, r) -> int:
-        n = super().read_from(r)
-        self._deleted.clear()
-        return n
+        # (soft deletes live in the library only — the device-side bitmap a ReadFrom loads included; no host mirror to fall out of step)
 
 
 class _TrainedIndex(VectorIndex):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """soak.py — randomized differential test: random index kinds / parameters / query options on the GPU against the CPU oracle, bit for
-bit, for a wall-clock budget (default 240 s). usage (on a GPU box): python tools/soak.py [seconds] [seed]"""
+bit, for a wall-clock budget (default 240 s). usage (on a GPU box): python tools/soak.py [seconds] [seed] [kinds, e.g. ivf,flat]"""
 import sys
 import time
 from pathlib import Path
@@ -14,6 +14,7 @@ import comet_amd as ca  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+KINDS = sys.argv[3].split(",") if len(sys.argv) > 3 else ["flat", "ivf", "pq", "ivfpq"]
 ctx = ca.Context(0)
 METRICS = [ca.EUCLIDEAN, ca.L2_SQUARED, ca.COSINE]
 bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
@@ -44,7 +45,7 @@ def compare(g, o, Q, k, tag, **kw):
 
 t_end, rounds, kinds = time.time() + budget, 0, {}
 while time.time() < t_end:
-    kind = rng.choice(["flat", "ivf", "pq", "ivfpq"])
+    kind = rng.choice(KINDS)
     metric = METRICS[int(rng.integers(0, 3))]
     d = int(rng.choice([8, 16, 24, 32, 48, 64, 96]))
     n = int(rng.integers(1500, 9000)) if kind != "flat" else int(rng.integers(6000, 30000))
