@@ -423,11 +423,15 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
     add_s = time.time() - t0
     pipe = Pipe(ctx, idx, q_ptrs, B, K, comm, nprobes=args.nprobe)
     pipe.step(2)
-    stat0 = (idx.stat("adc_pairs_alive"), idx.stat("adc_pairs_behind_nearest"))
-    i0 = pipe.i
+    # the library's search counters are device atomics (0.1 ms per batch when on): counted in a pass of their own, off in the timed regions
+    idx.stat("adc_stats_on"); idx.stat("adc_stats_reset")
+    pipe.step(NQB)
+    ctx.sync()
+    searches = NQB
+    stat0, stat1 = (0.0, 0.0), (idx.stat("adc_pairs_alive"), idx.stat("adc_pairs_behind_nearest"))
+    norm_kills = idx.stat("adc_norm_bound_kills")
+    idx.stat("adc_stats_off")
     rec, prof, med, times = measure(ctx, timer, args, pipe.step, "adc_scan", B)
-    searches = pipe.i - i0
-    stat1 = (idx.stat("adc_pairs_alive"), idx.stat("adc_pairs_behind_nearest"))
     g = pipe.results_of(0)
     out = {"workload": f"IVFPQ l2_squared {n}x{d} (clustered corpus), nlist={nlist} nprobe={args.nprobe} M={args.M} nbits={args.nbits}, batch={B}, K={K}"
                        + (f"; inverted lists sharded over {world} ranks" if world > 1 else ""), **rec,
@@ -436,7 +440,10 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
     out["two_stage"] = {"what": "stage 1 scans every query's nearest list and seeds the per-query K-th-best bounds; an exact lower bound per remaining (query, list) pair — "
                                 "the serial float32 sum of the pair's table row minima — removes the pairs none of whose candidates can pass; stage 2 scans the rest. "
                                 "Results are bit-identical to the every-candidate search.",
-                        "pairs_behind_nearest_lists_per_batch": behind / max(1, searches), "pairs_left_alive_fraction": (alive / behind) if behind else None}
+                        "pairs_behind_nearest_lists_per_batch": behind / max(1, searches), "pairs_left_alive_fraction": (alive / behind) if behind else None,
+                        "pairs_removed_by_the_table_free_bound_fraction": (norm_kills / behind) if behind else None,
+                        "table_free_bound": "before any table entry is formed: a candidate's sum is |r - x|^2 >= (|r| - R(list))^2 for the query's residual r and R(list) = the largest "
+                                            "decoded-residual norm among the list's members (kept per list); margins cover the float32 rounding of both sides (DESIGN.md 3.5)"}
     if rank == 0 and flat_exact is not None:
         f_ids = flat_exact.search_batch(Q0, K)[0]
         out["recall_at_10_vs_exact_flat"] = recall_of(f_ids, g[0], g[2], K)
@@ -451,13 +458,15 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
             p1 = Pipe(ctx, idx, q_ptrs, B, K, None, nprobes=args.nprobe, mode=1)
             p1.step(2)
             ex_steps = max(3, args.steps // 2)
-            idx.stat("adc_stats_reset")
-            ctx.profile_only("adc_scan"); ctx.profile(True); ctx.profile_reset()
-            ctx.sync(); t0 = time.perf_counter(); p1.step(ex_steps); ctx.sync(); ex_el = (time.perf_counter() - t0) / ex_steps
-            ex_prof = ctx.profile_dump(); ctx.profile_only(None); ctx.profile(False)
+            idx.stat("adc_stats_on"); idx.stat("adc_stats_reset")
+            p1.step(NQB); ctx.sync()
             ns = max(1.0, idx.stat("adc_searches"))              # per search (= per adc_scan launch here: one stage, one sub-batch)
             cand = idx.stat("adc_candidates") / ns / B
             code_bytes, table_bytes = idx.stat("adc_code_bytes") / ns, idx.stat("adc_table_bytes") / ns
+            idx.stat("adc_stats_off")
+            ctx.profile_only("adc_scan"); ctx.profile(True); ctx.profile_reset()
+            ctx.sync(); t0 = time.perf_counter(); p1.step(ex_steps); ctx.sync(); ex_el = (time.perf_counter() - t0) / ex_steps
+            ex_prof = ctx.profile_dump(); ctx.profile_only(None); ctx.profile(False)
             x = p1.results_of(0)
             p1.free()
             adc_ms = ex_prof.get("adc_scan", (0.0, 0))[0] / ex_steps

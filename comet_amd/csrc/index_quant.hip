@@ -654,6 +654,7 @@ struct PQFamilyIndex : comet_index {
     DevBuf codes_arr;   // arrival-order codes, n x M4 words (byte m of a row = code[m])
     DevBuf codes_il;    // compiled, block-interleaved
     DevBuf adc_stats;   // two-stage search counters (AdcFilter::stats), read by get_stat
+    mutable bool stats_on = false;   // adc_* counters are collected (get_stat "adc_stats_on" / "adc_stats_off")
     DevBuf list_rmax;   // per list: upper bound on the norm of its members' decoded residuals (IVFPQ; rebuilt with the interleaved codes)
     bool il_dirty = true;
     ListLayout lay;
@@ -812,7 +813,10 @@ struct PQFamilyIndex : comet_index {
             if (fuse) {
                 afl.cand = c->salloc<unsigned long long>((size_t)qb * ldD); afl.cursor = c->salloc<int32_t>(qb); afl.tq = c->salloc<uint32_t>(qb); afl.K = p.k; afl.thr = p.threshold;
                 if (!adc_stats.p) { adc_stats.reserve(32, c->stream, 0); HIP_CHECK(hipMemsetAsync(adc_stats.p, 0, 32, c->stream)); }
-                afl.stats = adc_stats.as<int32_t>();
+                // the counters are atomics on a few words: ~8 k of them per batch from the lower-bound kernel alone — same-address atomics retire
+                // one per ~12 ns in the L2, i.e. 0.1 ms of a 0.38 ms search was spent counting. They are taken only while a caller asked for
+                // them (get_stat("adc_stats_on") ... get_stat("adc_stats_off")): the bench counts in a pass of its own, outside the timed regions.
+                afl.stats = stats_on ? adc_stats.as<int32_t>() : nullptr;
                 // mode 1 ("strict"): the reference's literal work — every candidate of every probed list is scored. On a list shard of more
                 // than two ranks the single pass is used as well: a rank owns the nearest list of only 1 / world of the queries, the bounds of
                 // the others are seeded by a farther list and remove little, and the second set of launches costs more than it saves
@@ -975,6 +979,9 @@ struct PQFamilyIndex : comet_index {
             else if (k == "adc_table_bytes") *out = (double)h[3] * 2.0 * M * KL * 4.0;
             else if (k == "adc_candidates") *out = (double)h[4] * 64.0;
             else if (k == "adc_searches") *out = (double)h[5];
+            else if (k == "adc_norm_bound_kills") *out = (double)h[6];        // pairs the table-free bound removed before the walk over the subspaces
+            else if (k == "adc_stats_on") { stats_on = true; *out = 1.0; }
+            else if (k == "adc_stats_off") { stats_on = false; *out = 0.0; }
             else if (k == "adc_stats_reset") { if (adc_stats.p) { HIP_CHECK(hipMemsetAsync(adc_stats.p, 0, 32, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); } *out = 0.0; }
             else return false;
             return true;

@@ -595,6 +595,12 @@ __global__ __launch_bounds__(256) void pq_lb_kernel(const float* __restrict__ ro
 // (2 pairs: ~1.8 GB per batch). Built and measured as well: four such waves per workgroup sharing the slice through a three-stage
 // LDS-DMA ring two subspaces ahead, one voting barrier per subspace — 0.194 ms: a subspace step (~0.3 us) is far shorter than the
 // DMA's round trip, the ring would have to be six or more slices deep, and the workgroup lives as long as its slowest pair.
+// Round 3, measured on the same corpus (pq_bound 0.131 ms per batch at the start): the per-pair statistics atomics (8 k same-address atomics per
+// batch, ~12 ns each in the L2) were 0.025 ms of it — now opt-in; a table-free norm bound in front of the walk removes 22 % of the pairs at nlist 1024
+// and 97 % at nlist 4096 (lists finer than the clusters) for one pass over the residual; what remains, 0.10 ms, is the walk of the pairs that SURVIVE —
+// all M dependent steps at ~0.8 us each (a step's chain: 8-term sums, a 64-lane minimum, a ballot), whatever the other pairs do. Tried against it: two
+// slices of codewords in flight instead of one (0.125 ms: the step is not waiting for its loads), stopping the walk after 80 / 64 / 48 subspaces and
+// keeping what is still alive (pq_bound 0.099 / 0.093 / 0.077 ms, but the pairs that die late then reach the scan: step 0.362 / 0.419 / 0.547 ms).
 constexpr int BND_GP = 2;
 template <bool HAS_CENTROID, int DSUB>
 __global__ __launch_bounds__(64) void pq_bound_kernel(const float* __restrict__ Qp, int ld, const float* __restrict__ centroids,
@@ -617,30 +623,77 @@ __global__ __launch_bounds__(64) void pq_bound_kernel(const float* __restrict__ 
     }
     const unsigned behind = mask;
     const unsigned T = tq[q];
-    for (int t = 0; t < BND_GP; t++) {
-        if (!((mask >> t) & 1u)) continue;
-        const int pi = j0 + t * ng;
-        const unsigned L = probe_list[(long)q * ldp + pi];
-        const float* cen = HAS_CENTROID ? centroids + (long)L * ld : nullptr;
-        float rn2 = 0.0f;
-        for (int col = lane; col < dimc; col += 64) {
-            const float qv = Qp[(long)q * ld + col];
-            const float r = HAS_CENTROID ? qv - cen[col] : qv;
-            res[t * dimc + col] = r;
-            rn2 += r * r;
-        }
-        // A bound that needs no table entry: a candidate's sum is the float32 value of |r - x|^2 for its decoded residual x, and
-        // |r - x| >= |r| - |x| >= |r| - R(list). Float32 against real arithmetic: every term (fl(fl(r_i - x_i)^2)) and every addition of the
-        // non-negative terms loses at most one rounding, so the computed sum is >= (1 - (d + M + 3) 2^-24) times the real one (< 1 - 1e-4 for
-        // d <= 1500); the norm below is a float32 sum in another order (same relative bound) and R carries its own margin. The test is made
-        // with 1e-4 margins on every factor, so a pair it removes cannot hold a candidate at or under the query's bound — exactly the pairs the
-        // walk over the subspaces would remove later, found after one pass over the residual instead of ~40 % of the table arithmetic.
-        if (list_rmax && T < 0x7F800000u && dimc <= 1400) {
+    if (mask == 0u) {                                               // nothing behind the nearest list in this group
+        if (lane < BND_GP) { const int pi = j0 + lane * ng; if (pi < np) dead[(long)q * np + pi] = 1; }
+        return;
+    }
+    // residuals of the group's pairs -> LDS, and their squared norms. All row pieces (query + the pairs' centroids, 16 bytes per lane and
+    // piece) are requested before any is used (a load per loop iteration pays the L2 round trip twelve times per pair).
+    constexpr int NV = 6;                                           // 16-byte pieces per lane and row: rows up to 1536 floats
+    float rn2[BND_GP];
+    unsigned Lt[BND_GP];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) rn2 += __shfl_xor(rn2, o, 64);
-            const float gap = sqrtf(rn2 * 0.9999f) * 0.9999f - list_rmax[L] * 1.0001f;
-            if (gap > 0.0f && gap * gap * 0.9998f > __uint_as_float(T) * 1.0001f) mask &= ~(1u << t);      // wave-uniform
+    for (int t = 0; t < BND_GP; t++) { rn2[t] = 0.0f; const int pi = j0 + t * ng; Lt[t] = ((mask >> t) & 1u) ? probe_list[(long)q * ldp + pi] : 0u; }
+    if (dimc <= NV * 256 && (dimc & 3) == 0) {
+        f32x4q qv[NV], cv[BND_GP][NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) { const int c4 = (i * 64 + lane) * 4; if (c4 < dimc) qv[i] = *reinterpret_cast<const f32x4q*>(Qp + (long)q * ld + c4); }
+#pragma unroll
+        for (int t = 0; t < BND_GP; t++)
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                const int c4 = (i * 64 + lane) * 4;
+                if (HAS_CENTROID && ((mask >> t) & 1u) && c4 < dimc) cv[t][i] = *reinterpret_cast<const f32x4q*>(centroids + (long)Lt[t] * ld + c4);
+            }
+#pragma unroll
+        for (int t = 0; t < BND_GP; t++) {
+            if (!((mask >> t) & 1u)) continue;
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                const int c4 = (i * 64 + lane) * 4;
+                if (c4 < dimc) {
+                    f32x4q r = qv[i];
+                    if (HAS_CENTROID) { r[0] = r[0] - cv[t][i][0]; r[1] = r[1] - cv[t][i][1]; r[2] = r[2] - cv[t][i][2]; r[3] = r[3] - cv[t][i][3]; }
+                    *reinterpret_cast<f32x4q*>(res + t * dimc + c4) = r;
+                    rn2[t] += r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+                }
+            }
         }
+    } else {
+        for (int t = 0; t < BND_GP; t++) {
+            if (!((mask >> t) & 1u)) continue;
+            const float* cen = HAS_CENTROID ? centroids + (long)Lt[t] * ld : nullptr;
+            for (int col = lane; col < dimc; col += 64) {
+                const float qv = Qp[(long)q * ld + col];
+                const float r = HAS_CENTROID ? qv - cen[col] : qv;
+                res[t * dimc + col] = r;
+                rn2[t] += r * r;
+            }
+        }
+    }
+    // A bound that needs no table entry: a candidate's sum is the float32 value of |r - x|^2 for its decoded residual x, and
+    // |r - x| >= |r| - |x| >= |r| - R(list). Float32 against real arithmetic: every term (fl(fl(r_i - x_i)^2)) and every addition of the
+    // non-negative terms loses at most one rounding, so the computed sum is >= (1 - (d + M + 3) 2^-24) times the real one (< 1 - 1e-4 for
+    // d <= 1500); the norm below is a float32 sum in another order (same relative bound) and R carries its own margin. The test is made
+    // with 1e-4 margins on every factor, so a pair it removes cannot hold a candidate at or under the query's bound — pairs the walk over
+    // the subspaces would remove later, found after one pass over the residual instead of ~40 % of the table arithmetic.
+    if (list_rmax && T < 0x7F800000u && dimc <= 1400) {
+#pragma unroll
+        for (int t = 0; t < BND_GP; t++) {
+            if (!((mask >> t) & 1u)) continue;                      // wave-uniform
+            float v = rn2[t];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const float gap = sqrtf(v * 0.9999f) * 0.9999f - list_rmax[Lt[t]] * 1.0001f;
+            if (gap > 0.0f && gap * gap * 0.9998f > __uint_as_float(T) * 1.0001f) { mask &= ~(1u << t); if (stats && lane == 0) atomicAdd(&stats[6], 1); }
+        }
+    }
+    if (mask == 0u) {                                               // every pair of the group is out: no codeword is fetched
+        if (lane < BND_GP) {
+            const int pi = j0 + lane * ng;
+            if (pi < np) { dead[(long)q * np + pi] = 1; if (stats && ((behind >> lane) & 1u)) atomicAdd(&stats[1], 1); }
+        }
+        return;
     }
     const unsigned Ts = T >= 0x7F800000u ? 0xFFFFFFFFu : __float_as_uint(__uint_as_float(T) * 1.0000005f);
     float lb = 0.0f;                                                 // lanes 0 .. BND_GP-1: the running sum of pair `lane`

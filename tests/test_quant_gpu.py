@@ -443,6 +443,7 @@ def test_ivfpq_two_stage_lower_bound_pruning(ctx, metric):
         g.train(X[:4000]); assert o.train(X[:4000]) == 0
         g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
         Q = np.vstack([X[5:25] + np.float32(0.003), synth(73, 7, d) * np.float32(0.6), clustered(71, 9, d, 24, 0.4)])   # near corpus points, far from everything, between clusters
+        g.stat("adc_stats_on")                                # the counters are opt-in (device atomics)
         a0, b0 = g.stat("adc_pairs_alive"), g.stat("adc_pairs_behind_nearest")
         for k, npb in ((1, 2), (5, 8), (10, 24), (64, 6)):
             check_search(g, o, Q, k, npb)
@@ -473,6 +474,7 @@ def test_ivfpq_two_stage_subspace_widths(ctx, d, M):
     g.train(X[:3000]); assert o.train(X[:3000]) == 0
     g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
     Q = np.vstack([X[7:19] + np.float32(0.002), clustered(82 + d, 5, d, 16, 0.3)])
+    g.stat("adc_stats_on")
     a0, b0 = g.stat("adc_pairs_alive"), g.stat("adc_pairs_behind_nearest")
     for k, npb in ((3, 4), (10, 16)):
         check_search(g, o, Q, k, npb)
