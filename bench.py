@@ -687,7 +687,8 @@ def main():
     legs = set(args.legs.split(","))
     use_dist = world > 1 or os.environ.get("COMET_BENCH_FORCE_DIST") == "1"   # the env knob exercises the RCCL path at world size 1
     import comet_amd as ca
-    ctx = ca.Context(local_rank)
+    # COMET_BENCH_DEVICE: every rank on one device — only for exercising the multi-rank code path on a one-GPU box (with COMET_RCCL_LIB)
+    ctx = ca.Context(int(os.environ.get("COMET_BENCH_DEVICE", local_rank)))
     comm = None
     if use_dist:
         # RCCL lives inside libcomet_hip.so (comet_comm_*): the host only carries the 128-byte id from rank 0 to the others
