@@ -167,14 +167,18 @@ static void compact_rows(Ctx* c, DevBuf& buf, size_t row_bytes, const std::vecto
 
 // coarse step shared by IVF and IVFPQ (ivf_index_search.go:246-261): rank all centroids, keep nprobes.
 // probe_list[q][0..np) = centroid indices sorted by (distance, index).
-static void coarse_probe(Ctx* c, int metric, const float* centroids, int nlist, int ld, int dim, const float* Qp, int B, int np, uint32_t* probe_list) {
-    if (launch_coarse_probe_fast(c, metric, centroids, nlist, ld, dim, Qp, B, np, probe_list)) return;     // approximate ranking + exact re-scoring of the few that matter
+// list_len != nullptr: seg_off / cnts / uoff (see launch_probe_segments, launch_ivf_probe_units) are wanted as well; returns true if they were
+// written here (the fast ranking's pick kernel does it on its way out), false if the caller has to launch the bookkeeping kernel itself
+static bool coarse_probe(Ctx* c, int metric, const float* centroids, int nlist, int ld, int dim, const float* Qp, int B, int np, uint32_t* probe_list,
+                         const int32_t* list_len = nullptr, int32_t* seg_off = nullptr, int32_t* cnts = nullptr, int32_t* uoff = nullptr) {
+    if (launch_coarse_probe_fast(c, metric, centroids, nlist, ld, dim, Qp, B, np, probe_list, list_len, seg_off, cnts, uoff, ivf_fast_unit_rows())) return list_len != nullptr;     // approximate ranking + exact re-scoring of the few that matter
     const int64_t ldDc = round_up(nlist, 16);
     float* Dc = c->salloc<float>((size_t)B * ldDc);
     launch_dist_exact(c, metric, centroids, nlist, ld, Qp, B, Dc, ldDc, nullptr);
     float* psc = c->salloc<float>((size_t)B * np);
     int32_t* pcnt = c->salloc<int32_t>(B);
     launch_select_topk(c, Dc, ldDc, B, nlist, nullptr, 0.0f, np, probe_list, psc, pcnt, np);
+    return false;
 }
 static int sanitize_nprobes(int nprobes, int nlist) { return (nprobes <= 0 || nprobes > nlist) ? nlist : nprobes; }  // ivf_index_search.go:233-236
 
@@ -442,10 +446,10 @@ struct IVFIndex : comet_index {
         if (prep_queries_fused_ok(dim)) launch_prep_queries_fused(c, metric, queries_dev, bn, dim, Qp, ld, zflag, Qh, ldh, qn, err, fmode, xn2, st);
         else { launch_ingest_rows(c, metric, queries_dev, bn, dim, Qp, ld, zflag); launch_prep_queries_fast(c, Qp, bn, ld, dim, Qh, ldh, qn, err, fmode, xn2, st); }
         uint32_t* probe_list = c->salloc<uint32_t>((size_t)bn * np);
-        coarse_probe(c, metric, centroids.as<float>(), nlist, ld, dim, Qp, bn, np, probe_list);
         int32_t* seg_off = c->salloc<int32_t>((size_t)bn * (np + 1));
         int32_t* uoff = c->salloc<int32_t>((size_t)bn * (np + 1));
-        launch_ivf_probe_units(c, probe_list, np, lay.list_len.as<int32_t>(), bn, np, seg_off, uoff);
+        if (!coarse_probe(c, metric, centroids.as<float>(), nlist, ld, dim, Qp, bn, np, probe_list, lay.list_len.as<int32_t>(), seg_off, nullptr, uoff))
+            launch_ivf_probe_units(c, probe_list, np, lay.list_len.as<int32_t>(), bn, np, seg_off, uoff);
         const int64_t umax = std::max<int64_t>(lay.max_units(np), 1);
         const int64_t ldD = umax * ivf_fast_unit_rows();             // score row of a query: its probed lists' 64-row units in probe order
         const int64_t P = (int64_t)bn * np;
@@ -573,10 +577,10 @@ struct IVFIndex : comet_index {
         prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag, true);
         const int np = sanitize_nprobes(p.nprobes, nlist);
         uint32_t* probe_list = c->salloc<uint32_t>((size_t)B * np);
-        coarse_probe(c, metric, centroids.as<float>(), nlist, ld, dim, Qp, B, np, probe_list);
         int32_t* seg_off = c->salloc<int32_t>((size_t)B * (np + 1));
         int32_t* cnts = c->salloc<int32_t>(B);
-        launch_probe_segments(c, probe_list, np, nullptr, lay.list_len.as<int32_t>(), B, np, seg_off, cnts);
+        if (!coarse_probe(c, metric, centroids.as<float>(), nlist, ld, dim, Qp, B, np, probe_list, lay.list_len.as<int32_t>(), seg_off, cnts))
+            launch_probe_segments(c, probe_list, np, nullptr, lay.list_len.as<int32_t>(), B, np, seg_off, cnts);
         const int64_t Cmax = lay.max_candidates(np);
         uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
         if (Cmax > 0) {
@@ -783,11 +787,12 @@ struct PQFamilyIndex : comet_index {
         prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag, true);
         const int np = ivf ? sanitize_nprobes(p.nprobes, nlist) : 1;
         uint32_t* probe_list = c->salloc<uint32_t>((size_t)B * np);
-        if (ivf) coarse_probe(c, metric, centroids.as<float>(), nlist, ld, dim, Qp, B, np, probe_list);
-        else c->zero(probe_list, sizeof(uint32_t) * (size_t)B);
         int32_t* seg_off = c->salloc<int32_t>((size_t)B * (np + 1));
         int32_t* cnts = c->salloc<int32_t>(B);
-        launch_probe_segments(c, probe_list, np, nullptr, lay.list_len.as<int32_t>(), B, np, seg_off, cnts);
+        bool booked = false;
+        if (ivf) booked = coarse_probe(c, metric, centroids.as<float>(), nlist, ld, dim, Qp, B, np, probe_list, lay.list_len.as<int32_t>(), seg_off, cnts);
+        else c->zero(probe_list, sizeof(uint32_t) * (size_t)B);
+        if (!booked) launch_probe_segments(c, probe_list, np, nullptr, lay.list_len.as<int32_t>(), B, np, seg_off, cnts);
         const int64_t Cmax = lay.max_candidates(np);
         uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
         if (Cmax > 0) {

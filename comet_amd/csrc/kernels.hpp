@@ -24,7 +24,10 @@ void launch_vec_scale(Ctx* c, const float* x, int64_t n, int d, const float* nor
 // evaluation order (sequential over the dimension, no FMA). X: n x ld, Q: B x ld, D: B x ldD.
 // elig (nullable): per-row eligibility bytes; ineligible rows get the EXCLUDED sentinel in D.
 // coarse quantiser: probe_list[q][0..np) = the np nearest centroids by (exact distance, index); false = not applicable here
-bool launch_coarse_probe_fast(Ctx* c, int metric, const float* C, int nlist, int ld, int dim, const float* Qp, int B, int np, uint32_t* probe_list);
+// list_len != nullptr: the pick kernel also writes the probe bookkeeping — seg_off[q][0..np] (prefix of the probed lists' lengths), cnts[q]
+// (nullable) and uoff[q][0..np] (nullable: prefix of ceil(len / unit_rows)) — instead of a launch of its own behind it
+bool launch_coarse_probe_fast(Ctx* c, int metric, const float* C, int nlist, int ld, int dim, const float* Qp, int B, int np, uint32_t* probe_list,
+                              const int32_t* list_len = nullptr, int32_t* seg_off = nullptr, int32_t* cnts = nullptr, int32_t* uoff = nullptr, int unit_rows = 64);
 void launch_dist_exact(Ctx* c, int metric, const float* X, int64_t n, int ld, const float* Q, int B, float* D, int64_t ldD,
                        const uint8_t* elig);
 // ineligible / excluded candidates carry this bit pattern (a NaN the arithmetic cannot produce) in distance matrices

@@ -464,7 +464,9 @@ __device__ __forceinline__ unsigned cq_kappa_wave(const unsigned* keys, int nlis
 template <int METRIC>
 __global__ __launch_bounds__(256) void coarse_pick_kernel(const float* __restrict__ S, long ldS, const float* __restrict__ qn, const float* __restrict__ cn,
                                                           const float* __restrict__ C, int nlist, int ld, int dim, const float* __restrict__ Qp, int np,
-                                                          int n2, unsigned* __restrict__ probe_list, int nsplit, int B) {
+                                                          int n2, unsigned* __restrict__ probe_list, int nsplit, int B,
+                                                          const int* __restrict__ list_len /*nullable: also write the probe bookkeeping below*/, int* __restrict__ seg_off,
+                                                          int* __restrict__ cnts /*nullable*/, int* __restrict__ uoff /*nullable*/, int unit_rows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cqs[];
     unsigned long long* comp = reinterpret_cast<unsigned long long*>(cqs);                 // [n2] composites of the re-scored centroids
     unsigned* keys = reinterpret_cast<unsigned*>(comp + n2);                                  // [nlist] keys of the approximate distances
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(const float* __restric
             const unsigned long long me = comp[ci];
             int rank = 0;
             for (int j = 0; j < ncand; j++) rank += (comp[j] < me) ? 1 : 0;
-            if (rank < np) probe_list[(long)q * np + rank] = (unsigned)(me & 0xFFFFFFFFull);
+            if (rank < np) { probe_list[(long)q * np + rank] = (unsigned)(me & 0xFFFFFFFFull); keys[rank] = (unsigned)(me & 0xFFFFFFFFull); }
         }
     } else {
         int m2 = 64; while (m2 < ncand) m2 <<= 1;
@@ -576,11 +578,32 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(const float* __restric
                 }
                 __syncthreads();
             }
-        for (int i = t; i < np; i += 256) probe_list[(long)q * np + i] = (unsigned)(comp[i] & 0xFFFFFFFFull);
+        for (int i = t; i < np; i += 256) { probe_list[(long)q * np + i] = (unsigned)(comp[i] & 0xFFFFFFFFull); keys[i] = (unsigned)(comp[i] & 0xFFFFFFFFull); }
+    }
+    // probe bookkeeping of the list scans, fused (was a launch of its own behind this one: probe_segments_kernel / ivf_probe_units_kernel):
+    // seg_off[q][0..np] = prefix of the probed lists' lengths (cnts[q] = their total), uoff[q][0..np] = prefix of their unit counts.
+    // The probe list of this query is in `keys` (the approximate keys are not needed any more; np <= nlist / 4 entries).
+    if (list_len) {
+        __syncthreads();
+        if (w == 0) {
+            int run = 0, urun = 0;
+            for (int p0 = 0; p0 < np; p0 += 64) {
+                const int p = p0 + lane;
+                const int len = p < np ? list_len[keys[p]] : 0;
+                const int un = uoff ? (len + unit_rows - 1) / unit_rows : 0;
+                int inc = len, uinc = un;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64), u2 = __shfl_up(uinc, o, 64); if (lane >= o) { inc += v; uinc += u2; } }
+                if (p < np) { seg_off[(long)q * (np + 1) + p] = run + inc - len; if (uoff) uoff[(long)q * (np + 1) + p] = urun + uinc - un; }
+                run += __shfl(inc, 63, 64); urun += __shfl(uinc, 63, 64);
+            }
+            if (lane == 0) { seg_off[(long)q * (np + 1) + np] = run; if (cnts) cnts[q] = run; if (uoff) uoff[(long)q * (np + 1) + np] = urun; }
+        }
     }
 }
 // false: not applicable (too many lists for the LDS of the pick kernel, or most lists are probed anyway) — use the exact ranking
-bool launch_coarse_probe_fast(Ctx* c, int metric, const float* C, int nlist, int ld, int dim, const float* Qp, int B, int np, uint32_t* probe_list) {
+bool launch_coarse_probe_fast(Ctx* c, int metric, const float* C, int nlist, int ld, int dim, const float* Qp, int B, int np, uint32_t* probe_list,
+                              const int32_t* list_len, int32_t* seg_off, int32_t* cnts, int32_t* uoff, int unit_rows) {
     static const bool off = getenv("COMET_COARSE_EXACT") != nullptr;
     if (off || nlist > CQ_MAX_LISTS || nlist < 64 || (int64_t)np * 4 > nlist || B <= 0) return false;
     ScratchMark mark(c);
@@ -599,7 +622,7 @@ bool launch_coarse_probe_fast(Ctx* c, int metric, const float* C, int nlist, int
     const size_t lds = (size_t)n2 * 8 + (size_t)nlist * 8 + (size_t)ld * 4;
     { ProfScope ps(c, "coarse_pick");
 #define CP(M) do { HIP_CHECK(hipFuncSetAttribute((const void*)coarse_pick_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                   coarse_pick_kernel<M><<<dim3(B), dim3(256), lds, c->stream>>>(S, ldS, qn, cn, C, nlist, ld, dim, Qp, np, n2, probe_list, nsplit, B); } while (0)
+                   coarse_pick_kernel<M><<<dim3(B), dim3(256), lds, c->stream>>>(S, ldS, qn, cn, C, nlist, ld, dim, Qp, np, n2, probe_list, nsplit, B, list_len, seg_off, cnts, uoff, unit_rows); } while (0)
       switch (metric) { case COMET_L2: CP(COMET_L2); break; case COMET_L2SQ: CP(COMET_L2SQ); break; default: CP(COMET_COSINE); break; }
 #undef CP
       LAUNCH_CHECK(); }

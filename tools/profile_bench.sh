@@ -1,13 +1,14 @@
 #!/bin/bash
 # usage (on the GPU box): tools/profile_bench.sh <tag>
-#   1. the driver's bench line (with the CPU baseline)            -> gpurun_out/<tag>_bench_line.json
+#   1. the driver's bench line (with the CPU baselines)            -> gpurun_out/<tag>_bench_line.json
 #   2. rocprofv3 --kernel-trace --stats of a short run             -> gpurun_out/<tag>_bench_rocprofv3_kernel_stats.txt
 #   3. separate rocprofv3 --pmc passes (tools/pmc_bench.sh)        -> gpurun_out/<tag>_bench_pmc.json
-# Copy what should be judged into profiles/ afterwards.
+# Copy what should be judged into profiles/ afterwards. Every profiler run sits under its own timeout.
 T=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R && timeout 900 python bench.py 2> $O/${T}_bench.err | tail -1 > $O/${T}_bench_line.json
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/rp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rp -- python $R/bench.py --no-cpu-baseline --regions 2 --steps 10 > /tmp/rp.log 2>&1
+CMD="python $R/bench.py --legs flat,flat_l2,ivfpq,hybrid,hnsw --hnsw-rows 20000 --docs 20000 --no-cpu-baseline --regions 2 --steps 10 --sustain-s 0.2"
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/rp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp -- $CMD > /tmp/rp.log 2>&1
 DB=$(find /tmp/rp -name "*.db" | head -1); CSV=$(find /tmp/rp -name "*kernel_stats.csv" | head -1)
-python $R/tools/rocprof_summary.py "${DB:-$CSV}" $O/${T}_bench_rocprofv3_kernel_stats.txt
-sed -i "1s/.*/# rocprofv3 --kernel-trace --stats of \`python bench.py --no-cpu-baseline --regions 2 --steps 10\` (all legs: Flat cosine, Flat L2^2 B=1\/64\/256, IVFPQ incl. GPU train + add), MI355X, $T/" $O/${T}_bench_rocprofv3_kernel_stats.txt
+python $R/tools/rocprof_summary.py "${CSV:-$DB}" $O/${T}_bench_rocprofv3_kernel_stats.txt
+sed -i "1s|.*|# rocprofv3 --kernel-trace --stats of \`$CMD\` (Flat cosine, Flat L2^2 B=1/64/256, IVFPQ 1M incl. GPU train + add, IVF + BM25, HNSW 20k incl. GPU build), MI355X, $T|" $O/${T}_bench_rocprofv3_kernel_stats.txt
 cd $R && tools/pmc_bench.sh ${T}_bench_pmc
