@@ -461,8 +461,9 @@ struct IVFIndex : comet_index {
         int32_t* counts = scan_counts.as<int32_t>();       // persistent: get_stat reads the last launch's figures
         launch_ivf_items(c, probe_list, np, np, uoff, (int)P, nlist, lay.list_len.as<int32_t>(), lay.list_base.as<int64_t>(), groups, items, counts);
         float* D = c->salloc<float>((size_t)bn * ldD);
-        launch_ivf_scan_f16(c, fmode, Vh.p, ldh, Qh, rn_slot.as<float>(), qn, elig, groups, items, counts, D, ldD);
-        launch_ivf_post(c, metric, D, ldD, uoff, np, probe_list, np, lay.list_base.as<int64_t>(), lay.list_len.as<int32_t>(), lay.row_of_slot.as<uint32_t>(),
+        float* umin = c->salloc<float>((size_t)bn * umax);          // per (query, unit): the unit's smallest approximate distance
+        launch_ivf_scan_f16(c, fmode, Vh.p, ldh, Qh, rn_slot.as<float>(), qn, elig, groups, items, counts, D, ldD, umin, umax);
+        launch_ivf_post(c, metric, D, ldD, umin, umax, uoff, np, probe_list, np, lay.list_base.as<int64_t>(), lay.list_len.as<int32_t>(), lay.row_of_slot.as<uint32_t>(),
                         lay.ids_slot.as<uint32_t>(), elig, err, p.k, p.threshold, V.as<float>(), ld, Qp, bn, zflag, out_ids, out_scores, out_counts, k_cap, ovf, st);
         pend->nfast_slices++;
     }

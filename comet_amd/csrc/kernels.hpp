@@ -132,7 +132,7 @@ void launch_prep_queries_fast(Ctx* c, const float* Qp, int B, int ld, int dim, v
                               int32_t* stats4);
 
 // the same post stage over the key rows of the IVF fast path
-void launch_ivf_post(Ctx* c, int metric, const float* D, int64_t ldD, const int32_t* uoff, int np, const uint32_t* probe_list, int ldp,
+void launch_ivf_post(Ctx* c, int metric, const float* D, int64_t ldD, const float* umin, int64_t ldu, const int32_t* uoff, int np, const uint32_t* probe_list, int ldp,
                      const int64_t* list_base, const int32_t* list_len, const uint32_t* row_of_slot, const uint32_t* ids_slot, const uint8_t* elig,
                      const float* err_abs, int K, float thr, const float* X, int ld, const float* Qp, int B, const int32_t* zflag,
                      uint32_t* out_ids, float* out_scores, int32_t* out_counts, int k_cap, int32_t* overflow, int32_t* stats);
@@ -151,6 +151,6 @@ void launch_ivf_probe_units(Ctx* c, const uint32_t* probe_list, int ldp, const i
 void launch_ivf_items(Ctx* c, const uint32_t* probe_list, int ldp, int np, const int32_t* uoff, int n_pairs, int nlist, const int32_t* list_len,
                       const int64_t* list_base, void* groups, void* items, int32_t* counts);
 void launch_ivf_scan_f16(Ctx* c, int mode, const void* Vh, int ldh, const void* Qh, const float* rn, const float* qn, const uint8_t* elig,
-                         const void* groups, const void* items, const int32_t* counts, float* D, int64_t ldD);
+                         const void* groups, const void* items, const int32_t* counts, float* D, int64_t ldD, float* umin, int64_t ldu);
 
 }  // namespace comet

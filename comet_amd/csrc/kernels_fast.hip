@@ -890,7 +890,7 @@ __device__ __forceinline__ void post_append(bool want, unsigned v, unsigned* lis
 //             position -> probe j (binary search over uoff[q]) -> slot = list_base[list] + offset -> arrival row / id of the slot.
 struct FlatGeom {
     long n_units; int unit_rows; long n; const unsigned char* elig; const unsigned* ids_table;
-    static constexpr bool kSlots = false, kDense = false;
+    static constexpr bool kSlots = false, kDense = false, kHier = false;
     struct Unit { long row0; long nvalid; };
     __device__ __forceinline__ void bind(int) {}
     __device__ __forceinline__ long units() const { return n_units; }
@@ -904,8 +904,9 @@ struct FlatGeom {
 struct IvfGeom {
     const int* uoff; int np; const unsigned* probe_list; int ldp; const long* list_base; const int* list_len;
     const unsigned* row_of_slot; const unsigned* ids_slot; const unsigned char* elig;      // elig per slot
+    const float* umin; long ldu;                                                            // per (query, unit): the smallest approximate distance of the unit (written by the scan)
     const int* uo = nullptr; const unsigned* pl = nullptr;                                  // this query's rows (bind)
-    static constexpr bool kSlots = true, kDense = true;                                      // dense: the key row holds one approximate distance per position (+inf: no candidate)
+    static constexpr bool kSlots = true, kDense = true, kHier = true;                                      // dense: the key row holds one approximate distance per position (+inf: no candidate)
     struct Unit { long row0; long nvalid; };                                                // row0 = first slot of the unit
     __device__ __forceinline__ void bind(int q) { uo = uoff + (long)q * (np + 1); pl = probe_list + (long)q * ldp; }
     __device__ __forceinline__ long units() const { return uo[np]; }
@@ -951,6 +952,97 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
     const float* bd = DENSE ? nullptr : bound + (long)q * ldB;
     const float INF = __builtin_inff();
     if (t == 0) { s_cnt = 0; s_exp = 0; s_valid = 0; }
+    float tau = INF;
+    bool hier_done = false;
+    if constexpr (GEOM::kHier) {
+        // Two levels for dense rows (IVF): the scan also wrote every unit's MINIMUM. The K-th smallest unit minimum bounds the K-th smallest
+        // value of the row from above (K distinct positions), and every value at or below a bound lives in a unit whose minimum is: kappa and
+        // then the candidates are found from the few units that can hold them (~K .. 2K of several hundred) instead of three passes over all
+        // of the row's values. Anything unusual (more than 8192 units, more than 4096 units or 1024 values under the bound: mass ties, K beyond
+        // the finite values) leaves through the general dense path below.
+        __shared__ float h_lo[16], h_hi[16]; __shared__ int h_ct[16]; __shared__ int s_nu; __shared__ unsigned s_kap;
+        const float* __restrict__ um = geom.umin + (long)q * geom.ldu;
+        const int nu = (int)n_tiles;
+        constexpr int HU = 8;
+        if (kappa_rank > 0 && nu > 0 && nu <= HU * POST_THREADS) {
+            float ur[HU];
+#pragma unroll
+            for (int j = 0; j < HU; j++) { const int i = j * POST_THREADS + t; ur[j] = i < nu ? um[i] : INF; }
+            int cnt = 0; float lo = INF, hi = 0.0f;
+#pragma unroll
+            for (int j = 0; j < HU; j++) if (ur[j] != INF) { cnt++; lo = fminf(lo, ur[j]); hi = fmaxf(hi, ur[j]); }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); cnt += __shfl_xor(cnt, off, 64); }
+            if (lane == 0) { h_lo[wid] = lo; h_hi[wid] = hi; h_ct[wid] = cnt; }
+            __syncthreads();
+            int cnt_all = 0;
+            for (int w = 0; w < POST_WAVES; w++) { lo = fminf(lo, h_lo[w]); hi = fmaxf(hi, h_hi[w]); cnt_all += h_ct[w]; }
+            __syncthreads();
+            float B0 = 3.0e38f;                                          // fewer than K finite unit minima: every unit is looked at
+            if (cnt_all >= kappa_rank) {
+                const float scale = hi > lo ? 4095.0f / (hi - lo) : 0.0f;
+                auto ubin = [&](float v) { const int bq = (int)((v - lo) * scale); return bq < 0 ? 0 : (bq > 4095 ? 4095 : bq); };
+                for (int i = t; i < 4096; i += POST_THREADS) hist[i] = 0;
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < HU; j++) if (ur[j] != INF) atomicAdd(&hist[ubin(ur[j])], 1u);
+                __syncthreads();
+                post_find_bin(hist, kappa_rank, wsum, &s_bin, &s_before);
+                const int bbin = s_bin;
+                float bmax = 0.0f;
+#pragma unroll
+                for (int j = 0; j < HU; j++) if (ur[j] != INF && ubin(ur[j]) <= bbin) bmax = fmaxf(bmax, ur[j]);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, off, 64));
+                if (lane == 0) h_hi[wid] = bmax;
+                __syncthreads();
+                for (int w = 0; w < POST_WAVES; w++) bmax = fmaxf(bmax, h_hi[w]);
+                B0 = bmax;
+            }
+            unsigned* ulist = hist;                                      // units that can hold a value at or under the bound
+            if (t == 0) { s_nu = 0; s_cnt = 0; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < HU; j++) post_append(ur[j] <= B0, (unsigned)(j * POST_THREADS + t), ulist, &s_nu, 4096);
+            __syncthreads();
+            const int nu1 = s_nu;
+            if (nu1 <= 4096) {
+                for (int e = wid; e < nu1; e += POST_WAVES) {
+                    const float v = s0[(long)ulist[e] * 64 + lane];
+                    post_append(v <= B0, __float_as_uint(v), lst, &s_cnt, POST_CAP);
+                }
+                __syncthreads();
+                const int m = s_cnt;
+                if (m >= kappa_rank && m <= 1024) {
+                    if (t < m) {
+                        const unsigned me = lst[t]; int less = 0;
+                        for (int j = 0; j < m; j++) { const unsigned o = lst[j]; less += (o < me || (o == me && j < t)) ? 1 : 0; }
+                        if (less == kappa_rank - 1) s_kap = me;          // exactly one thread
+                    }
+                    __syncthreads();
+                    const float kappa = __uint_as_float(s_kap);
+                    tau = kappa + 2.0f * err_abs[q] + 1.0e-4f * fabsf(kappa) + 1e-30f;
+                    if (t == 0) { s_nu = 0; s_cnt = 0; }
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < HU; j++) post_append(ur[j] <= tau, (unsigned)(j * POST_THREADS + t), ulist, &s_nu, 4096);
+                    __syncthreads();
+                    const int nu2 = s_nu;
+                    if (nu2 <= 4096) {
+                        for (int e = wid; e < nu2; e += POST_WAVES) {
+                            const unsigned u = ulist[e];
+                            const float v = s0[(long)u * 64 + lane];
+                            post_append(v <= tau && v != INF, u * 64u + (unsigned)lane, lst, &s_cnt, POST_CAP);
+                        }
+                        hier_done = true;
+                    }
+                }
+            }
+            __syncthreads();
+            if (!hier_done) { tau = INF; if (t == 0) s_cnt = 0; }
+            __syncthreads();
+        }
+    }
     // The query's unit keys (two per unit) and unit bounds are read ONCE, into registers, when they fit (<= POST_RU units per
     // thread: 1M rows at 128-row units); every pass below then runs out of registers. Longer rows are streamed from L2 per pass.
     // Dense rows (one approximate distance per position): POST_RD values per thread, value j of thread t = position j * 1024 + t.
@@ -959,7 +1051,7 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
     const bool reg = DENSE ? nkeys <= POST_RD * POST_THREADS * 4 : n_tiles <= (long)POST_RU * POST_THREADS;
     f32x2v kreg[POST_RU]; float breg[POST_RU]; f32x4v dreg[POST_RD];
     const f32x4v INF4 = {INF, INF, INF, INF};
-    if (reg) {
+    if (reg && !hier_done) {
         if constexpr (DENSE) {
 #pragma unroll
             for (int j = 0; j < POST_RD; j++) { const int i = (j * POST_THREADS + t) * 4; dreg[j] = i < nkeys ? *reinterpret_cast<const f32x4v*>(s0 + i) : INF4; }
@@ -1005,8 +1097,7 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
         }
     };
     // ---- 1. kappa ----
-    float tau = INF;
-    if (kappa_rank > 0) {
+    if (kappa_rank > 0 && !hier_done) {
         // keys >= 0 so bit order = value order. The keys of a query crowd into a few exponent bins, so radix histograms
         // serialise on LDS atomics: bin them LINEARLY over [min, max] instead (monotone: float subtract, multiply and floor
         // are), locate the bin of the K-th smallest, and rank the handful of keys inside it directly.
@@ -1145,7 +1236,8 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
             post_append(key <= tau && key != INF, (unsigned)(tl * unit_rows + (__float_as_uint(key) & (unsigned)(unit_rows - 1))), lst, &s_cnt, POST_CAP);
         }
     };
-    if constexpr (DENSE) {                               // every position whose approximate distance is within tau
+    if (hier_done) {                                     // the two-level path collected them already
+    } else if constexpr (DENSE) {                        // every position whose approximate distance is within tau
         for_keys_idx([&](float v, int i) { post_append(v <= tau && v != INF, (unsigned)i, lst, &s_cnt, POST_CAP); });
     } else if (reg) {
 #pragma unroll
@@ -1332,14 +1424,14 @@ void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const fl
 }
 
 // the same post stage over the key rows of the IVF fast path (kernels_ivf.hip): units of the probed lists in probe order
-void launch_ivf_post(Ctx* c, int metric, const float* D, int64_t ldD, const int32_t* uoff, int np, const uint32_t* probe_list, int ldp,
+void launch_ivf_post(Ctx* c, int metric, const float* D, int64_t ldD, const float* umin, int64_t ldu, const int32_t* uoff, int np, const uint32_t* probe_list, int ldp,
                      const int64_t* list_base, const int32_t* list_len, const uint32_t* row_of_slot, const uint32_t* ids_slot, const uint8_t* elig,
                      const float* err_abs, int K, float thr, const float* X, int ld, const float* Qp, int B, const int32_t* zflag,
                      uint32_t* out_ids, float* out_scores, int32_t* out_counts, int k_cap, int32_t* overflow, int32_t* stats) {
     if (B <= 0) return;
     static unsigned long long* trace = [] { unsigned long long* p = nullptr; if (getenv("COMET_POST_TRACE")) { HIP_CHECK(hipMalloc(&p, 64)); HIP_CHECK(hipMemset(p, 0, 64)); } return p; }();
     ProfScope ps(c, "ivf_post");
-    const IvfGeom geom{uoff, np, probe_list, ldp, (const long*)list_base, list_len, row_of_slot, ids_slot, (const unsigned char*)elig};
+    const IvfGeom geom{uoff, np, probe_list, ldp, (const long*)list_base, list_len, row_of_slot, ids_slot, (const unsigned char*)elig, umin, (long)ldu};
     const size_t lds = POST_LDS + (size_t)POST_CAP * 4;
     const int kr = K >= 1 ? K : 0;       // fewer valid keys than K (or K <= 0 = all): tau = inf inside the kernel, every unit is expanded
 #define POST(M) do { HIP_CHECK(hipFuncSetAttribute((const void*)fast_post_kernel<M, IvfGeom>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \

@@ -205,7 +205,8 @@ __global__ __launch_bounds__(IV_THREADS) void ivf_scan_f16_kernel(const _Float16
                                                                   const float* __restrict__ rn /*per slot*/, const float* __restrict__ qn,
                                                                   const unsigned char* __restrict__ elig /*per slot, nullable*/,
                                                                   const IvfGroup* __restrict__ groups, const IvfItem* __restrict__ items, const int* __restrict__ counts,
-                                                                  float* __restrict__ D /*[query][unit position x 64]: approximate distances, +inf for rows that are no candidates*/, long ldD) {
+                                                                  float* __restrict__ D /*[query][unit position x 64]: approximate distances, +inf for rows that are no candidates*/, long ldD,
+                                                                  float* __restrict__ Umin /*[query][unit position]: the unit's smallest approximate distance*/, long ldU) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [buf][X 32 KiB | Q 8 KiB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(IV_THREADS) void ivf_scan_f16_kernel(const _Float16
             if constexpr (MODE == 1) qnv = qn[q];
             const bool check = nvalid < IV_UNIT || elig != nullptr;           // wave-uniform
             float* __restrict__ drow = D + (long)q * ldD + ukey * IV_UNIT;
+            float umn = INF;
 #pragma unroll
             for (int mb = 0; mb < 2; mb++) {
 #pragma unroll
@@ -308,21 +310,24 @@ __global__ __launch_bounds__(IV_THREADS) void ivf_scan_f16_kernel(const _Float16
                         a = fmaxf(a, 0.0f);
                         if (check) { bool ok = r0 + e1 < nvalid; if (ok && elig) ok = elig[slot0 + r0 + e1] != 0; a = ok ? a : INF; }
                         v[e1] = a;
+                        umn = fminf(umn, a);
                     }
                     if (live) *reinterpret_cast<f32x4v*>(drow + r0) = v;
                 }
             }
+            umn = fminf(umn, __shfl_xor(umn, 32, 64));                        // the other half-wave holds the unit's other 32 rows of this query
+            if (live && lane < 32) Umin[(long)q * ldU + ukey] = umn;
         }
     }
 }
 void launch_ivf_scan_f16(Ctx* c, int mode, const void* Vh, int ldh, const void* Qh, const float* rn, const float* qn, const uint8_t* elig,
-                         const void* groups, const void* items, const int32_t* counts, float* D, int64_t ldD) {
+                         const void* groups, const void* items, const int32_t* counts, float* D, int64_t ldD, float* umin, int64_t ldu) {
     const size_t lds = 2 * IV_STAGE;
     const long grid = (long)round_up(c->prop.multiProcessorCount, 8) * 2;     // persistent: two workgroups per CU
     auto go = [&](auto kernel) {
         HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         c->launch_timed("ivf_scan_f16", kernel, dim3((unsigned)grid), dim3(IV_THREADS), lds, (const _Float16*)Vh, ldh, (const _Float16*)Qh, rn, qn, (const unsigned char*)elig,
-                        (const IvfGroup*)groups, (const IvfItem*)items, (const int*)counts, D, (long)ldD);
+                        (const IvfGroup*)groups, (const IvfItem*)items, (const int*)counts, D, (long)ldD, umin, (long)ldu);
     };
     if (mode == 0) go(ivf_scan_f16_kernel<0>); else go(ivf_scan_f16_kernel<1>);
     LAUNCH_CHECK();
