@@ -21,6 +21,9 @@
 //      kappa = K-th smallest approximate distance, tau = kappa + 2E, candidates = every row with approximation <= tau, exact
 //      float32 rescoring in the reference's order, (score, scan position) order — bit-identical to the strict path.
 //
+// Measured and not kept (round 3): fetching the NEXT item's descriptor during the current item and requesting its first K step before the
+// current item's epilogue (scan 0.2785 ms against 0.278: the second workgroup of the CU already covers an item's prologue and epilogue).
+//
 // The scan is HBM-bound by construction: every probed list is streamed once per group of 64 of its queries (12 GFLOP of MFMA work
 // for 1.5 GB of rows at 1M x 768, nprobe 32, B 256). Algorithmic bytes per launch = sum over items of the tile's rows x ldh x 2.
 #include "kernels.hpp"
