@@ -795,7 +795,7 @@ def main():
             if rank == 0:         # exact ground truth at 10M rows: a Flat index of the same rows (30 GB + 15 GB of fp16 shadow: nothing on a 288 GB part)
                 fx = ca.FlatIndex(ctx, args.dim, ca.L2_SQUARED)
                 add_rows(ctx, fx, 0, nb, args.dim, mix_fill(ctx, args.dim, nsub))
-            r = leg_ivfpq(ctx, ca, args, timer, fx, qb, Qb, nb, args.big_nlist, "ivfpq10m", comm, rank, world, every_candidate=False, nsub=nsub)
+            r = leg_ivfpq(ctx, ca, args, timer, fx, qb, Qb, nb, args.big_nlist, "ivfpq10m", comm, rank, world, every_candidate=True, nsub=nsub)
             r["corpus"] = f"{MIX_CENTERS} centres, {nsub} sub-centres at {MIX_SIGMA}, noise {MIX_NOISE}"
             if fx is not None:
                 fx.close()
