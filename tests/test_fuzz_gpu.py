@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as orc
-from comet_amd import COSINE, EUCLIDEAN, L2_SQUARED, FlatIndex, IVFPQIndex
+from comet_amd import COSINE, EUCLIDEAN, L2_SQUARED, FlatIndex, IVFIndex, IVFPQIndex
 
 pytestmark = pytest.mark.gpu
 
@@ -93,6 +93,51 @@ def test_ivfpq_random_operation_sequence(ctx):
             for b, q in enumerate(Q):
                 n, oi, os_ = o.search(q, k, npb)
                 assert cnt[b] == n and np.array_equal(ids[b, :n], oi) and np.array_equal(bits(sc[b, :n]), bits(os_)), (step, b)
+
+
+@pytest.mark.parametrize("metric,seed", [(L2_SQUARED, 31), (COSINE, 32), (EUCLIDEAN, 33)])
+def test_ivf_random_operation_sequence(ctx, metric, seed):
+    """IVF with its fast path in the loop: the slot layout and the fp16 shadow are rebuilt lazily after every add / flush, soft deletes and
+    filters become eligibility bytes per slot, batches beyond one slice, k beyond the fast path (0 = all, 2000) fall back to the exact kernels,
+    asynchronous searches are interleaved with mutations."""
+    rng = np.random.default_rng(seed)
+    d, nlist = int(rng.choice([24, 40, 72])), 10
+    train = rng.standard_normal((800, d)).astype(np.float32)
+    g = IVFIndex(ctx, d, nlist, metric); o = orc.IVF(d, metric, nlist)
+    g.train(train); assert o.train(train) == 0
+    next_id, live = 1, []
+    for step in range(40):
+        op = rng.random()
+        if op < 0.35 or len(live) < 100:
+            m = int(rng.integers(1, 4000))
+            X = rng.standard_normal((m, d)).astype(np.float32) * np.float32(rng.choice([0.2, 1.0, 20.0]))
+            ids = np.arange(next_id, next_id + m, dtype=np.uint32); next_id += m
+            g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
+            live.extend(ids.tolist())
+        elif op < 0.5 and live:
+            for _ in range(int(rng.integers(1, 30))):
+                if not live:
+                    break
+                i = live.pop(int(rng.integers(0, len(live))))
+                g.remove(i); assert o.remove(i) == 0
+        elif op < 0.55:
+            g.flush(); o.flush()
+        else:
+            B = int(rng.choice([1, 7, 33, 90, 300])); k = int(rng.choice([1, 10, 40, 0, 2000])); npb = int(rng.choice([1, 3, 10, 0]))
+            Q = rng.standard_normal((B, d)).astype(np.float32)
+            kw = {}
+            if rng.random() < 0.3 and live:
+                kw["filter_ids"] = [int(x) for x in rng.choice(live, size=min(len(live), int(rng.integers(1, 300))), replace=False)]
+            if rng.random() < 0.3:
+                probe = o.search(Q[0], 20, npb)[2]
+                if len(probe):
+                    kw["threshold"] = float(probe[len(probe) // 2])
+            kcap = max(1, min(len(live) + 8, 2500)) if k in (0, 2000) else k
+            ids, sc, cnt = g.search_batch(Q, k, nprobes=npb, threshold=kw.get("threshold", 0.0), document_ids=kw.get("filter_ids", ()), k_cap=kcap)
+            for b, q in enumerate(Q):
+                n, oi, os_ = o.search(q, k, npb, **kw)
+                m = min(n, ids.shape[1])
+                assert cnt[b] == n and np.array_equal(ids[b, :m], oi[:m]) and np.array_equal(bits(sc[b, :m]), bits(os_[:m])), (step, b, k, npb)
 
 
 def test_bm25_random_operation_sequence(ctx):
