@@ -68,7 +68,8 @@ using namespace comet;
 struct comet_comm {
     Ctx* c = nullptr; int rank = 0, world = 1;
     void* comm = nullptr;
-    hipStream_t xstream = nullptr;       // exchange + merge
+    hipStream_t xstream = nullptr;       // exchange + merge (+ the bound all-reduce of sharded IVFPQ searches): every collective is issued here
+    hipEvent_t bound_a = nullptr, bound_b = nullptr;
     DevBuf scalar;                       // small device scratch for barrier / all-reduce
     struct Slot {
         bool active = false; uint64_t ticket = 0, search_ticket = 0;
@@ -124,6 +125,7 @@ int comet_comm_destroy(comet_comm* cm) {
         Ctx* c = cm->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind();
         (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(cm->xstream);
         for (auto& s : cm->slots) { if (s.searched) (void)hipEventDestroy(s.searched); if (s.merged) (void)hipEventDestroy(s.merged); }
+        if (cm->bound_a) { (void)hipEventDestroy(cm->bound_a); (void)hipEventDestroy(cm->bound_b); }
         if (cm->comm && rccl().CommDestroy) (void)rccl().CommDestroy(cm->comm);
         (void)hipStreamDestroy(cm->xstream);
         delete cm;
@@ -170,10 +172,16 @@ int comet_index_search_sharded_async(comet_index* idx, comet_comm* cm, const flo
         struct Guard { comet_index* i; ~Guard() { i->bound_exchange = nullptr; i->bound_exchange_user = nullptr; } } guard{idx};
         if (cm->world > 1) {
             idx->bound_exchange_user = cm;
+            // every collective of the communicator is issued on ONE stream (the exchange stream): the search stream hands over with an event
+            // and waits for the reduced bounds with another
             idx->bound_exchange = [](void* user, uint32_t* tq, int n) {
                 comet_comm* m = static_cast<comet_comm*>(user);
-                ProfScope ps(m->c, "shard_bound_allreduce");
-                RCCL_CHECK(rccl().AllReduce(tq, tq, (size_t)n, NCCL_FLOAT32, NCCL_MIN, m->comm, m->c->stream));
+                if (!m->bound_a) { HIP_CHECK(hipEventCreateWithFlags(&m->bound_a, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&m->bound_b, hipEventDisableTiming)); }
+                HIP_CHECK(hipEventRecord(m->bound_a, m->c->stream));
+                HIP_CHECK(hipStreamWaitEvent(m->xstream, m->bound_a, 0));
+                RCCL_CHECK(rccl().AllReduce(tq, tq, (size_t)n, NCCL_FLOAT32, NCCL_MIN, m->comm, m->xstream));
+                HIP_CHECK(hipEventRecord(m->bound_b, m->xstream));
+                HIP_CHECK(hipStreamWaitEvent(m->c->stream, m->bound_b, 0));
             };
         }
         s->search_ticket = idx->search_begin(queries_dev, B, *p, pids, psc, pcn, k_cap);
