@@ -53,6 +53,20 @@ struct FlatIndex : comet_index {
     int ldh = 0;
     DevBuf Xh, rn, stats_dev;
     float xmax_abs = 0.0f, xmax_norm2 = 0.0f;
+    // int8 shadow for the wide scan tile (more than 64 queries per slice): codes in the fp16 shadow's tiled layout, one scale per tile,
+    // the largest quantisation-residual norm of any row (squared). The slice falls back to the fp16 shadow while int8 screening is
+    // too coarse for the data: a search whose int8 slices overflowed or proposed more than kI8MaxCand candidates per query
+    // switches the index to fp16 for a while (doubling back-off) — results are identical either way, only the time differs.
+    int ld8 = 0;
+    DevBuf X8, sx;
+    float xmax_err2 = 0.0f;
+    static constexpr int64_t kI8MaxCand = 1536;
+    int i8_policy = [] { const char* e = getenv("COMET_FLAT_I8"); return e ? atoi(e) : -1; }();   // 0 never, 1 always, otherwise adaptive
+    int64_t n_searches = 0, i8_resume_at = 0, st_i8_slices = 0, st_i8_backoffs = 0; int i8_strikes = 0;
+    bool i8_usable(int bn) const {
+        if (i8_policy == 0 || bn <= 64 || !prep_queries_i8_ok(dim) || !std::isfinite(xmax_err2)) return false;
+        return i8_policy == 1 || n_searches >= i8_resume_at;
+    }
     // counters of the last fast-path search (bench / tests)
     int64_t st_candidates = 0, st_overflows = 0, st_expansions = 0, st_fast_queries = 0, st_strict_queries = 0;
     // Deferred verification of fast-path searches: the candidate-overflow flags of a search are copied to pinned host
@@ -60,7 +74,7 @@ struct FlatIndex : comet_index {
     // the strict kernels. This keeps the stream busy across batches (no host round trip inside a search).
     struct Pending {
         bool active = false; uint64_t ticket = 0; hipEvent_t ev = nullptr;
-        int B = 0, k_cap = 0, nfast_slices = 0;
+        int B = 0, k_cap = 0, nfast_slices = 0; uint64_t i8_mask = 0;   // bit sl: slice sl was screened on the int8 shadow
         const float* queries = nullptr; comet_search_params p{}; std::vector<uint32_t> flt;
         uint32_t* out_ids = nullptr; float* out_scores = nullptr; int32_t* out_counts = nullptr;
         int32_t* flags = nullptr;   // pinned: per fast slice [256 overflow flags | 4 stats]
@@ -116,15 +130,25 @@ struct FlatIndex : comet_index {
                 if (new_tiles > old_tiles) c->zero((char*)Xh.p + old_tiles * tile_bytes, (new_tiles - old_tiles) * tile_bytes);
             }
             rn.reserve((size_t)(n + added) * 4, c->stream, (size_t)n * 4);
-            stats_dev.reserve(8, c->stream, 0);
-            c->zero(stats_dev.p, 8);
+            stats_dev.reserve(16, c->stream, 0);
+            c->zero(stats_dev.p, 16);
             launch_to_half_rows(c, dst, added, ld, Xh.p, ldh, n, rn.as<float>() + n, stats_dev.as<uint32_t>());
-            uint32_t hs[2] = {0, 0};
-            c->d2h(hs, stats_dev.p, 8);
+            if (i8_policy != 0 && prep_queries_i8_ok(dim)) {
+                const size_t tile_bytes = (size_t)256 * ld8;
+                const size_t old_tiles = (size_t)ceil_div(n, 256), new_tiles = (size_t)ceil_div(n + added, 256);
+                X8.reserve(new_tiles * tile_bytes, c->stream, old_tiles * tile_bytes);
+                if (new_tiles > old_tiles) c->zero((char*)X8.p + old_tiles * tile_bytes, (new_tiles - old_tiles) * tile_bytes);
+                sx.reserve(new_tiles * 4, c->stream, old_tiles * 4);
+                // the tile the batch starts in is quantised again as a whole: its scale follows the largest component of all its rows
+                launch_to_i8_tiles(c, X.as<float>(), n + added, ld, X8.p, ld8, n / 256, sx.as<float>(), stats_dev.as<uint32_t>());
+            }
+            uint32_t hs[4] = {0, 0, 0, 0};
+            c->d2h(hs, stats_dev.p, 16);
             HIP_CHECK(hipStreamSynchronize(c->stream));
-            float fa, fn; std::memcpy(&fa, &hs[0], 4); std::memcpy(&fn, &hs[1], 4);
+            float fa, fn, fe; std::memcpy(&fa, &hs[0], 4); std::memcpy(&fn, &hs[1], 4); std::memcpy(&fe, &hs[2], 4);
             if (!(fa <= xmax_abs)) xmax_abs = fa;       // NaN-propagating max
             if (!(fn <= xmax_norm2)) xmax_norm2 = fn;
+            if (!(fe <= xmax_err2)) xmax_err2 = fe;
             ids.insert(ids.end(), ids_h, ids_h + added);
             for (int64_t i = 0; i < added; i++) id_count[ids_h[i]]++;
             n += added; first_row_dirty = true;
@@ -162,6 +186,12 @@ struct FlatIndex : comet_index {
             c->zero(Xh.p, tiles * 256 * ldh * 2);
             rn.reserve(std::max<size_t>(1, nk) * 4, c->stream, 0);
             launch_to_half_rows(c, X.as<float>(), (int64_t)nk, ld, Xh.p, ldh, 0, rn.as<float>(), nullptr);
+            if (X8.p) {   // and the int8 one (the residual maximum stays: it is an upper bound for the surviving rows)
+                X8.reserve(tiles * 256 * ld8, c->stream, 0);
+                c->zero(X8.p, tiles * 256 * ld8);
+                sx.reserve(tiles * 4, c->stream, 0);
+                launch_to_i8_tiles(c, X.as<float>(), (int64_t)nk, ld, X8.p, ld8, 0, sx.as<float>(), nullptr);
+            }
             HIP_CHECK(hipStreamSynchronize(c->stream));
         }
         ids.swap(nids); n = (int64_t)nk; first_row_dirty = true;
@@ -208,22 +238,26 @@ struct FlatIndex : comet_index {
         ScratchMark sm(c);
         // key units: the scan emits, per query, 2 keys + 1 bound for every 128-row unit (64-row units on the narrow tile for <= 64 queries
         // and where 128-row units would often be expanded: small indexes / large k)
-        const int unit_rows = flat_fast_unit_rows(bn, n, p.k, ldh);
+        const bool i8 = i8_usable(bn) && X8.p != nullptr;
+        const int unit_rows = flat_fast_unit_rows(bn, n, p.k, i8 ? ld8 / 2 : ldh);
         const int64_t n_tiles = ceil_div(n, flat_fast_tile_rows()) * (flat_fast_tile_rows() / unit_rows);
         const int64_t ldS = round_up(2 * n_tiles, 16), ldB = round_up(n_tiles, 16);
         const int NB = flat_fast_batch();
-        void* Qh = c->scratch_alloc((size_t)NB * ldh * 2 * 2);   // row-major copy + MFMA-fragment-ordered copy
+        void* Qh = i8 ? c->scratch_alloc((size_t)NB * ld8) : c->scratch_alloc((size_t)NB * ldh * 2 * 2);   // fp16: row-major copy + MFMA-fragment-ordered copy; int8: fragment-ordered codes
         float* qn = c->salloc<float>(NB);
+        float* sqv = i8 ? c->salloc<float>(NB) : nullptr;
         float* err = c->salloc<float>(NB);
         int32_t* flags = pend->dflags + (size_t)pend->nfast_slices * kSliceInts;     // [256 overflow flags | 4 stats] of this slice
         int32_t* ovf = flags; int32_t* st = flags + 256;
         const int fmode = metric == COMET_COSINE ? 0 : 1;
         const float xn2 = metric == COMET_COSINE ? 1.0002f : xmax_norm2;
-        if (raw_queries) launch_prep_queries_fused(c, metric, raw_queries, bn, dim, const_cast<float*>(Qp), ld, zflag, Qh, ldh, qn, err, fmode, xn2, st);
+        if (i8) launch_prep_queries_i8(c, metric, raw_queries, bn, dim, const_cast<float*>(Qp), ld, raw_queries ? zflag : nullptr, Qh, ld8, sqv, qn, err, fmode, xn2, std::sqrt(xmax_err2), st);
+        else if (raw_queries) launch_prep_queries_fused(c, metric, raw_queries, bn, dim, const_cast<float*>(Qp), ld, zflag, Qh, ldh, qn, err, fmode, xn2, st);
         else launch_prep_queries_fast(c, Qp, bn, ld, dim, Qh, ldh, qn, err, fmode, xn2, st);
         float* S0 = c->salloc<float>((size_t)NB * ldS);
         float* bound = c->salloc<float>((size_t)NB * ldB);
-        launch_flat_scan_f16(c, fmode, Xh.p, n, ldh, Qh, bn, rn.as<float>(), qn, elig, S0, ldS, bound, ldB, unit_rows);
+        if (i8) { launch_flat_scan_i8(c, fmode, X8.p, n, ld8, Qh, bn, rn.as<float>(), qn, sx.as<float>(), sqv, elig, S0, ldS, bound, ldB, unit_rows); pend->i8_mask |= 1ull << pend->nfast_slices; }
+        else launch_flat_scan_f16(c, fmode, Xh.p, n, ldh, Qh, bn, rn.as<float>(), qn, elig, S0, ldS, bound, ldB, unit_rows);
         // kappa: exact K-th smallest emitted key per query
         const int64_t keff = (p.k <= 0 || p.k > n) ? n : p.k;
         const int Kq = (int)std::min<int64_t>(keff, 2 * n_tiles);
@@ -289,11 +323,12 @@ struct FlatIndex : comet_index {
         if (!slot->dflags) HIP_CHECK(hipMalloc((void**)&slot->dflags, sizeof(int32_t) * kSliceInts * kMaxSlices));
         if (!slot->ev_post) HIP_CHECK(hipEventCreateWithFlags(&slot->ev_post, hipEventDisableTiming));
         if (!copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-        slot->ticket = next_ticket++; slot->B = B; slot->k_cap = k_cap; slot->nfast_slices = 0; slot->queries = queries_dev;
+        slot->ticket = next_ticket++; slot->B = B; slot->k_cap = k_cap; slot->nfast_slices = 0; slot->i8_mask = 0; slot->queries = queries_dev;
+        n_searches++;
         slot->p = p; slot->flt.clear();
         if (p.filter_ids && p.n_filter > 0) { slot->flt.assign(p.filter_ids, p.filter_ids + p.n_filter); slot->p.filter_ids = slot->flt.data(); }
         slot->out_ids = out_ids; slot->out_scores = out_scores; slot->out_counts = out_counts;
-        st_candidates = st_overflows = st_expansions = st_fast_queries = st_strict_queries = 0;
+        st_candidates = st_overflows = st_expansions = st_fast_queries = st_strict_queries = st_i8_slices = 0;
         search_core(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap, slot);
         if (slot->nfast_slices > 0) {
             // overflow flags + statistics go to pinned host memory on the copy stream: the copy (a kernel of its own plus two launch
@@ -319,6 +354,12 @@ struct FlatIndex : comet_index {
             const int32_t* hf = slot->flags + (size_t)sl * kSliceInts;
             const int bn = std::min(NB, slot->B - sl * NB);
             st_candidates += hf[256]; st_overflows += hf[257]; st_expansions += hf[258];
+            if ((slot->i8_mask >> sl) & 1ull) {
+                st_i8_slices++;
+                if (i8_policy != 1 && (hf[257] > 0 || hf[256] > kI8MaxCand * bn) && n_searches >= i8_resume_at) {   // too coarse for this data: fp16 for a while
+                    i8_resume_at = n_searches + ((int64_t)32 << std::min(i8_strikes, 10)); i8_strikes++; st_i8_backoffs++;
+                }
+            }
             int nfast = bn;
             for (int q = 0; q < bn; q++) if (hf[q]) { redo.push_back(sl * NB + q); nfast--; }
             st_fast_queries += nfast;
@@ -346,6 +387,9 @@ struct FlatIndex : comet_index {
         else if (k == "fast_expansions") *out = (double)st_expansions;
         else if (k == "fast_queries") *out = (double)st_fast_queries;
         else if (k == "strict_queries") *out = (double)st_strict_queries;
+        else if (k == "i8_slices") *out = (double)st_i8_slices;
+        else if (k == "i8_backoffs") *out = (double)st_i8_backoffs;
+        else if (k == "i8_max_residual") *out = std::sqrt((double)xmax_err2);
         else if (k == "max_abs") *out = (double)xmax_abs;
         else if (k == "max_norm2") *out = (double)xmax_norm2;
         else return false;
@@ -381,7 +425,7 @@ struct FlatIndex : comet_index {
     void read_from(Source& s) override {
         read_header(s, "FLAT", dim, metric);
         const uint32_t count = s.u32("vector count");
-        FlatIndex t; t.c = c; t.kind = kind; t.dim = dim; t.ld = ld; t.ldh = ldh; t.metric = metric; t.trained = true; t.raw_ingest = true;
+        FlatIndex t; t.c = c; t.kind = kind; t.dim = dim; t.ld = ld; t.ldh = ldh; t.ld8 = ld8; t.metric = metric; t.trained = true; t.raw_ingest = true;
         const int64_t chunk = 16384;
         std::vector<float> host((size_t)std::min<int64_t>(chunk, std::max<int64_t>(count, 1)) * dim);
         std::vector<uint32_t> hid(std::min<int64_t>(chunk, std::max<int64_t>(count, 1)));
@@ -405,7 +449,8 @@ struct FlatIndex : comet_index {
         for (auto& r : ring) if (r.active) search_finish(r.ticket);
         std::swap(X.p, t.X.p); std::swap(X.cap, t.X.cap); std::swap(ids_dev.p, t.ids_dev.p); std::swap(ids_dev.cap, t.ids_dev.cap);
         std::swap(Xh.p, t.Xh.p); std::swap(Xh.cap, t.Xh.cap); std::swap(rn.p, t.rn.p); std::swap(rn.cap, t.rn.cap);
-        ids.swap(t.ids); id_count.swap(t.id_count); n = t.n; xmax_abs = t.xmax_abs; xmax_norm2 = t.xmax_norm2; first_row_dirty = true;
+        std::swap(X8.p, t.X8.p); std::swap(X8.cap, t.X8.cap); std::swap(sx.p, t.sx.p); std::swap(sx.cap, t.sx.cap);
+        ids.swap(t.ids); id_count.swap(t.id_count); n = t.n; xmax_abs = t.xmax_abs; xmax_norm2 = t.xmax_norm2; xmax_err2 = t.xmax_err2; first_row_dirty = true;
         deleted.clear(); deleted.insert(del.begin(), del.end()); deleted_dirty = true;
     }
 
@@ -422,7 +467,7 @@ struct FlatIndex : comet_index {
 
 comet_index* make_flat(Ctx* c, int dim, int metric) {
     auto* f = new FlatIndex();
-    f->c = c; f->kind = COMET_KIND_FLAT; f->dim = dim; f->ld = padded_dim(dim); f->ldh = (int)round_up(dim, 64); f->metric = metric; f->trained = true;
+    f->c = c; f->kind = COMET_KIND_FLAT; f->dim = dim; f->ld = padded_dim(dim); f->ldh = (int)round_up(dim, 64); f->ld8 = (int)round_up(dim, 256); f->metric = metric; f->trained = true;
     return f;
 }
 

@@ -27,6 +27,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
 
 namespace comet {
 
@@ -64,6 +67,81 @@ void launch_to_half_rows(Ctx* c, const float* X, int64_t n, int ld, void* Xh, in
     if (n <= 0) return;
     ProfScope ps(c, "to_half_rows");
     to_half_rows_kernel<<<dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, c->stream>>>(X, n, ld, (_Float16*)Xh, ldh, row_base, rn, stats);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 padded rows -> int8 shadow (round 3): x_i = s_T * c_i + delta_i, c_i in [-127, 127], ONE SCALE PER 256-ROW TILE
+// ------------------------------------------------------------------------------------------------
+// The wide scan tile is matrix-pipe / power bound on fp16 (0.45-0.48 ms for 1M x 768 x 256 queries); v_mfma_i32_32x32x32_i8 does the
+// same tile in half the instructions from half the bytes. The int8 dot product s_T s_q sum c_i e_i is the EXACT dot product of the two
+// dequantised vectors; what it misses of x . q is  delta . q_hat + x . eps  (delta, eps: the quantisation residuals of row and query),
+// bounded by Cauchy-Schwarz with the residual NORMS MEASURED here (not a worst-case model): |x.q - x_hat.q_hat| <= ||delta|| ||q_hat|| +
+// ||x|| ||eps||. The index keeps max ||delta|| over its rows (stats[2]); prep_queries_i8_kernel turns it into the per-query E.
+// Scale per tile, not per row: the rows of a tile compete inside key units, and with a common scale the selection network runs on the
+// raw integer sums (one conversion per accumulator more than the fp16 epilogue). A per-row scale needs a second per-row LDS stream
+// in the L2 epilogue, which drove hipcc into spilling 260-600 registers, in-flight query fragments among them. The price: a row
+// is quantised as coarsely as the largest component of its 255 neighbours demands — measured, so still rigorous.
+// Layout: the fp16 shadow's, byte for byte — [256-row tile][64-byte slab][row][64 bytes], a K step (two slabs, 128 bytes per row) now
+// holds 128 dimensions; ld8 = dimensions padded to 256 (the query-stationary tile runs K steps in pairs).
+__device__ __forceinline__ long tiled_off8(long row, int k, int ld8) {
+    const long tile = row >> 8; const int r = (int)(row & 255);
+    return ((tile * (ld8 >> 6) + (k >> 6)) * 256 + r) * 64 + (k & 63);
+}
+__device__ __forceinline__ unsigned pack4_i8(float a, float b, float c, float d) {
+    return ((unsigned)(int)a & 0xFFu) | (((unsigned)(int)b & 0xFFu) << 8) | (((unsigned)(int)c & 0xFFu) << 16) | (((unsigned)(int)d & 0xFFu) << 24);
+}
+// One workgroup per tile, (re)quantising ALL rows the tile holds: rows [tile * 256, min(n, tile * 256 + 256)) of X (X = row 0 of the index).
+__global__ __launch_bounds__(256) void to_i8_tiles_kernel(const float* __restrict__ X, long n, int ld, signed char* __restrict__ X8, int ld8, long tile0,
+                                                          float* __restrict__ st /*scale per tile*/, unsigned* __restrict__ stats /*[2] = max ||delta||^2 bits*/) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long tile = tile0 + blockIdx.x, r0 = tile * 256, r1 = r0 + 256 < n ? r0 + 256 : n;
+    float amax = 0.0f;
+    for (long row = r0 + w; row < r1; row += 4) {
+        const float* x = X + row * (long)ld;                   // ld is a multiple of 32, rows are 16-byte aligned
+        for (int i0 = lane * 4; i0 < ld; i0 += 256) {
+            const f32x4v v = *reinterpret_cast<const f32x4v*>(x + i0);
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    if (lane == 0) red[w] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float s = amax > 0.0f ? amax / 127.0f : 1.0f;
+    float e2max = 0.0f;
+    for (long row = r0 + w; row < r1; row += 4) {
+        const float* x = X + row * (long)ld;
+        float e2 = 0.0f;
+        for (int i0 = lane * 16; i0 < ld8; i0 += 1024) {
+            u32x4 out;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                f32x4v v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (i0 + 4 * j < ld) v = *reinterpret_cast<const f32x4v*>(x + i0 + 4 * j);
+                float cq[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    cq[e] = fminf(fmaxf(rintf(v[e] / s), -127.0f), 127.0f);
+                    const float dl = v[e] - s * cq[e];
+                    e2 += dl * dl;
+                }
+                out[j] = pack4_i8(cq[0], cq[1], cq[2], cq[3]);
+            }
+            *reinterpret_cast<u32x4*>(X8 + tiled_off8(row, i0, ld8)) = out;
+        }
+        for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off, 64);
+        e2max = fmaxf(e2max, e2);
+    }
+    if (threadIdx.x == 0) st[tile] = s;
+    if (lane == 0 && stats) atomicMax(&stats[2], __float_as_uint(e2max));
+}
+void launch_to_i8_tiles(Ctx* c, const float* X, int64_t n, int ld, void* X8, int ld8, int64_t tile0, float* st, uint32_t* stats) {
+    const int64_t tiles = ceil_div(n, 256) - tile0;
+    if (tiles <= 0) return;
+    ProfScope ps(c, "to_i8_tiles");
+    to_i8_tiles_kernel<<<dim3((unsigned)tiles), dim3(256), 0, c->stream>>>(X, n, ld, (signed char*)X8, ld8, tile0, st, stats);
     LAUNCH_CHECK();
 }
 
@@ -329,7 +407,6 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_n64_kernel(const _Fl
 //   * a wave owns whole (query, 128-row) key units, so the epilogue needs no cross-wave merge.
 // Per K step a wave issues 32 MFMAs, 32 ds_read_b128, 4 DMA pieces and 4 query loads.
 // ------------------------------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // barrier that waits for this wave's LDS traffic only (not for the LDS-DMA of later slabs, which __syncthreads() would drain)
 __device__ __forceinline__ void __syncthreads_lds_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr int FQ_STAGES = 4, FQ_STAGE_BYTES = 32768;
@@ -369,17 +446,26 @@ __device__ __forceinline__ void ins3max(float& t0, float& t1, float& t2, float v
 // tau carries as an absolute slack (FAST_PACK_SLACK).
 // UR = rows per key unit: 128, or 64 where 128-row units would often hold three candidates (small indexes / large k: every such unit
 // is rescored whole by the post stage).
-template <int MODE, bool CHECK, int UR>
-__device__ __forceinline__ void scan_epilogue_q(f32x16 (&acc)[8], int wid, long tile, long row0, long n, const float* __restrict__ rn_lds /*256 floats, MODE 1*/,
+// I8 (int8 shadow): the accumulators are the integer dot products of the codes; the score is s_T[tile] * s_q[query] * acc, both
+// scales positive and common to the rows a lane compares: the selection runs on float(acc) (cosine; the survivors are scaled) resp.
+// on 2 s_T s_q float(acc) - rn (L2): one conversion per accumulator more than the fp16 epilogue.
+template <int MODE, bool CHECK, int UR, bool I8 = false>
+__device__ __forceinline__ void scan_epilogue_q(std::conditional_t<I8, i32x16, f32x16> (&acc)[8], int wid, long tile, long row0, long n, const float* __restrict__ rn_lds /*256 floats, MODE 1*/,
                                                 const float* __restrict__ qn, const unsigned char* __restrict__ elig,
-                                                float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, unsigned long long* etr = nullptr) {
+                                                float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, unsigned long long* etr = nullptr,
+                                                const float* __restrict__ sq = nullptr, float st = 1.0f /*I8: tile scale*/) {
     // C layout of the 32x32 MFMA: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); tile mb covers rows mb*32..
     const int lane = threadIdx.x & 63, khalf = lane >> 5;
-    const int q = wid * 32 + (lane & 31);
+    int q = wid * 32 + (lane & 31);
+    // opaque to the optimiser: otherwise the per-lane output addresses (S0 + q ldS, bound + q ldB) are hoisted out of the persistent K loop,
+    // live across it in 64-bit register pairs, spilled, and their reloads put a conservative s_waitcnt vmcnt(0) into the K steps
+    asm volatile("" : "+v"(q));
     const float INF = __builtin_inff();
     const long nvalid = n - row0;
-    float qnv = 0.0f;
+    float qnv = 0.0f, sqv = 1.0f;
     if constexpr (MODE == 1) qnv = qn[q];
+    if constexpr (I8) sqv = sq[q] * st;
+    const float sq2 = 2.0f * sqv;
     constexpr int NU = 256 / UR, MBU = UR / 32;
 #pragma unroll
     for (int u = 0; u < NU; u++) {                              // key unit = UR rows (tiles mb = MBU*u .. MBU*u + MBU-1)
@@ -391,6 +477,7 @@ __device__ __forceinline__ void scan_epilogue_q(f32x16 (&acc)[8], int wid, long 
         float t0 = -INF, t1 = -INF, t2 = -INF;
 #pragma unroll
         for (int mb = 0; mb < MBU; mb++) {
+            // I8: keep the scheduler from pulling every block's scale loads and conversions to the top (the L2 form spilled 260 registers)
 #pragma unroll
             for (int e4 = 0; e4 < 4; e4++) {
                 f32x4v rnv;
@@ -400,7 +487,10 @@ __device__ __forceinline__ void scan_epilogue_q(f32x16 (&acc)[8], int wid, long 
                     const int e = e4 * 4 + e1;
                     const int rconst = mb * 32 + e1 + 8 * e4;              // compile-time part of the row-in-unit (bit 2 = lane >> 5 is added to the survivors)
                     float v;
-                    if constexpr (MODE == 0) v = acc[MBU * u + mb][e];
+                    if constexpr (I8) {
+                        if constexpr (MODE == 0) v = (float)acc[MBU * u + mb][e];
+                        else v = __builtin_fmaf(sq2, (float)acc[MBU * u + mb][e], -rnv[e1]);
+                    } else if constexpr (MODE == 0) v = acc[MBU * u + mb][e];
                     else v = __builtin_fmaf(2.0f, acc[MBU * u + mb][e], -rnv[e1]);
                     v = __uint_as_float((__float_as_uint(v) & 0xFFFFFF00u) | (unsigned)rconst);
                     if constexpr (CHECK) v = ((okmask >> (mb * 16 + e)) & 1ull) ? v : -INF;
@@ -420,7 +510,7 @@ __device__ __forceinline__ void scan_epilogue_q(f32x16 (&acc)[8], int wid, long 
                 const unsigned row = __float_as_uint(v) & 0xFFu;
                 const float clean = __uint_as_float(__float_as_uint(v) & 0xFFFFFF00u);
                 float a;
-                if constexpr (MODE == 0) a = 1.0f - clean; else a = qnv - clean;      // clean = -(rn - 2 s)
+                if constexpr (MODE == 0) a = 1.0f - (I8 ? sqv * clean : clean); else a = qnv - clean;      // clean = -(rn - 2 s)
                 a = fmaxf(a, 0.0f);
                 return __uint_as_float((__float_as_uint(a) & 0xFFFFFF00u) | row);
             };
@@ -436,13 +526,16 @@ __device__ __forceinline__ void scan_epilogue_q(f32x16 (&acc)[8], int wid, long 
 // pairs — the slab ring and the counted waits run straight across tile boundaries, so the first slabs of tile T+1 are in flight
 // while the waves run tile T's last K steps and its epilogue (a one-shot tile exposes ~4000 cycles of HBM latency before its
 // first MFMA: s_memtime trace in profiles/r02_flat_scan_investigation.txt).
-template <int MODE, int UR>
+// I8: the int8 shadow (to_i8_rows_kernel) on v_mfma_i32_32x32x32_i8 — the data path is byte-identical (a K step of 128 bytes per row
+// holds 128 dimensions instead of 64; `ldh` is then the row's BYTES / 2), half the K steps per tile.
+template <int MODE, int UR, bool I8 = false>
 __global__ __launch_bounds__(FB_THREADS) void flat_scan_q8_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
                                                                   const _Float16* __restrict__ QF /*fragment-ordered queries*/,
                                                                   const float* __restrict__ rn, const float* __restrict__ qn,
                                                                   const unsigned char* __restrict__ elig,
                                                                   float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles,
-                                                                  unsigned long long* __restrict__ trace /*nullable: s_memtime stamps of workgroup 8 (tools/scan_check)*/) {
+                                                                  unsigned long long* __restrict__ trace /*nullable: s_memtime stamps of workgroup 8 (tools/scan_check)*/,
+                                                                  const float* __restrict__ sx = nullptr /*I8: tile scales*/, const float* __restrict__ sq = nullptr /*I8: query scales*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // FQ_STAGES x 32 KiB row slabs (+ 1 KiB of row norms, MODE 1)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -456,7 +549,7 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_q8_kernel(const _Float16
     const long total = my_tiles * nk;                          // global steps of this workgroup
     float* rn_lds = reinterpret_cast<float*>(smem + FQ_STAGES * FQ_STAGE_BYTES);
 
-    f32x16 acc[8];
+    std::conditional_t<I8, i32x16, f32x16> acc[8];
     // ---- row slabs: each wave moves 4 pieces (8 rows x 128 B) per K step, XOR swizzle on the source side ----
     const int prow = lane >> 3, pslot = lane & 7;
     int poff[4], ldsoff[4];                                   // byte offset of the piece inside a (tile, K step) slab pair / inside the ring stage
@@ -521,7 +614,7 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_q8_kernel(const _Float16
 #pragma unroll
             for (int i = 0; i < 8; i++)
 #pragma unroll
-                for (int e = 0; e < 16; e++) acc[i][e] = 0.0f;
+                for (int e = 0; e < 16; e++) acc[i][e] = 0;
         }
         const unsigned char* xb = smem + (g & (FQ_STAGES - 1)) * FQ_STAGE_BYTES;
         const int ktn = kt + 1 < nk ? kt + 1 : 0;                      // next step's K index (wraps into the next tile)
@@ -543,7 +636,8 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_q8_kernel(const _Float16
                 for (int m2 = 0; m2 < 4; m2++) {
                     const int mb = h * 4 + m2;
                     if (ks < 3) a[(ks + 1) & 1][mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, (ks + 1) * 2 + khalf));
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][mb], b, acc[mb], 0, 0, 0);
+                    if constexpr (I8) acc[mb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, a[ks & 1][mb]), __builtin_bit_cast(i32x4v, b), acc[mb], 0, 0, 0);
+                    else acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][mb], b, acc[mb], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const int gi = ks * 2 + h;
@@ -566,9 +660,11 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_q8_kernel(const _Float16
                 if (tid < FB_M) { const long r = row0 + tid; rn_lds[tid] = rn[r < n ? r : n - 1]; }
                 __syncthreads_lds_only();
             }
+            float stv = 1.0f;
+            if constexpr (I8) stv = sx[tile];
             unsigned long long* etr = (tr && g < 2 * nk + 2) ? trace + 8 * 32 * 4 + wid * 8 : nullptr;
-            if ((n - row0 < FB_M) || elig != nullptr) scan_epilogue_q<MODE, true, UR>(acc, wid, tile, row0, n, rn_lds, qn, elig, S0, ldS, bound, ldB, etr);   // workgroup-uniform
-            else scan_epilogue_q<MODE, false, UR>(acc, wid, tile, row0, n, rn_lds, qn, elig, S0, ldS, bound, ldB, etr);
+            if ((n - row0 < FB_M) || elig != nullptr) scan_epilogue_q<MODE, true, UR, I8>(acc, wid, tile, row0, n, rn_lds, qn, elig, S0, ldS, bound, ldB, etr, sq, stv);   // workgroup-uniform
+            else scan_epilogue_q<MODE, false, UR, I8>(acc, wid, tile, row0, n, rn_lds, qn, elig, S0, ldS, bound, ldB, etr, sq, stv);
             stamp(g, 3);
         }
     };
@@ -627,7 +723,8 @@ void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, 
         const _Float16* QF = (const _Float16*)Qh + (size_t)FB_N * ldh;
         auto go = [&](auto kernel) {
             HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
-            c->launch_timed(scope, kernel, dim3((unsigned)gridq), dim3(FB_THREADS), ldsq, (const _Float16*)Xh, (long)n, ldh, QF, rn, qn, (const unsigned char*)elig, S0, (long)ldS, bound, (long)ldB, n_tiles, g_scan_trace);
+            c->launch_timed(scope, kernel, dim3((unsigned)gridq), dim3(FB_THREADS), ldsq, (const _Float16*)Xh, (long)n, ldh, QF, rn, qn, (const unsigned char*)elig, S0, (long)ldS, bound, (long)ldB, n_tiles, g_scan_trace,
+                            (const float*)nullptr, (const float*)nullptr);
         };
         if (unit_rows == 64) { if (mode == 0) go(flat_scan_q8_kernel<0, 64>); else go(flat_scan_q8_kernel<1, 64>); }
         else { if (mode == 0) go(flat_scan_q8_kernel<0, 128>); else go(flat_scan_q8_kernel<1, 128>); }
@@ -642,6 +739,23 @@ void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, 
         c->launch_timed(scope, kernel, dim3((unsigned)grid), dim3(FB_THREADS), lds, (const _Float16*)Xh, (long)n, ldh, (const _Float16*)Qh, rn, qn, (const unsigned char*)elig, S0, (long)ldS, bound, (long)ldB, n_tiles);
     };
     if (mode == 0) go2(flat_scan_f16_kernel<0>); else go2(flat_scan_f16_kernel<1>);
+    LAUNCH_CHECK();
+}
+// The wide tile on the int8 shadow (more than 64 queries; ld8 a multiple of 256). Q8F: fragment-ordered int8 queries
+// (prep_queries_i8_kernel), sx / sq: tile / query scales. Keys and bounds come out exactly as from the fp16 tile.
+void launch_flat_scan_i8(Ctx* c, int mode, const void* X8, int64_t n, int ld8, const void* Q8F, int nq_used, const float* rn, const float* qn,
+                         const float* sx, const float* sq, const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB, int unit_rows) {
+    if (nq_used <= FN_N || (ld8 & 255) != 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "the int8 scan is the wide tile's (more than 64 queries, rows padded to 256 bytes)");
+    const long n_tiles = ceil_div(n, FB_M);
+    const size_t ldsq = (size_t)FQ_STAGES * FQ_STAGE_BYTES + 1024;
+    const long gridq = std::min<long>(round_up(n_tiles, 8), (long)round_up(c->prop.multiProcessorCount, 8));
+    auto go = [&](auto kernel) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
+        c->launch_timed("flat_scan_i8", kernel, dim3((unsigned)gridq), dim3(FB_THREADS), ldsq, (const _Float16*)X8, (long)n, ld8 / 2, (const _Float16*)Q8F, rn, qn, (const unsigned char*)elig, S0, (long)ldS, bound,
+                        (long)ldB, n_tiles, g_scan_trace, sx, sq);
+    };
+    if (unit_rows == 64) { if (mode == 0) go(flat_scan_q8_kernel<0, 64, true>); else go(flat_scan_q8_kernel<1, 64, true>); }
+    else { if (mode == 0) go(flat_scan_q8_kernel<0, 128, true>); else go(flat_scan_q8_kernel<1, 128, true>); }
     LAUNCH_CHECK();
 }
 int flat_fast_tile_rows() { return FB_M; }
@@ -790,6 +904,116 @@ __global__ __launch_bounds__(256) void prep_queries_fused_kernel(int metric, con
     }
 }
 bool prep_queries_fused_ok(int dim) { return dim <= PREPF_MAX_D; }
+
+// The int8 side of a query slice, a wave per query: Distance.Preprocess (raw queries: the cosine normalisation exactly as in
+// prep_queries_fused_kernel; src == nullptr: Qp is preprocessed already), then q_i = s_q e_i + eps_i with one scale per query,
+// the codes in MFMA fragment order [wave = q / 32][K step of 128][ks][lane = khalf * 32 + q % 32][16 codes], and the rigorous bound
+//   |approx - exact| <= E = dx_max ||q_hat|| + ||x||_max ||eps||  (+ float32 evaluation on both sides, + key packing)
+// from the MEASURED residual norms (dx_max: the index's largest row residual norm, to_i8_tiles_kernel).
+__global__ __launch_bounds__(256) void prep_queries_i8_kernel(int metric, const float* __restrict__ src, int B, int d, float* __restrict__ Qp, int ld,
+                                                              int* __restrict__ zero_flag, signed char* __restrict__ Q8F, int ld8, float* __restrict__ sq,
+                                                              float* __restrict__ qn, float* __restrict__ err_abs, int mode, float xmax_norm2, float dx_max,
+                                                              int* __restrict__ stats4) {
+    extern __shared__ __attribute__((aligned(16))) float sqm[];   // [4 waves][ld8]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + w;
+    if (stats4 && blockIdx.x == 0 && threadIdx.x < 4) stats4[threadIdx.x] = 0;   // the post stage accumulates into these
+    if (q >= FB_N) return;
+    float* my = sqm + (long)w * ld8;
+    const bool live = q < B;
+    const float* sp = src ? src + (long)q * d : Qp + (long)q * ld;
+    const int dsrc = src ? d : ld;                               // readable elements of the source row
+    const bool vec = src ? ((d & 3) == 0 && ((unsigned long long)src & 15ull) == 0ull) : true;
+    auto load4 = [&](int i0, float (&v)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = 0.0f;
+        if (!live) return;
+        if (vec && i0 + 4 <= dsrc) { const f32x4v a = *reinterpret_cast<const f32x4v*>(sp + i0); v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; }
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) if (i0 + e < dsrc) v[e] = sp[i0 + e];
+        }
+    };
+    float scale = 1.0f; int zf = 0;
+    if (live && src && metric == COMET_COSINE) {                  // float32(math.Sqrt(float64(sum))) over the serial float32 sum of squares
+        const int dpad = (d + 3) & ~3;
+        for (int i0 = lane * 4; i0 < dpad; i0 += 256) {
+            float v[4]; load4(i0, v);
+            *reinterpret_cast<f32x4v*>(&my[i0]) = f32x4v{v[0] * v[0], v[1] * v[1], v[2] * v[2], v[3] * v[3]};
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        float sum = 0.0f;
+        if (lane == 0) {
+#pragma unroll 8
+            for (int i = 0; i < dpad; i += 4) {
+                const f32x4v p = *reinterpret_cast<const f32x4v*>(&my[i]);
+                sum = sum + p[0]; sum = sum + p[1]; sum = sum + p[2]; sum = sum + p[3];
+            }
+        }
+        sum = __shfl(sum, 0, 64);
+        const float norm = (float)__builtin_sqrt((double)sum);
+        if (norm == 0.0f) zf = 1; else scale = 1.0f / norm;
+    }
+    float s = 0.0f, amax = 0.0f;
+    for (int i0 = lane * 4; i0 < ld8; i0 += 256) {
+        float v[4]; load4(i0, v);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (src && metric == COMET_COSINE && !zf) v[e] = v[e] * scale;
+            s += v[e] * v[e];
+            amax = fmaxf(amax, fabsf(v[e]));
+        }
+        if (src && live && i0 < ld) *reinterpret_cast<f32x4v*>(Qp + (long)q * ld + i0) = f32x4v{v[0], v[1], v[2], v[3]};   // ld is a multiple of 32; beyond d: zeros
+        *reinterpret_cast<f32x4v*>(&my[i0]) = f32x4v{v[0], v[1], v[2], v[3]};
+    }
+    if (src && live) for (int i = ld8 + lane; i < ld; i += 64) Qp[(long)q * ld + i] = 0.0f;
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); amax = fmaxf(amax, __shfl_xor(amax, off, 64)); }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const float sc = (amax > 0.0f && amax < __builtin_inff()) ? amax / 127.0f : 1.0f;
+    const int nk = ld8 >> 7;
+    float e2 = 0.0f, h2 = 0.0f;
+    for (int i0 = lane * 16; i0 < ld8; i0 += 1024) {
+        u32x4 out;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const f32x4v v = *reinterpret_cast<const f32x4v*>(&my[i0 + 4 * j]);
+            float cq[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                cq[e] = fminf(fmaxf(rintf(v[e] / sc), -127.0f), 127.0f);
+                const float dq = sc * cq[e], dl = v[e] - dq;
+                e2 += dl * dl; h2 += dq * dq;
+            }
+            out[j] = pack4_i8(cq[0], cq[1], cq[2], cq[3]);
+        }
+        *reinterpret_cast<u32x4*>(Q8F + ((((long)(q >> 5) * nk + (i0 >> 7)) * 4 + ((i0 >> 5) & 3)) * 64 + ((i0 >> 4) & 1) * 32 + (q & 31)) * 16) = out;
+    }
+    for (int off = 32; off > 0; off >>= 1) { e2 += __shfl_xor(e2, off, 64); h2 += __shfl_xor(h2, off, 64); }
+    if (lane == 0) {
+        if (live && zero_flag) zero_flag[q] = zf;
+        qn[q] = s; sq[q] = sc;
+        const float nq = sqrtf(s) * 1.0001f, nx = sqrtf(xmax_norm2) * 1.0001f, dd = (float)d;
+        // measured parts: residual norms are float sums of squares of float differences (relative error ~ d 2^-24 + 2^-24 ||x|| / ||delta||
+        // per component, carried by the 1.002 and the 1e-7 terms); model parts: the exact side's float32 accumulation (d 2^-23), the
+        // scan's int -> float conversion and two multiplications, the key packing (6.2e-5, see prep_queries_fast_kernel)
+        const float nqh = sqrtf(h2) * 1.002f, neps = sqrtf(e2) * 1.002f + 1.0e-7f * nq, ndx = dx_max * 1.002f + 1.0e-7f * nx;
+        float edot = ndx * nqh + nx * neps + 1.25f * (2.0f * dd + 8.0f) * 1.2e-7f * nq * nx;
+        float e = mode == 0 ? edot : 2.0f * edot + 1.25f * (dd + 8.0f) * 1.2e-7f * (nq + nx) * (nq + nx);
+        e += 1.25f * 6.2e-5f * (mode == 0 ? nq * nx : nx * nx + 2.0f * nq * nx);
+        err_abs[q] = e;
+    }
+}
+void launch_prep_queries_i8(Ctx* c, int metric, const float* src, int B, int dim, float* Qp, int ld, int32_t* zero_flag, void* Q8F, int ld8, float* sq, float* qn,
+                            float* err_abs, int mode, float xmax_norm2, float dx_max, int32_t* stats4) {
+    ProfScope ps(c, "prep_queries");
+    const size_t lds = (size_t)4 * ld8 * sizeof(float);
+    if (lds > 65536) COMET_FAIL(COMET_ERR_INVALID_ARG, "int8 query preparation holds a query row in LDS (dimension <= 4096)");
+    prep_queries_i8_kernel<<<dim3(FB_N / 4), dim3(256), lds, c->stream>>>(metric, src, B, dim, Qp, ld, zero_flag, (signed char*)Q8F, ld8, sq, qn, err_abs, mode, xmax_norm2, dx_max, stats4);
+    LAUNCH_CHECK();
+}
+bool prep_queries_i8_ok(int dim) { return round_up(dim, 256) <= 4096; }
 void launch_prep_queries_fused(Ctx* c, int metric, const float* src, int B, int dim, float* Qp, int ld, int32_t* zero_flag, void* Qh, int ldh, float* qn,
                                float* err_abs, int mode, float xmax_norm2, int32_t* stats4) {
     ProfScope ps(c, "prep_queries");
@@ -953,6 +1177,7 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
     const float INF = __builtin_inff();
     if (t == 0) { s_cnt = 0; s_exp = 0; s_valid = 0; }
     float tau = INF;
+    float kappa_v = INF; bool kappa_ok = false;          // the K-th smallest emitted key (general path), for the anchored threshold below
     bool hier_done = false;
     if constexpr (GEOM::kHier) {
         // Two levels for dense rows (IVF): the scan also wrote every unit's MINIMUM. The K-th smallest unit minimum bounds the K-th smallest
@@ -1051,7 +1276,7 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
     const bool reg = DENSE ? nkeys <= POST_RD * POST_THREADS * 4 : n_tiles <= (long)POST_RU * POST_THREADS;
     f32x2v kreg[POST_RU]; float breg[POST_RU]; f32x4v dreg[POST_RD];
     const f32x4v INF4 = {INF, INF, INF, INF};
-    if (reg && !hier_done) {
+    auto load_keys = [&]() {
         if constexpr (DENSE) {
 #pragma unroll
             for (int j = 0; j < POST_RD; j++) { const int i = (j * POST_THREADS + t) * 4; dreg[j] = i < nkeys ? *reinterpret_cast<const f32x4v*>(s0 + i) : INF4; }
@@ -1064,7 +1289,8 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
                 breg[j] = lv ? bd[tl] : INF;
             }
         }
-    }
+    };
+    if (reg && !hier_done) load_keys();
     // dense rows beyond the registers: streamed per pass, 4 x 16 bytes per thread in flight (a one-load-per-iteration loop pays the
     // L2 / HBM latency once per value: ~300 iterations for a query that probes a 40 k-row list); every thread makes the same
     // number of calls (absent values arrive as +inf), so f may use wave-wide ballots
@@ -1211,15 +1437,40 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
         if (have_kap) {
             const float kappa = __uint_as_float(kap);
             tau = kappa + 2.0f * err_abs[q] + 1.0e-4f * fabsf(kappa) + 1e-30f;   // 1e-4 ~ 3 * 2^-15: key packing slack, both sides
+            kappa_v = kappa; kappa_ok = true;
         }
     }
     __syncthreads();
+    // ---- 1b. anchored threshold (unit keys; round 3) ----
+    // tau = kappa + 2E pays E twice: once because the exact K-th distance may exceed kappa by E, once because a true neighbour's key may
+    // exceed its exact distance by E. The first E can be MEASURED instead: the >= K rows whose keys are <= kappa are rescored exactly
+    // (phase 0), U = their largest exact distance bounds the exact K-th distance from above, and every true neighbour has
+    // key <= U + E. Worth its extra pass when tau admits many candidates (the int8 shadow's E is ~6x the fp16 one: 707 -> ~300 rows
+    // rescored per query at 1M x 768, K = 100); phase 1 is the unchanged collection + rescoring with the lower tau.
+    int anchor = 0;
+    if constexpr (!DENSE) {
+        if (kappa_ok) {                                   // workgroup-uniform
+            int c = 0;
+            for_keys([&](float v) { c += (v <= tau) ? 1 : 0; });
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+            int* wct = reinterpret_cast<int*>(hist);
+            if (lane == 0) wct[wid] = c;
+            __syncthreads();
+            int tot = 0;
+            for (int w = 0; w < POST_WAVES; w++) tot += wct[w];
+            __syncthreads();
+            anchor = tot > 2 * kappa_rank + 64 ? 1 : 0;
+        }
+    }
     TR(0);
+    int cnt = 0, cnt_anchor = 0;
     // ---- 2. candidates ----
+    auto collect = [&](const float tau_c, const bool expand_ok) {
     auto candidates_of = [&](long t0, float bnd, float k0, float k1) {
         const long tl = t0 + t;
         const bool live = tl < n_tiles;
-        const bool expand = live && bnd <= tau;
+        const bool expand = live && expand_ok && bnd <= tau_c;
         // rare: some non-emitted row of a tile may qualify -> take the whole tile; the wave does it together, one tile at a time
         unsigned long long em = __ballot(expand);
         while (em) {
@@ -1233,12 +1484,12 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const float key = (live && !expand) ? (e ? k1 : k0) : INF;
-            post_append(key <= tau && key != INF, (unsigned)(tl * unit_rows + (__float_as_uint(key) & (unsigned)(unit_rows - 1))), lst, &s_cnt, POST_CAP);
+            post_append(key <= tau_c && key != INF, (unsigned)(tl * unit_rows + (__float_as_uint(key) & (unsigned)(unit_rows - 1))), lst, &s_cnt, POST_CAP);
         }
     };
     if (hier_done) {                                     // the two-level path collected them already
     } else if constexpr (DENSE) {                        // every position whose approximate distance is within tau
-        for_keys_idx([&](float v, int i) { post_append(v <= tau && v != INF, (unsigned)i, lst, &s_cnt, POST_CAP); });
+        for_keys_idx([&](float v, int i) { post_append(v <= tau_c && v != INF, (unsigned)i, lst, &s_cnt, POST_CAP); });
     } else if (reg) {
 #pragma unroll
         for (int j = 0; j < POST_RU; j++) if ((long)j * POST_THREADS < n_tiles) candidates_of((long)j * POST_THREADS, breg[j], kreg[j][0], kreg[j][1]);
@@ -1250,23 +1501,8 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
         }
     }
     __syncthreads();
-    TR(1);
-    const int cnt = s_cnt;
-    if (cnt > POST_CAP) {                              // empty row; the host re-runs this query on the strict path
-        for (int i = t; i < k_cap; i += POST_THREADS) { out_ids[(long)q * k_cap + i] = 0u; out_scores[(long)q * k_cap + i] = 0.0f; }
-        if (t == 0) { out_counts[q] = 0; overflow[q] = 1; if (stats) atomicAdd(&stats[1], 1); }
-        return;
-    }
-    int n2 = 64; while (n2 < cnt) n2 <<= 1;
-    for (int i = cnt + t; i < n2; i += POST_THREADS) lst[i] = 0xFFFFFFFFu;
-    __syncthreads();
-    post_sort(lst, cnt, n2, hist);                     // ascending row = canonical tie order of the strict path (hist: 16 KiB scratch)
-    if constexpr (GEOM::kSlots) {                      // position -> slot, once per candidate
-        for (int i = t; i < cnt; i += POST_THREADS) slotv[i] = (unsigned)geom.slot_of(lst[i]);
-        __syncthreads();
-    }
-    TR(2);
-    // ---- 3. exact distances ----
+    };
+    // ---- 3. exact distances (of lst[0 .. cnt) into sc[]) ----
     float* terms = reinterpret_cast<float*>(psm) + wid * (POST_CPW * POST_CHUNK);   // 4 KiB per wave over the key area
     // The query is staged in LDS (the 16 KiB histogram area is idle here): read from global memory inside the slice loop it
     // would be the youngest load of every iteration, and waiting for it (loads return in order) would also wait for the
@@ -1274,10 +1510,12 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
     const float* __restrict__ qv = Qp + (long)q * ld;
     const bool q_lds = ld <= 4096;
     float* qs = reinterpret_cast<float*>(hist);      // stays an LDS pointer for the compiler (a generic one would make the reads
-    if (q_lds) {                                     // flat loads, which count in vmcnt AND lgkmcnt and drain both every slice)
-        for (int i = t * 4; i < ld; i += POST_THREADS * 4) *reinterpret_cast<f32x4v*>(qs + i) = *reinterpret_cast<const f32x4v*>(qv + i);
-        __syncthreads();
-    }
+    auto stage_query = [&]() {                       // flat loads, which count in vmcnt AND lgkmcnt and drain both every slice)
+        if (q_lds) {
+            for (int i = t * 4; i < ld; i += POST_THREADS * 4) *reinterpret_cast<f32x4v*>(qs + i) = *reinterpret_cast<const f32x4v*>(qv + i);
+            __syncthreads();
+        }
+    };
     const int sub = lane / POST_LPC, lp = lane % POST_LPC;   // a load instruction covers POST_CPI candidates x POST_CHUNK floats
     // Row slices are random 128-byte reads and a candidate's sum is one serial chain, so the stage is latency-bound: spread the
     // candidates over all 16 waves (8, 16 or 32 per wave) and keep more slices in flight the fewer candidates a wave has.
@@ -1346,7 +1584,7 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
         }
     }
     };
-    {
+    auto rescore_all = [&]() {
         const int per = (cnt + POST_WAVES - 1) / POST_WAVES;
         using T = std::true_type; using F = std::false_type;
         if (q_lds) {
@@ -1354,8 +1592,59 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
             else if (per <= 16) rescore(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{}, T{});
             else rescore(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{}, T{});
         } else rescore(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{}, F{});
+        __syncthreads();
+    };
+    if (anchor) {                                        // phase 0: the rows under kappa, exactly (no order needed, no expansions)
+        collect(kappa_v, false);
+        cnt = s_cnt;
+        if (cnt <= POST_CAP && cnt >= kappa_rank) {      // (more than POST_CAP: mass ties at kappa — the plain threshold decides)
+        if constexpr (GEOM::kSlots) {
+            for (int i = t; i < cnt; i += POST_THREADS) slotv[i] = (unsigned)geom.slot_of(lst[i]);
+            __syncthreads();
+        }
+        stage_query();
+        rescore_all();
+        // U = the largest exact distance among the (at least K) rows under kappa, in the keys' space (squared for the L2 family:
+        // sqrt is monotone, and U^2 (1 + 2^-21) is no smaller than the sum the largest score was rooted from)
+        float u = 0.0f;
+        for (int i = t; i < cnt; i += POST_THREADS) u = fmaxf(u, sc[i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) u = fmaxf(u, __shfl_xor(u, off, 64));
+        float* wmx = reinterpret_cast<float*>(hist);
+        if (lane == 0) wmx[wid] = u;
+        __syncthreads();
+        for (int w = 0; w < POST_WAVES; w++) u = fmaxf(u, wmx[w]);
+        if constexpr (METRIC == COMET_L2) u = u * u * 1.0000005f;
+        const float tau_a = u + err_abs[q] + 1.0e-4f * fabsf(u) + 1e-30f;
+        if (tau_a < tau) tau = tau_a;
+        cnt_anchor = cnt;
+        }
+        __syncthreads();
+        if (t == 0) s_cnt = 0;
+        // the key registers are loaded again (L2 hits) rather than kept alive across the rescoring above: 24 registers the
+        // 128-register budget of a 1024-thread workgroup does not have
+        if (reg) load_keys();
+        __syncthreads();
     }
+    collect(tau, true);
+    TR(1);
+    cnt = s_cnt;
+    if (cnt > POST_CAP) {                              // empty row; the host re-runs this query on the strict path
+        for (int i = t; i < k_cap; i += POST_THREADS) { out_ids[(long)q * k_cap + i] = 0u; out_scores[(long)q * k_cap + i] = 0.0f; }
+        if (t == 0) { out_counts[q] = 0; overflow[q] = 1; if (stats) atomicAdd(&stats[1], 1); }
+        return;
+    }
+    int n2 = 64; while (n2 < cnt) n2 <<= 1;
+    for (int i = cnt + t; i < n2; i += POST_THREADS) lst[i] = 0xFFFFFFFFu;
     __syncthreads();
+    post_sort(lst, cnt, n2, hist);                     // ascending row = canonical tie order of the strict path (hist: 16 KiB scratch)
+    if constexpr (GEOM::kSlots) {                      // position -> slot, once per candidate
+        for (int i = t; i < cnt; i += POST_THREADS) slotv[i] = (unsigned)geom.slot_of(lst[i]);
+        __syncthreads();
+    }
+    TR(2);
+    stage_query();
+    rescore_all();
     TR(3);
     // ---- 4. final order: (score, row position) ----
     unsigned long long* comp = reinterpret_cast<unsigned long long*>(psm);   // POST_CAP composites (32 KiB) over the slices
@@ -1393,10 +1682,10 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
     if (t == 0) {
         out_counts[q] = (zflag && zflag[q]) ? -(int)COMET_ERR_ZERO_VECTOR : kq;      // a zero cosine query fails as a whole (ErrZeroVector)
         overflow[q] = 0;
-        if (stats) { atomicAdd(&stats[0], cnt); atomicAdd(&stats[2], s_exp); }
+        if (stats) { atomicAdd(&stats[0], cnt + cnt_anchor); atomicAdd(&stats[2], s_exp); }      // rows rescored exactly (both phases)
     }
     TR(4);
-    if (trace && threadIdx.x == 0) { atomicAdd(&trace[5], (unsigned long long)cnt); atomicAdd(&trace[6], 1ull); }
+    if (trace && threadIdx.x == 0) { atomicAdd(&trace[5], (unsigned long long)(cnt + cnt_anchor)); atomicAdd(&trace[6], 1ull); }
 }
 void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const float* bound, int64_t ldB, int64_t n_tiles, int unit_rows, int64_t n, const uint8_t* elig,
                       const float* err_abs, int K, int kappa_rank, float thr, const float* X, int ld, const float* Qp, int B,

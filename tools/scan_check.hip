@@ -40,18 +40,65 @@ int main(int argc, char** argv) {
     int bad_total = 0;
     unsigned long long* dtrace = nullptr;
     if (getenv("SCAN_TRACE")) { HIP_CHECK(hipMalloc(&dtrace, (8 * 32 * 4 + 64) * 8)); HIP_CHECK(hipMemset(dtrace, 0, (8 * 32 * 4 + 64) * 8)); g_scan_trace = dtrace; }
-    for (int variant : {0, 1}) {
+    // variant 8: the int8 shadow on the wide tile (reference = float64 dot product of the DEQUANTISED operands read back from the device)
+    const int ld8 = (int)round_up(dim, 256);
+    void *X8 = nullptr, *Q8F = nullptr; float *sxd = nullptr, *sqd = nullptr, *qn8 = nullptr, *err8 = nullptr; uint32_t* st8 = nullptr;
+    std::vector<float> X8r, Q8r;          // dequantised rows / queries, [row][ld8]
+    if (B > 64) {
+        HIP_CHECK(hipMalloc(&X8, (size_t)tiles * 256 * ld8)); HIP_CHECK(hipMemset(X8, 0, (size_t)tiles * 256 * ld8));
+        HIP_CHECK(hipMalloc(&Q8F, (size_t)256 * ld8)); HIP_CHECK(hipMalloc(&sxd, tiles * 4)); HIP_CHECK(hipMalloc(&sqd, 1024)); HIP_CHECK(hipMalloc(&qn8, 1024)); HIP_CHECK(hipMalloc(&err8, 1024));
+        HIP_CHECK(hipMalloc(&st8, 16)); HIP_CHECK(hipMemset(st8, 0, 16));
+        launch_to_i8_tiles(&c, dX, n, ld, X8, ld8, 0, sxd, st8);
+        uint32_t hst[4]; HIP_CHECK(hipMemcpy(hst, st8, 16, hipMemcpyDeviceToHost)); float dx2; memcpy(&dx2, &hst[2], 4);
+        launch_prep_queries_i8(&c, 0, nullptr, B, dim, dQ, ld, nullptr, Q8F, ld8, sqd, qn8, err8, 0, 1.0002f, std::sqrt(dx2), st4);
+        HIP_CHECK(hipStreamSynchronize(c.stream));
+        if (n <= 20000) {
+        std::vector<signed char> hx((size_t)tiles * 256 * ld8), hq((size_t)256 * ld8); std::vector<float> hsx(tiles), hsq(256), herr(256);
+        HIP_CHECK(hipMemcpy(hx.data(), X8, hx.size(), hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(hq.data(), Q8F, hq.size(), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(hsx.data(), sxd, tiles * 4, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(hsq.data(), sqd, 1024, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(herr.data(), err8, 1024, hipMemcpyDeviceToHost));
+        X8r.assign((size_t)n * ld8, 0.f); Q8r.assign((size_t)256 * ld8, 0.f);
+        const int nk8 = ld8 >> 7;
+        double worst = 0, worst_in = 0;
+        for (long r = 0; r < n; r++) for (int k = 0; k < ld8; k++) {
+            const long off = (((r >> 8) * (ld8 >> 6) + (k >> 6)) * 256 + (r & 255)) * 64 + (k & 63);
+            X8r[r * ld8 + k] = hsx[r >> 8] * (float)hx[off];
+        }
+        for (int q = 0; q < 256; q++) for (int k = 0; k < ld8; k++) {
+            const long off = ((((long)(q >> 5) * nk8 + (k >> 7)) * 4 + ((k >> 5) & 3)) * 64 + ((k >> 4) & 1) * 32 + (q & 31)) * 16 + (k & 15);
+            Q8r[(size_t)q * ld8 + k] = hsq[q] * (float)hq[off];
+        }
+        // the bound: |x.q - xhat.qhat| <= E for every (row, query) checked
+        for (int q = 0; q < B; q += 5) for (long r = 0; r < n; r += 97) {
+            double ex = 0, ap = 0; for (int j = 0; j < dim; j++) { ex += (double)X[r * ld + j] * Q[q * ld + j]; ap += (double)X8r[r * ld8 + j] * Q8r[(size_t)q * ld8 + j]; }
+            worst = std::max(worst, std::fabs(ex - ap) / herr[q]); worst_in = std::max(worst_in, std::fabs(ex - ap));
+        }
+        printf("int8 shadow: max ||delta|| %.3e, E(query 0) %.3e, worst |x.q - xhat.qhat| %.3e = %.3f of E\n", std::sqrt(dx2), herr[0], worst_in, worst);
+        if (worst > 1.0) { printf("int8 bound VIOLATED\n"); bad_total++; }
+        }
+    }
+    for (int variant : {0, 1, 8}) {
         if (variant == 1 && unit == 64 && B > 64) continue;
-        setenv("COMET_SCAN_VARIANT_RT", variant ? "1" : "0", 1);
+        if (variant == 8 && B <= 64) continue;
+        setenv("COMET_SCAN_VARIANT_RT", variant == 1 ? "1" : "0", 1);
         HIP_CHECK(hipMemset(S0, 0xFF, (size_t)256 * ldS * 4)); HIP_CHECK(hipMemset(bound, 0xFF, (size_t)256 * ldB * 4));
-        launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, B, rn, qn, nullptr, S0, ldS, bound, ldB, unit);
+        auto run = [&]() {
+            if (variant == 8) launch_flat_scan_i8(&c, 0, X8, n, ld8, Q8F, B, rn, qn8, sxd, sqd, nullptr, S0, ldS, bound, ldB, unit);
+            else launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, B, rn, qn, nullptr, S0, ldS, bound, ldB, unit);
+        };
+        run();
         HIP_CHECK(hipStreamSynchronize(c.stream));
         std::vector<float> hS((size_t)256 * ldS), hB((size_t)256 * ldB);
         HIP_CHECK(hipMemcpy(hS.data(), S0, hS.size() * 4, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(hB.data(), bound, hB.size() * 4, hipMemcpyDeviceToHost));
         int bad = 0; double maxerr = 0;
-        for (int q = 0; q < B && bad < 10; q += 7) for (long u = 0; u < units; u++) {
+        if (variant == 8 && X8r.empty()) printf("variant 8: keys not checked at this size\n");
+        else for (int q = 0; q < B && bad < 10; q += 7) for (long u = 0; u < units; u++) {
             std::vector<std::pair<double, int>> d;
-            for (int r = 0; r < unit; r++) { const long row = u * unit + r; if (row >= n) break; double s = 0; for (int j = 0; j < dim; j++) s += (double)Xr[row * ld + j] * Qr[q * ld + j]; d.push_back({std::max(0.0, 1.0 - s), r}); }
+            for (int r = 0; r < unit; r++) {
+                const long row = u * unit + r; if (row >= n) break; double s = 0;
+                if (variant == 8) for (int j = 0; j < dim; j++) s += (double)X8r[row * ld8 + j] * Q8r[(size_t)q * ld8 + j];
+                else for (int j = 0; j < dim; j++) s += (double)Xr[row * ld + j] * Qr[q * ld + j];
+                d.push_back({std::max(0.0, 1.0 - s), r});
+            }
             std::sort(d.begin(), d.end());
             for (int e = 0; e < 2 && e < (int)d.size(); e++) {
                 const float key = hS[(size_t)q * ldS + 2 * u + e]; uint32_t kb; memcpy(&kb, &key, 4);
@@ -79,9 +126,9 @@ int main(int argc, char** argv) {
         bad_total += bad;
         if (iters > 0) {
             hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-            for (int i = 0; i < 3; i++) launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, B, rn, qn, nullptr, S0, ldS, bound, ldB, unit);
+            for (int i = 0; i < 3; i++) run();
             HIP_CHECK(hipEventRecord(a, c.stream));
-            for (int i = 0; i < iters; i++) launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, B, rn, qn, nullptr, S0, ldS, bound, ldB, unit);
+            for (int i = 0; i < iters; i++) run();
             HIP_CHECK(hipEventRecord(b, c.stream)); HIP_CHECK(hipEventSynchronize(b));
             float ms; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
             printf("variant %d: %.4f ms per launch (%ld rows x %d, %d queries)\n", variant, ms / iters, n, dim, B);
