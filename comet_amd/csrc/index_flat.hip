@@ -53,7 +53,7 @@ struct FlatIndex : comet_index {
     int ldh = 0;
     DevBuf Xh, rn, stats_dev;
     float xmax_abs = 0.0f, xmax_norm2 = 0.0f;
-    // int8 shadow for the wide scan tile (more than 64 queries per slice): codes in the fp16 shadow's tiled layout, one scale per tile,
+    // int8 shadow of the scan tiles: codes in the fp16 shadow's tiled layout, one scale per tile,
     // the largest quantisation-residual norm of any row (squared). The slice falls back to the fp16 shadow while int8 screening is
     // too coarse for the data: a search whose int8 slices overflowed or proposed more than kI8MaxCand candidates per query
     // switches the index to fp16 for a while (doubling back-off) — results are identical either way, only the time differs.
@@ -64,7 +64,8 @@ struct FlatIndex : comet_index {
     int i8_policy = [] { const char* e = getenv("COMET_FLAT_I8"); return e ? atoi(e) : -1; }();   // 0 never, 1 always, otherwise adaptive
     int64_t n_searches = 0, i8_resume_at = 0, st_i8_slices = 0, st_i8_backoffs = 0; int i8_strikes = 0;
     bool i8_usable(int bn) const {
-        if (i8_policy == 0 || bn <= 64 || !prep_queries_i8_ok(dim) || !std::isfinite(xmax_err2)) return false;
+        (void)bn;
+        if (i8_policy == 0 || !prep_queries_i8_ok(dim) || !std::isfinite(xmax_err2)) return false;
         return i8_policy == 1 || n_searches >= i8_resume_at;
     }
     // counters of the last fast-path search (bench / tests)
@@ -243,7 +244,8 @@ struct FlatIndex : comet_index {
         const int64_t n_tiles = ceil_div(n, flat_fast_tile_rows()) * (flat_fast_tile_rows() / unit_rows);
         const int64_t ldS = round_up(2 * n_tiles, 16), ldB = round_up(n_tiles, 16);
         const int NB = flat_fast_batch();
-        void* Qh = i8 ? c->scratch_alloc((size_t)NB * ld8) : c->scratch_alloc((size_t)NB * ldh * 2 * 2);   // fp16: row-major copy + MFMA-fragment-ordered copy; int8: fragment-ordered codes
+        void* Qh = i8 ? c->scratch_alloc((size_t)NB * ld8 * 2) : c->scratch_alloc((size_t)NB * ldh * 2 * 2);   // row-major copy + MFMA-fragment-ordered copy (fp16 values / int8 codes)
+        void* Q8R = i8 ? (char*)Qh + (size_t)NB * ld8 : nullptr;
         float* qn = c->salloc<float>(NB);
         float* sqv = i8 ? c->salloc<float>(NB) : nullptr;
         float* err = c->salloc<float>(NB);
@@ -251,12 +253,12 @@ struct FlatIndex : comet_index {
         int32_t* ovf = flags; int32_t* st = flags + 256;
         const int fmode = metric == COMET_COSINE ? 0 : 1;
         const float xn2 = metric == COMET_COSINE ? 1.0002f : xmax_norm2;
-        if (i8) launch_prep_queries_i8(c, metric, raw_queries, bn, dim, const_cast<float*>(Qp), ld, raw_queries ? zflag : nullptr, Qh, ld8, sqv, qn, err, fmode, xn2, std::sqrt(xmax_err2), st);
+        if (i8) launch_prep_queries_i8(c, metric, raw_queries, bn, dim, const_cast<float*>(Qp), ld, raw_queries ? zflag : nullptr, Qh, bn <= 64 ? Q8R : nullptr, ld8, sqv, qn, err, fmode, xn2, std::sqrt(xmax_err2), st);
         else if (raw_queries) launch_prep_queries_fused(c, metric, raw_queries, bn, dim, const_cast<float*>(Qp), ld, zflag, Qh, ldh, qn, err, fmode, xn2, st);
         else launch_prep_queries_fast(c, Qp, bn, ld, dim, Qh, ldh, qn, err, fmode, xn2, st);
         float* S0 = c->salloc<float>((size_t)NB * ldS);
         float* bound = c->salloc<float>((size_t)NB * ldB);
-        if (i8) { launch_flat_scan_i8(c, fmode, X8.p, n, ld8, Qh, bn, rn.as<float>(), qn, sx.as<float>(), sqv, elig, S0, ldS, bound, ldB, unit_rows); pend->i8_mask |= 1ull << pend->nfast_slices; }
+        if (i8) { launch_flat_scan_i8(c, fmode, X8.p, n, ld8, Qh, Q8R, bn, rn.as<float>(), qn, sx.as<float>(), sqv, elig, S0, ldS, bound, ldB, unit_rows); pend->i8_mask |= 1ull << pend->nfast_slices; }
         else launch_flat_scan_f16(c, fmode, Xh.p, n, ldh, Qh, bn, rn.as<float>(), qn, elig, S0, ldS, bound, ldB, unit_rows);
         // kappa: exact K-th smallest emitted key per query
         const int64_t keff = (p.k <= 0 || p.k > n) ? n : p.k;

@@ -128,11 +128,12 @@ void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const fl
 // int8 shadow of the wide tile (round 3): rows [256-row tile][64-byte slab][row][64 codes] + one scale per TILE. Quantises every row of
 // tiles tile0 .. ceil(n / 256) - 1 (X: row 0 of the index, n: its rows); stats[2] = max ||x - s c||^2 bits (atomicMax)
 void launch_to_i8_tiles(Ctx* c, const float* X, int64_t n, int ld, void* X8, int ld8, int64_t tile0, float* st, uint32_t* stats);
-void launch_flat_scan_i8(Ctx* c, int mode, const void* X8, int64_t n, int ld8, const void* Q8F, int nq_used, const float* rn, const float* qn,
+void launch_flat_scan_i8(Ctx* c, int mode, const void* X8, int64_t n, int ld8, const void* Q8F, const void* Q8R, int nq_used, const float* rn, const float* qn,
                          const float* sx, const float* sq, const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB, int unit_rows);
 bool prep_queries_i8_ok(int dim);
-// src != nullptr: raw queries (B x dim), preprocessed into Qp; src == nullptr: Qp holds preprocessed padded rows. Q8F: 256 x ld8 codes in fragment order.
-void launch_prep_queries_i8(Ctx* c, int metric, const float* src, int B, int dim, float* Qp, int ld, int32_t* zero_flag, void* Q8F, int ld8, float* sq, float* qn,
+// src != nullptr: raw queries (B x dim), preprocessed into Qp; src == nullptr: Qp holds preprocessed padded rows. Q8F: 256 x ld8 codes in fragment order
+// (wide tile), Q8R: the same codes row-major (narrow tile; nullable).
+void launch_prep_queries_i8(Ctx* c, int metric, const float* src, int B, int dim, float* Qp, int ld, int32_t* zero_flag, void* Q8F, void* Q8R, int ld8, float* sq, float* qn,
                             float* err_abs, int mode, float xmax_norm2, float dx_max, int32_t* stats4);
 bool prep_queries_fused_ok(int dim);
 void launch_prep_queries_fused(Ctx* c, int metric, const float* src, int B, int dim, float* Qp, int ld, int32_t* zero_flag, void* Qh, int ldh, float* qn,

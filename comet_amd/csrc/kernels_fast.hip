@@ -326,12 +326,15 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_kernel(const _Float1
 // CU. A quarter of the MFMA work and of the query staging of the 256-query tile; key units are the 64-row wave groups.
 // ------------------------------------------------------------------------------------------------
 constexpr int FN_N = 64, FN_UNIT = 64, FN_STAGE = 32768 + 8192;
-template <int MODE>
+// I8: the int8 shadow (per-tile scale) — same bytes per K step, 128 dimensions instead of 64; `ldh` = row bytes / 2, Qh = row-major int8
+// queries (64 x ld8), sx / sq = tile / query scales: the integer sums are scaled to scores before the shared epilogue.
+template <int MODE, bool I8 = false>
 __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_n64_kernel(const _Float16* __restrict__ Xh, long n, int ldh,
                                                                        const _Float16* __restrict__ Qh /*>= 64 x ldh*/,
                                                                        const float* __restrict__ rn, const float* __restrict__ qn,
                                                                        const unsigned char* __restrict__ elig,
-                                                                       float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles) {
+                                                                       float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles,
+                                                                       const float* __restrict__ sx = nullptr, const float* __restrict__ sq = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [buf][X 32 KiB | Q 8 KiB]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -343,11 +346,11 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_n64_kernel(const _Fl
         if (idx >= (xcd < r ? q + 1 : q)) return;
     }
     const long row0 = tile * FB_M;
-    f32x16 acc[2][1];
+    std::conditional_t<I8, i32x16, f32x16> acc[2][1];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[i][0][e] = 0.0f;
+        for (int e = 0; e < 16; e++) acc[i][0][e] = 0;
     // staging: 32 row pieces (4 per wave) + 8 query pieces (1 per wave), 8 rows x 128 B each
     const int prow = lane >> 3, pslot = lane & 7;
     const char* xsrc[4]; int xdst[4];
@@ -386,11 +389,22 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_f16_n64_kernel(const _Fl
             for (int mb = 0; mb < 2; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + swz_off(arow + mb * 32, ks * 2 + khalf));
             b = *reinterpret_cast<const half8*>(qb + swz_off(brow, ks * 2 + khalf));
 #pragma unroll
-            for (int mb = 0; mb < 2; mb++) acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b, acc[mb][0], 0, 0, 0);
+            for (int mb = 0; mb < 2; mb++) {
+                if constexpr (I8) acc[mb][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, a[mb]), __builtin_bit_cast(i32x4v, b), acc[mb][0], 0, 0, 0);
+                else acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b, acc[mb][0], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
-    scan_epilogue<MODE, 2, 1, 2>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
+    if constexpr (I8) {
+        const float scale = sx[tile] * sq[brow];          // C layout: the lane's column = query brow
+        f32x16 accf[2][1];
+#pragma unroll
+        for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) accf[mb][0][e] = (float)acc[mb][0][e] * scale;
+        scan_epilogue<MODE, 2, 1, 2>(accf, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
+    } else scan_epilogue<MODE, 2, 1, 2>(acc, smem, tile, row0, n, rn, qn, elig, S0, ldS, bound, ldB);
 }
 // ------------------------------------------------------------------------------------------------
 // Query-stationary scan tile (round 2): the 256-query batch never goes through LDS.
@@ -711,9 +725,10 @@ void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, 
         const long gridn = round_up(n_tiles, 8);
         auto gon = [&](auto kernel) {
             HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
-            c->launch_timed(scope, kernel, dim3((unsigned)gridn), dim3(FB_THREADS), ldsn, (const _Float16*)Xh, (long)n, ldh, (const _Float16*)Qh, rn, qn, (const unsigned char*)elig, S0, (long)ldS, bound, (long)ldB, n_tiles);
+            c->launch_timed(scope, kernel, dim3((unsigned)gridn), dim3(FB_THREADS), ldsn, (const _Float16*)Xh, (long)n, ldh, (const _Float16*)Qh, rn, qn, (const unsigned char*)elig, S0, (long)ldS, bound, (long)ldB, n_tiles,
+                            (const float*)nullptr, (const float*)nullptr);
         };
-        if (mode == 0) gon(flat_scan_f16_n64_kernel<0>); else gon(flat_scan_f16_n64_kernel<1>);
+        if (mode == 0) gon(flat_scan_f16_n64_kernel<0, false>); else gon(flat_scan_f16_n64_kernel<1, false>);
         LAUNCH_CHECK();
         return;
     }
@@ -743,10 +758,22 @@ void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, 
 }
 // The wide tile on the int8 shadow (more than 64 queries; ld8 a multiple of 256). Q8F: fragment-ordered int8 queries
 // (prep_queries_i8_kernel), sx / sq: tile / query scales. Keys and bounds come out exactly as from the fp16 tile.
-void launch_flat_scan_i8(Ctx* c, int mode, const void* X8, int64_t n, int ld8, const void* Q8F, int nq_used, const float* rn, const float* qn,
+void launch_flat_scan_i8(Ctx* c, int mode, const void* X8, int64_t n, int ld8, const void* Q8F, const void* Q8R, int nq_used, const float* rn, const float* qn,
                          const float* sx, const float* sq, const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB, int unit_rows) {
-    if (nq_used <= FN_N || (ld8 & 255) != 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "the int8 scan is the wide tile's (more than 64 queries, rows padded to 256 bytes)");
+    if ((ld8 & 255) != 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "int8 shadow rows are padded to 256 bytes");
     const long n_tiles = ceil_div(n, FB_M);
+    if (nq_used <= FN_N) {      // the narrow tile (64-row units), row-major queries through LDS
+        const size_t ldsn = 2 * FN_STAGE;
+        const long gridn = round_up(n_tiles, 8);
+        auto gon = [&](auto kernel) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
+            c->launch_timed("flat_scan_i8_n64", kernel, dim3((unsigned)gridn), dim3(FB_THREADS), ldsn, (const _Float16*)X8, (long)n, ld8 / 2, (const _Float16*)Q8R, rn, qn, (const unsigned char*)elig, S0, (long)ldS,
+                            bound, (long)ldB, n_tiles, sx, sq);
+        };
+        if (mode == 0) gon(flat_scan_f16_n64_kernel<0, true>); else gon(flat_scan_f16_n64_kernel<1, true>);
+        LAUNCH_CHECK();
+        return;
+    }
     const size_t ldsq = (size_t)FQ_STAGES * FQ_STAGE_BYTES + 1024;
     const long gridq = std::min<long>(round_up(n_tiles, 8), (long)round_up(c->prop.multiProcessorCount, 8));
     auto go = [&](auto kernel) {
@@ -911,7 +938,7 @@ bool prep_queries_fused_ok(int dim) { return dim <= PREPF_MAX_D; }
 //   |approx - exact| <= E = dx_max ||q_hat|| + ||x||_max ||eps||  (+ float32 evaluation on both sides, + key packing)
 // from the MEASURED residual norms (dx_max: the index's largest row residual norm, to_i8_tiles_kernel).
 __global__ __launch_bounds__(256) void prep_queries_i8_kernel(int metric, const float* __restrict__ src, int B, int d, float* __restrict__ Qp, int ld,
-                                                              int* __restrict__ zero_flag, signed char* __restrict__ Q8F, int ld8, float* __restrict__ sq,
+                                                              int* __restrict__ zero_flag, signed char* __restrict__ Q8F, signed char* __restrict__ Q8R /*nullable: row-major copy (narrow tile)*/, int ld8, float* __restrict__ sq,
                                                               float* __restrict__ qn, float* __restrict__ err_abs, int mode, float xmax_norm2, float dx_max,
                                                               int* __restrict__ stats4) {
     extern __shared__ __attribute__((aligned(16))) float sqm[];   // [4 waves][ld8]
@@ -989,6 +1016,7 @@ __global__ __launch_bounds__(256) void prep_queries_i8_kernel(int metric, const 
             out[j] = pack4_i8(cq[0], cq[1], cq[2], cq[3]);
         }
         *reinterpret_cast<u32x4*>(Q8F + ((((long)(q >> 5) * nk + (i0 >> 7)) * 4 + ((i0 >> 5) & 3)) * 64 + ((i0 >> 4) & 1) * 32 + (q & 31)) * 16) = out;
+        if (Q8R) *reinterpret_cast<u32x4*>(Q8R + (long)q * ld8 + i0) = out;
     }
     for (int off = 32; off > 0; off >>= 1) { e2 += __shfl_xor(e2, off, 64); h2 += __shfl_xor(h2, off, 64); }
     if (lane == 0) {
@@ -1005,12 +1033,12 @@ __global__ __launch_bounds__(256) void prep_queries_i8_kernel(int metric, const 
         err_abs[q] = e;
     }
 }
-void launch_prep_queries_i8(Ctx* c, int metric, const float* src, int B, int dim, float* Qp, int ld, int32_t* zero_flag, void* Q8F, int ld8, float* sq, float* qn,
+void launch_prep_queries_i8(Ctx* c, int metric, const float* src, int B, int dim, float* Qp, int ld, int32_t* zero_flag, void* Q8F, void* Q8R, int ld8, float* sq, float* qn,
                             float* err_abs, int mode, float xmax_norm2, float dx_max, int32_t* stats4) {
     ProfScope ps(c, "prep_queries");
     const size_t lds = (size_t)4 * ld8 * sizeof(float);
     if (lds > 65536) COMET_FAIL(COMET_ERR_INVALID_ARG, "int8 query preparation holds a query row in LDS (dimension <= 4096)");
-    prep_queries_i8_kernel<<<dim3(FB_N / 4), dim3(256), lds, c->stream>>>(metric, src, B, dim, Qp, ld, zero_flag, (signed char*)Q8F, ld8, sq, qn, err_abs, mode, xmax_norm2, dx_max, stats4);
+    prep_queries_i8_kernel<<<dim3(FB_N / 4), dim3(256), lds, c->stream>>>(metric, src, B, dim, Qp, ld, zero_flag, (signed char*)Q8F, (signed char*)Q8R, ld8, sq, qn, err_abs, mode, xmax_norm2, dx_max, stats4);
     LAUNCH_CHECK();
 }
 bool prep_queries_i8_ok(int dim) { return round_up(dim, 256) <= 4096; }

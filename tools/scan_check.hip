@@ -42,15 +42,16 @@ int main(int argc, char** argv) {
     if (getenv("SCAN_TRACE")) { HIP_CHECK(hipMalloc(&dtrace, (8 * 32 * 4 + 64) * 8)); HIP_CHECK(hipMemset(dtrace, 0, (8 * 32 * 4 + 64) * 8)); g_scan_trace = dtrace; }
     // variant 8: the int8 shadow on the wide tile (reference = float64 dot product of the DEQUANTISED operands read back from the device)
     const int ld8 = (int)round_up(dim, 256);
-    void *X8 = nullptr, *Q8F = nullptr; float *sxd = nullptr, *sqd = nullptr, *qn8 = nullptr, *err8 = nullptr; uint32_t* st8 = nullptr;
+    void *X8 = nullptr, *Q8F = nullptr, *Q8R = nullptr; float *sxd = nullptr, *sqd = nullptr, *qn8 = nullptr, *err8 = nullptr; uint32_t* st8 = nullptr;
     std::vector<float> X8r, Q8r;          // dequantised rows / queries, [row][ld8]
-    if (B > 64) {
+    {
+        HIP_CHECK(hipMalloc(&Q8R, (size_t)256 * ld8));
         HIP_CHECK(hipMalloc(&X8, (size_t)tiles * 256 * ld8)); HIP_CHECK(hipMemset(X8, 0, (size_t)tiles * 256 * ld8));
         HIP_CHECK(hipMalloc(&Q8F, (size_t)256 * ld8)); HIP_CHECK(hipMalloc(&sxd, tiles * 4)); HIP_CHECK(hipMalloc(&sqd, 1024)); HIP_CHECK(hipMalloc(&qn8, 1024)); HIP_CHECK(hipMalloc(&err8, 1024));
         HIP_CHECK(hipMalloc(&st8, 16)); HIP_CHECK(hipMemset(st8, 0, 16));
         launch_to_i8_tiles(&c, dX, n, ld, X8, ld8, 0, sxd, st8);
         uint32_t hst[4]; HIP_CHECK(hipMemcpy(hst, st8, 16, hipMemcpyDeviceToHost)); float dx2; memcpy(&dx2, &hst[2], 4);
-        launch_prep_queries_i8(&c, 0, nullptr, B, dim, dQ, ld, nullptr, Q8F, ld8, sqd, qn8, err8, 0, 1.0002f, std::sqrt(dx2), st4);
+        launch_prep_queries_i8(&c, 0, nullptr, B, dim, dQ, ld, nullptr, Q8F, Q8R, ld8, sqd, qn8, err8, 0, 1.0002f, std::sqrt(dx2), st4);
         HIP_CHECK(hipStreamSynchronize(c.stream));
         if (n <= 20000) {
         std::vector<signed char> hx((size_t)tiles * 256 * ld8), hq((size_t)256 * ld8); std::vector<float> hsx(tiles), hsq(256), herr(256);
@@ -78,11 +79,10 @@ int main(int argc, char** argv) {
     }
     for (int variant : {0, 1, 8}) {
         if (variant == 1 && unit == 64 && B > 64) continue;
-        if (variant == 8 && B <= 64) continue;
         setenv("COMET_SCAN_VARIANT_RT", variant == 1 ? "1" : "0", 1);
         HIP_CHECK(hipMemset(S0, 0xFF, (size_t)256 * ldS * 4)); HIP_CHECK(hipMemset(bound, 0xFF, (size_t)256 * ldB * 4));
         auto run = [&]() {
-            if (variant == 8) launch_flat_scan_i8(&c, 0, X8, n, ld8, Q8F, B, rn, qn8, sxd, sqd, nullptr, S0, ldS, bound, ldB, unit);
+            if (variant == 8) launch_flat_scan_i8(&c, 0, X8, n, ld8, Q8F, Q8R, B, rn, qn8, sxd, sqd, nullptr, S0, ldS, bound, ldB, unit);
             else launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, B, rn, qn, nullptr, S0, ldS, bound, ldB, unit);
         };
         run();
