@@ -211,13 +211,26 @@ struct IVFIndex : comet_index {
     DevBuf Vh, rn_slot, stats_dev, scan_counts;
     uint64_t shadow_version = 0;
     float xmax_abs = 0.0f, xmax_norm2 = 0.0f;
+    // int8 shadow (one scale per 64-slot unit; kernels_ivf.hip ivf_shadow_i8_kernel): half the bytes of the HBM-bound scan. Policy as in
+    // FlatIndex: a search whose int8 slices overflowed or proposed more than kI8MaxCand candidates per query sends the index back to the
+    // fp16 shadow for a while (doubling back-off); COMET_IVF_I8 = 0 never / 1 always.
+    int ld8 = 0;
+    DevBuf V8, su;
+    float xmax_err2 = 0.0f;
+    static constexpr int64_t kI8MaxCand = 1024;
+    int i8_policy = [] { const char* e = getenv("COMET_IVF_I8"); return e ? atoi(e) : -1; }();
+    int64_t n_searches = 0, i8_resume_at = 0, st_i8_slices = 0, st_i8_backoffs = 0; int i8_strikes = 0;
+    bool i8_usable() const {
+        if (i8_policy == 0 || !prep_queries_i8_ok(dim) || !std::isfinite(xmax_err2) || !V8.p) return false;
+        return i8_policy == 1 || n_searches >= i8_resume_at;
+    }
     int64_t st_candidates = 0, st_overflows = 0, st_expansions = 0, st_fast_queries = 0, st_strict_queries = 0;
     // deferred verification of fast-path searches, as FlatIndex does it: the post stage leaves per-query overflow flags (candidate
     // list beyond its LDS capacity: adversarial clustering / mass ties) which travel to pinned memory on a second stream;
     // search_finish() waits for the search's event and re-runs the flagged queries on the exact kernels
     struct Pending {
         bool active = false; uint64_t ticket = 0; hipEvent_t ev = nullptr, ev_post = nullptr;
-        int B = 0, k_cap = 0, nfast_slices = 0, slice = 256;
+        int B = 0, k_cap = 0, nfast_slices = 0, slice = 256; uint64_t i8_mask = 0;    // bit sl: slice sl was screened on the int8 shadow
         const float* queries = nullptr; comet_search_params p{}; std::vector<uint32_t> flt;
         uint32_t* out_ids = nullptr; float* out_scores = nullptr; int32_t* out_counts = nullptr;
         int32_t* flags = nullptr;   // pinned: per fast slice [256 overflow flags | 4 stats]
@@ -411,13 +424,19 @@ struct IVFIndex : comet_index {
         const int64_t ns = std::max<int64_t>(lay.nslots, 64);
         Vh.reserve((size_t)ns * ldh * 2, c->stream, 0);
         rn_slot.reserve((size_t)ns * 4, c->stream, 0);
-        stats_dev.reserve(8, c->stream, 0);
-        c->zero(stats_dev.p, 8);
+        stats_dev.reserve(16, c->stream, 0);
+        c->zero(stats_dev.p, 16);
         launch_ivf_shadow(c, V.as<float>(), ld, lay.row_of_slot.as<uint32_t>(), lay.nslots, Vh.p, ldh, rn_slot.as<float>(), stats_dev.as<uint32_t>());
-        uint32_t hs[2] = {0, 0};
-        c->d2h(hs, stats_dev.p, 8);
+        if (i8_policy != 0 && prep_queries_i8_ok(dim)) {
+            const int64_t nu = ceil_div(ns, 64);
+            V8.reserve((size_t)nu * 64 * ld8, c->stream, 0);
+            su.reserve((size_t)nu * 4, c->stream, 0);
+            launch_ivf_shadow_i8(c, V.as<float>(), ld, lay.row_of_slot.as<uint32_t>(), lay.nslots, V8.p, ld8, su.as<float>(), stats_dev.as<uint32_t>());
+        }
+        uint32_t hs[4] = {0, 0, 0, 0};
+        c->d2h(hs, stats_dev.p, 16);
         HIP_CHECK(hipStreamSynchronize(c->stream));
-        std::memcpy(&xmax_abs, &hs[0], 4); std::memcpy(&xmax_norm2, &hs[1], 4);
+        std::memcpy(&xmax_abs, &hs[0], 4); std::memcpy(&xmax_norm2, &hs[1], 4); std::memcpy(&xmax_err2, &hs[2], 4);
         shadow_version = lay.version;
     }
     bool fast_usable(int B, const comet_search_params& p) {
@@ -436,14 +455,18 @@ struct IVFIndex : comet_index {
         const int NB = kFastBatch;
         float* Qp = c->salloc<float>((size_t)bn * ld);
         int32_t* zflag = c->salloc<int32_t>(bn);
-        void* Qh = c->scratch_alloc((size_t)NB * ldh * 2 * 2);      // row-major copy (the scan gathers its query rows from it) + the fragment-ordered copy of the Flat scan
+        const bool i8 = i8_usable();
+        void* Qh = i8 ? c->scratch_alloc((size_t)NB * ld8 * 2) : c->scratch_alloc((size_t)NB * ldh * 2 * 2);      // row-major copy (the scan gathers its query rows from it) + the fragment-ordered copy of the Flat scan
+        void* Q8R = i8 ? (char*)Qh + (size_t)NB * ld8 : nullptr;
+        float* sqv = i8 ? c->salloc<float>(NB) : nullptr;
         float* qn = c->salloc<float>(NB);
         float* err = c->salloc<float>(NB);
         int32_t* flags = pend->dflags + (size_t)pend->nfast_slices * kSliceInts;
         int32_t* ovf = flags; int32_t* st = flags + 256;
         const int fmode = metric == COMET_COSINE ? 0 : 1;
         const float xn2 = metric == COMET_COSINE ? 1.0002f : xmax_norm2;
-        if (prep_queries_fused_ok(dim)) launch_prep_queries_fused(c, metric, queries_dev, bn, dim, Qp, ld, zflag, Qh, ldh, qn, err, fmode, xn2, st);
+        if (i8) launch_prep_queries_i8(c, metric, queries_dev, bn, dim, Qp, ld, zflag, Qh, Q8R, ld8, sqv, qn, err, fmode, xn2, std::sqrt(xmax_err2), st);
+        else if (prep_queries_fused_ok(dim)) launch_prep_queries_fused(c, metric, queries_dev, bn, dim, Qp, ld, zflag, Qh, ldh, qn, err, fmode, xn2, st);
         else { launch_ingest_rows(c, metric, queries_dev, bn, dim, Qp, ld, zflag); launch_prep_queries_fast(c, Qp, bn, ld, dim, Qh, ldh, qn, err, fmode, xn2, st); }
         uint32_t* probe_list = c->salloc<uint32_t>((size_t)bn * np);
         int32_t* seg_off = c->salloc<int32_t>((size_t)bn * (np + 1));
@@ -462,7 +485,8 @@ struct IVFIndex : comet_index {
         launch_ivf_items(c, probe_list, np, np, uoff, (int)P, nlist, lay.list_len.as<int32_t>(), lay.list_base.as<int64_t>(), groups, items, counts);
         float* D = c->salloc<float>((size_t)bn * ldD);
         float* umin = c->salloc<float>((size_t)bn * umax);          // per (query, unit): the unit's smallest approximate distance
-        launch_ivf_scan_f16(c, fmode, Vh.p, ldh, Qh, rn_slot.as<float>(), qn, elig, groups, items, counts, D, ldD, umin, umax);
+        if (i8) { launch_ivf_scan_i8(c, fmode, V8.p, ld8, Q8R, rn_slot.as<float>(), qn, su.as<float>(), sqv, elig, groups, items, counts, D, ldD, umin, umax); pend->i8_mask |= 1ull << pend->nfast_slices; }
+        else launch_ivf_scan_f16(c, fmode, Vh.p, ldh, Qh, rn_slot.as<float>(), qn, elig, groups, items, counts, D, ldD, umin, umax);
         launch_ivf_post(c, metric, D, ldD, umin, umax, uoff, np, probe_list, np, lay.list_base.as<int64_t>(), lay.list_len.as<int32_t>(), lay.row_of_slot.as<uint32_t>(),
                         lay.ids_slot.as<uint32_t>(), elig, err, p.k, p.threshold, V.as<float>(), ld, Qp, bn, zflag, out_ids, out_scores, out_counts, k_cap, ovf, st);
         pend->nfast_slices++;
@@ -511,11 +535,12 @@ struct IVFIndex : comet_index {
         if (!slot->flags) HIP_CHECK(hipHostMalloc((void**)&slot->flags, sizeof(int32_t) * kSliceInts * kMaxSlices, hipHostMallocDefault));
         if (!slot->dflags) HIP_CHECK(hipMalloc((void**)&slot->dflags, sizeof(int32_t) * kSliceInts * kMaxSlices));
         if (!copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-        slot->ticket = next_ticket++; slot->B = B; slot->k_cap = k_cap; slot->nfast_slices = 0; slot->queries = queries_dev;
+        slot->ticket = next_ticket++; slot->B = B; slot->k_cap = k_cap; slot->nfast_slices = 0; slot->i8_mask = 0; slot->queries = queries_dev;
+        n_searches++;
         slot->p = p; slot->flt.clear();
         if (p.filter_ids && p.n_filter > 0) { slot->flt.assign(p.filter_ids, p.filter_ids + p.n_filter); slot->p.filter_ids = slot->flt.data(); }
         slot->out_ids = out_ids; slot->out_scores = out_scores; slot->out_counts = out_counts;
-        st_candidates = st_overflows = st_expansions = st_fast_queries = st_strict_queries = 0;
+        st_candidates = st_overflows = st_expansions = st_fast_queries = st_strict_queries = st_i8_slices = 0;
         search_core(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap, slot);
         if (slot->nfast_slices > 0) {
             HIP_CHECK(hipEventRecord(slot->ev_post, c->stream));
@@ -537,6 +562,12 @@ struct IVFIndex : comet_index {
             const int32_t* hf = slot->flags + (size_t)sl * kSliceInts;
             const int bn = std::min(slot->slice, slot->B - sl * slot->slice);
             st_candidates += hf[256]; st_overflows += hf[257]; st_expansions += hf[258];
+            if ((slot->i8_mask >> sl) & 1ull) {
+                st_i8_slices++;
+                if (i8_policy != 1 && (hf[257] > 0 || hf[256] > kI8MaxCand * bn) && n_searches >= i8_resume_at) {
+                    i8_resume_at = n_searches + ((int64_t)32 << std::min(i8_strikes, 10)); i8_strikes++; st_i8_backoffs++;
+                }
+            }
             int nfast = bn;
             for (int q = 0; q < bn; q++) if (hf[q]) { redo.push_back(sl * slot->slice + q); nfast--; }
             st_fast_queries += nfast;
@@ -561,6 +592,9 @@ struct IVFIndex : comet_index {
         else if (k == "fast_expansions") *out = (double)st_expansions;
         else if (k == "fast_queries") *out = (double)st_fast_queries;
         else if (k == "strict_queries") *out = (double)st_strict_queries;
+        else if (k == "i8_slices") *out = (double)st_i8_slices;
+        else if (k == "i8_backoffs") *out = (double)st_i8_backoffs;
+        else if (k == "i8_max_residual") *out = std::sqrt((double)xmax_err2);
         else if (k == "max_list_len") { const_cast<ListLayout&>(lay).compile(c); *out = (double)lay.max_len; }
         else if (k == "ivf_scan_rows" || k == "ivf_scan_items") {       // rows the last fast slice's scan streamed (x ldh x 2 = its algorithmic bytes) / its work items
             int32_t h[4] = {0, 0, 0, 0};
@@ -643,7 +677,7 @@ struct IVFIndex : comet_index {
 comet_index* make_ivf(Ctx* c, int dim, int metric, int nlist) {
     auto* f = new IVFIndex();
     f->c = c; f->kind = COMET_KIND_IVF; f->dim = dim; f->ld = padded_dim(dim); f->metric = metric; f->nlist = nlist;
-    f->ldh = (int)round_up(dim, 64);
+    f->ldh = (int)round_up(dim, 64); f->ld8 = (int)round_up(dim, 128);
     f->lay.nlist = nlist; f->lay.align = ivf_fast_unit_rows();   // every list starts on a 64-slot key unit of the fast path's shadow
     return f;
 }

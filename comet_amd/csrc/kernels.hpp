@@ -160,6 +160,10 @@ void launch_ivf_probe_units(Ctx* c, const uint32_t* probe_list, int ldp, const i
 // (query, list) pairs -> groups of <= 64 queries per list -> (group, 256-row tile) items; counts[0] = items, counts[1] = groups
 void launch_ivf_items(Ctx* c, const uint32_t* probe_list, int ldp, int np, const int32_t* uoff, int n_pairs, int nlist, const int32_t* list_len,
                       const int64_t* list_base, void* groups, void* items, int32_t* counts);
+// int8 shadow of the IVF scan: one scale per 64-slot unit (su), codes in the fp16 shadow's layout with 128 dimensions per 128-byte K step; ld8 % 128 == 0
+void launch_ivf_shadow_i8(Ctx* c, const float* V, int ld, const uint32_t* row_of_slot, int64_t nslots, void* V8, int ld8, float* su, uint32_t* stats);
+void launch_ivf_scan_i8(Ctx* c, int mode, const void* V8, int ld8, const void* Q8R, const float* rn, const float* qn, const float* su, const float* sq, const uint8_t* elig,
+                        const void* groups, const void* items, const int32_t* counts, float* D, int64_t ldD, float* umin, int64_t ldu);
 void launch_ivf_scan_f16(Ctx* c, int mode, const void* Vh, int ldh, const void* Qh, const float* rn, const float* qn, const uint8_t* elig,
                          const void* groups, const void* items, const int32_t* counts, float* D, int64_t ldD, float* umin, int64_t ldu);
 

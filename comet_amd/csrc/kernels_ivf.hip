@@ -26,11 +26,15 @@
 //
 // The scan is HBM-bound by construction: every probed list is streamed once per group of 64 of its queries (12 GFLOP of MFMA work
 // for 1.5 GB of rows at 1M x 768, nprobe 32, B 256). Algorithmic bytes per launch = sum over items of the tile's rows x ldh x 2.
+#include <type_traits>
 #include "kernels.hpp"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
 
 namespace comet {
 
@@ -77,6 +81,68 @@ void launch_ivf_shadow(Ctx* c, const float* V, int ld, const uint32_t* row_of_sl
     if (nslots <= 0) return;
     ProfScope ps(c, "ivf_shadow");
     ivf_shadow_kernel<<<dim3((unsigned)ceil_div(nslots, 4)), dim3(256), 0, c->stream>>>(V, ld, row_of_slot, nslots, (_Float16*)Vh, ldh, rn, stats);
+    LAUNCH_CHECK();
+}
+
+// int8 shadow (round 3; the Flat one's rationale and bound: kernels_fast.hip to_i8_tiles_kernel): x_i = s_U c_i + delta_i with ONE SCALE PER
+// 64-SLOT UNIT (a unit belongs to one list and is what a wave scans), codes in the fp16 shadow's layout byte for byte —
+// [unit][K step of 128 bytes][row][128 bytes], a K step now holds 128 dimensions; ld8 = dimensions padded to 128. The scan is HBM-bound:
+// half the bytes. stats[2] = max ||delta||^2 over all rows (atomicMax), su[unit] = the unit's scale.
+__global__ __launch_bounds__(256) void ivf_shadow_i8_kernel(const float* __restrict__ V, int ld, const unsigned* __restrict__ row_of_slot, long nslots,
+                                                            signed char* __restrict__ V8, int ld8, float* __restrict__ su, unsigned* __restrict__ stats) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long unit = blockIdx.x, s0 = unit * 64;
+    float amax = 0.0f;
+    for (int r = w; r < 64; r += 4) {
+        const long slot = s0 + r;
+        const unsigned row = slot < nslots ? row_of_slot[slot] : 0xFFFFFFFFu;
+        if (row == 0xFFFFFFFFu) continue;                      // wave-uniform
+        const float* x = V + (long)row * ld;
+        for (int i0 = lane * 4; i0 < ld; i0 += 256) {
+            const f32x4v v = *reinterpret_cast<const f32x4v*>(x + i0);
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    if (lane == 0) red[w] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float s = amax > 0.0f ? amax / 127.0f : 1.0f;
+    const int nk = ld8 >> 7;
+    float e2max = 0.0f;
+    for (int r = w; r < 64; r += 4) {
+        const long slot = s0 + r;
+        const unsigned row = slot < nslots ? row_of_slot[slot] : 0xFFFFFFFFu;
+        const float* x = V + (long)(row == 0xFFFFFFFFu ? 0 : row) * ld;
+        float e2 = 0.0f;
+        for (int i0 = lane * 16; i0 < ld8; i0 += 1024) {
+            u32x4 out;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                f32x4v v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (row != 0xFFFFFFFFu && i0 + 4 * j < ld) v = *reinterpret_cast<const f32x4v*>(x + i0 + 4 * j);
+                float cq[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    cq[e] = fminf(fmaxf(rintf(v[e] / s), -127.0f), 127.0f);
+                    const float dl = v[e] - s * cq[e];
+                    e2 += dl * dl;
+                }
+                out[j] = ((unsigned)(int)cq[0] & 0xFFu) | (((unsigned)(int)cq[1] & 0xFFu) << 8) | (((unsigned)(int)cq[2] & 0xFFu) << 16) | (((unsigned)(int)cq[3] & 0xFFu) << 24);
+            }
+            *reinterpret_cast<u32x4*>(V8 + ((unit * nk + (i0 >> 7)) * 64 + r) * 128 + (i0 & 127)) = out;
+        }
+        for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off, 64);
+        e2max = fmaxf(e2max, e2);
+    }
+    if (threadIdx.x == 0) su[unit] = s;
+    if (lane == 0) atomicMax(&stats[2], __float_as_uint(e2max));
+}
+void launch_ivf_shadow_i8(Ctx* c, const float* V, int ld, const uint32_t* row_of_slot, int64_t nslots, void* V8, int ld8, float* su, uint32_t* stats) {
+    if (nslots <= 0) return;
+    ProfScope ps(c, "ivf_shadow_i8");
+    ivf_shadow_i8_kernel<<<dim3((unsigned)ceil_div(nslots, 64)), dim3(256), 0, c->stream>>>(V, ld, row_of_slot, nslots, (signed char*)V8, ld8, su, stats);
     LAUNCH_CHECK();
 }
 
@@ -203,13 +269,16 @@ size_t ivf_item_bytes() { return sizeof(IvfItem); }
 __device__ __forceinline__ int iv_swz_off(int row, int kslot) { return row * 128 + ((kslot ^ ((row >> 1) & 7)) << 4); }
 // MODE 0: cosine   key = max(0, 1 - s)
 // MODE 1: L2 family key = max(0, qn[q] + rn[slot] - 2 s)
-template <int MODE>
+// I8: the int8 shadow — `ldh` = row bytes / 2, Qh = row-major int8 queries, su / sq = unit / query scales (the integer sums become
+// scores in the epilogue; everything else is byte-identical).
+template <int MODE, bool I8 = false>
 __global__ __launch_bounds__(IV_THREADS) void ivf_scan_f16_kernel(const _Float16* __restrict__ Vh, int ldh, const _Float16* __restrict__ Qh /*row-major fp16 queries, ldh*/,
                                                                   const float* __restrict__ rn /*per slot*/, const float* __restrict__ qn,
                                                                   const unsigned char* __restrict__ elig /*per slot, nullable*/,
                                                                   const IvfGroup* __restrict__ groups, const IvfItem* __restrict__ items, const int* __restrict__ counts,
                                                                   float* __restrict__ D /*[query][unit position x 64]: approximate distances, +inf for rows that are no candidates*/, long ldD,
-                                                                  float* __restrict__ Umin /*[query][unit position]: the unit's smallest approximate distance*/, long ldU) {
+                                                                  float* __restrict__ Umin /*[query][unit position]: the unit's smallest approximate distance*/, long ldU,
+                                                                  const float* __restrict__ su = nullptr, const float* __restrict__ sq = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [buf][X 32 KiB | Q 8 KiB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -258,11 +327,11 @@ __global__ __launch_bounds__(IV_THREADS) void ivf_scan_f16_kernel(const _Float16
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc + (long)kt * 128),
                                                  (__attribute__((address_space(3))) void*)(sb + qdst), 16, 0, 0);
         };
-        f32x16 acc[2];
+        std::conditional_t<I8, i32x16, f32x16> acc[2];
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][e] = 0.0f;
+            for (int e = 0; e < 16; e++) acc[i][e] = 0;
         stage(0, 0);
         __syncthreads();
         const int arow = wm * 64 + (lane & 31), brow = wn * 32 + (lane & 31);
@@ -279,7 +348,10 @@ __global__ __launch_bounds__(IV_THREADS) void ivf_scan_f16_kernel(const _Float16
                     for (int mb = 0; mb < 2; mb++) a[mb] = *reinterpret_cast<const half8*>(xb + iv_swz_off(arow + mb * 32, ks * 2 + khalf));
                     b = *reinterpret_cast<const half8*>(qb + iv_swz_off(brow, ks * 2 + khalf));
 #pragma unroll
-                    for (int mb = 0; mb < 2; mb++) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b, acc[mb], 0, 0, 0);
+                    for (int mb = 0; mb < 2; mb++) {
+                        if constexpr (I8) acc[mb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, a[mb]), __builtin_bit_cast(i32x4v, b), acc[mb], 0, 0, 0);
+                        else acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b, acc[mb], 0, 0, 0);
+                    }
                 }
             }
             __syncthreads();
@@ -292,8 +364,9 @@ __global__ __launch_bounds__(IV_THREADS) void ivf_scan_f16_kernel(const _Float16
             const long ukey = (long)G->kb[live ? s : 0] + 4 * tl + wm;        // unit index inside the query's score row
             const long slot0 = (unit_g0 + wm) * IV_UNIT;
             const int nvalid = len - (4 * tl + wm) * IV_UNIT;                 // rows of the unit that are list members (>= 1 here)
-            float qnv = 0.0f;
+            float qnv = 0.0f, scl = 1.0f;
             if constexpr (MODE == 1) qnv = qn[q];
+            if constexpr (I8) scl = su[unit_g0 + wm] * sq[q];
             const bool check = nvalid < IV_UNIT || elig != nullptr;           // wave-uniform
             float* __restrict__ drow = D + (long)q * ldD + ukey * IV_UNIT;
             float umn = INF;
@@ -307,9 +380,10 @@ __global__ __launch_bounds__(IV_THREADS) void ivf_scan_f16_kernel(const _Float16
                     if constexpr (MODE == 1) rnv = *reinterpret_cast<const f32x4v*>(rn + slot0 + r0);
 #pragma unroll
                     for (int e1 = 0; e1 < 4; e1++) {
-                        float a;
-                        if constexpr (MODE == 0) a = 1.0f - acc[mb][e4 * 4 + e1];
-                        else a = (qnv + rnv[e1]) - 2.0f * acc[mb][e4 * 4 + e1];
+                        float a, sdot;
+                        if constexpr (I8) sdot = (float)acc[mb][e4 * 4 + e1] * scl; else sdot = acc[mb][e4 * 4 + e1];
+                        if constexpr (MODE == 0) a = 1.0f - sdot;
+                        else a = (qnv + rnv[e1]) - 2.0f * sdot;
                         a = fmaxf(a, 0.0f);
                         if (check) { bool ok = r0 + e1 < nvalid; if (ok && elig) ok = elig[slot0 + r0 + e1] != 0; a = ok ? a : INF; }
                         v[e1] = a;
@@ -330,9 +404,21 @@ void launch_ivf_scan_f16(Ctx* c, int mode, const void* Vh, int ldh, const void* 
     auto go = [&](auto kernel) {
         HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         c->launch_timed("ivf_scan_f16", kernel, dim3((unsigned)grid), dim3(IV_THREADS), lds, (const _Float16*)Vh, ldh, (const _Float16*)Qh, rn, qn, (const unsigned char*)elig,
-                        (const IvfGroup*)groups, (const IvfItem*)items, (const int*)counts, D, (long)ldD, umin, (long)ldu);
+                        (const IvfGroup*)groups, (const IvfItem*)items, (const int*)counts, D, (long)ldD, umin, (long)ldu, (const float*)nullptr, (const float*)nullptr);
     };
-    if (mode == 0) go(ivf_scan_f16_kernel<0>); else go(ivf_scan_f16_kernel<1>);
+    if (mode == 0) go(ivf_scan_f16_kernel<0, false>); else go(ivf_scan_f16_kernel<1, false>);
+    LAUNCH_CHECK();
+}
+void launch_ivf_scan_i8(Ctx* c, int mode, const void* V8, int ld8, const void* Q8R, const float* rn, const float* qn, const float* su, const float* sq, const uint8_t* elig,
+                        const void* groups, const void* items, const int32_t* counts, float* D, int64_t ldD, float* umin, int64_t ldu) {
+    const size_t lds = 2 * IV_STAGE;
+    const long grid = (long)round_up(c->prop.multiProcessorCount, 8) * 2;
+    auto go = [&](auto kernel) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        c->launch_timed("ivf_scan_i8", kernel, dim3((unsigned)grid), dim3(IV_THREADS), lds, (const _Float16*)V8, ld8 / 2, (const _Float16*)Q8R, rn, qn, (const unsigned char*)elig,
+                        (const IvfGroup*)groups, (const IvfItem*)items, (const int*)counts, D, (long)ldD, umin, (long)ldu, su, sq);
+    };
+    if (mode == 0) go(ivf_scan_f16_kernel<0, true>); else go(ivf_scan_f16_kernel<1, true>);
     LAUNCH_CHECK();
 }
 
