@@ -56,7 +56,9 @@ MIX_SEED, MIX_CENTERS, MIX_SIGMA, MIX_SUB, MIX_NOISE = 0xC0FFEE + 4, 2048, 0.15,
 HBM_PEAK_GBS = 8000.0
 NQB = 8               # distinct query batches a leg rotates through
 DTYPE = ("f32 results: every returned score is the reference's serial float32 sum (bit-identical to the CPU path); candidates are "
-         "screened on fp16 MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate) with a rigorous error bound, PQ tables / BM25 in f32 / f64")
+         "screened on int8 MFMA (v_mfma_i32_32x32x32_i8, exact int32 accumulate; fp16 v_mfma_f32_32x32x16_f16 where int8 is too coarse for the "
+         "data) with a rigorous error bound from measured quantisation residuals, PQ tables / BM25 in f32 / f64")
+INT8_PEAK_TOPS = 5000.0   # dense int8 MFMA peak (2 x the 2.5 PF fp16 peak; MI355X_MICROARCH.md: >= 3944 TOPS measured)
 
 
 def parse():
@@ -192,7 +194,12 @@ def pmc_traffic(kernel, rows_local):
         try:
             pm = json.loads(f.read_text())
             for kname, kv in pm.get("kernels", {}).items():
-                names = {"flat_scan_f16": ("flat_scan_q8_kernelILi0E", "flat_scan_f16_kernel")}.get(kernel, (kernel + "_kernel",))
+                names = {"flat_scan_f16": ("flat_scan_q8_kernelILi0ELi128ELb0E", "flat_scan_q8_kernel<0, 128, false>", "flat_scan_f16_kernel"),
+                         "flat_scan_i8": ("flat_scan_q8_kernelILi0ELi128ELb1E", "flat_scan_q8_kernel<0, 128, true>"),
+                         "flat_scan_f16_n64": ("flat_scan_f16_n64_kernelILi1ELb0E", "flat_scan_f16_n64_kernel<1, false>"),
+                         "flat_scan_i8_n64": ("flat_scan_f16_n64_kernelILi1ELb1E", "flat_scan_f16_n64_kernel<1, true>"),
+                         "ivf_scan_f16": ("ivf_scan_f16_kernelILi0ELb0E", "ivf_scan_f16_kernel<0, false>"),
+                         "ivf_scan_i8": ("ivf_scan_f16_kernelILi0ELb1E", "ivf_scan_f16_kernel<0, true>")}.get(kernel, (kernel + "_kernel",))
                 if kname.split("<")[0].strip() == kernel or any(nm in kname for nm in names):
                     if pm.get("source_sha") != sha:
                         stale = f.name
@@ -209,24 +216,32 @@ def pmc_traffic(kernel, rows_local):
             else "not measured in this run (PMC needs its own rocprofv3 pass: tools/pmc_bench.sh)")
 
 
+FLAT_SCAN_SCOPES = "flat_scan_i8|flat_scan_f16|flat_scan_i8_n64|flat_scan_f16_n64"
+IVF_SCAN_SCOPES = "ivf_scan_i8|ivf_scan_f16"
+
+
 def flat_roofline(prof, rows_local, dim, nq):
-    ldh = (dim + 63) // 64 * 64
-    name = "flat_scan_f16_n64" if (nq <= 64 and "flat_scan_f16_n64" in prof) else ("flat_scan_f16" if "flat_scan_f16" in prof else "dist_exact")
+    """roofline of the scan kernel the timed regions actually ran: the int8 shadow (1 byte per dimension, rows padded to 256) or the fp16 one"""
+    cands = ("flat_scan_i8_n64", "flat_scan_f16_n64") if nq <= 64 else ("flat_scan_i8", "flat_scan_f16")
+    name = next((c for c in sorted(cands, key=lambda c: -prof.get(c, (0.0, 0))[1]) if c in prof), "dist_exact")
     avg_ms, n = kernel_stats(prof, name)
-    if name.startswith("flat_scan_f16"):
+    extra = {}
+    if name.startswith("flat_scan"):
         qtile = 64 if name.endswith("n64") else 256
-        alg = rows_local * ldh * 2 + qtile * ldh * 2          # the fp16 shadow once + the staged query tile
-        flops = 2.0 * qtile * rows_local * ldh
+        i8 = "_i8" in name
+        ldr, eb = ((dim + 255) // 256 * 256, 1) if i8 else ((dim + 63) // 64 * 64, 2)
+        alg = rows_local * ldr * eb + qtile * ldr * eb        # the shadow once + the staged query tile
+        flops = 2.0 * qtile * rows_local * ldr
+        tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        extra = ({"mfma_tops_int8": tf, "mfma_frac_of_5000": tf / INT8_PEAK_TOPS, "shadow": "int8, one scale per 256-row tile"} if i8
+                 else {"mfma_tflops": tf, "mfma_frac_of_2500": tf / 2500.0, "shadow": "fp16"})
     else:
         alg = rows_local * dim * 4                            # exact-arithmetic scan: every fp32 row once (SURVEY 8d N*d*4)
-        flops = 0.0
     ach = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic, src = pmc_traffic(name, rows_local)
-    tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "avg_kernel_ms": avg_ms, "launches": n,
-            "algorithmic_bytes_per_launch": alg, "fp32_rows_bytes_per_pass": rows_local * dim * 4,
-            "mfma_tflops": tf, "mfma_frac_of_2500": tf / 2500.0}
+            "algorithmic_bytes_per_launch": alg, "fp32_rows_bytes_per_pass": rows_local * dim * 4, **extra}
 
 
 def threads_map(fn, n_items, T):
@@ -385,7 +400,7 @@ def leg_flat_l2(ctx, ca, args, timer, flat2, q_ptrs):
     for B in (1, 64, 256):
         pipe = Pipe(ctx, flat2, q_ptrs, B, K)
         pipe.step(2)
-        rec, prof, _med, _t = measure(ctx, timer, args, pipe.step, "flat_scan_f16_n64" if B <= 64 else "flat_scan_f16", B)
+        rec, prof, _med, _t = measure(ctx, timer, args, pipe.step, FLAT_SCAN_SCOPES, B)
         rec["roofline"] = flat_roofline(prof, args.rows, args.dim, B)
         out[f"batch{B}"] = rec
         pipe.free()
@@ -593,18 +608,20 @@ def leg_hybrid(ctx, ca, args, timer, q_ptrs, Q0):
     for npb in (args.nprobe, 1):
         pipe = Pipe(ctx, ivf, q_ptrs, B, K, None, nprobes=npb)
         pipe.step(2)
-        rec, prof, med, times = measure(ctx, timer, args, pipe.step, "ivf_scan_f16", B)
+        rec, prof, med, times = measure(ctx, timer, args, pipe.step, IVF_SCAN_SCOPES, B)
         g = pipe.results_of(0)
         scan_rows = ivf.stat("ivf_scan_rows")
-        avg_ms, nl = kernel_stats(prof, "ivf_scan_f16")
-        alg = scan_rows * ldh * 2
+        kname = "ivf_scan_i8" if prof.get("ivf_scan_i8", (0.0, 0))[1] >= prof.get("ivf_scan_f16", (0.0, 0))[1] and "ivf_scan_i8" in prof else "ivf_scan_f16"
+        avg_ms, nl = kernel_stats(prof, kname)
+        row_bytes = (d + 127) // 128 * 128 if kname == "ivf_scan_i8" else ldh * 2
+        alg = scan_rows * row_bytes
         ach = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, src = pmc_traffic("ivf_scan_f16", n)
-        rec["roofline"] = {"bound": "hbm", "kernel": "ivf_scan_f16", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+        traffic, src = pmc_traffic(kname, n)
+        rec["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_source": src, "avg_kernel_ms": avg_ms, "launches": nl, "algorithmic_bytes_per_launch": alg,
-                           "algorithmic_bytes_are": "fp16 shadow rows of every probed list, once per group of <= 64 of its queries (counted by the kernel that lays out the "
-                                                    f"work: {int(scan_rows)} rows of query batch 0) x {ldh} x 2 bytes"}
-        rec["fast_path"] = {k: ivf.stat(k) for k in ("fast_queries", "strict_queries", "fast_candidates", "fast_overflows")}
+                           "algorithmic_bytes_are": ("int8" if kname == "ivf_scan_i8" else "fp16") + " shadow rows of every probed list, once per group of <= 64 of its "
+                                                    f"queries (counted by the kernel that lays out the work: {int(scan_rows)} rows of query batch 0) x {row_bytes} bytes"}
+        rec["fast_path"] = {k: ivf.stat(k) for k in ("fast_queries", "strict_queries", "fast_candidates", "fast_overflows", "i8_slices", "i8_backoffs")}
         x = pipe.results_of(0, mode=1)                                                     # the exact kernels (search mode 1) on the same batch
         rec["identical_to_exact_kernels"] = bool(np.array_equal(x[2], g[2]) and np.array_equal(x[0], g[0]) and np.array_equal(x[1].view(np.uint32), g[1].view(np.uint32)))
         p1 = Pipe(ctx, ivf, q_ptrs, B, K, None, nprobes=npb, mode=1)
@@ -718,8 +735,7 @@ def main():
     q_ptrs = query_batches(ctx, B, args.dim, lambda p, i: ctx.synth_fill(p, QUERY_SEED, i * B * args.dim, B * args.dim))
     pipe = Pipe(ctx, idx, q_ptrs, B, K, comm, mode=args.mode)
     pipe.step(1)
-    dominant = "flat_scan_f16" if B > 64 else "flat_scan_f16_n64"
-    rec, prof, med, times = measure(ctx, timer, args, pipe.step, dominant, B)
+    rec, prof, med, times = measure(ctx, timer, args, pipe.step, FLAT_SCAN_SCOPES, B)
     g0 = pipe.results_of(0)
 
     line = None
@@ -737,7 +753,7 @@ def main():
                        "mode": {0: "auto", 1: "strict", 2: "fast"}[args.mode], "sharding": f"rows/{world}", "build_s": round(build_s, 2)},
             "roofline": flat_roofline(prof, hi - lo, args.dim, B),
             "kernels_ms_per_step": rec["kernels_ms_per_step"],
-            "fast_path": {k: idx.stat(k) for k in ("fast_queries", "strict_queries", "fast_candidates", "fast_expansions", "fast_overflows")},
+            "fast_path": {k: idx.stat(k) for k in ("fast_queries", "strict_queries", "fast_candidates", "fast_expansions", "fast_overflows", "i8_slices", "i8_backoffs", "i8_max_residual")},
             "recall_at_10": {"flat": 1.0},
             "scaling_note": None if world == 1 else "strong scaling of the named config: the 1M-row corpus is split over the ranks and every rank searches its shard for the "
                             "same 256 queries; per batch a rank keeps a fixed cost that does not shrink with its shard (post stage per shard, query preparation, "

@@ -87,7 +87,7 @@ struct Ctx {
     void* pinned = nullptr; size_t pinned_cap = 0;
     // profiling
     bool profile = false;
-    std::string prof_only;       // non-empty: only scopes of this name are timed (event records are barrier packets: ~5 us each in a chain of short kernels)
+    std::string prof_only;       // non-empty: only the scopes named in this '|'-separated list are timed (event records are barrier packets: ~5 us each in a chain of short kernels)
     bool prof_open = false;
     struct Pending { std::string name; hipEvent_t a, b; };
     std::vector<Pending> pending;
@@ -128,8 +128,19 @@ struct Ctx {
     void d2d(void* dst, const void* src, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream)); }
     void zero(void* dst, size_t bytes) { if (bytes) HIP_CHECK(hipMemsetAsync(dst, 0, bytes, stream)); }
 
+    // prof_only: "" = every scope, otherwise the scopes named in a '|'-separated list
+    bool prof_wants(const char* name) const {
+        if (prof_only.empty()) return true;
+        const size_t ln = std::strlen(name);
+        for (size_t a = 0; a <= prof_only.size();) {
+            size_t b = prof_only.find('|', a); if (b == std::string::npos) b = prof_only.size();
+            if (b - a == ln && prof_only.compare(a, ln, name) == 0) return true;
+            a = b + 1;
+        }
+        return false;
+    }
     void prof_begin(const char* name) {
-        prof_open = profile && (prof_only.empty() || prof_only == name);
+        prof_open = profile && prof_wants(name);
         if (!prof_open) return;
         Pending p; p.name = name;
         HIP_CHECK(hipEventCreate(&p.a)); HIP_CHECK(hipEventCreate(&p.b));
@@ -147,7 +158,7 @@ struct Ctx {
     // is the kernel's, not the kernel plus the wait for its predecessor.
     template <class K, class... A>
     void launch_timed(const char* name, K kernel, dim3 grid, dim3 block, size_t lds, A... args) {
-        if (profile && (prof_only.empty() || prof_only == name)) {
+        if (profile && prof_wants(name)) {
             Pending p; p.name = name;
             HIP_CHECK(hipEventCreate(&p.a)); HIP_CHECK(hipEventCreate(&p.b));
             hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds, stream, p.a, p.b, 0, args...);

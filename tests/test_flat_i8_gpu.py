@@ -126,3 +126,49 @@ def test_anchored_threshold_keeps_ties(ctx):
         g.add_batch(ids, X)
         same(g.search_batch(Q, k, mode=2), g.search_batch(Q, k, mode=1))
         same(g.search_batch(Q, 30, mode=2), g.search_batch(Q, 30, mode=1))
+
+
+# ---------------------------------------------------------------------------------------------- the IVF list scan's int8 shadow
+def make_ivf(ctx, d, nlist, metric, policy):
+    from comet_amd import IVFIndex
+    old = os.environ.get("COMET_IVF_I8")
+    os.environ["COMET_IVF_I8"] = str(policy)
+    try:
+        return IVFIndex(ctx, d, nlist, metric)
+    finally:
+        if old is None:
+            os.environ.pop("COMET_IVF_I8")
+        else:
+            os.environ["COMET_IVF_I8"] = old
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_ivf_i8_screen_is_used_and_exact(ctx, metric):
+    n, d, nlist, B, k = 30000, 200, 48, 150, 12         # d = 200: rows padded to 256 codes (two 128-wide K steps)
+    centers = synth(51, 40, d)
+    X = (centers[np.arange(n) % 40] + synth(52, n, d) * np.float32(0.2)).astype(np.float32)
+    X[77] *= np.float32(30.0)                            # a row that dictates its unit's scale
+    Q = (centers[np.arange(B) % 40] + synth(53, B, d) * np.float32(0.2)).astype(np.float32)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    res = {}
+    for pol in (1, 0):
+        g = make_ivf(ctx, d, nlist, metric, pol)
+        g.train(X[:6000]); g.add_batch(ids, X)
+        for npb in (1, 6, 0):
+            r = g.search_batch(Q, k, nprobes=npb, mode=2)
+            assert g.stat("i8_slices") == (1 if pol else 0), (pol, npb)
+            assert g.stat("fast_queries") + g.stat("fast_overflows") == B
+            same(r, g.search_batch(Q, k, nprobes=npb, mode=1))
+            if pol:
+                res[npb] = r
+            else:
+                same(r, res[npb])
+        if pol:                                          # deletes + filter + re-layout after more rows (the shadow is rebuilt with the slot layout)
+            for i in range(1, 3000, 5):
+                g.remove(i)
+            flt = list(range(2, n, 3))
+            same(g.search_batch(Q, k, nprobes=6, mode=2, document_ids=flt), g.search_batch(Q, k, nprobes=6, mode=1, document_ids=flt))
+            g.add_batch(np.arange(n + 1, n + 501, dtype=np.uint32), X[:500] * np.float32(1.5))
+            r = g.search_batch(Q, k, nprobes=6, mode=2)
+            assert g.stat("i8_slices") == 1
+            same(r, g.search_batch(Q, k, nprobes=6, mode=1))

@@ -81,9 +81,10 @@ for npb in probes:
         if mode == 0:
             res[name]["fast_queries"] = ivf.stat("fast_queries"); res[name]["candidates_per_query"] = ivf.stat("fast_candidates") / B
             res[name]["overflows"] = ivf.stat("fast_overflows"); res[name]["scan_rows"] = ivf.stat("ivf_scan_rows")
-            if res[name]["scan_rows"] and "ivf_scan_f16" in res[name]["kernels_ms"]:
-                by = res[name]["scan_rows"] * ((d + 63) // 64 * 64) * 2
-                res[name]["scan_bytes"] = by; res[name]["scan_TBps"] = round(by / (res[name]["kernels_ms"]["ivf_scan_f16"] * 1e-3) / 1e12, 3)
+            sk = "ivf_scan_i8" if "ivf_scan_i8" in res[name]["kernels_ms"] else "ivf_scan_f16"
+            if res[name]["scan_rows"] and sk in res[name]["kernels_ms"]:
+                by = res[name]["scan_rows"] * ((d + 127) // 128 * 128 if sk == "ivf_scan_i8" else (d + 63) // 64 * 64 * 2)
+                res[name]["scan_bytes"] = by; res[name]["scan_TBps"] = round(by / (res[name]["kernels_ms"][sk] * 1e-3) / 1e12, 3)
             res["identical"] = bool(np.array_equal(r[2], ref[2]) and np.array_equal(r[0], ref[0]) and np.array_equal(r[1].view(np.uint32), ref[1].view(np.uint32)))
         else:
             ref = r
