@@ -595,6 +595,7 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_q8_kernel(const _Float16
     const int arow = lane & 31, khalf = lane >> 5;
     u32x4 qa[4], qb[4];
     long cur_tile = tile_of(0);
+    int rn_par = 0;
     const bool tr = trace != nullptr && blockIdx.x == 8 && lane == 0;
     auto stamp = [&](long g, int slot) { if (tr && g < 2 * nk + 2) trace[(wid * 32 + g) * 4 + slot] = __builtin_amdgcn_s_memtime(); };
 
@@ -629,6 +630,16 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_q8_kernel(const _Float16
             for (int i = 0; i < 8; i++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[i][e] = 0;
+            if constexpr (MODE == 1) {
+                // the tile's 256 row norms go straight into LDS (one 4-byte LDS-DMA piece per lane of waves 0..3) while its K steps run; older
+                // than this step's query loads, so the next step's counted wait covers it. Two buffers: the previous tile's epilogue may
+                // still be reading the other one in a slower wave.
+                if (wid < 4) {
+                    const long r = cur_tile * FB_M + tid;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rn + (r < n ? r : n - 1)),
+                                                     (__attribute__((address_space(3))) void*)(rn_lds + rn_par * 256 + wid * 64), 4, 0, 0);
+                }
+            }
         }
         const unsigned char* xb = smem + (g & (FQ_STAGES - 1)) * FQ_STAGE_BYTES;
         const int ktn = kt + 1 < nk ? kt + 1 : 0;                      // next step's K index (wraps into the next tile)
@@ -668,17 +679,13 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_q8_kernel(const _Float16
         if (kt == nk - 1) {                                            // tile finished: its epilogue runs while the next tile's slabs arrive
             const long tile = cur_tile, row0 = tile * FB_M;
             cur_tile += wgs_per_xcd;
-            if constexpr (MODE == 1) {
-                // shadow norms of the tile's rows -> LDS (behind the ring), read back as broadcast b128s
-                __builtin_amdgcn_s_barrier();
-                if (tid < FB_M) { const long r = row0 + tid; rn_lds[tid] = rn[r < n ? r : n - 1]; }
-                __syncthreads_lds_only();
-            }
+            const float* rn_tile = rn_lds + rn_par * 256;             // MODE 1: landed and visible since the tile's second K step
+            rn_par ^= 1;
             float stv = 1.0f;
             if constexpr (I8) stv = sx[tile];
             unsigned long long* etr = (tr && g < 2 * nk + 2) ? trace + 8 * 32 * 4 + wid * 8 : nullptr;
-            if ((n - row0 < FB_M) || elig != nullptr) scan_epilogue_q<MODE, true, UR, I8>(acc, wid, tile, row0, n, rn_lds, qn, elig, S0, ldS, bound, ldB, etr, sq, stv);   // workgroup-uniform
-            else scan_epilogue_q<MODE, false, UR, I8>(acc, wid, tile, row0, n, rn_lds, qn, elig, S0, ldS, bound, ldB, etr, sq, stv);
+            if ((n - row0 < FB_M) || elig != nullptr) scan_epilogue_q<MODE, true, UR, I8>(acc, wid, tile, row0, n, rn_tile, qn, elig, S0, ldS, bound, ldB, etr, sq, stv);   // workgroup-uniform
+            else scan_epilogue_q<MODE, false, UR, I8>(acc, wid, tile, row0, n, rn_tile, qn, elig, S0, ldS, bound, ldB, etr, sq, stv);
             stamp(g, 3);
         }
     };
@@ -733,7 +740,7 @@ void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, 
         return;
     }
     if (scan_uses_q8(ldh)) {          // query-stationary tile: rows through a 4-stage LDS ring, query fragments straight from L2
-        const size_t ldsq = (size_t)FQ_STAGES * FQ_STAGE_BYTES + 1024;
+        const size_t ldsq = (size_t)FQ_STAGES * FQ_STAGE_BYTES + 2048;
         const long gridq = std::min<long>(round_up(n_tiles, 8), (long)round_up(c->prop.multiProcessorCount, 8));   // persistent: one workgroup per CU
         const _Float16* QF = (const _Float16*)Qh + (size_t)FB_N * ldh;
         auto go = [&](auto kernel) {
@@ -774,7 +781,7 @@ void launch_flat_scan_i8(Ctx* c, int mode, const void* X8, int64_t n, int ld8, c
         LAUNCH_CHECK();
         return;
     }
-    const size_t ldsq = (size_t)FQ_STAGES * FQ_STAGE_BYTES + 1024;
+    const size_t ldsq = (size_t)FQ_STAGES * FQ_STAGE_BYTES + 2048;
     const long gridq = std::min<long>(round_up(n_tiles, 8), (long)round_up(c->prop.multiProcessorCount, 8));
     auto go = [&](auto kernel) {
         HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
