@@ -26,6 +26,12 @@ def data(n, d, clusters):
     x = c[np.arange(n) % clusters] + orc.synth(seed + 1, 0, n * d).reshape(n, d) * np.float32(rng.choice([0.05, 0.2, 0.5]))
     if rng.random() < 0.3:                                   # exact duplicates: score ties
         k = int(rng.integers(1, max(2, n // 10))); x[n - k:] = x[:k]
+    if rng.random() < 0.3:                                   # rows of very different magnitude / outlier components (the int8 shadows' scales)
+        sel = rng.random(n) < 0.1
+        x[sel] *= np.float32(10.0) ** rng.uniform(-2, 2, size=(int(sel.sum()), 1)).astype(np.float32)
+        x[int(rng.integers(0, n)), int(rng.integers(0, d))] *= np.float32(50.0)
+    if rng.random() < 0.15:
+        x += np.float32(rng.uniform(0.5, 3.0))               # an offset: non-centred data
     return x.astype(np.float32)
 
 
@@ -47,11 +53,11 @@ t_end, rounds, kinds = time.time() + budget, 0, {}
 while time.time() < t_end:
     kind = rng.choice(KINDS)
     metric = METRICS[int(rng.integers(0, 3))]
-    d = int(rng.choice([8, 16, 24, 32, 48, 64, 96]))
+    d = int(rng.choice([8, 16, 24, 32, 48, 64, 96, 130, 200]))
     n = int(rng.integers(1500, 9000)) if kind != "flat" else int(rng.integers(6000, 30000))
     X = data(n, d, int(rng.integers(5, 60)))
     ids = np.arange(1, n + 1, dtype=np.uint32)
-    B = int(rng.choice([1, 3, 8, 17, 40]))
+    B = int(rng.choice([1, 3, 8, 17, 40, 70, 130, 256], p=[0.2, 0.15, 0.15, 0.15, 0.15, 0.08, 0.07, 0.05]))
     Q = np.vstack([data(B, d, 7)[:max(1, B - 1)], X[:1]])[:B]
     k = int(rng.choice([0, 1, 5, 10, 33, 64, 65, 200]))
     kw = {}
