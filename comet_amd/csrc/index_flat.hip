@@ -63,10 +63,14 @@ struct FlatIndex : comet_index {
     static constexpr int64_t kI8MaxCand = 1536;
     int i8_policy = [] { const char* e = getenv("COMET_FLAT_I8"); return e ? atoi(e) : -1; }();   // 0 never, 1 always, otherwise adaptive
     int64_t n_searches = 0, i8_resume_at = 0, st_i8_slices = 0, st_i8_backoffs = 0; int i8_strikes = 0;
-    bool i8_usable(int bn) const {
-        (void)bn;
+    bool i8_usable(int bn, int64_t keff) const {
         if (i8_policy == 0 || !prep_queries_i8_ok(dim) || !std::isfinite(xmax_err2)) return false;
-        return i8_policy == 1 || n_searches >= i8_resume_at;
+        if (i8_policy == 1) return true;
+        // the int8 screen saves ~0.15-0.2 ns of scan per row and costs the post stage the extra candidates of its wider bound (measured at
+        // d 768, B 256: +0.035 ms at K 100, +0.012 ms at K 10): int8 beats fp16 from ~190 k rows at K 100, below 125 k rows at K 10
+        // (62.5 k / 125 k / 250 k / 500 k rows, K 100: fp16 0.117 / 0.146 / 0.210 / 0.328 ms per batch, int8 0.149 / 0.160 / 0.191 / 0.256)
+        const int64_t need = bn > 64 ? 60000 + 1500 * keff : 30000 + 500 * keff;
+        return n >= need && n_searches >= i8_resume_at;
     }
     // counters of the last fast-path search (bench / tests)
     int64_t st_candidates = 0, st_overflows = 0, st_expansions = 0, st_fast_queries = 0, st_strict_queries = 0;
@@ -187,11 +191,17 @@ struct FlatIndex : comet_index {
             c->zero(Xh.p, tiles * 256 * ldh * 2);
             rn.reserve(std::max<size_t>(1, nk) * 4, c->stream, 0);
             launch_to_half_rows(c, X.as<float>(), (int64_t)nk, ld, Xh.p, ldh, 0, rn.as<float>(), nullptr);
-            if (X8.p) {   // and the int8 one (the residual maximum stays: it is an upper bound for the surviving rows)
+            if (X8.p) {   // and the int8 one: compaction regroups the rows into other tiles, i.e. other scales — the residual maximum is measured anew
                 X8.reserve(tiles * 256 * ld8, c->stream, 0);
                 c->zero(X8.p, tiles * 256 * ld8);
                 sx.reserve(tiles * 4, c->stream, 0);
-                launch_to_i8_tiles(c, X.as<float>(), (int64_t)nk, ld, X8.p, ld8, 0, sx.as<float>(), nullptr);
+                stats_dev.reserve(16, c->stream, 0);
+                c->zero(stats_dev.p, 16);
+                launch_to_i8_tiles(c, X.as<float>(), (int64_t)nk, ld, X8.p, ld8, 0, sx.as<float>(), stats_dev.as<uint32_t>());
+                uint32_t hs[4] = {0, 0, 0, 0};
+                c->d2h(hs, stats_dev.p, 16);
+                HIP_CHECK(hipStreamSynchronize(c->stream));
+                std::memcpy(&xmax_err2, &hs[2], 4);
             }
             HIP_CHECK(hipStreamSynchronize(c->stream));
         }
@@ -239,7 +249,7 @@ struct FlatIndex : comet_index {
         ScratchMark sm(c);
         // key units: the scan emits, per query, 2 keys + 1 bound for every 128-row unit (64-row units on the narrow tile for <= 64 queries
         // and where 128-row units would often be expanded: small indexes / large k)
-        const bool i8 = i8_usable(bn) && X8.p != nullptr;
+        const bool i8 = i8_usable(bn, (p.k <= 0 || p.k > n) ? n : p.k) && X8.p != nullptr;
         const int unit_rows = flat_fast_unit_rows(bn, n, p.k, i8 ? ld8 / 2 : ldh);
         const int64_t n_tiles = ceil_div(n, flat_fast_tile_rows()) * (flat_fast_tile_rows() / unit_rows);
         const int64_t ldS = round_up(2 * n_tiles, 16), ldB = round_up(n_tiles, 16);

@@ -98,7 +98,7 @@ def test_i8_hostile_rows(ctx, metric):
 def test_i8_backs_off_where_it_is_too_coarse(ctx):
     """High-dimensional rows whose distances to a query all sit within the int8 bound of each other: the int8 slice proposes (nearly)
     everything, the index switches to the fp16 shadow for the following searches — and every result is the strict one."""
-    n, d, B, k = 30000, 512, 80, 10
+    n, d, B, k = 90000, 256, 80, 10                         # auto mode screens on int8 from 60 000 + 1500 k rows (wide tile)
     rng = np.random.default_rng(7)
     X = (np.float32(1.0) + np.float32(1e-3) * rng.standard_normal((n, d))).astype(np.float32)   # all rows within ~0.03 of each other
     Q = (np.float32(1.0) + np.float32(1e-3) * rng.standard_normal((B, d))).astype(np.float32)

@@ -108,10 +108,12 @@ int main(int argc, char** argv) {
             }
         }
         printf("variant %d: %s (max |key - float64| = %.2e)\n", variant, bad ? "MISMATCH" : "ok", maxerr);
-        if (dtrace && variant == 0) {
+        if (dtrace && (variant == 0 || variant == 8) && B > 64) {
             std::vector<unsigned long long> t(8 * 32 * 4 + 64);
             HIP_CHECK(hipMemcpy(t.data(), dtrace, t.size() * 8, hipMemcpyDeviceToHost));
-            const int nk = ldh / 64;
+            HIP_CHECK(hipMemset(dtrace, 0, (8 * 32 * 4 + 64) * 8));
+            const int nk = variant == 8 ? ld8 / 128 : ldh / 64;
+            printf("TRACE of variant %d (%d K steps per tile)\n", variant, nk);
             for (int w : {0, 4}) {
                 for (int g = 0; g < 2 * nk && g < 31; g++) {
                     const unsigned long long* p = &t[(w * 32 + g) * 4]; const unsigned long long nxt = t[(w * 32 + g + 1) * 4];
