@@ -1501,7 +1501,8 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
     TR(0);
     int cnt = 0, cnt_anchor = 0;
     // ---- 2. candidates ----
-    auto collect = [&](const float tau_c, const bool expand_ok) {
+    // rows with key <= tau_c, except the emitted rows with key <= key_lo (phase 0 holds those already, -1: none); at most cap of them
+    auto collect = [&](const float tau_c, const bool expand_ok, const float key_lo, const int cap) {
     auto candidates_of = [&](long t0, float bnd, float k0, float k1) {
         const long tl = t0 + t;
         const bool live = tl < n_tiles;
@@ -1513,18 +1514,21 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
             const long te = t0 + (t & ~63) + src;      // tile of lane `src`
             if (lane == src) atomicAdd(&s_exp, 1);
             const typename GEOM::Unit U = geom.unit(te);
+            const float e0 = __shfl(k0, src, 64), e1 = __shfl(k1, src, 64);     // the unit's emitted keys: phase 0 took those <= key_lo
+            const int r0 = e0 <= key_lo ? (int)(__float_as_uint(e0) & (unsigned)(unit_rows - 1)) : -1;
+            const int r1 = e1 <= key_lo ? (int)(__float_as_uint(e1) & (unsigned)(unit_rows - 1)) : -1;
             for (int j = lane; j < unit_rows; j += 64)
-                post_append(geom.ok(U, j), (unsigned)(te * unit_rows + j), lst, &s_cnt, POST_CAP);
+                post_append(geom.ok(U, j) && j != r0 && j != r1, (unsigned)(te * unit_rows + j), lst, &s_cnt, cap);
         }
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const float key = (live && !expand) ? (e ? k1 : k0) : INF;
-            post_append(key <= tau_c && key != INF, (unsigned)(tl * unit_rows + (__float_as_uint(key) & (unsigned)(unit_rows - 1))), lst, &s_cnt, POST_CAP);
+            post_append(key <= tau_c && key > key_lo && key != INF, (unsigned)(tl * unit_rows + (__float_as_uint(key) & (unsigned)(unit_rows - 1))), lst, &s_cnt, cap);
         }
     };
     if (hier_done) {                                     // the two-level path collected them already
     } else if constexpr (DENSE) {                        // every position whose approximate distance is within tau
-        for_keys_idx([&](float v, int i) { post_append(v <= tau_c && v != INF, (unsigned)i, lst, &s_cnt, POST_CAP); });
+        for_keys_idx([&](float v, int i) { post_append(v <= tau_c && v != INF, (unsigned)i, lst, &s_cnt, cap); });
     } else if (reg) {
 #pragma unroll
         for (int j = 0; j < POST_RU; j++) if ((long)j * POST_THREADS < n_tiles) candidates_of((long)j * POST_THREADS, breg[j], kreg[j][0], kreg[j][1]);
@@ -1629,10 +1633,15 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
         } else rescore(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{}, F{});
         __syncthreads();
     };
+    // phase 0's rows and scores wait behind the score array (the 16 KiB the slot geometries use for their slots): they are not collected or
+    // rescored a second time, the final order merges them
+    constexpr int POST_ACAP = 2048;
+    unsigned* lstA = slotv; float* scA = reinterpret_cast<float*>(slotv + POST_ACAP);
+    float key_lo = -1.0f;                                // keys are >= 0
     if (anchor) {                                        // phase 0: the rows under kappa, exactly (no order needed, no expansions)
-        collect(kappa_v, false);
+        collect(kappa_v, false, -1.0f, POST_CAP);
         cnt = s_cnt;
-        if (cnt <= POST_CAP && cnt >= kappa_rank) {      // (more than POST_CAP: mass ties at kappa — the plain threshold decides)
+        if (cnt <= POST_ACAP && cnt >= kappa_rank) {     // (more: mass ties at kappa — the plain threshold decides)
         if constexpr (GEOM::kSlots) {
             for (int i = t; i < cnt; i += POST_THREADS) slotv[i] = (unsigned)geom.slot_of(lst[i]);
             __syncthreads();
@@ -1652,7 +1661,8 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
         if constexpr (METRIC == COMET_L2) u = u * u * 1.0000005f;
         const float tau_a = u + err_abs[q] + 1.0e-4f * fabsf(u) + 1e-30f;
         if (tau_a < tau) tau = tau_a;
-        cnt_anchor = cnt;
+        cnt_anchor = cnt; key_lo = kappa_v;
+        for (int i = t; i < cnt; i += POST_THREADS) { lstA[i] = lst[i]; scA[i] = sc[i]; }
         }
         __syncthreads();
         if (t == 0) s_cnt = 0;
@@ -1661,10 +1671,10 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
         if (reg) load_keys();
         __syncthreads();
     }
-    collect(tau, true);
+    collect(tau, true, key_lo, POST_CAP - cnt_anchor);
     TR(1);
     cnt = s_cnt;
-    if (cnt > POST_CAP) {                              // empty row; the host re-runs this query on the strict path
+    if (cnt > POST_CAP - cnt_anchor) {                 // empty row; the host re-runs this query on the strict path
         for (int i = t; i < k_cap; i += POST_THREADS) { out_ids[(long)q * k_cap + i] = 0u; out_scores[(long)q * k_cap + i] = 0.0f; }
         if (t == 0) { out_counts[q] = 0; overflow[q] = 1; if (stats) atomicAdd(&stats[1], 1); }
         return;
@@ -1682,14 +1692,19 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
     rescore_all();
     TR(3);
     // ---- 4. final order: (score, row position) ----
+    // unit-key geometries: the composite's low word is the ROW (= position; ascending row is what the index in the row-sorted list stood
+    // for), so that phase 0's rows merge in; slot geometries keep the index (their slot sits in slotv[index])
     unsigned long long* comp = reinterpret_cast<unsigned long long*>(psm);   // POST_CAP composites (32 KiB) over the slices
+    const int tot = cnt + cnt_anchor;
+    int n3 = n2; while (n3 < tot) n3 <<= 1;
     int mine = 0;
-    for (int i = t; i < n2; i += POST_THREADS) {
+    for (int i = t; i < n3; i += POST_THREADS) {
         unsigned long long v = ~0ull;
-        if (i < cnt) {
-            const unsigned bits = __float_as_uint(sc[i]);
-            const bool ok = !(thr > 0.0f && sc[i] > thr);                    // `s.threshold > 0 && dist > s.threshold`
-            if (ok) { v = ((unsigned long long)pf2key(bits) << 32) | (unsigned)i; mine++; }
+        if (i < tot) {
+            const float sv = i < cnt ? sc[i] : scA[i - cnt];
+            const unsigned low = GEOM::kSlots ? (unsigned)i : (i < cnt ? lst[i] : lstA[i - cnt]);
+            const bool ok = !(thr > 0.0f && sv > thr);                       // `s.threshold > 0 && dist > s.threshold`
+            if (ok) { v = ((unsigned long long)pf2key(__float_as_uint(sv)) << 32) | low; mine++; }
         }
         comp[i] = v;
     }
@@ -1697,7 +1712,7 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
     __syncthreads();
     if (mine) atomicAdd(&s_valid, mine);
     __syncthreads();
-    post_sort(comp, cnt, n2, comp + POST_CAP);           // second half of the 64 KiB key area as scratch
+    post_sort(comp, tot, n3, comp + POST_CAP);           // second half of the 64 KiB key area as scratch
     const int valid = s_valid;
     const int kq = (K <= 0 || K > valid) ? valid : K;                          // sanitizeK limiter.go:12-17
     const int nw = kq < k_cap ? kq : k_cap;
@@ -1706,7 +1721,7 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
             const unsigned long long cc = comp[i];
             const unsigned ci = (unsigned)(cc & 0xFFFFFFFFull);
             long slot;
-            if constexpr (GEOM::kSlots) slot = (long)slotv[ci]; else slot = (long)lst[ci];
+            if constexpr (GEOM::kSlots) slot = (long)slotv[ci]; else slot = (long)ci;
             out_ids[(long)q * k_cap + i] = geom.id_of(slot);     // VectorResult.Node.ID()
             out_scores[(long)q * k_cap + i] = __uint_as_float(pkey2f((unsigned)(cc >> 32)));
         } else {
@@ -1730,8 +1745,9 @@ void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const fl
     static unsigned long long* trace = [] { unsigned long long* p = nullptr; if (getenv("COMET_POST_TRACE")) { HIP_CHECK(hipMalloc(&p, 64)); HIP_CHECK(hipMemset(p, 0, 64)); } return p; }();
     ProfScope ps(c, "flat_post");
     const FlatGeom geom{(long)n_tiles, unit_rows, (long)n, (const unsigned char*)elig, ids_table};
-#define POST(M) do { HIP_CHECK(hipFuncSetAttribute((const void*)fast_post_kernel<M, FlatGeom>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POST_LDS)); \
-        fast_post_kernel<M, FlatGeom><<<dim3(B), dim3(POST_THREADS), POST_LDS, c->stream>>>(geom, S0, ldS, bound, ldB, err_abs, K, kappa_rank, thr, X, ld, Qp, \
+    const size_t lds_flat = POST_LDS + (size_t)POST_CAP * 4;     // + phase 0's rows and scores
+#define POST(M) do { HIP_CHECK(hipFuncSetAttribute((const void*)fast_post_kernel<M, FlatGeom>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_flat)); \
+        fast_post_kernel<M, FlatGeom><<<dim3(B), dim3(POST_THREADS), lds_flat, c->stream>>>(geom, S0, ldS, bound, ldB, err_abs, K, kappa_rank, thr, X, ld, Qp, \
                                                                                  zflag, out_ids, out_scores, out_counts, k_cap, overflow, stats, trace); } while (0)
     switch (metric) { case COMET_L2: POST(COMET_L2); break; case COMET_L2SQ: POST(COMET_L2SQ); break; default: POST(COMET_COSINE); break; }
 #undef POST
