@@ -566,12 +566,12 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_q8_kernel(const _Float16
     std::conditional_t<I8, i32x16, f32x16> acc[8];
     // ---- row slabs: each wave moves 4 pieces (8 rows x 128 B) per K step, XOR swizzle on the source side ----
     const int prow = lane >> 3, pslot = lane & 7;
-    int poff[4], ldsoff[4];                                   // byte offset of the piece inside a (tile, K step) slab pair / inside the ring stage
+    unsigned poff[4]; int ldsoff[4];                          // byte offset of the piece inside a (tile, K step) slab pair / inside the ring stage
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int r = (wid * 4 + i) * 8 + prow;
         const int ks = pslot ^ ((r >> 1) & 7);
-        poff[i] = ((ks >> 2) * 256 + r) * 64 + (ks & 3) * 16;
+        poff[i] = (unsigned)(((ks >> 2) * 256 + r) * 64 + (ks & 3) * 16);
         ldsoff[i] = (wid * 4 + i) * 8 * 128;
     }
     const long tile_bytes = (long)(ldh >> 5) * 256 * 64;       // fp16 shadow bytes of one 256-row tile
@@ -584,7 +584,9 @@ __global__ __launch_bounds__(FB_THREADS) void flat_scan_q8_kernel(const _Float16
     auto pre_advance = [&]() { pre_ptr += 256 * 128; if (++pre_kt == nk) { pre_kt = 0; pre_ptr += tile_jump; } };
     auto stage_piece = [&](long g, int i) {
         unsigned char* xb = smem + (g & (FQ_STAGES - 1)) * FQ_STAGE_BYTES;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre_ptr + poff[i]), (__attribute__((address_space(3))) void*)(xb + ldsoff[i]), 16, 0, FAST_ROW_AUX);
+        unsigned po = poff[i];
+        asm volatile("" : "+v"(po));          // the 64-bit lane address is formed here, per piece: hoisted, the four zero-extended pairs cost 8 registers
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pre_ptr + po), (__attribute__((address_space(3))) void*)(xb + ldsoff[i]), 16, 0, FAST_ROW_AUX);
     };
     // ---- query fragments: [wave][K step][ks][lane] 16-byte pieces, 4 KiB contiguous per (wave, K step); the same for every tile ----
     const char* qbase = reinterpret_cast<const char*>(QF) + ((long)wid * nk) * 4096 + lane * 16;
