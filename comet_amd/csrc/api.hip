@@ -8,7 +8,11 @@ namespace {
 void check_metric(int m) { if (m < COMET_L2 || m > COMET_COSINE) COMET_FAIL(COMET_ERR_UNKNOWN_METRIC, "unknown distance kind"); }  // distance.go:9
 struct CallGuard {   // serialise calls on a context, bind the device, reset the per-call scratch arena
     Ctx* c; std::unique_lock<std::recursive_mutex> lk;
-    explicit CallGuard(Ctx* c_) : c(c_), lk(c_->mu) { c->bind(); c->scratch_reset(); }
+    // every call but an asynchronous search: lane 0, and lane 1 idle first (the call may change what a search in flight there reads)
+    explicit CallGuard(Ctx* c_) : c(c_), lk(c_->mu) { c->bind(); c->switch_lane(0); c->quiesce_alt(); c->scratch_reset(); }
+    // an asynchronous search enqueued on `lane` (its stream, its scratch arena); lane 0 is current again when the guard goes
+    CallGuard(Ctx* c_, int lane) : c(c_), lk(c_->mu) { c->bind(); c->switch_lane(lane); c->scratch_reset(); }
+    ~CallGuard() { if (c->cur_lane != 0) { c->alt_dirty = true; c->switch_lane(0); } }
 };
 }  // namespace
 
@@ -50,9 +54,14 @@ int comet_ctx_destroy(comet_ctx* c) {
     return guarded([&] {
         if (!c) return COMET_OK;
         c->bind();
+        c->switch_lane(0);
         (void)hipStreamSynchronize(c->stream);
+        if (c->alt.stream) (void)hipStreamSynchronize(c->alt.stream);
         c->collect_profile();
         c->scratch_reset();
+        for (void* r : c->alt.retired) (void)hipFree(r);
+        if (c->alt.scratch) (void)hipFree(c->alt.scratch);
+        if (c->alt.stream) (void)hipStreamDestroy(c->alt.stream);
         if (c->scratch) (void)hipFree(c->scratch);
         if (c->pinned) (void)hipHostFree(c->pinned);
         (void)hipStreamDestroy(c->stream);
@@ -195,7 +204,7 @@ int comet_ivfpq_create(comet_ctx* c, int dim, int metric, int nlist, int M, int 
     });
 }
 int comet_index_destroy(comet_index* idx) {
-    return guarded([&] { if (!idx) return (int)COMET_OK; Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); (void)hipStreamSynchronize(c->stream); delete idx; return (int)COMET_OK; });
+    return guarded([&] { if (!idx) return (int)COMET_OK; Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->quiesce_all(); delete idx; return (int)COMET_OK; });
 }
 int comet_index_kind(const comet_index* idx) { return idx->kind; }
 int comet_index_dim(const comet_index* idx) { return idx->dim; }
@@ -318,7 +327,10 @@ int comet_index_search_dev_async(comet_index* idx, const float* queries_dev, int
         check_search_args(idx, B, p, k_cap);
         if (out_ticket) *out_ticket = 0;
         if (B == 0) return (int)COMET_OK;
-        CallGuard g(idx->c);
+        // every other asynchronous search of an index goes to the context's second lane (Ctx::alt)
+        int lane = 0;
+        { std::lock_guard<std::recursive_mutex> lk(idx->c->mu); if (idx->c->lanes > 1 && idx->lanes_ok()) lane = (idx->lane_toggle ^= 1); }
+        CallGuard g(idx->c, lane);
         uint64_t t = idx->search_begin(queries_dev, B, *p, out_ids_dev, out_scores_dev, out_counts_dev, k_cap);
         if (out_ticket) *out_ticket = t;
         return (int)COMET_OK;

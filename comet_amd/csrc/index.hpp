@@ -29,7 +29,7 @@ struct comet_index {
     // ranks of the communicator (the stage-1 bound exchange of the sharded two-stage IVFPQ search); null outside a sharded search
     void (*bound_exchange)(void* user, uint32_t* tq, int n) = nullptr; void* bound_exchange_user = nullptr;
 
-    virtual ~comet_index() {}
+    virtual ~comet_index() { for (auto& r : done_ring) if (r.ev) (void)hipEventDestroy(r.ev); }
     virtual int64_t size() const = 0;
     virtual int default_nprobes() const { return 0; }
     virtual void train_dev(const float* /*vecs_dev*/, int64_t /*n*/) {}   // VectorIndex.Train; no-op for Flat (flat_index.go:150)
@@ -49,9 +49,28 @@ struct comet_index {
     // asynchronous form: begin enqueues the search and returns a ticket; finish(ticket) makes the results final
     // (index kinds without deferred work run everything in begin)
     virtual uint64_t search_begin(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
-                                  int32_t* out_counts, int k_cap) { search_dev(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap); return 0; }
+                                  int32_t* out_counts, int k_cap) { search_dev(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap); return record_done(); }
     // returns true if it had to enqueue further device work (the Flat fast path's rare strict re-run)
-    virtual bool search_finish(uint64_t /*ticket*/) { return false; }
+    virtual bool search_finish(uint64_t ticket) { wait_done(ticket); return false; }
+    // may this kind's asynchronous searches alternate between the context's two execution lanes? (a search must then touch nothing
+    // persistent on the device except read-only index data, its own ring slot and per-lane buffers)
+    virtual bool lanes_ok() const { return false; }
+    int lane_toggle = 0;
+    // completion tickets of the index kinds without deferred work: an event behind the search on the stream it was enqueued on
+    struct DoneEv { uint64_t ticket = 0; hipEvent_t ev = nullptr; bool active = false; };
+    DoneEv done_ring[8]; uint64_t done_next = 1;
+    uint64_t record_done() {
+        DoneEv* slot = nullptr;
+        for (auto& r : done_ring) if (!r.active) { slot = &r; break; }
+        if (!slot) { slot = &done_ring[0]; for (auto& r : done_ring) if (r.ticket < slot->ticket) slot = &r; HIP_CHECK(hipEventSynchronize(slot->ev)); }
+        if (!slot->ev) HIP_CHECK(hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(slot->ev, c->stream));
+        slot->ticket = done_next++; slot->active = true;
+        return slot->ticket;
+    }
+    void wait_done(uint64_t ticket) {
+        for (auto& r : done_ring) if (r.active && r.ticket == ticket) { HIP_CHECK(hipEventSynchronize(r.ev)); r.active = false; return; }
+    }
     virtual int64_t list_size(int /*list*/) const { return size(); }
     virtual void list_read(int /*list*/, uint32_t* /*ids*/, uint8_t* /*codes*/, float* /*vecs*/) const {}
     virtual void export_all(uint32_t* /*ids*/, int32_t* /*lists*/, uint8_t* /*codes*/) const { COMET_FAIL(COMET_ERR_UNSUPPORTED, "export not supported for this index kind"); }
@@ -65,6 +84,7 @@ struct comet_index {
     // sorted device copy of the soft-delete set (rebuilt lazily)
     const uint32_t* deleted_sorted_dev() {
         if (deleted_dirty) {
+            c->quiesce_all();      // a search in flight on either lane may still be reading the list that is about to be replaced
             std::vector<uint32_t> v(deleted.begin(), deleted.end());
             std::sort(v.begin(), v.end());
             deleted_dev.reserve(std::max<size_t>(4, v.size() * 4), c->stream, 0);

@@ -208,7 +208,8 @@ struct IVFIndex : comet_index {
     // fp16 shadow for the MFMA fast path (kernels_ivf.hip): slot-ordered rows, squared norms per slot, magnitude statistics;
     // rebuilt lazily when the slot layout was recompiled (shadow_version != lay.version)
     int ldh = 0;
-    DevBuf Vh, rn_slot, stats_dev, scan_counts;
+    DevBuf Vh, rn_slot, stats_dev, scan_counts[2];       // scan_counts: written by every search's item builder — one per execution lane
+    int last_lane = 0;
     uint64_t shadow_version = 0;
     float xmax_abs = 0.0f, xmax_norm2 = 0.0f;
     // int8 shadow (one scale per 64-slot unit; kernels_ivf.hip ivf_shadow_i8_kernel): half the bytes of the HBM-bound scan. Policy as in
@@ -246,6 +247,7 @@ struct IVFIndex : comet_index {
     }
 
     int64_t size() const override { return lay.n; }
+    bool lanes_ok() const override { return true; }      // searches write scratch, their ring slot / per-lane counters and (opt-in) atomics only
     int default_nprobes() const override { return (int)std::sqrt((double)nlist); }   // ivf_index.go:406-413
     bool contains_id(uint32_t id) const override { return lay.id_count.count(id) != 0; }
     void export_all(uint32_t* oids, int32_t* olists, uint8_t*) const override {
@@ -480,8 +482,9 @@ struct IVFIndex : comet_index {
         const int64_t imax = ceil_div(P, 64) * ceil_div(std::max(lay.max_len, 1), 256) + lay.total_tiles256 + 1;
         void* groups = c->scratch_alloc((size_t)gmax * ivf_group_bytes());
         void* items = c->scratch_alloc((size_t)imax * ivf_item_bytes());
-        scan_counts.reserve(16, c->stream, 0);
-        int32_t* counts = scan_counts.as<int32_t>();       // persistent: get_stat reads the last launch's figures
+        DevBuf& sc_buf = scan_counts[c->cur_lane]; last_lane = c->cur_lane;
+        sc_buf.reserve(16, c->stream, 0);
+        int32_t* counts = sc_buf.as<int32_t>();            // persistent: get_stat reads the last launch's figures
         launch_ivf_items(c, probe_list, np, np, uoff, (int)P, nlist, lay.list_len.as<int32_t>(), lay.list_base.as<int64_t>(), groups, items, counts);
         float* D = c->salloc<float>((size_t)bn * ldD);
         float* umin = c->salloc<float>((size_t)bn * umax);          // per (query, unit): the unit's smallest approximate distance
@@ -598,7 +601,7 @@ struct IVFIndex : comet_index {
         else if (k == "max_list_len") { const_cast<ListLayout&>(lay).compile(c); *out = (double)lay.max_len; }
         else if (k == "ivf_scan_rows" || k == "ivf_scan_items") {       // rows the last fast slice's scan streamed (x ldh x 2 = its algorithmic bytes) / its work items
             int32_t h[4] = {0, 0, 0, 0};
-            if (scan_counts.p) { c->d2h(h, scan_counts.p, 16); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+            if (scan_counts[last_lane].p) { c->quiesce_all(); c->d2h(h, scan_counts[last_lane].p, 16); HIP_CHECK(hipStreamSynchronize(c->stream)); }
             *out = k == "ivf_scan_rows" ? (double)h[2] * 64.0 : (double)h[0];
         }
         else return false;
@@ -699,6 +702,7 @@ struct PQFamilyIndex : comet_index {
     ListLayout lay;
 
     int64_t size() const override { return lay.n; }
+    bool lanes_ok() const override { return true; }      // searches write scratch, their ring slot / per-lane counters and (opt-in) atomics only
     int default_nprobes() const override { return ivf ? (int)std::sqrt((double)nlist) : 0; }   // ivfpq_index.go:442-449
     bool contains_id(uint32_t id) const override { return lay.id_count.count(id) != 0; }
 
