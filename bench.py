@@ -54,6 +54,7 @@ CORPUS_SEED, QUERY_SEED = 0xC0FFEE + 2, 0xBEEF + 2
 # a query's true neighbours are the rows of its own sub-centre
 MIX_SEED, MIX_CENTERS, MIX_SIGMA, MIX_SUB, MIX_NOISE = 0xC0FFEE + 4, 2048, 0.15, 65536, 0.02
 HBM_PEAK_GBS = 8000.0
+LANES = max(1, min(2, int(os.environ.get("COMET_LANES", "2"))))    # execution lanes of the timed regions (the library's default: 2)
 NQB = 8               # distinct query batches a leg rotates through
 DTYPE = ("f32 results: every returned score is the reference's serial float32 sum (bit-identical to the CPU path); candidates are "
          "screened on int8 MFMA (v_mfma_i32_32x32x32_i8, exact int32 accumulate; fp16 v_mfma_f32_32x32x16_f16 where int8 is too coarse for the "
@@ -140,16 +141,22 @@ class Timer:
 def timed(ctx, timer, step, args, dominant):
     """Timed regions with HIP events around the DOMINANT kernel only (every timed scope is two event records — barrier packets —
     and ~10 us of dispatch latency in a chain of short kernels; with all scopes timed a Flat step is 6 % slower), then one
-    untimed region with every scope timed for the per-kernel breakdown. Returns (median s, region times, dominant-kernel
-    profile of the timed regions, per-kernel ms per step of the breakdown region)."""
+    untimed region with every scope timed for the per-kernel breakdown. The timed regions run as the library runs by default: two
+    execution lanes, the two batches in flight on two streams — a kernel's event-to-event duration there includes what it shares
+    the GPU with. The breakdown region runs on ONE lane, where a kernel's duration is its own. Returns (median s, region times,
+    dominant-kernel profile of the timed regions, {kernel: (total ms, launches)} of the one-lane region)."""
     ctx.profile_only(dominant); ctx.profile(True); ctx.profile_reset()
     med, times = timer.run(step, args.steps, args.warmup, args.regions)
     prof = ctx.profile_dump()
     ctx.profile_only(None); ctx.profile_reset()
+    ctx.set_lanes(1)
+    step(2)
+    ctx.sync(); ctx.profile_reset()
     step(args.steps)
     ctx.sync()
     allk = ctx.profile_dump(); ctx.profile(False)
-    return med, times, prof, {k: round(v[0] / args.steps, 4) for k, v in sorted(allk.items())}
+    ctx.set_lanes(LANES)
+    return med, times, prof, allk
 
 
 def measure(ctx, timer, args, step, dominant, B):
@@ -158,8 +165,28 @@ def measure(ctx, timer, args, step, dominant, B):
     n_sus, el_sus = timer.sustained(step, args.steps, med, args.sustain_s)
     rec = {"qps": B * args.steps / med, "ms_per_step": med / args.steps * 1e3, "region_ms": [round(t * 1e3, 3) for t in times],
            "sustained": {"seconds": round(el_sus, 3), "steps": n_sus, "qps": B * n_sus / el_sus, "ms_per_step": el_sus / n_sus * 1e3},
-           "kernels_ms_per_step": allk}
+           "execution_lanes": LANES,
+           "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(allk.items())},
+           "kernels_ms_per_step_are": "per-kernel HIP-event durations of a region of their own on ONE execution lane (each kernel alone on the GPU)"}
+    prof = dict(prof); prof["__one_lane__"] = allk
     return rec, prof, med, times
+
+
+def one_lane_stats(prof, name):
+    """(average ms, launches) of a kernel in the one-lane region: its duration with the GPU to itself"""
+    ms, n = (prof.get("__one_lane__") or {}).get(name, (0.0, 0))
+    return (ms / n if n else 0.0), n
+
+
+ROOFLINE_MEASURED = ("HIP events on the kernel's own dispatch in a timed region of this run on ONE execution lane (the kernel alone on the GPU); in the regions "
+                     "`value` is measured on, the two batches in flight run on two streams and a kernel's event-to-event duration includes what it shares "
+                     "the GPU with: `in_value_regions`")
+
+
+def in_value_regions(prof, name, alg_bytes):
+    avg, n = kernel_stats(prof, name)
+    ach = alg_bytes / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+    return {"avg_kernel_ms": avg, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "launches": n, "execution_lanes": LANES}
 
 
 def host_buffers_qps(fn, B, reps=5):
@@ -224,7 +251,7 @@ def flat_roofline(prof, rows_local, dim, nq):
     """roofline of the scan kernel the timed regions actually ran: the int8 shadow (1 byte per dimension, rows padded to 256) or the fp16 one"""
     cands = ("flat_scan_i8_n64", "flat_scan_f16_n64") if nq <= 64 else ("flat_scan_i8", "flat_scan_f16")
     name = next((c for c in sorted(cands, key=lambda c: -prof.get(c, (0.0, 0))[1]) if c in prof), "dist_exact")
-    avg_ms, n = kernel_stats(prof, name)
+    avg_ms, n = one_lane_stats(prof, name)
     extra = {}
     if name.startswith("flat_scan"):
         qtile = 64 if name.endswith("n64") else 256
@@ -241,7 +268,8 @@ def flat_roofline(prof, rows_local, dim, nq):
     traffic, src = pmc_traffic(name, rows_local)
     return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "avg_kernel_ms": avg_ms, "launches": n,
-            "algorithmic_bytes_per_launch": alg, "fp32_rows_bytes_per_pass": rows_local * dim * 4, **extra}
+            "algorithmic_bytes_per_launch": alg, "fp32_rows_bytes_per_pass": rows_local * dim * 4, **extra,
+            "measured": ROOFLINE_MEASURED, "in_value_regions": in_value_regions(prof, name, alg)}
 
 
 def threads_map(fn, n_items, T):
@@ -470,6 +498,7 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
         list_len = np.bincount(e_lists, minlength=nlist)
         out.update({"max_list_len": int(list_len.max()), "mean_list_len": float(list_len.mean())})
         if every_candidate:
+            ctx.set_lanes(1)                                      # the kernel's own rate: one scan at a time on the GPU
             p1 = Pipe(ctx, idx, q_ptrs, B, K, None, nprobes=args.nprobe, mode=1)
             p1.step(2)
             ex_steps = max(3, args.steps // 2)
@@ -484,6 +513,7 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
             ex_prof = ctx.profile_dump(); ctx.profile_only(None); ctx.profile(False)
             x = p1.results_of(0)
             p1.free()
+            ctx.set_lanes(LANES)
             adc_ms = ex_prof.get("adc_scan", (0.0, 0))[0] / ex_steps
             phys = code_bytes + table_bytes
             same = bool(np.array_equal(x[2], g[2]) and all(np.array_equal(x[0][b, :g[2][b]], g[0][b, :g[2][b]]) and
@@ -502,7 +532,7 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
             traffic, src = pmc_traffic("adc_scan", n)
             out["every_candidate_search"] = {"qps": B / ex_el, "ms_per_step": ex_el * 1e3, "steps": ex_steps, "adc_scan_ms": adc_ms, "identical_to_pruned_search": same,
                                              "candidates_per_query": cand}
-            out["roofline"] = {"bound": "hbm", "kernel": "adc_scan", "measured_on": "the every-candidate search (mode 1): the pruned search's launches see only what the lower bound left",
+            out["roofline"] = {"bound": "hbm", "kernel": "adc_scan", "measured_on": "the every-candidate search (mode 1) on one execution lane: the pruned search's launches see only what the lower bound left, and two lanes would overlap two scans",
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                                "avg_kernel_ms": adc_ms,
                                "algorithmic_bytes_per_launch": must,
@@ -612,7 +642,7 @@ def leg_hybrid(ctx, ca, args, timer, q_ptrs, Q0):
         g = pipe.results_of(0)
         scan_rows = ivf.stat("ivf_scan_rows")
         kname = "ivf_scan_i8" if prof.get("ivf_scan_i8", (0.0, 0))[1] >= prof.get("ivf_scan_f16", (0.0, 0))[1] and "ivf_scan_i8" in prof else "ivf_scan_f16"
-        avg_ms, nl = kernel_stats(prof, kname)
+        avg_ms, nl = one_lane_stats(prof, kname)
         row_bytes = (d + 127) // 128 * 128 if kname == "ivf_scan_i8" else ldh * 2
         alg = scan_rows * row_bytes
         ach = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -620,7 +650,8 @@ def leg_hybrid(ctx, ca, args, timer, q_ptrs, Q0):
         rec["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_source": src, "avg_kernel_ms": avg_ms, "launches": nl, "algorithmic_bytes_per_launch": alg,
                            "algorithmic_bytes_are": ("int8" if kname == "ivf_scan_i8" else "fp16") + " shadow rows of every probed list, once per group of <= 64 of its "
-                                                    f"queries (counted by the kernel that lays out the work: {int(scan_rows)} rows of query batch 0) x {row_bytes} bytes"}
+                                                    f"queries (counted by the kernel that lays out the work: {int(scan_rows)} rows of query batch 0) x {row_bytes} bytes",
+                           "measured": ROOFLINE_MEASURED, "in_value_regions": in_value_regions(prof, kname, alg)}
         rec["fast_path"] = {k: ivf.stat(k) for k in ("fast_queries", "strict_queries", "fast_candidates", "fast_overflows", "i8_slices", "i8_backoffs")}
         x = pipe.results_of(0, mode=1)                                                     # the exact kernels (search mode 1) on the same batch
         rec["identical_to_exact_kernels"] = bool(np.array_equal(x[2], g[2]) and np.array_equal(x[0], g[0]) and np.array_equal(x[1].view(np.uint32), g[1].view(np.uint32)))

@@ -84,6 +84,7 @@ def load() -> C.CDLL:
         "comet_profile_enable": (i32, [p, i32]),
         "comet_profile_reset": (i32, [p]),
         "comet_profile_only": (i32, [p, C.c_char_p]),
+        "comet_ctx_set_lanes": (i32, [p, i32]),
         "comet_profile_get": (i32, [p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
         "comet_profile_dump": (i32, [p, C.c_char_p, sz]),
         "comet_distance": (i32, [p, i32, p, p, i32, p]),

@@ -88,6 +88,13 @@ int comet_synth_mixture_dev(comet_ctx* c, uint64_t seed, int32_t n_centers, floa
     return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); launch_synth_mixture(c, seed, n_centers, sigma, n_sub, sigma_noise, row_base, n_rows, dim, out_dev); return COMET_OK; });
 }
 
+int comet_ctx_set_lanes(comet_ctx* c, int32_t lanes) {
+    return guarded([&] {
+        if (lanes < 1 || lanes > 2) COMET_FAIL(COMET_ERR_INVALID_ARG, "a context has 1 or 2 execution lanes");
+        std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->switch_lane(0); c->quiesce_all(); c->lanes = lanes;
+        return COMET_OK;
+    });
+}
 int comet_profile_enable(comet_ctx* c, int on) { return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->sync(); c->profile = on != 0; return COMET_OK; }); }
 int comet_profile_only(comet_ctx* c, const char* name) { return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->sync(); c->prof_only = name ? name : ""; return COMET_OK; }); }
 int comet_profile_reset(comet_ctx* c) { return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->sync(); c->prof.clear(); return COMET_OK; }); }

@@ -100,6 +100,10 @@ class Context:
     def profile(self, on: bool = True):
         check(self.lib.comet_profile_enable(self.h, 1 if on else 0))
 
+    def set_lanes(self, lanes: int) -> None:
+        """1 or 2 execution lanes: with 2 (the default) every other asynchronous search of an index runs on a second stream"""
+        check(self.lib.comet_ctx_set_lanes(self.h, int(lanes)))
+
     def profile_only(self, name: str | None) -> None:
         """time only the launches of one profiling scope (None: all of them)"""
         check(self.lib.comet_profile_only(self.h, (name or "").encode()))

@@ -81,10 +81,16 @@ COMET_API int comet_synth_fill_dev(comet_ctx* ctx, uint64_t seed, uint64_t offse
 COMET_API int comet_synth_mixture_dev(comet_ctx* ctx, uint64_t seed, int32_t n_centers, float sigma, int32_t n_sub, float sigma_noise,
                                       uint64_t row_base, uint64_t n_rows, int32_t dim, float* out_dev);
 
+/* Execution lanes of a context (1 or 2; default 2, or COMET_LANES): with two, every other asynchronous search of an index
+ * (comet_index_search_dev_async) is enqueued on a second stream with a scratch arena of its own, so that the short latency-bound kernels
+ * of one batch run beside the other batch's — results and the meaning of comet_index_search_wait are unchanged; every other call first
+ * waits for the second lane. Replaces nothing in the reference (a Go caller overlaps searches with goroutines); waits for both lanes. */
+COMET_API int comet_ctx_set_lanes(comet_ctx* ctx, int32_t lanes);
+
 /* per-kernel timing (HIP events recorded on the context's stream around each launch) */
 COMET_API int comet_profile_enable(comet_ctx* ctx, int on);
 COMET_API int comet_profile_reset(comet_ctx* ctx);
-/* time only the scopes called `name` (NULL or "": all). Every timed scope costs two event records — barrier packets in the
+/* time only the scopes named in the '|'-separated list `name` (NULL or "": all). Every timed scope costs two event records — barrier packets in the
  * stream — which is ~10 us in a chain of short dependent kernels; a benchmark times just the kernel its roofline is about. */
 COMET_API int comet_profile_only(comet_ctx* ctx, const char* name);
 /* total milliseconds and launch count of kernels whose name starts with `prefix` since the last reset */

@@ -7,7 +7,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$1; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 # COMET_ADC_ONE_STAGE=1: every adc_scan launch of the pass is the every-candidate scan the bench line's IVFPQ roofline is measured on
 # (the pruned search's launches read a few percent of that and would only dilute the per-launch average)
-RUN="env COMET_ADC_ONE_STAGE=1 python $GRAFT_REPO_ROOT/bench.py --legs flat,flat_l2,ivfpq,hybrid --docs 2000 --no-cpu-baseline --regions 1 --steps 3 --warmup 1 --sustain-s 0.05"
+RUN="env COMET_ADC_ONE_STAGE=1 COMET_LANES=1 python $GRAFT_REPO_ROOT/bench.py --legs flat,flat_l2,ivfpq,hybrid --docs 2000 --no-cpu-baseline --regions 1 --steps 3 --warmup 1 --sustain-s 0.05"
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
   i=$((i+1))

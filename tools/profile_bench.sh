@@ -6,7 +6,8 @@
 # Copy what should be judged into profiles/ afterwards. Every profiler run sits under its own timeout.
 T=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R && timeout 900 python bench.py 2> $O/${T}_bench.err | tail -1 > $O/${T}_bench_line.json
-CMD="python $R/bench.py --legs flat,flat_l2,ivfpq,hybrid,hnsw --hnsw-rows 20000 --docs 20000 --no-cpu-baseline --regions 2 --steps 10 --sustain-s 0.2"
+# one execution lane (COMET_LANES=1): a kernel's duration under the profiler is its own, as in the line's `roofline` (measured in a one-lane region)
+CMD="env COMET_LANES=1 python $R/bench.py --legs flat,flat_l2,ivfpq,hybrid,hnsw --hnsw-rows 20000 --docs 20000 --no-cpu-baseline --regions 2 --steps 10 --sustain-s 0.2"
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/rp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp -- $CMD > /tmp/rp.log 2>&1
 DB=$(find /tmp/rp -name "*.db" | head -1); CSV=$(find /tmp/rp -name "*kernel_stats.csv" | head -1)
 python $R/tools/rocprof_summary.py "${CSV:-$DB}" $O/${T}_bench_rocprofv3_kernel_stats.txt
