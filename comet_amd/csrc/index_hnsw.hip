@@ -467,6 +467,21 @@ struct HNSWIndex : comet_index {
     uint32_t entry_id = 0;
     bool del_dirty = true;
     uint64_t st_evals = 0, st_exp = 0;
+    // Asynchronous searches (round 3): search_begin enqueues the search with the LDS heaps sized for its efSearch and copies the overflow
+    // flag and the counters to pinned memory behind it; search_finish waits for the search's event and, if a query's live candidates
+    // outgrew the heap (rare), runs the whole search again synchronously with the escalation of search_dev. Nothing persistent is
+    // written on the device, so every other asynchronous search may use the context's second lane: at B = 256 a search occupies
+    // 256 waves — one per CU — and two of them run side by side.
+    struct Pending {
+        bool active = false; uint64_t ticket = 0; hipEvent_t ev = nullptr;
+        int B = 0, k_cap = 0; const float* queries = nullptr; comet_search_params p{}; std::vector<uint32_t> flt;
+        uint32_t* out_ids = nullptr; float* out_scores = nullptr; int32_t* out_counts = nullptr;
+        unsigned long long* host = nullptr;      // pinned: [0] evals, [1] expansions, [2] overflow flag
+    };
+    static constexpr int kRing = 8;
+    Pending ring[kRing]; uint64_t next_ticket = 1;
+    ~HNSWIndex() override { for (auto& r : ring) { if (r.ev) (void)hipEventDestroy(r.ev); if (r.host) (void)hipHostFree(r.host); } }
+    bool lanes_ok() const override { return true; }
 
     int64_t size() const override { return n; }
     bool contains_id(uint32_t id) const override { return id2idx.count(id) != 0; }
@@ -752,6 +767,7 @@ struct HNSWIndex : comet_index {
     const uint32_t* deleted_bitmap() {
         if (deleted.empty()) return nullptr;
         if (del_dirty || deleted_dirty) {
+            c->quiesce_all();      // a search in flight on either lane may still be reading the bitmap that is about to be replaced
             std::vector<uint32_t> bm((n + 31) / 32, 0);
             for (uint32_t id : deleted) { auto it = id2idx.find(id); if (it != id2idx.end()) bm[it->second >> 5] |= 1u << (it->second & 31); }
             del_bm.reserve(bm.size() * 4, c->stream, 0);
@@ -763,7 +779,38 @@ struct HNSWIndex : comet_index {
     }
     // hnswIndexSearch.searchSingleQuery hnsw_index_search.go:248-354
     void search_dev(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
-                    int32_t* out_counts, int k_cap) override {
+                    int32_t* out_counts, int k_cap) override { search_impl(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap, nullptr); }
+    uint64_t search_begin(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
+                          int32_t* out_counts, int k_cap) override {
+        Pending* slot = nullptr;
+        for (auto& r : ring) if (!r.active) { slot = &r; break; }
+        if (!slot) { slot = &ring[0]; for (auto& r : ring) if (r.ticket < slot->ticket) slot = &r; search_finish(slot->ticket); }
+        if (!slot->ev) HIP_CHECK(hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
+        if (!slot->host) HIP_CHECK(hipHostMalloc((void**)&slot->host, 32, hipHostMallocDefault));
+        slot->ticket = next_ticket++; slot->B = B; slot->k_cap = k_cap; slot->queries = queries_dev; slot->p = p; slot->flt.clear();
+        if (p.filter_ids && p.n_filter > 0) { slot->flt.assign(p.filter_ids, p.filter_ids + p.n_filter); slot->p.filter_ids = slot->flt.data(); }
+        slot->out_ids = out_ids; slot->out_scores = out_scores; slot->out_counts = out_counts;
+        slot->host[0] = slot->host[1] = slot->host[2] = 0;
+        search_impl(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap, slot->host);
+        HIP_CHECK(hipEventRecord(slot->ev, c->stream));
+        slot->active = true;
+        return slot->ticket;
+    }
+    bool search_finish(uint64_t ticket) override {
+        Pending* slot = nullptr;
+        for (auto& r : ring) if (r.active && r.ticket == ticket) { slot = &r; break; }
+        if (!slot) return false;
+        HIP_CHECK(hipEventSynchronize(slot->ev));
+        slot->active = false;
+        st_evals = slot->host[0]; st_exp = slot->host[1];
+        if (!slot->host[2]) return false;
+        ScratchMark sm(c);       // a candidate heap overflowed: the search again, synchronously, with the larger heaps
+        search_impl(slot->queries, slot->B, slot->p, slot->out_ids, slot->out_scores, slot->out_counts, slot->k_cap, nullptr);
+        return true;
+    }
+    // deferred != nullptr: no host round trip — the overflow flag and the counters are copied to `deferred` (pinned) behind the search
+    void search_impl(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
+                     int32_t* out_counts, int k_cap, unsigned long long* deferred) {
         float* Qp; int32_t* zflag;
         prepare_queries(c, metric, queries_dev, B, dim, ld, &Qp, &zflag, true);
         uint32_t* pos = c->salloc<uint32_t>((size_t)B * k_cap);
@@ -809,7 +856,7 @@ struct HNSWIndex : comet_index {
         };
         bool spill = ef > HN_EF_MAX;
         run(spill);
-        while (!spill) {      // more live candidates than the LDS heap holds: the same search again with the full-size heap, then with the heaps in HBM
+        while (!spill && !deferred) {      // more live candidates than the LDS heap holds: the same search again with the full-size heap, then with the heaps in HBM
             int32_t hs = 0;
             c->d2h(&hs, status, 4);
             HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -830,6 +877,11 @@ struct HNSWIndex : comet_index {
         launch_select_topk(c, D, ef_ld, B, ef_ld, res_cnt, p.threshold, p.k, pos2, out_scores, out_counts, k_cap);
         launch_gather_indirect(c, res_idx, ef_ld, pos2, B, k_cap, pos);
         launch_finalize(c, ids_dev.as<uint32_t>(), pos, B, k_cap, zflag, out_ids, out_counts);
+        if (deferred) {          // counters and overflow flag follow the search to pinned memory; search_finish reads them
+            HIP_CHECK(hipMemcpyAsync(deferred, st, 16, hipMemcpyDeviceToHost, c->stream));
+            if (!spill) HIP_CHECK(hipMemcpyAsync(deferred + 2, status, 4, hipMemcpyDeviceToHost, c->stream));
+            return;
+        }
         unsigned long long hst[2];
         c->d2h(hst, st, 16);
         HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as orc
-from comet_amd import COSINE, L2_SQUARED, FlatIndex, IVFIndex, IVFPQIndex, PQIndex
+from comet_amd import COSINE, L2_SQUARED, FlatIndex, HNSWIndex, IVFIndex, IVFPQIndex, PQIndex
 
 pytestmark = pytest.mark.gpu
 
@@ -27,6 +27,8 @@ def make(ctx, kind, d, X):
     ids = np.arange(1, len(X) + 1, dtype=np.uint32)
     if kind == "flat":
         g = FlatIndex(ctx, d, COSINE)
+    elif kind == "hnsw":
+        g = HNSWIndex(ctx, d, L2_SQUARED, 8, 40, 24)          # graph built by the GPU insert kernel
     elif kind == "ivf":
         g = IVFIndex(ctx, d, 32, L2_SQUARED); g.train(X[:4000])
     elif kind == "ivfpq":
@@ -37,13 +39,13 @@ def make(ctx, kind, d, X):
     return g
 
 
-@pytest.mark.parametrize("kind", ["flat", "ivf", "ivfpq", "pq"])
+@pytest.mark.parametrize("kind", ["flat", "ivf", "ivfpq", "pq", "hnsw"])
 def test_alternating_lanes_equal_sync(ctx, kind):
-    n, d, B, k, nb = 30000, 64, 96, 7, 6
+    n, d, B, k, nb = (30000 if kind != "hnsw" else 4000), 64, 96, 7, 6
     centers = synth(61, 50, d)
     X = (centers[np.arange(n) % 50] + synth(62, n, d) * np.float32(0.3)).astype(np.float32)
     g = make(ctx, kind, d, X)
-    kw = {} if kind in ("flat", "pq") else {"nprobes": 5}
+    kw = {} if kind in ("flat", "pq", "hnsw") else {"nprobes": 5}
     batches = [(centers[np.arange(B) % 50] + synth(70 + i, B, d) * np.float32(0.3)).astype(np.float32) for i in range(nb)]
     qd = [ctx.alloc(B * d * 4) for _ in batches]
     outs = [(ctx.alloc(B * k * 4), ctx.alloc(B * k * 4), ctx.alloc(B * 4)) for _ in batches]
