@@ -123,7 +123,7 @@ int comet_comm_destroy(comet_comm* cm) {
     return guarded([&] {
         if (!cm) return (int)COMET_OK;
         Ctx* c = cm->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind();
-        (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(cm->xstream);
+        c->quiesce_all(); (void)hipStreamSynchronize(cm->xstream);
         for (auto& s : cm->slots) { if (s.searched) (void)hipEventDestroy(s.searched); if (s.merged) (void)hipEventDestroy(s.merged); }
         if (cm->bound_a) { (void)hipEventDestroy(cm->bound_a); (void)hipEventDestroy(cm->bound_b); }
         if (cm->comm && rccl().CommDestroy) (void)rccl().CommDestroy(cm->comm);
@@ -139,7 +139,7 @@ int comet_comm_world(const comet_comm* cm) { return cm->world; }
 int comet_comm_allreduce_f64(comet_comm* cm, double* inout, int32_t op) {
     return guarded([&] {
         Ctx* c = cm->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind();
-        HIP_CHECK(hipStreamSynchronize(c->stream));                       // everything enqueued so far on the search stream is part of "before the barrier"
+        c->quiesce_all();                                                 // everything enqueued so far on the search streams is part of "before the barrier"
         double* d = cm->scalar.as<double>();
         HIP_CHECK(hipMemcpyAsync(d, inout, 8, hipMemcpyHostToDevice, cm->xstream));
         RCCL_CHECK(rccl().AllReduce(d, d + 1, 1, NCCL_FLOAT64, op == 0 ? NCCL_MAX : NCCL_SUM, cm->comm, cm->xstream));
@@ -156,7 +156,12 @@ int comet_index_search_sharded_async(comet_index* idx, comet_comm* cm, const flo
     return guarded([&] {
         if (!p || B <= 0 || k_cap <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "bad batch size / k_cap");
         if (idx->c != cm->c) COMET_FAIL(COMET_ERR_INVALID_ARG, "index and communicator live on different contexts");
-        Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->scratch_reset();
+        Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind();
+        // every other sharded search of an index on the context's second lane, like comet_index_search_dev_async: a rank's
+        // short kernels (query preparation, post stage, coarse ranking) are the part of its step that does not shrink with the shard
+        struct LaneBack { Ctx* c; ~LaneBack() { if (c->cur_lane != 0) { c->alt_dirty = true; c->switch_lane(0); } } } lane_back{c};
+        c->switch_lane((c->lanes > 1 && idx->lanes_ok()) ? (idx->lane_toggle ^= 1) : 0);
+        c->scratch_reset();
         comet_comm::Slot* s = &cm->slots[cm->next_ticket % comet_comm::kSlots];   // round robin: a slot is reused four searches later
         if (s->active) s = nullptr;
         if (!s) COMET_FAIL(COMET_ERR_INVALID_ARG, "more than %d sharded searches in flight: wait for one first", comet_comm::kSlots);
@@ -222,7 +227,7 @@ int comet_index_search_sharded_wait(comet_index* idx, comet_comm* cm, uint64_t t
     });
 }
 int comet_comm_sync(comet_comm* cm) {
-    return guarded([&] { Ctx* c = cm->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); HIP_CHECK(hipStreamSynchronize(c->stream)); HIP_CHECK(hipStreamSynchronize(cm->xstream)); c->collect_profile(); return (int)COMET_OK; });
+    return guarded([&] { Ctx* c = cm->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->quiesce_all(); HIP_CHECK(hipStreamSynchronize(cm->xstream)); c->collect_profile(); return (int)COMET_OK; });
 }
 
 }  // extern "C"
