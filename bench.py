@@ -54,7 +54,7 @@ CORPUS_SEED, QUERY_SEED = 0xC0FFEE + 2, 0xBEEF + 2
 # a query's true neighbours are the rows of its own sub-centre
 MIX_SEED, MIX_CENTERS, MIX_SIGMA, MIX_SUB, MIX_NOISE = 0xC0FFEE + 4, 2048, 0.15, 65536, 0.02
 HBM_PEAK_GBS = 8000.0
-LANES = max(1, min(2, int(os.environ.get("COMET_LANES", "2"))))    # execution lanes of the timed regions (the library's default: 2)
+LANES = max(1, min(4, int(os.environ.get("COMET_LANES", "4"))))    # execution lanes of the timed regions (the library's default: 4; Flat / IVF use two of them)
 NQB = 8               # distinct query batches a leg rotates through
 DTYPE = ("f32 results: every returned score is the reference's serial float32 sum (bit-identical to the CPU path); candidates are "
          "screened on int8 MFMA (v_mfma_i32_32x32x32_i8, exact int32 accumulate; fp16 v_mfma_f32_32x32x16_f16 where int8 is too coarse for the "
@@ -165,7 +165,7 @@ def measure(ctx, timer, args, step, dominant, B):
     n_sus, el_sus = timer.sustained(step, args.steps, med, args.sustain_s)
     rec = {"qps": B * args.steps / med, "ms_per_step": med / args.steps * 1e3, "region_ms": [round(t * 1e3, 3) for t in times],
            "sustained": {"seconds": round(el_sus, 3), "steps": n_sus, "qps": B * n_sus / el_sus, "ms_per_step": el_sus / n_sus * 1e3},
-           "execution_lanes": LANES,
+           "execution_lanes": LANES, "batches_in_flight": getattr(getattr(step, "__self__", None), "depth", None),
            "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(allk.items())},
            "kernels_ms_per_step_are": "per-kernel HIP-event durations of a region of their own on ONE execution lane (each kernel alone on the GPU)"}
     prof = dict(prof); prof["__one_lane__"] = allk
@@ -285,26 +285,30 @@ def same_rows(g_ids, g_sc, g_cn, b, cnt, oi, os_):
 
 
 class Pipe:
-    """Two batches in flight on device-resident buffers, rotating NQB query batches: batch i+1 is enqueued before batch i is waited for."""
+    """`depth` batches in flight on device-resident buffers (2, or 4 for the index kinds whose searches use four execution lanes), rotating
+    NQB query batches: batch i + depth - 1 is enqueued before batch i is waited for."""
 
-    def __init__(self, ctx, idx, q_ptrs, B, K, comm=None, **params):
+    def __init__(self, ctx, idx, q_ptrs, B, K, comm=None, depth=2, **params):
         self.ctx, self.idx, self.q, self.B, self.K, self.comm, self.params = ctx, idx, q_ptrs, B, K, comm, params
-        self.bufs = [(ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)) for _ in range(3)]
+        self.depth = max(1, min(int(depth), 4 if comm is None else 3))      # a communicator has four slots
+        self.bufs = [(ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)) for _ in range(self.depth + 1)]
         self.i = 0
 
     def step(self, nsteps):
-        prev = None
+        flying = []
         for _ in range(nsteps):
-            w = self.i % 3; q = self.q[self.i % len(self.q)]; self.i += 1
+            w = self.i % len(self.bufs); q = self.q[self.i % len(self.q)]; self.i += 1
             if self.comm is not None:
                 t = self.comm.search_async(self.idx, q, self.B, self.K, *self.bufs[w], self.K, **self.params)
             else:
                 t = self.idx.search_batch_dev_async(q, self.B, self.K, *self.bufs[w], self.K, **self.params)
-            if prev is not None:
+            flying.append(t)
+            if len(flying) >= self.depth:
+                prev = flying.pop(0)
                 self.comm.search_wait(self.idx, prev, block=False) if self.comm is not None else self.idx.search_wait(prev)
-            prev = t
-        if prev is not None:
-            self.comm.search_wait(self.idx, prev, block=True) if self.comm is not None else self.idx.search_wait(prev)
+        for j, prev in enumerate(flying):
+            last = j == len(flying) - 1
+            self.comm.search_wait(self.idx, prev, block=last) if self.comm is not None else self.idx.search_wait(prev)
 
     def results_of(self, qi, **override):
         """one blocking search of query batch qi; host copies of (ids, scores, counts)"""
@@ -464,7 +468,7 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
     add_rows(ctx, idx, 0, n, d, mix_fill(ctx, d, nsub))
     ctx.sync()
     add_s = time.time() - t0
-    pipe = Pipe(ctx, idx, q_ptrs, B, K, comm, nprobes=args.nprobe)
+    pipe = Pipe(ctx, idx, q_ptrs, B, K, comm, depth=4, nprobes=args.nprobe)     # no kernel of an IVFPQ step fills the GPU: four searches in flight on four lanes
     pipe.step(2)
     # the library's search counters are device atomics (0.1 ms per batch when on): counted in a pass of their own, off in the timed regions
     idx.stat("adc_stats_on"); idx.stat("adc_stats_reset")
@@ -583,7 +587,7 @@ def leg_hnsw(ctx, ca, args, timer):
     q_ptrs = query_batches(ctx, 8192, d, lambda p, i: ctx.synth_mixture(p, MIX_SEED + 1, MIX_CENTERS, MIX_SIGMA, nsub, MIX_NOISE, n + 7 + i * 8192, 8192, d))   # 8 x 8192 fresh draws (the sweep's largest batch)
     Q0 = ctx.download(q_ptrs[0], (B, d), np.float32)
     params = dict(ef_search=efs)
-    pipe = Pipe(ctx, g, q_ptrs, B, K, None, **params)
+    pipe = Pipe(ctx, g, q_ptrs, B, K, None, depth=4, **params)                 # a 256-query search is 256 waves: four of them side by side
     pipe.step(2)
     rec, prof, med, times = measure(ctx, timer, args, pipe.step, "hnsw_search", B)
     gr = pipe.results_of(0)
@@ -605,7 +609,7 @@ def leg_hnsw(ctx, ca, args, timer):
                         "algorithmic_bytes_are": "distance evaluations x d x 4 + expansions x 2M x 4, both counted by the kernel (random 1.5 KB row reads: latency-bound, one wave per query)"}}
     sweep = {}
     for Bs in (1024, 4096, 8192):
-        p2 = Pipe(ctx, g, q_ptrs, Bs, K, None, **params)
+        p2 = Pipe(ctx, g, q_ptrs, Bs, K, None, depth=4, **params)
         p2.step(2)
         ctx.sync(); t0 = time.perf_counter(); p2.step(6); ctx.sync(); el = (time.perf_counter() - t0) / 6
         sweep[f"batch{Bs}"] = {"qps": Bs / el, "ms_per_step": el * 1e3}

@@ -12,7 +12,7 @@ struct CallGuard {   // serialise calls on a context, bind the device, reset the
     explicit CallGuard(Ctx* c_) : c(c_), lk(c_->mu) { c->bind(); c->switch_lane(0); c->quiesce_alt(); c->scratch_reset(); }
     // an asynchronous search enqueued on `lane` (its stream, its scratch arena); lane 0 is current again when the guard goes
     CallGuard(Ctx* c_, int lane) : c(c_), lk(c_->mu) { c->bind(); c->switch_lane(lane); c->scratch_reset(); }
-    ~CallGuard() { if (c->cur_lane != 0) { c->alt_dirty = true; c->switch_lane(0); } }
+    ~CallGuard() { if (c->cur_lane != 0) { c->mark_dirty(); c->switch_lane(0); } }
 };
 }  // namespace
 
@@ -56,12 +56,14 @@ int comet_ctx_destroy(comet_ctx* c) {
         c->bind();
         c->switch_lane(0);
         (void)hipStreamSynchronize(c->stream);
-        if (c->alt.stream) (void)hipStreamSynchronize(c->alt.stream);
+        for (int l = 1; l < Ctx::kMaxLanes; l++) if (c->parked[l].stream) (void)hipStreamSynchronize(c->parked[l].stream);
         c->collect_profile();
         c->scratch_reset();
-        for (void* r : c->alt.retired) (void)hipFree(r);
-        if (c->alt.scratch) (void)hipFree(c->alt.scratch);
-        if (c->alt.stream) (void)hipStreamDestroy(c->alt.stream);
+        for (int l = 1; l < Ctx::kMaxLanes; l++) {
+            for (void* r : c->parked[l].retired) (void)hipFree(r);
+            if (c->parked[l].scratch) (void)hipFree(c->parked[l].scratch);
+            if (c->parked[l].stream) (void)hipStreamDestroy(c->parked[l].stream);
+        }
         if (c->scratch) (void)hipFree(c->scratch);
         if (c->pinned) (void)hipHostFree(c->pinned);
         (void)hipStreamDestroy(c->stream);
@@ -90,7 +92,7 @@ int comet_synth_mixture_dev(comet_ctx* c, uint64_t seed, int32_t n_centers, floa
 
 int comet_ctx_set_lanes(comet_ctx* c, int32_t lanes) {
     return guarded([&] {
-        if (lanes < 1 || lanes > 2) COMET_FAIL(COMET_ERR_INVALID_ARG, "a context has 1 or 2 execution lanes");
+        if (lanes < 1 || lanes > Ctx::kMaxLanes) COMET_FAIL(COMET_ERR_INVALID_ARG, "a context has 1 to %d execution lanes", Ctx::kMaxLanes);
         std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->switch_lane(0); c->quiesce_all(); c->lanes = lanes;
         return COMET_OK;
     });
@@ -334,9 +336,9 @@ int comet_index_search_dev_async(comet_index* idx, const float* queries_dev, int
         check_search_args(idx, B, p, k_cap);
         if (out_ticket) *out_ticket = 0;
         if (B == 0) return (int)COMET_OK;
-        // every other asynchronous search of an index goes to the context's second lane (Ctx::alt)
+        // the asynchronous searches of an index rotate through the context's execution lanes (as many as the kind gains from)
         int lane = 0;
-        { std::lock_guard<std::recursive_mutex> lk(idx->c->mu); if (idx->c->lanes > 1 && idx->lanes_ok()) lane = (idx->lane_toggle ^= 1); }
+        { std::lock_guard<std::recursive_mutex> lk(idx->c->mu); const int m = std::min(idx->c->lanes, idx->max_lanes()); if (m > 1) lane = idx->lane_toggle = (idx->lane_toggle + 1) % m; }
         CallGuard g(idx->c, lane);
         uint64_t t = idx->search_begin(queries_dev, B, *p, out_ids_dev, out_scores_dev, out_counts_dev, k_cap);
         if (out_ticket) *out_ticket = t;

@@ -159,8 +159,8 @@ int comet_index_search_sharded_async(comet_index* idx, comet_comm* cm, const flo
         Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind();
         // every other sharded search of an index on the context's second lane, like comet_index_search_dev_async: a rank's
         // short kernels (query preparation, post stage, coarse ranking) are the part of its step that does not shrink with the shard
-        struct LaneBack { Ctx* c; ~LaneBack() { if (c->cur_lane != 0) { c->alt_dirty = true; c->switch_lane(0); } } } lane_back{c};
-        c->switch_lane((c->lanes > 1 && idx->lanes_ok()) ? (idx->lane_toggle ^= 1) : 0);
+        struct LaneBack { Ctx* c; ~LaneBack() { if (c->cur_lane != 0) { c->mark_dirty(); c->switch_lane(0); } } } lane_back{c};
+        { const int m = std::min(c->lanes, idx->max_lanes()); c->switch_lane(m > 1 ? (idx->lane_toggle = (idx->lane_toggle + 1) % m) : 0); }
         c->scratch_reset();
         comet_comm::Slot* s = &cm->slots[cm->next_ticket % comet_comm::kSlots];   // round robin: a slot is reused four searches later
         if (s->active) s = nullptr;

@@ -84,31 +84,39 @@ struct Ctx {
     // scratch arena: bump allocator over one device allocation, reset at the start of every call.
     void* scratch = nullptr; size_t scratch_cap = 0, scratch_off = 0;
     std::vector<void*> retired;  // old arenas kept alive until the call that outgrew them finishes
-    // Second execution lane (round 3). Two batches in flight on ONE stream do not overlap on the GPU, and a search step is a chain of
+    // Execution lanes (round 3). Two batches in flight on ONE stream do not overlap on the GPU, and a search step is a chain of
     // short latency-bound kernels around one big scan: with every other asynchronous search on a second stream (and a scratch arena
     // of its own — the arena is recycled in stream order) the small kernels of batch i+1 run beside batch i's post stage
     // (tools/two_ctx_probe.py: IVF 854 k -> 1.14 M q/s, IVFPQ 843 k -> 1.29 M, Flat 783 k -> 883 k with two contexts).
-    // `stream` / `scratch*` / `retired` always describe the CURRENT lane; `alt` holds the other one's. Lane 0 is current whenever no
-    // asynchronous search is being enqueued; everything that is not such a search first waits for lane 1 (quiesce_alt).
-    struct LaneState { hipStream_t stream = nullptr; void* scratch = nullptr; size_t scratch_cap = 0, scratch_off = 0; std::vector<void*> retired; } alt;
+    // Up to four lanes: index kinds whose step has no kernel that fills the GPU (HNSW: 256 waves per search; IVFPQ) keep gaining up to four
+    // searches in flight (tools/two_ctx_probe.py, one stream per context: HNSW 672 k / 1.19 M / 1.60 M / 1.89 M q/s with 1 / 2 / 3 / 4, IVFPQ
+    // 828 k / 1.30 M / 1.56 M / 1.69 M; IVF and Flat peak at two: 858 k / 1.16 M / 0.99 M, 800 k / 895 k / 861 k) — comet_index::max_lanes().
+    // `stream` / `scratch*` / `retired` always describe the CURRENT lane; `parked` holds the others'. Lane 0 is current whenever no
+    // asynchronous search is being enqueued; everything that is not such a search first waits for the other lanes (quiesce_alt).
+    static constexpr int kMaxLanes = 4;
+    struct LaneState { hipStream_t stream = nullptr; void* scratch = nullptr; size_t scratch_cap = 0, scratch_off = 0; std::vector<void*> retired; };
+    LaneState parked[kMaxLanes]; // parked[l]: lane l's state while another lane is current (parked[cur_lane] is stale)
     int cur_lane = 0;
-    bool alt_dirty = false;      // work was enqueued on lane 1 since it was last synchronised
-    int lanes = [] { const char* e = getenv("COMET_LANES"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 2 ? 2 : v); }();
+    unsigned dirty_mask = 0;     // bit l: work was enqueued on lane l >= 1 since it was last synchronised
+    int lanes = [] { const char* e = getenv("COMET_LANES"); const int v = e ? atoi(e) : kMaxLanes; return v < 1 ? 1 : (v > kMaxLanes ? kMaxLanes : v); }();
     void switch_lane(int l) {
         if (l == cur_lane) return;
-        if (!alt.stream) HIP_CHECK(hipStreamCreateWithFlags(&alt.stream, hipStreamNonBlocking));
-        std::swap(stream, alt.stream); std::swap(scratch, alt.scratch); std::swap(scratch_cap, alt.scratch_cap); std::swap(scratch_off, alt.scratch_off);
-        retired.swap(alt.retired);
+        LaneState& p = parked[cur_lane];
+        p.stream = stream; p.scratch = scratch; p.scratch_cap = scratch_cap; p.scratch_off = scratch_off; p.retired = std::move(retired);
+        LaneState& n = parked[l];
+        if (!n.stream) HIP_CHECK(hipStreamCreateWithFlags(&n.stream, hipStreamNonBlocking));
+        stream = n.stream; scratch = n.scratch; scratch_cap = n.scratch_cap; scratch_off = n.scratch_off; retired = std::move(n.retired); n.retired.clear();
         cur_lane = l;
     }
-    void quiesce_alt() {         // called with lane 0 current
-        if (alt_dirty && alt.stream) HIP_CHECK(hipStreamSynchronize(alt.stream));
-        alt_dirty = false;
+    void mark_dirty() { if (cur_lane) dirty_mask |= 1u << cur_lane; }
+    void quiesce_alt() {         // called with lane 0 current: the other lanes idle
+        for (int l = 1; l < kMaxLanes; l++) if (((dirty_mask >> l) & 1u) && parked[l].stream) HIP_CHECK(hipStreamSynchronize(parked[l].stream));
+        dirty_mask = 0;
     }
-    void quiesce_all() {         // both lanes idle (whichever is current)
+    void quiesce_all() {         // every lane idle (whichever is current)
         HIP_CHECK(hipStreamSynchronize(stream));
-        if (alt.stream) HIP_CHECK(hipStreamSynchronize(alt.stream));
-        alt_dirty = false;
+        for (int l = 0; l < kMaxLanes; l++) if (l != cur_lane && parked[l].stream) HIP_CHECK(hipStreamSynchronize(parked[l].stream));
+        dirty_mask = 0;
     }
     // pinned host staging for small readbacks
     void* pinned = nullptr; size_t pinned_cap = 0;
@@ -149,7 +157,7 @@ struct Ctx {
         }
         return pinned;
     }
-    void sync() { HIP_CHECK(hipStreamSynchronize(stream)); if (alt_dirty && alt.stream) { HIP_CHECK(hipStreamSynchronize(alt.stream)); alt_dirty = false; } collect_profile(); }
+    void sync() { quiesce_all(); collect_profile(); }
     void h2d(void* dst, const void* src, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream)); }
     void d2h(void* dst, const void* src, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream)); }
     void d2d(void* dst, const void* src, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream)); }

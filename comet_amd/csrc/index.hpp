@@ -52,9 +52,10 @@ struct comet_index {
                                   int32_t* out_counts, int k_cap) { search_dev(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap); return record_done(); }
     // returns true if it had to enqueue further device work (the Flat fast path's rare strict re-run)
     virtual bool search_finish(uint64_t ticket) { wait_done(ticket); return false; }
-    // may this kind's asynchronous searches alternate between the context's two execution lanes? (a search must then touch nothing
-    // persistent on the device except read-only index data, its own ring slot and per-lane buffers)
-    virtual bool lanes_ok() const { return false; }
+    // how many of the context's execution lanes this kind's asynchronous searches rotate through (> 1: a search touches nothing persistent on
+    // the device except read-only index data, its own ring slot and per-lane buffers). Two where one kernel of the step fills the GPU
+    // (Flat, IVF: a third search in flight only adds contention), four where none does (PQ / IVFPQ, HNSW).
+    virtual int max_lanes() const { return 1; }
     int lane_toggle = 0;
     // completion tickets of the index kinds without deferred work: an event behind the search on the stream it was enqueued on
     struct DoneEv { uint64_t ticket = 0; hipEvent_t ev = nullptr; bool active = false; };

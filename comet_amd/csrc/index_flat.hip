@@ -96,7 +96,7 @@ struct FlatIndex : comet_index {
     }
 
     int64_t size() const override { return n; }
-    bool lanes_ok() const override { return true; }     // a search writes its own ring slot and scratch only
+    int max_lanes() const override { return 2; }        // a search writes its own ring slot and scratch only
     bool contains_id(uint32_t id) const override { return id_count.count(id) != 0; }
     std::unordered_map<uint32_t, int64_t> first_row; bool first_row_dirty = true;
     int64_t row_of_id(uint32_t id) override {

@@ -208,7 +208,7 @@ struct IVFIndex : comet_index {
     // fp16 shadow for the MFMA fast path (kernels_ivf.hip): slot-ordered rows, squared norms per slot, magnitude statistics;
     // rebuilt lazily when the slot layout was recompiled (shadow_version != lay.version)
     int ldh = 0;
-    DevBuf Vh, rn_slot, stats_dev, scan_counts[2];       // scan_counts: written by every search's item builder — one per execution lane
+    DevBuf Vh, rn_slot, stats_dev, scan_counts[4];       // scan_counts: written by every search's item builder — one per execution lane
     int last_lane = 0;
     uint64_t shadow_version = 0;
     float xmax_abs = 0.0f, xmax_norm2 = 0.0f;
@@ -247,7 +247,7 @@ struct IVFIndex : comet_index {
     }
 
     int64_t size() const override { return lay.n; }
-    bool lanes_ok() const override { return true; }      // searches write scratch, their ring slot / per-lane counters and (opt-in) atomics only
+    int max_lanes() const override { return 2; }      // searches write scratch, their ring slot / per-lane counters and (opt-in) atomics only
     int default_nprobes() const override { return (int)std::sqrt((double)nlist); }   // ivf_index.go:406-413
     bool contains_id(uint32_t id) const override { return lay.id_count.count(id) != 0; }
     void export_all(uint32_t* oids, int32_t* olists, uint8_t*) const override {
@@ -702,7 +702,7 @@ struct PQFamilyIndex : comet_index {
     ListLayout lay;
 
     int64_t size() const override { return lay.n; }
-    bool lanes_ok() const override { return true; }      // searches write scratch, their ring slot / per-lane counters and (opt-in) atomics only
+    int max_lanes() const override { return 4; }      // searches write scratch, their ring slot / per-lane counters and (opt-in) atomics only
     int default_nprobes() const override { return ivf ? (int)std::sqrt((double)nlist) : 0; }   // ivfpq_index.go:442-449
     bool contains_id(uint32_t id) const override { return lay.id_count.count(id) != 0; }
 

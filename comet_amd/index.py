@@ -101,7 +101,7 @@ class Context:
         check(self.lib.comet_profile_enable(self.h, 1 if on else 0))
 
     def set_lanes(self, lanes: int) -> None:
-        """1 or 2 execution lanes: with 2 (the default) every other asynchronous search of an index runs on a second stream"""
+        """1 .. 4 execution lanes (default 4): the asynchronous searches of an index rotate through up to that many streams"""
         check(self.lib.comet_ctx_set_lanes(self.h, int(lanes)))
 
     def profile_only(self, name: str | None) -> None:
