@@ -513,7 +513,11 @@ int comet_index_export(const comet_index* idx, uint32_t* out_ids, int32_t* out_l
     return guarded([&] { CallGuard g(idx->c); idx->export_all(out_ids, out_lists, out_codes); return (int)COMET_OK; });
 }
 int comet_index_get_stat(const comet_index* idx, const char* name, double* out) {
-    return guarded([&] { if (!idx->get_stat(name, out)) COMET_FAIL(COMET_ERR_INVALID_ARG, "unknown stat '%s'", name); return (int)COMET_OK; });
+    return guarded([&] {
+        std::lock_guard<std::recursive_mutex> lk(idx->c->mu); idx->c->bind();      // some statistics are read back from the device
+        if (!idx->get_stat(name, out)) COMET_FAIL(COMET_ERR_INVALID_ARG, "unknown stat '%s'", name);
+        return (int)COMET_OK;
+    });
 }
 
 }  // extern "C"
