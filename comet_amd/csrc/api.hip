@@ -368,9 +368,25 @@ static void segments_search(comet_index* const* segs, int S, const float* querie
     float* sc = c->salloc<float>((size_t)S * B * k);
     int32_t* cn = c->salloc<int32_t>((size_t)S * B);
     std::vector<uint64_t> tickets(S);
+    // The segments' searches rotate through the context's execution lanes: they are independent, and each is a chain of short
+    // kernels. The other lanes start behind what lane 0 holds so far (the queries' upload); the merge starts when every search is final
+    // (search_finish waits on the host). A lane's scratch arena is reset once per call and then grows across its segments.
+    static thread_local hipEvent_t ev = nullptr;
+    if (!ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(ev, c->stream));
+    struct LaneBack { Ctx* c; ~LaneBack() { c->switch_lane(0); } } lane_back{c};
+    bool used[Ctx::kMaxLanes] = {true, false, false, false};
+    int rot = 0;
     // newest first, as the reference walks memtables and segments (the order has no effect on the merged result)
-    for (int s = S - 1; s >= 0; s--)
+    for (int s = S - 1; s >= 0; s--) {
+        const int m = std::min(c->lanes, segs[s]->max_lanes());
+        const int lane = m > 1 ? (rot++ % m) : 0;
+        c->switch_lane(lane);
+        if (!used[lane]) { used[lane] = true; c->scratch_reset(); HIP_CHECK(hipStreamWaitEvent(c->stream, ev, 0)); }
         tickets[s] = segs[s]->search_begin(queries_dev, B, *p, ids + (size_t)s * B * k, sc + (size_t)s * B * k, cn + (size_t)s * B, k);
+        c->mark_dirty();
+    }
+    c->switch_lane(0);
     for (int s = S - 1; s >= 0; s--) segs[s]->search_finish(tickets[s]);
     launch_merge_segments(c, ids, sc, cn, S, B, k, k, out_ids, out_scores, out_counts, k_cap);
 }
