@@ -166,6 +166,7 @@ def measure(ctx, timer, args, step, dominant, B):
     rec = {"qps": B * args.steps / med, "ms_per_step": med / args.steps * 1e3, "region_ms": [round(t * 1e3, 3) for t in times],
            "sustained": {"seconds": round(el_sus, 3), "steps": n_sus, "qps": B * n_sus / el_sus, "ms_per_step": el_sus / n_sus * 1e3},
            "execution_lanes": LANES, "batches_in_flight": getattr(getattr(step, "__self__", None), "depth", None),
+           "batch_latency_ms_about": (getattr(getattr(step, "__self__", None), "depth", None) or 1) * med / args.steps * 1e3,   # a batch stays in the pipe for ~ depth steps
            "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(allk.items())},
            "kernels_ms_per_step_are": "per-kernel HIP-event durations of a region of their own on ONE execution lane (each kernel alone on the GPU)"}
     prof = dict(prof); prof["__one_lane__"] = allk
