@@ -784,6 +784,7 @@ def main():
             "dtype": DTYPE, "data": "synthetic",
             "timing": {"regions": len(times), "reported": "median region", "region_ms": rec["region_ms"], "query_batches_rotated": NQB},
             "sustained": rec["sustained"],
+            "execution_lanes": rec["execution_lanes"], "batches_in_flight": rec["batches_in_flight"], "batch_latency_ms_about": rec["batch_latency_ms_about"],
             "config": {"workload": f"Flat {args.metric} {args.rows}x{args.dim}, batch={B} queries, K={K} (BASELINE configs[1])",
                        "rows": args.rows, "dim": args.dim, "batch": B, "k": K, "metric": args.metric,
                        "mode": {0: "auto", 1: "strict", 2: "fast"}[args.mode], "sharding": f"rows/{world}", "build_s": round(build_s, 2)},
