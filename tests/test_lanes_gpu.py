@@ -85,3 +85,27 @@ def test_alternating_lanes_equal_sync(ctx, kind):
     ctx.sync()
     for p in qd + [x for o in outs for x in o]:
         ctx.free(p)
+
+
+def test_set_lanes_bounds_and_single_lane(ctx):
+    from comet_amd import CometError
+    for bad in (0, 5, -1):
+        with pytest.raises(CometError):
+            ctx.set_lanes(bad)
+    n, d, B, k = 20000, 48, 64, 5
+    X = synth(91, n, d); Q = synth(92, B, d)
+    g = make(ctx, "ivfpq", d, X)
+    want = g.search_batch(Q, k, nprobes=4)
+    qd = ctx.alloc(B * d * 4); ctx.upload(qd, Q)
+    outs = [(ctx.alloc(B * k * 4), ctx.alloc(B * k * 4), ctx.alloc(B * 4)) for _ in range(4)]
+    try:
+        for lanes in (1, 3, 4):
+            ctx.set_lanes(lanes)
+            ts = [g.search_batch_dev_async(qd, B, k, *o, k, nprobes=4) for o in outs]
+            for t, o in zip(ts, outs):
+                g.search_wait(t)
+                same((ctx.download(o[0], (B, k), np.uint32), ctx.download(o[1], (B, k), np.float32), ctx.download(o[2], (B,), np.int32)), want)
+    finally:
+        ctx.set_lanes(4)
+    for p in [qd] + [x for o in outs for x in o]:
+        ctx.free(p)
