@@ -66,7 +66,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--sustain-s", type=float, default=2.0, help="length of the sustained (back-to-back) measurement of every leg")
     ap.add_argument("--rows", type=int, default=N_ROWS)
@@ -88,6 +88,7 @@ def parse():
     ap.add_argument("--docs", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--full-line", action="store_true", help="print the full record (tens of KB) instead of the compact line; the full record is always written to bench_legs.json")
     return ap.parse_args()
 
 
@@ -169,6 +170,14 @@ def measure(ctx, timer, args, step, dominant, B):
            "batch_latency_ms_about": (getattr(getattr(step, "__self__", None), "depth", None) or 1) * med / args.steps * 1e3,   # a batch stays in the pipe for ~ depth steps
            "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(allk.items())},
            "kernels_ms_per_step_are": "per-kernel HIP-event durations of a region of their own on ONE execution lane (each kernel alone on the GPU)"}
+    # single stream: ONE execution lane, ONE batch in flight (enqueue, wait, enqueue ...) — what a caller that does not pipeline its batches sees
+    pipe = getattr(step, "__self__", None)
+    if isinstance(pipe, Pipe):
+        d0 = pipe.depth
+        pipe.depth = 1; ctx.set_lanes(1)
+        m1, _t1 = timer.run(step, args.steps, 2, 3)
+        pipe.depth = d0; ctx.set_lanes(LANES)
+        rec["single_stream"] = {"qps": B * args.steps / m1, "ms_per_step": m1 / args.steps * 1e3, "execution_lanes": 1, "batches_in_flight": 1}
     prof = dict(prof); prof["__one_lane__"] = allk
     return rec, prof, med, times
 
@@ -234,13 +243,16 @@ def pmc_traffic(kernel, rows_local):
                         continue
                     per = kv.get("hbm_read_bytes_per_launch_corrected", 0) + kv.get("hbm_write_bytes_per_launch_uncalibrated", 0)
                     rows_ref = pm.get("rows", 1_000_000)
-                    best = (per * rows_local / rows_ref, f"profiles/{f.name} (separate rocprofv3 --pmc pass on these kernel sources [{sha}]: FETCH_SIZE x2 gfx950 "
-                                                         f"correction + WRITE_SIZE, measured at {rows_ref} rows, scaled to {rows_local})")
+                    if rows_ref != rows_local:       # a counter value is a measurement of ONE size: never scaled to another
+                        stale = f"{f.name} (measured at {rows_ref} rows, this leg has {rows_local})"
+                        continue
+                    best = (per, f"profiles/{f.name} (separate rocprofv3 --pmc pass on these kernel sources [{sha}]: FETCH_SIZE x2 gfx950 "
+                                                         f"correction + WRITE_SIZE, measured at {rows_ref} rows)")
         except Exception:
             continue
     if best:
         return best
-    return (None, f"not quoted: the newest committed PMC pass naming this kernel ({stale}) was measured on other kernel sources" if stale
+    return (None, f"not quoted: the newest committed PMC pass naming this kernel ({stale}) was measured on other kernel sources or at another size" if stale
             else "not measured in this run (PMC needs its own rocprofv3 pass: tools/pmc_bench.sh)")
 
 
@@ -783,7 +795,7 @@ def main():
             "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": DTYPE, "data": "synthetic",
             "timing": {"regions": len(times), "reported": "median region", "region_ms": rec["region_ms"], "query_batches_rotated": NQB},
-            "sustained": rec["sustained"],
+            "sustained": rec["sustained"], "single_stream": rec.get("single_stream"),
             "execution_lanes": rec["execution_lanes"], "batches_in_flight": rec["batches_in_flight"], "batch_latency_ms_about": rec["batch_latency_ms_about"],
             "config": {"workload": f"Flat {args.metric} {args.rows}x{args.dim}, batch={B} queries, K={K} (BASELINE configs[1])",
                        "rows": args.rows, "dim": args.dim, "batch": B, "k": K, "metric": args.metric,
@@ -869,12 +881,126 @@ def main():
         comm.close()
     if rank == 0:
         line["wall_s"] = round(time.time() - t_start, 1)
-        # RCCL writes its version banner through C stdio: flush that first so that the JSON line is the LAST line of stdout
-        try:
-            C.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(line), flush=True)
+        # the full record (every leg's regions, rooflines, notes: tens of KB) goes to a file; stdout's LAST line is a compact record the
+        # driver can parse from the tail it keeps
+        full_json = json.dumps(line)
+        for dst in (ROOT / "bench_legs.json", ROOT / "gpurun_out" / "bench_legs.json"):
+            try:
+                if dst.parent.is_dir():
+                    dst.write_text(full_json + "\n")
+            except OSError:
+                pass
+        sys.stdout.flush()
+        print(full_json if args.full_line else json.dumps(compact_line(line)), flush=True)
+
+
+def _rnd(x, nd=4):
+    if isinstance(x, float):
+        return float(f"{x:.{nd + 2}g}") if abs(x) < 1 else round(x, nd)
+    return x
+
+
+def _roof(r):
+    if not isinstance(r, dict):
+        return None
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_kernel_ms", "launches", "algorithmic_bytes_per_launch", "mfma_tops_int8",
+            "mfma_frac_of_5000", "mfma_tflops", "mfma_frac_of_2500", "lds_frac_of_measured_ceiling")
+    return {k: _rnd(r[k]) for k in keep if k in r}
+
+
+def _cpu(c):
+    if not isinstance(c, dict):
+        return None
+    keep = ("value", "unit", "cores", "kind", "single_thread_qps", "single_thread_latency_s", "parity_checked_queries", "parity_mismatches")
+    out = {k: _rnd(c[k]) for k in keep if k in c}
+    if "sample" in c:
+        out["sample"] = str(c["sample"])[:150]
+    return out
+
+
+def _leg(rec):
+    """one small summary per leg: qps, ms_per_step, single-stream qps, roofline fraction + kernel, parity mismatches"""
+    if not isinstance(rec, dict):
+        return None
+    if "error" in rec:
+        return {"error": str(rec["error"])[:200]}
+    out = {}
+    for k in ("qps", "ms_per_step", "execution_lanes", "batches_in_flight"):
+        if k in rec:
+            out[k] = _rnd(rec[k])
+    if isinstance(rec.get("sustained"), dict):
+        out["sustained_qps"] = _rnd(rec["sustained"].get("qps"))
+    if isinstance(rec.get("single_stream"), dict):
+        out["single_stream_qps"] = _rnd(rec["single_stream"].get("qps"))
+    if isinstance(rec.get("host_buffers"), dict):
+        out["host_buffers_qps"] = _rnd(rec["host_buffers"].get("qps"))
+    r = rec.get("roofline")
+    if isinstance(r, dict):
+        out["roofline"] = {k: _rnd(r.get(k)) for k in ("kernel", "frac", "avg_kernel_ms", "traffic") if k in r}
+        if "lds_frac_of_measured_ceiling" in r:
+            out["roofline"]["lds_frac"] = _rnd(r["lds_frac_of_measured_ceiling"])
+    c = rec.get("cpu_baseline")
+    if isinstance(c, dict):
+        out["cpu_qps"] = _rnd(c.get("value")); out["cpu_cores"] = c.get("cores"); out["parity_mismatches"] = c.get("parity_mismatches")
+        out["parity_checked"] = c.get("parity_checked_queries")
+    for k in ("recall_at_10_vs_exact_flat", "recall_at_10_vs_oracle_ivfpq", "rows", "build_s", "train_s", "add_s", "identical_to_exact_kernels"):
+        if k in rec:
+            out[k] = _rnd(rec[k])
+    return out
+
+
+def compact_line(full):
+    """the driver-facing record: the contract's keys + roofline + cpu_baseline of the headline + one small summary per leg (< 6 KB)"""
+    out = {"metric": "queries/sec + recall@10, 1M x 768 Flat & IVFPQ (value = Flat leg, exact search; IVFPQ + other configs under `legs`)"}
+    for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline"):
+        out[k] = full.get(k)
+    out["dtype"] = "int8 MFMA screening (i32 accumulate) + exact f32 rescoring: returned scores are f32, bit-identical to the CPU path"
+    out["data"] = full.get("data")
+    cfg = full.get("config") or {}
+    out["config"] = {k: cfg.get(k) for k in ("workload", "rows", "dim", "batch", "k", "metric", "sharding") if k in cfg}
+    out["timing"] = {"regions": (full.get("timing") or {}).get("regions"), "reported": "median region", "region_ms": (full.get("timing") or {}).get("region_ms")}
+    out["roofline"] = _roof(full.get("roofline"))
+    out["cpu_baseline"] = _cpu(full.get("cpu_baseline"))
+    out["lanes"] = full.get("execution_lanes"); out["batches_in_flight"] = full.get("batches_in_flight")
+    out["note_overlap"] = "value is measured with `batches_in_flight` batches on `lanes` streams (kernels of different batches overlap: per-kernel sums can exceed ms_per_step); single_stream_qps = 1 lane, 1 batch in flight"
+    if isinstance(full.get("single_stream"), dict):
+        out["single_stream_qps"] = _rnd(full["single_stream"].get("qps"))
+    if isinstance(full.get("sustained"), dict):
+        out["sustained_qps"] = _rnd(full["sustained"].get("qps"))
+    if isinstance(full.get("host_buffers"), dict):
+        out["host_buffers_qps"] = _rnd(full["host_buffers"].get("qps"))
+    out["recall_at_10"] = {k: _rnd(v) for k, v in (full.get("recall_at_10") or {}).items()}
+    legs = {}
+    for name in ("c1", "flat_l2", "ivfpq", "ivfpq_uniform", "ivfpq10m", "hnsw", "hnsw_navigable", "hybrid"):
+        rec = full.get(name)
+        if not isinstance(rec, dict):
+            continue
+        if "error" in rec:
+            legs[name] = {"error": str(rec["error"])[:200]}
+            continue
+        if name == "flat_l2":
+            legs[name] = {b: _leg(rec[b]) for b in ("batch1", "batch64", "batch256") if b in rec}
+        elif name == "hybrid":
+            legs[name] = {b: _leg(rec[b]) for b in rec if b.startswith("ivf_nprobe") or b == "bm25"}
+            for b in ("rrf", "end_to_end", "end_to_end_nprobe32"):
+                if isinstance(rec.get(b), dict):
+                    legs[name][b] = {k: _rnd(v) for k, v in rec[b].items() if isinstance(v, (int, float))}
+            if isinstance(rec.get("cpu_baseline"), dict):
+                legs[name]["cpu_qps"] = _rnd(rec["cpu_baseline"].get("value")); legs[name]["parity_mismatches"] = rec["cpu_baseline"].get("parity_mismatches")
+        elif name == "c1":
+            legs[name] = {k: _rnd(v) for k, v in rec.items() if isinstance(v, (int, float, bool))}
+        else:
+            legs[name] = _leg(rec)
+            ec = rec.get("every_candidate_search")
+            if isinstance(ec, dict):
+                legs[name]["every_candidate_qps"] = _rnd(ec.get("qps")); legs[name]["adc_scan_ms"] = _rnd(ec.get("adc_scan_ms"))
+            ts = rec.get("two_stage")
+            if isinstance(ts, dict):
+                legs[name]["pairs_left_alive_fraction"] = _rnd(ts.get("pairs_left_alive_fraction"))
+    out["legs"] = legs
+    out["full_record"] = "bench_legs.json (every leg's regions, kernels, rooflines with their definitions, CPU baselines)"
+    out["wall_s"] = full.get("wall_s")
+    return out
 
 
 if __name__ == "__main__":

@@ -75,6 +75,7 @@ def load() -> C.CDLL:
         "comet_ctx_destroy": (i32, [p]),
         "comet_ctx_sync": (i32, [p]),
         "comet_ctx_stream": (p, [p]),
+        "comet_ctx_fence": (i32, [p]),
         "comet_dev_alloc": (i32, [p, sz, pp]),
         "comet_dev_free": (i32, [p, p]),
         "comet_memcpy_h2d": (i32, [p, p, p, sz]),

@@ -9,10 +9,15 @@ void check_metric(int m) { if (m < COMET_L2 || m > COMET_COSINE) COMET_FAIL(COME
 struct CallGuard {   // serialise calls on a context, bind the device, reset the per-call scratch arena
     Ctx* c; std::unique_lock<std::recursive_mutex> lk;
     // every call but an asynchronous search: lane 0, and lane 1 idle first (the call may change what a search in flight there reads)
+    bool search = false;
     explicit CallGuard(Ctx* c_) : c(c_), lk(c_->mu) { c->bind(); c->switch_lane(0); c->quiesce_alt(); c->scratch_reset(); }
-    // an asynchronous search enqueued on `lane` (its stream, its scratch arena); lane 0 is current again when the guard goes
-    CallGuard(Ctx* c_, int lane) : c(c_), lk(c_->mu) { c->bind(); c->switch_lane(lane); c->scratch_reset(); }
-    ~CallGuard() { if (c->cur_lane != 0) { c->mark_dirty(); c->switch_lane(0); } }
+    // an asynchronous search enqueued on `lane` (its stream, its scratch arena); lane 0 is current again when the guard goes. A lane
+    // other than 0 starts behind whatever non-search work lane 0 was last given (Ctx::lane0_fence): the queries may still be being written there
+    CallGuard(Ctx* c_, int lane) : c(c_), lk(c_->mu), search(true) { c->bind(); c->switch_lane(lane); c->scratch_reset(); c->follow_lane0(); }
+    ~CallGuard() {
+        if (c->cur_lane != 0) { c->mark_dirty(); try { c->switch_lane(0); } catch (...) {} }
+        if (!search) { try { c->fence_lane0(); } catch (...) {} }     // what this call left queued on lane 0 is what later searches on lanes 1.. start behind
+    }
 };
 }  // namespace
 
@@ -65,6 +70,8 @@ int comet_ctx_destroy(comet_ctx* c) {
             if (c->parked[l].stream) (void)hipStreamDestroy(c->parked[l].stream);
         }
         if (c->scratch) (void)hipFree(c->scratch);
+        if (c->lane0_fence) (void)hipEventDestroy(c->lane0_fence);
+        if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
         if (c->pinned) (void)hipHostFree(c->pinned);
         (void)hipStreamDestroy(c->stream);
         delete c;
@@ -72,7 +79,8 @@ int comet_ctx_destroy(comet_ctx* c) {
     });
 }
 int comet_ctx_sync(comet_ctx* c) { return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->sync(); return COMET_OK; }); }
-void* comet_ctx_stream(comet_ctx* c) { return (void*)c->stream; }
+void* comet_ctx_stream(comet_ctx* c) { std::lock_guard<std::recursive_mutex> lk(c->mu); return (void*)(c->cur_lane == 0 ? c->stream : c->parked[0].stream); }
+int comet_ctx_fence(comet_ctx* c) { return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->switch_lane(0); c->fence_lane0(); return COMET_OK; }); }
 int comet_dev_alloc(comet_ctx* c, size_t bytes, void** out) { return guarded([&] { c->bind(); HIP_CHECK(hipMalloc(out, bytes ? bytes : 4)); return COMET_OK; }); }
 int comet_dev_free(comet_ctx* c, void* p) { return guarded([&] { c->bind(); if (p) HIP_CHECK(hipFree(p)); return COMET_OK; }); }
 int comet_memcpy_h2d(comet_ctx* c, void* d, const void* s, size_t bytes) {
@@ -371,10 +379,11 @@ static void segments_search(comet_index* const* segs, int S, const float* querie
     // The segments' searches rotate through the context's execution lanes: they are independent, and each is a chain of short
     // kernels. The other lanes start behind what lane 0 holds so far (the queries' upload); the merge starts when every search is final
     // (search_finish waits on the host). A lane's scratch arena is reset once per call and then grows across its segments.
-    static thread_local hipEvent_t ev = nullptr;
-    if (!ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (!c->fork_ev) HIP_CHECK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));    // the context's (c->mu is held): an event belongs to one device
+    hipEvent_t ev = c->fork_ev;
     HIP_CHECK(hipEventRecord(ev, c->stream));
-    struct LaneBack { Ctx* c; ~LaneBack() { c->switch_lane(0); } } lane_back{c};
+    // whatever happens below (a search_begin that throws half-way included), lanes that were given work are marked for quiesce_alt()
+    struct LaneBack { Ctx* c; ~LaneBack() { try { c->switch_lane(0); } catch (...) {} } } lane_back{c};
     bool used[Ctx::kMaxLanes] = {true, false, false, false};
     int rot = 0;
     // newest first, as the reference walks memtables and segments (the order has no effect on the merged result)
@@ -383,8 +392,8 @@ static void segments_search(comet_index* const* segs, int S, const float* querie
         const int lane = m > 1 ? (rot++ % m) : 0;
         c->switch_lane(lane);
         if (!used[lane]) { used[lane] = true; c->scratch_reset(); HIP_CHECK(hipStreamWaitEvent(c->stream, ev, 0)); }
+        c->mark_dirty();          // before the enqueue: a search_begin that throws has still left kernels on this lane
         tickets[s] = segs[s]->search_begin(queries_dev, B, *p, ids + (size_t)s * B * k, sc + (size_t)s * B * k, cn + (size_t)s * B, k);
-        c->mark_dirty();
     }
     c->switch_lane(0);
     for (int s = S - 1; s >= 0; s--) segs[s]->search_finish(tickets[s]);

@@ -162,6 +162,7 @@ int comet_index_search_sharded_async(comet_index* idx, comet_comm* cm, const flo
         struct LaneBack { Ctx* c; ~LaneBack() { if (c->cur_lane != 0) { c->mark_dirty(); c->switch_lane(0); } } } lane_back{c};
         { const int m = std::min(c->lanes, idx->max_lanes()); c->switch_lane(m > 1 ? (idx->lane_toggle = (idx->lane_toggle + 1) % m) : 0); }
         c->scratch_reset();
+        c->follow_lane0();          // lanes 1..: behind the non-search work lane 0 was last given (the queries' upload / generation)
         comet_comm::Slot* s = &cm->slots[cm->next_ticket % comet_comm::kSlots];   // round robin: a slot is reused four searches later
         if (s->active) s = nullptr;
         if (!s) COMET_FAIL(COMET_ERR_INVALID_ARG, "more than %d sharded searches in flight: wait for one first", comet_comm::kSlots);

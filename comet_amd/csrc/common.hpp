@@ -109,6 +109,22 @@ struct Ctx {
         cur_lane = l;
     }
     void mark_dirty() { if (cur_lane) dirty_mask |= 1u << cur_lane; }
+    // Ordering between lane 0 and the other lanes. Lane 0's stream is the one comet_ctx_stream() hands out and the one every call that is
+    // not an asynchronous search enqueues on (uploads, comet_synth_*, adds ...). Such a call may return with its work still queued; an
+    // asynchronous search that lands on lane 1..3 must start behind it. `lane0_fence` is recorded on lane 0 when a non-search call ends
+    // (CallGuard) or when the caller asks for it after enqueueing its own kernels on comet_ctx_stream() (comet_ctx_fence); a search on
+    // another lane waits for the newest record. Searches on lane 0 do NOT move the fence: a search on lane 1 must not queue up behind the
+    // search that lane 0 is running (that would serialise the lanes).
+    hipEvent_t lane0_fence = nullptr; bool lane0_fence_set = false;
+    hipEvent_t fork_ev = nullptr;   // segments_search: the other lanes start behind what lane 0 holds at the call (owned by the context: an event belongs to a device)
+    void fence_lane0() {            // lane 0 current
+        if (!lane0_fence) HIP_CHECK(hipEventCreateWithFlags(&lane0_fence, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(lane0_fence, stream));
+        lane0_fence_set = true;
+    }
+    void follow_lane0() {           // the current lane (>= 1) starts behind the newest fence of lane 0
+        if (cur_lane != 0 && lane0_fence_set) HIP_CHECK(hipStreamWaitEvent(stream, lane0_fence, 0));
+    }
     void quiesce_alt() {         // called with lane 0 current: the other lanes idle
         for (int l = 1; l < kMaxLanes; l++) if (((dirty_mask >> l) & 1u) && parked[l].stream) HIP_CHECK(hipStreamSynchronize(parked[l].stream));
         dirty_mask = 0;

@@ -846,7 +846,9 @@ struct HNSWIndex : comet_index {
             ProfScope ps(c, spill ? "hnsw_search_spill" : "hnsw_search");
             for (int b0 = 0; b0 < B; b0 += bs) {
                 const int bn = std::min(bs, B - b0);
-#define HS(MT) do { HIP_CHECK(hipFuncSetAttribute((const void*)hnsw_search_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                // the attribute is per function and process-wide: always the maximum any launch may ask for (two contexts on two threads may interleave
+                // "set" and "launch"); only the launch parameter varies
+#define HS(MT) do { HIP_CHECK(hipFuncSetAttribute((const void*)hnsw_search_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HN_LDS_BYTES)); \
                     hnsw_search_kernel<MT><<<dim3(bn), dim3(64), lds, c->stream>>>(g, Qp + (size_t)b0 * ld, ef, vis + (size_t)b0 * vwords, vwords, res_idx + (size_t)b0 * ef_ld, \
                         res_dist + (size_t)b0 * ef_ld, res_cnt + b0, status, st, slab, s_cand, s_res, ef_ld, spill ? 64 : cand_cap, spill ? 64 : res_cap); } while (0)
                 switch (metric) { case COMET_L2: HS(COMET_L2); break; case COMET_L2SQ: HS(COMET_L2SQ); break; default: HS(COMET_COSINE); break; }

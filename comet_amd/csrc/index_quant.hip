@@ -851,7 +851,12 @@ struct PQFamilyIndex : comet_index {
             const bool fuse = !fuse_off && p.k >= 1 && p.k <= ADC_FILTER_MAX_K && p.k <= k_cap;
             // fused: the scan keeps only the candidates under a running per-query bound (8-byte composites in a row as long as the
             // candidate row, almost all of it never touched); otherwise it writes the distance matrix for the generic selection
-            const int qb = (int)std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(budget / ((size_t)ldD * (fuse ? 8 : 4)))));
+            // A sharded search that exchanges stage-1 bounds keeps the whole batch in ONE outer sub-batch: this split depends on the rank's own lists
+            // (Cmax), and the ranks' collectives must pair up — the only sub-batching left is launch_adc_scan's, which is the same on every rank
+            const bool exchanging = fuse && shard_world > 1 && bound_exchange != nullptr;
+            if (exchanging && (size_t)B * (size_t)ldD * 8 > ((size_t)64 << 30))
+                COMET_FAIL(COMET_ERR_UNSUPPORTED, "sharded IVFPQ search: %d queries x %lld candidates per query do not fit one sub-batch; search smaller batches", B, (long long)ldD);
+            const int qb = exchanging ? B : (int)std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(budget / ((size_t)ldD * (fuse ? 8 : 4)))));
             float* D = fuse ? nullptr : c->salloc<float>((size_t)qb * ldD);
             AdcFilter afl{};
             if (fuse) {
@@ -882,6 +887,12 @@ struct PQFamilyIndex : comet_index {
                                         out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);
             }
         } else {
+            // nothing to scan on this rank (an empty shard): its peers still exchange their stage-1 bounds — take part with +inf
+            static const bool fuse_off0 = getenv("COMET_ADC_NO_FUSE") != nullptr;
+            if (shard_world > 1 && bound_exchange && !fuse_off0 && p.k >= 1 && p.k <= ADC_FILTER_MAX_K && p.k <= k_cap && p.mode != 1) {
+                AdcFilter idle{}; idle.tq = c->salloc<uint32_t>(B); idle.exchange = bound_exchange; idle.exchange_user = bound_exchange_user; idle.one_stage = 0;
+                adc_exchange_idle(c, &idle, M, Ksub, np, B, ivf ? nlist : 1);
+            }
             launch_select_topk(c, nullptr, 0, B, 0, nullptr, 0.0f, p.k, pos, out_scores, out_counts, k_cap);
         }
         launch_finalize_probe(c, pos, B, k_cap, probe_list, np, seg_off, np, lay.list_base.as<int64_t>(), lay.ids_slot.as<uint32_t>(),

@@ -1270,19 +1270,38 @@ static size_t adc_lut_budget() {
     static size_t b = [] { const char* e = getenv("COMET_ADC_LUT_MB"); long mb = e ? atol(e) : 1024; if (mb < 1) mb = 1; return (size_t)mb << 20; }();
     return b;
 }
+// Sub-batching of launch_adc_scan and whether it runs the two-stage search: functions of (M, Ksub, np, B, nlist, the filter's mode) only — the same on
+// every rank of a sharded search, whatever the rank's own lists hold. The stage-1 bound exchange (one collective per sub-batch) relies on that.
+static int64_t adc_sub_batch(int M, int Ksub, int np, int B) {
+    const int KL = Ksub < 256 ? Ksub : 256;
+    const size_t lut_pair = (size_t)M * KL * sizeof(float);
+    const int64_t qc = std::max<int64_t>(1, (int64_t)(adc_lut_budget() / (lut_pair * (size_t)np)));
+    return std::min<int64_t>(qc, B);
+}
+static bool adc_two_stage(const AdcFilter* flt, int np, int nlist) {
+    static const bool two_stage_on = getenv("COMET_ADC_ONE_STAGE") == nullptr;
+    return flt != nullptr && np >= 2 && nlist <= ORDER_MAX_LISTS && two_stage_on && !flt->one_stage;
+}
+// A rank of a sharded search that has nothing to scan (an empty shard) still takes part in every exchange its peers issue: +inf bounds, the same
+// sub-batches. `tq` must hold B words.
+void adc_exchange_idle(Ctx* c, const AdcFilter* flt, int M, int Ksub, int np, int B, int nlist) {
+    if (!flt || !flt->exchange || B <= 0 || np <= 0 || !adc_two_stage(flt, np, nlist)) return;
+    HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)flt->tq, 0x7F800000, (size_t)B, c->stream));
+    const int qc = (int)adc_sub_batch(M, Ksub, np, B);
+    for (int b0 = 0; b0 < B; b0 += qc) flt->exchange(flt->exchange_user, flt->tq + b0, std::min(qc, B - b0));
+}
 void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* centroids, const float* codebooks, int M, int Ksub, int dsub,
                      const uint32_t* codes, int M4, const int64_t* list_base, const int32_t* list_len, const uint32_t* probe_list, int ldp,
                      int np, const int32_t* seg_off, const uint8_t* elig, int B, int nlist, int max_list_len, float* D, int64_t ldD, const AdcFilter* flt) {
-    if (B <= 0 || np <= 0 || max_list_len <= 0) return;
+    if (B <= 0 || np <= 0) return;
+    if (max_list_len <= 0) { adc_exchange_idle(c, flt, M, Ksub, np, B, nlist); return; }
     const int KL = Ksub < 256 ? Ksub : 256;
     const int kl_shift = 31 - __builtin_clz((unsigned)KL);
     const size_t lds = adc_lds_bytes(M, Ksub, dim);
     const int mp = std::max(16, (int)(ADC_BUF_BYTES / ((size_t)KL * 8)) / 16 * 16);        // subspaces per phase buffer (KL <= 256: >= 32)
-    const size_t lut_pair = (size_t)M * KL * sizeof(float);
     const bool identity = nlist > ORDER_MAX_LISTS;
     // queries per sub-batch: tables of a sub-batch live in HBM between the two kernels
-    int64_t qc = std::max<int64_t>(1, (int64_t)(adc_lut_budget() / (lut_pair * (size_t)np)));
-    qc = std::min<int64_t>(qc, B);
+    const int64_t qc = adc_sub_batch(M, Ksub, np, B);
     const bool lead = flt != nullptr && np >= 2 && !identity;
     auto slots_for = [&](int64_t n_pairs) { return identity ? 2 * n_pairs : (lead ? 2 * (n_pairs / np) : 0) + round_up(n_pairs + std::min<int64_t>(nlist, n_pairs), 2); };
     const int64_t max_slots = slots_for(qc * np);
@@ -1313,8 +1332,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
     // removes every pair none of whose candidates can pass the bound (no table, no slot, no item), and stage 2 scans what is left.
     // Exact: a removed candidate's sum is above a bound that only ever tightens. On clustered data almost everything behind the
     // nearest lists goes (bench corpus: 98.6 % of the candidates); on unclustered data the cost is the row-minima kernel.
-    static const bool two_stage_on = getenv("COMET_ADC_ONE_STAGE") == nullptr;
-    const bool two_stage = flt != nullptr && np >= 2 && !identity && two_stage_on && !flt->one_stage;
+    const bool two_stage = adc_two_stage(flt, np, nlist);
     int32_t* used = c->salloc<int32_t>(4);
     float* rowmin = two_stage ? c->salloc<float>((size_t)qc * np * M) : nullptr;
     uint8_t* dead = two_stage ? c->salloc<uint8_t>((size_t)qc * np) : nullptr;

@@ -71,6 +71,10 @@ class Context:
     def stream(self) -> int:
         return int(self.lib.comet_ctx_stream(self.h) or 0)
 
+    def fence(self) -> None:
+        """after the caller's OWN kernels on `stream` (lane 0): asynchronous searches enqueued afterwards start behind them, whichever lane they run on"""
+        check(self.lib.comet_ctx_fence(self.h))
+
     # raw device memory (for callers that keep queries / results resident in HBM)
     def alloc(self, nbytes: int) -> int:
         p = C.c_void_p()

@@ -46,6 +46,15 @@ func (c *Context) SetLanes(lanes int) error {
 	return nil
 }
 
+// Fence marks everything queued so far on the context's lane-0 stream (comet_ctx_stream) as a dependency of every asynchronous search
+// enqueued afterwards. Only callers that run their own HIP work on that stream need it; the library's own calls place the fence themselves.
+func (c *Context) Fence() error {
+	if rc := C.comet_ctx_fence(c.h); rc != C.COMET_OK {
+		return lastError(rc)
+	}
+	return nil
+}
+
 // lastError maps a comet_status to the error values the reference returns.
 func lastError(rc C.int) error {
 	msg := C.GoString(C.comet_last_error())

@@ -10,7 +10,8 @@
  *    message whose text mirrors the reference's fmt.Errorf strings where one exists.
  *  - host-pointer entry points copy their inputs before returning (cgo may not retain Go pointers).
  *  - `*_dev` entry points take DEVICE pointers (memory from comet_dev_alloc or any HIP allocation on
- *    the context's device) and run asynchronously on the context's stream; comet_ctx_sync() waits.
+ *    the context's device) and run asynchronously on the context's stream (lane 0; asynchronous searches on
+ *    one of the context's execution lanes, see comet_ctx_stream / comet_ctx_set_lanes); comet_ctx_sync() waits for all of them.
  *  - one search call = B independent queries -> B result rows (the Go shim maps the reference's
  *    "multi-query Execute() aggregates into one list" semantics onto it, flat_index_search.go:143-153).
  *  - result rows are sorted ascending by score; exact score ties are ordered by scan order (the
@@ -65,8 +66,15 @@ COMET_API int comet_device_count(int* out_count);
 COMET_API int comet_ctx_create(int device_id, comet_ctx** out);
 COMET_API int comet_ctx_destroy(comet_ctx* ctx);
 COMET_API int comet_ctx_sync(comet_ctx* ctx);
-/* raw HIP stream handle (hipStream_t) searches are enqueued on — for HIP-event timing by the caller */
+/* raw HIP stream handle (hipStream_t) of execution lane 0: the stream every call that is not an asynchronous search enqueues on
+ * (uploads, comet_synth_*, adds, the synchronous searches). Asynchronous searches rotate through the context's lanes (comet_ctx_set_lanes);
+ * a search that lands on another lane starts behind the work the LIBRARY last queued on lane 0 (so `comet_synth_fill_dev(queries)` followed by
+ * `comet_index_search_dev_async(queries)` is ordered), but the library cannot see kernels the caller enqueues on this stream itself: call
+ * comet_ctx_fence() after them (or comet_ctx_sync()) before an asynchronous search that reads what they write. */
 COMET_API void* comet_ctx_stream(comet_ctx* ctx);
+/* Marks "everything queued on lane 0's stream up to here" as a dependency of every asynchronous search enqueued afterwards, whichever lane it runs
+ * on. No host wait. Needed only after the caller's OWN work on comet_ctx_stream(); the library's own calls place the fence themselves. */
+COMET_API int comet_ctx_fence(comet_ctx* ctx);
 COMET_API int comet_dev_alloc(comet_ctx* ctx, size_t bytes, void** out_dev);
 COMET_API int comet_dev_free(comet_ctx* ctx, void* dev);
 COMET_API int comet_memcpy_h2d(comet_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
@@ -222,11 +230,12 @@ COMET_API int comet_index_search_dev(comet_index* idx, const float* queries_dev,
                                      const comet_search_params* p, uint32_t* out_ids_dev, float* out_scores_dev,
                                      int32_t* out_counts_dev, int32_t k_cap);
 
-/* Pipelined form: `_async` only ENQUEUES the search on the context's stream and returns a ticket;
- * comet_index_search_wait(ticket) blocks until that search has finished on the device and makes its results final
+/* Pipelined form: `_async` only ENQUEUES the search — on one of the context's execution lanes (streams), rotating per index — and
+ * returns a ticket; comet_index_search_wait(ticket) blocks until THAT search has finished on the device and makes its results final
  * (the Flat fast path re-runs the rare queries whose candidate list overflowed on the exact kernels there).
- * Queries and output buffers must stay untouched until the wait returns. Several searches may be in flight;
- * they complete in order. comet_index_search_dev == async + wait. */
+ * Queries and output buffers must stay untouched until the wait returns. Several searches may be in flight; with more than one lane
+ * they run beside each other and may finish in any order (wait for the ticket whose results you read). A search starts behind the
+ * non-search work the library last queued on lane 0 (see comet_ctx_stream / comet_ctx_fence). comet_index_search_dev == async + wait. */
 COMET_API int comet_index_search_dev_async(comet_index* idx, const float* queries_dev, int32_t B, const comet_search_params* p,
                                            uint32_t* out_ids_dev, float* out_scores_dev, int32_t* out_counts_dev, int32_t k_cap,
                                            uint64_t* out_ticket);
