@@ -765,6 +765,311 @@ void launch_flat_scan_f16(Ctx* c, int mode, const void* Xh, int64_t n, int ldh, 
     if (mode == 0) go2(flat_scan_f16_kernel<0>); else go2(flat_scan_f16_kernel<1>);
     LAUNCH_CHECK();
 }
+// ------------------------------------------------------------------------------------------------
+// Register-stationary scan tile for the int8 shadow (round 4): the QUERIES live in registers for the whole launch.
+//
+// What held the query-stationary tile above at a third of either roofline (0.245-0.277 ms for 1M x 768 x 256: HBM floor 0.12 ms,
+// int8 MFMA floor 0.09 ms): per K step its eight waves pull the SAME 32 KiB of query fragments from L2 again for every row tile —
+// as many bytes through the CU's vector-memory path as the corpus rows themselves — every A fragment read from LDS feeds ONE
+// MFMA, eight waves meet at a barrier every 32 MFMAs, and the selection epilogue (a quarter of an int8 tile) runs with the matrix
+// pipe idle because both waves of a SIMD reach it together.
+// Here: four waves per workgroup, ONE per SIMD, 512 registers each (launch_bounds(256, 1)):
+//   * wave w keeps the int8 fragments of queries 64 w .. 64 w + 63 for the whole K range in registers (ld8 / 4 of them: 192 at d = 768),
+//     loaded once per launch: no query traffic in the loop at all;
+//   * the rows stream HBM -> LDS by LDS-DMA in PASSES of 64 rows x ld8 bytes (48 KiB at 768) through a ring of whole passes; a wave's
+//     tile is 64 rows x 64 queries (2 x 2 MFMA blocks), so an A fragment read from LDS feeds two MFMAs (half the LDS traffic per
+//     MFMA) and there is ONE barrier per pass (96 MFMAs per wave at 768), placed one fragment-prefetch ahead of the pass boundary;
+//   * the selection epilogue of pass p-1 (accumulators double-buffered: 2 x 64 registers) is issued between the MFMAs of pass p,
+//     a few VALU instructions per MFMA: the matrix pipe never waits for it;
+//   * work is dealt in 128-row halves of the 256-row shadow tiles (XCD-contiguous, round robin inside an XCD).
+// Keys and bounds come out exactly as from flat_scan_q8_kernel<MODE, UR, true> (same packed values, same unit numbering).
+// ------------------------------------------------------------------------------------------------
+constexpr int QR_THREADS = 256, QR_PASS_ROWS = 64;
+__device__ __forceinline__ int qr_med3_i32(int a, int b, int c) { int d; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// keep the three LARGEST of (t0 >= t1 >= t2) U {v}. INT: signed integer keys; otherwise float keys carried as bits (all three updates through
+// v_med3_f32: fmaxf() would put a canonicalising v_max_f32 v, v, v in front of every comparison of a value that came out of bit operations)
+template <bool INT> __device__ __forceinline__ void qr_ins3(int& t0, int& t1, int& t2, int v) {
+    if constexpr (INT) {
+        const int n2 = qr_med3_i32(t1, t2, v), n1 = qr_med3_i32(t0, t1, v);
+        t0 = t0 > v ? t0 : v; t1 = n1; t2 = n2;
+    } else {
+        const float f0 = __int_as_float(t0), f1 = __int_as_float(t1), f2 = __int_as_float(t2), fv = __int_as_float(v);
+        const float n2 = __builtin_amdgcn_fmed3f(f1, f2, fv), n1 = __builtin_amdgcn_fmed3f(f0, f1, fv), n0 = __builtin_amdgcn_fmed3f(f0, fv, __builtin_inff());
+        t0 = __float_as_int(n0); t1 = __float_as_int(n1); t2 = __float_as_int(n2);
+    }
+}
+// LDS-DMA pieces issued from inline asm: 16 bytes (resp. 4) per lane from `sbase + voff` to LDS byte address `lds_addr` + lane * 16 (4), non-temporal.
+// Not the builtin: hipcc's wait-count pass treats a pending LDS-DMA as a FLAT access that may complete on either counter and then turns
+// EVERY lgkmcnt wait into lgkmcnt(0) for as long as it has not seen a vmcnt wait for the DMA (the kernel's counted vmcnt waits are asm and invisible
+// to it): the fragment prefetch (reads for step kk + 1 in flight under step kk's MFMAs) would be drained at every second step. M0 is
+// saved and restored inside the statement (it is compiler-reserved).
+__device__ __forceinline__ void qr_dma16(const char* sbase /*wave-uniform*/, unsigned voff, unsigned lds_addr /*wave-uniform*/) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void qr_dma4(const char* sbase /*wave-uniform*/, unsigned voff, unsigned lds_addr /*wave-uniform*/) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+template <int I, int N, class F> __device__ __forceinline__ void qr_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); qr_static_for<I + 1, N>(f); }
+}
+template <int NKS> struct QrGeom {
+    static constexpr int NKK = NKS * 4;                        // 32-dimension MFMA steps per row
+    static constexpr int STAGE = NKS * 8192;                   // bytes of one pass in LDS: [K step][64 rows][128 B]
+    static constexpr int RING = (144 * 1024) / STAGE > 8 ? 8 : (144 * 1024) / STAGE;   // passes in the ring (3 at 768, 4 at 512, 8 at 256)
+    static constexpr int PPW = 2 * NKS;                        // DMA pieces (1 KiB) per wave per pass
+    static constexpr int LDS = RING * STAGE + (RING + 1) * 256; // + the row norms of the ring's passes and of the pass whose selection is still running (MODE 1)
+};
+// s_waitcnt vmcnt(K * VMW), K a run-time pass count in 0 .. KMAX (the immediate must be a constant)
+template <int VMW, int KMAX> __device__ __forceinline__ void qr_wait_passes(int k) {
+    static_assert(KMAX * VMW <= 63 && KMAX <= 6, "vmcnt is a 6-bit counter");
+    if (KMAX >= 6 && k >= 6) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KMAX >= 6 ? 6 * VMW : 0) : "memory");
+    else if (KMAX >= 5 && k == 5) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KMAX >= 5 ? 5 * VMW : 0) : "memory");
+    else if (KMAX >= 4 && k == 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KMAX >= 4 ? 4 * VMW : 0) : "memory");
+    else if (KMAX >= 3 && k == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KMAX >= 3 ? 3 * VMW : 0) : "memory");
+    else if (KMAX >= 2 && k == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KMAX >= 2 ? 2 * VMW : 0) : "memory");
+    else if (KMAX >= 1 && k == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KMAX >= 1 ? 1 * VMW : 0) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int MODE, int UR, int NKS>
+__global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qr_kernel(const signed char* __restrict__ X8, long n, const signed char* __restrict__ Q8F,
+                                                                     const float* __restrict__ rn, const float* __restrict__ qn,
+                                                                     const unsigned char* __restrict__ elig,
+                                                                     float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles,
+                                                                     const float* __restrict__ sx, const float* __restrict__ sq) {
+    using G = QrGeom<NKS>;
+    constexpr int NKK = G::NKK, STAGE = G::STAGE, RING = G::RING, PPW = G::PPW;
+    constexpr int VMW = PPW + (MODE == 1 ? 1 : 0);              // vector-memory operations a wave issues per pass (pieces + its share of the row norms)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* rn_ring = reinterpret_cast<float*>(smem + RING * STAGE);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- work split: 128-row halves; every XCD owns a contiguous range, its workgroups take them round robin ----
+    const long nx = 8, xcd = blockIdx.x % nx, wgx = blockIdx.x / nx, W = gridDim.x / nx;
+    const long H = n_tiles * 2, hq = H / nx, hrem = H % nx;
+    const long xbase = xcd < hrem ? xcd * (hq + 1) : hrem * (hq + 1) + (xcd - hrem) * hq, xcount = xcd < hrem ? hq + 1 : hq;
+    const long my_halves = wgx < xcount ? (xcount - wgx + W - 1) / W : 0;
+    if (my_halves == 0) return;
+    const int P = (int)(my_halves * 2);                          // passes of this workgroup (even)
+    auto row0_of = [&](int p) __attribute__((always_inline)) { return ((xbase + wgx + (long)(p >> 1) * W) * 2 + (p & 1)) * (long)QR_PASS_ROWS; };
+    // ---- per-lane constants ----
+    // fragment reads: row l31 (+ 32 mb) of the pass, 16-byte slot (kk & 3) * 2 + khalf of the K step, XOR swizzle of swz_off()
+    unsigned sw[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) sw[j] = (unsigned)(l31 * 128 + (((j * 2 + khalf) ^ ((l31 >> 1) & 7)) << 4));
+    // DMA pieces: piece i of wave w = K step i >> 1, row group 4 (i & 1) + w (8 rows x 128 B); the lane's source offset inside the K step's slab pair
+    const int prow = lane >> 3, pslot = lane & 7;
+    const int ksl = pslot ^ (((wid & 1) * 4 + (prow >> 1)) & 7);
+    const unsigned po0 = (unsigned)((ksl >> 2) * 16384 + (wid * 8 + prow) * 64 + (ksl & 3) * 16);
+    const long tile_bytes = (long)NKS * 2 * 16384;              // int8 shadow bytes of one 256-row tile
+    auto pass_src = [&](int p) __attribute__((always_inline)) {                                 // uniform: first byte of the pass's rows in slab 0 of its tile
+        const long r0 = row0_of(p);
+        return reinterpret_cast<const char*>(X8) + (r0 >> 8) * tile_bytes + (r0 & 255) * 64;
+    };
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;      // LDS byte address of the ring
+    auto dma_piece = [&](const char* src, int slot, int i) __attribute__((always_inline)) {
+        qr_dma16(src + (long)(i >> 1) * 32768, po0 + (unsigned)((i & 1) * 2048), lds0 + (unsigned)(slot * STAGE + (i >> 1) * 8192 + ((i & 1) * 4 + wid) * 1024));
+    };
+    auto dma_rn = [&](int p, int slot) __attribute__((always_inline)) {                         // MODE 1: 16 row norms per wave (lanes 16 w .. 16 w + 15 of a 4-byte piece)
+        if constexpr (MODE == 1) {
+            const long r0 = row0_of(p);
+            const long last = n - 1 - r0;                          // rows past n read the last row's norm (their keys are masked)
+            const unsigned voff = (unsigned)((long)lane < last ? (long)lane : (last > 0 ? last : 0)) * 4u;
+            if ((lane >> 4) == wid) qr_dma4(reinterpret_cast<const char*>(rn + r0), voff, lds0 + (unsigned)(RING * STAGE + slot * 256));
+        }
+    };
+    // ---- prologue: passes 0 .. RING-2 in flight ----
+#pragma unroll
+    for (int pp = 0; pp < RING - 1; pp++) {
+        if (pp < P) {
+            const char* src = pass_src(pp);
+#pragma unroll
+            for (int i = 0; i < PPW; i++) dma_piece(src, pp, i);
+            dma_rn(pp, pp);
+        }
+    }
+    // ---- queries: fragments [group of 32 queries][kk][lane] 16 bytes (prep_queries_i8_kernel), groups 2 w and 2 w + 1 ----
+    // Loaded AFTER the prologue's DMA pieces and pinned as landed before the loop: hipcc does not see the asm DMAs, so a counted vmcnt wait it
+    // placed for a query load inside the loop would count the ring's pieces as its own younger loads and drain the ring on every pass.
+    i32x4v Q[2][NKK];
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+        for (int kk = 0; kk < NKK; kk++)
+            Q[nb][kk] = *reinterpret_cast<const i32x4v*>(Q8F + ((long)(wid * 2 + nb) * NKK + kk) * 1024 + lane * 16);
+    float sqv[2], qnv[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) { sqv[nb] = sq[wid * 64 + nb * 32 + l31]; qnv[nb] = MODE == 1 ? qn[wid * 64 + nb * 32 + l31] : 0.0f; }
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) {
+#pragma unroll
+        for (int kk = 0; kk < NKK; kk++) asm volatile("" : "+a"(Q[nb][kk]));     // "a": the fragments live in the accumulator half of the register file (MFMA reads B from there)
+        asm volatile("" : "+v"(sqv[nb]), "+v"(qnv[nb]));
+    }
+    const float INF = __builtin_inff();
+    i32x16 acc[2][2][2];                                         // [parity][mb][nb]
+    // Selection keys. MODE 0 (cosine): the score s_T s_q acc is monotone in the integer sum, so the network runs on EXACT integer keys
+    // (acc << 7) | row-in-unit (|acc| <= 127^2 * 768 < 2^24: no overflow; bit 2 of the row = the half-wave, added at the merge) — no
+    // conversion, nothing lost to the packing. MODE 1 (L2 family): float keys 2 s - rn with the row in the low 8 mantissa bits, as in
+    // scan_epilogue_q. NONE = "no row yet" (below every key).
+    constexpr bool IK = MODE == 0;
+    const int NONE = IK ? (int)0x80000000 : __float_as_int(-INF);
+    int t0[2], t1[2], t2[2];                                     // running three largest of the current key unit, per query block
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) { t0[nb] = NONE; t1[nb] = NONE; t2[nb] = NONE; }
+
+    // unit end: merge the two half-waves (rows + 4), turn the three survivors into keys, store (lanes 0..31: query block 0, lanes 32..63: block 1)
+    auto unit_end = [&](long un, float stv) __attribute__((always_inline)) {
+        int m0[2], m1[2], m2[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; nb++) {
+            const int mybit = 4 * khalf, otherbit = 4 * (khalf ^ 1);
+            auto tag = [&](int v, int bit) __attribute__((always_inline)) { return v == NONE ? v : (v | bit); };
+            auto other = [&](int v) __attribute__((always_inline)) {                          // the value lane ^ 32 holds
+                const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+                return (int)(khalf ? r[0] : r[1]);
+            };
+            const int o0 = other(t0[nb]), o1 = other(t1[nb]), o2 = other(t2[nb]);
+            int a0 = tag(t0[nb], mybit), a1 = tag(t1[nb], mybit), a2 = tag(t2[nb], mybit);
+            qr_ins3<IK>(a0, a1, a2, tag(o0, otherbit)); qr_ins3<IK>(a0, a1, a2, tag(o1, otherbit)); qr_ins3<IK>(a0, a1, a2, tag(o2, otherbit));
+            m0[nb] = a0; m1[nb] = a1; m2[nb] = a2;
+            t0[nb] = NONE; t1[nb] = NONE; t2[nb] = NONE;
+        }
+        // both half-waves hold the merged triples of both blocks: the lower half stores block 0's, the upper half block 1's
+        const int k0 = khalf ? m0[1] : m0[0], k1 = khalf ? m1[1] : m1[0], k2 = khalf ? m2[1] : m2[0];
+        const float sqs = (khalf ? sqv[1] : sqv[0]) * stv, qns = khalf ? qnv[1] : qnv[0];
+        auto to_key = [&](int v) __attribute__((always_inline)) {
+            if (v == NONE) return INF;
+            float a; unsigned row;
+            if constexpr (IK) { row = (unsigned)v & 0x7Fu; a = 1.0f - sqs * (float)(v >> 7); }
+            else { row = (unsigned)v & 0xFFu; a = qns - __uint_as_float((unsigned)v & 0xFFFFFF00u); }    // the key is -(rn - 2 s)
+            a = fmaxf(a, 0.0f);
+            return __uint_as_float((__float_as_uint(a) & 0xFFFFFF00u) | row);
+        };
+        int q = wid * 64 + lane;                                  // lane = khalf * 32 + l31: query l31 of block khalf
+        asm volatile("" : "+v"(q));                              // (keeps the output addresses out of the loop-carried state)
+        S0[(long)q * ldS + 2 * un] = to_key(k0);
+        S0[(long)q * ldS + 2 * un + 1] = to_key(k1);
+        bound[(long)q * ldB + un] = to_key(k2);
+    };
+
+    // one element of the selection: block (mb, nb), accumulator register e of the pass with unit half `ppar`
+    auto select_one = [&](const i32x16 (&prev)[2][2], int ppar, int pslot_, float s2_0, float s2_1, int x, bool ok) __attribute__((always_inline)) {
+        // element order: nb fastest (two independent chains), then e, then mb
+        const int xnb = x & 1, xe = (x >> 1) & 15, xmb = x >> 5;
+        const int rconst = (UR == 128 ? ppar * 64 : 0) + xmb * 32 + (xe & 3) + 8 * (xe >> 2);
+        int v_;
+        if constexpr (IK) v_ = (prev[xmb][xnb][xe] << 7) | rconst;
+        else {
+            const float rnv = rn_ring[pslot_ * 64 + xmb * 32 + (xe & 3) + 8 * (xe >> 2) + 4 * khalf];
+            const float f = __builtin_fmaf(xnb ? s2_1 : s2_0, (float)prev[xmb][xnb][xe], -rnv);
+            v_ = (int)((__float_as_uint(f) & 0xFFFFFF00u) | (unsigned)rconst);
+        }
+        if (!ok) v_ = NONE;
+        qr_ins3<IK>(t0[xnb], t1[xnb], t2[xnb], v_);
+    };
+    // standalone (not interleaved) selection of a finished pass: the workgroup's last pass, and every pass that needs row masks
+    // (rows past n, soft deletes, filters)
+    auto epilogue_plain = [&](const i32x16 (&prev)[2][2], int ppar, long prow0, int pslot_, float stv, bool check) __attribute__((always_inline)) {
+        unsigned okm = 0xFFFFFFFFu;
+        if (check) {
+            okm = 0u;
+            for (int mb = 0; mb < 2; mb++)
+                for (int e = 0; e < 16; e++) {
+                    const long r = prow0 + mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
+                    if (r < n && (!elig || elig[r])) okm |= 1u << (mb * 16 + e);
+                }
+        }
+        const float s2_0 = 2.0f * (sqv[0] * stv), s2_1 = 2.0f * (sqv[1] * stv);
+        qr_static_for<0, 64>([&](auto X) __attribute__((always_inline)) {
+            constexpr int x = decltype(X)::value;
+            select_one(prev, ppar, pslot_, s2_0, s2_1, x, (okm >> ((x >> 5) * 16 + ((x >> 1) & 15))) & 1u);
+        });
+        if (UR == 64 || ppar == 1) unit_end(prow0 / UR, stv);
+    };
+
+    // ---- first pass ready: own pieces of pass 0 landed (the younger passes of the prologue may still be in flight), then everybody's ----
+    qr_wait_passes<VMW, RING - 2>(RING - 2 < P - 1 ? RING - 2 : P - 1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // A fragments, double-buffered: [buffer][mb]
+    i32x4v A[2][2];
+    auto lds_frag = [&](int slot, int kk, int mb) __attribute__((always_inline)) {
+        return *reinterpret_cast<const i32x4v*>(smem + slot * STAGE + (kk >> 2) * 8192 + mb * 4096 + sw[kk & 3]);
+    };
+    A[0][0] = lds_frag(0, 0, 0); A[0][1] = lds_frag(0, 0, 1);
+
+    int slot = 0;                                                // ring slot of the current pass
+    int rslot = 0;                                               // its slot in the row-norm ring (RING + 1 entries: the norms of pass p - 1 are read by its selection all through pass p)
+    long prev_row0 = 0; int prev_slot = 0; float st_prev = 1.0f; bool prev_check = false;
+    const i32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    // The body of pass p with accumulator parity PAR (= p & 1 = the pass's 64-row half of its 128-row unit). INTER: the previous pass's
+    // selection is issued between this pass's MFMAs (spread over the first 7/8 of them; the unit's merge + stores follow). Every index
+    // below is a compile-time constant (static_for): accumulators, fragments and queries stay in registers.
+    auto pass_body = [&](auto PAR_c, auto INTER_c, int p) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_c)::value, PPAR = PAR ^ 1;
+        constexpr bool INTER = decltype(INTER_c)::value;
+        const int nslot = slot + 1 == RING ? 0 : slot + 1;
+        const int fslot = slot == 0 ? RING - 1 : slot - 1;   // the slot pass p - 1 has left = where pass p + RING - 1 lands
+        const bool more = p + RING - 1 < P;
+        const char* nsrc = pass_src(more ? p + RING - 1 : p);
+        const float s2_0 = 2.0f * (sqv[0] * st_prev), s2_1 = 2.0f * (sqv[1] * st_prev);
+        qr_static_for<0, NKK>([&](auto KK) __attribute__((always_inline)) {
+            constexpr int kk = decltype(KK)::value, ab = kk & 1;
+            if constexpr (kk == NKK - 1) {
+                // pass p + 1 readable by all: this wave's pieces of it have landed once only the passes issued after it are outstanding;
+                // this wave's fragment reads of pass p are done (lgkmcnt), so after the barrier pass p's slot may be overwritten
+                if (p + 1 < P) {
+                    qr_wait_passes<VMW, RING - 2>(RING - 2 < P - 2 - p ? RING - 2 : P - 2 - p);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    A[ab ^ 1][0] = lds_frag(nslot, 0, 0); A[ab ^ 1][1] = lds_frag(nslot, 0, 1);
+                }
+            } else {
+                A[ab ^ 1][0] = lds_frag(slot, kk + 1, 0); A[ab ^ 1][1] = lds_frag(slot, kk + 1, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            qr_static_for<0, 4>([&](auto J) __attribute__((always_inline)) {
+                constexpr int mb = decltype(J)::value >> 1, nb = decltype(J)::value & 1, m = kk * 4 + decltype(J)::value;
+                if constexpr (kk == 0) acc[PAR][mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ab][mb], Q[nb][kk], zero16, 0, 0, 0);
+                else acc[PAR][mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ab][mb], Q[nb][kk], acc[PAR][mb][nb], 0, 0, 0);
+                if constexpr (INTER) {
+                    constexpr int NM = 4 * NKK, NME = NM - NM / 8;
+                    constexpr int e_lo = m * 64 / NME < 64 ? m * 64 / NME : 64, e_hi = (m + 1) * 64 / NME < 64 ? (m + 1) * 64 / NME : 64;
+                    qr_static_for<e_lo, e_hi>([&](auto X) __attribute__((always_inline)) { select_one(acc[PPAR], PPAR, prev_slot, s2_0, s2_1, decltype(X)::value, true); });
+                    if constexpr (m == NME && (UR == 64 || PPAR == 1)) unit_end(prev_row0 / UR, st_prev);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // one DMA piece of pass p + RING - 1 per MFMA group, into the slot pass p - 1 has left (free since the barrier of pass p - 1)
+            if constexpr (kk < PPW) { if (more) dma_piece(nsrc, fslot, kk); }
+            else if constexpr (kk == PPW) { if (more) dma_rn(p + RING - 1, rslot + RING - 1 > RING ? rslot - 2 : rslot + RING - 1); }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto one_pass = [&](auto PAR_c, int p) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_c)::value;
+        const long row0 = row0_of(p);
+        if (p > 0 && prev_check) epilogue_plain(acc[PAR ^ 1], PAR ^ 1, prev_row0, prev_slot, st_prev, true);
+        if (p > 0 && !prev_check) pass_body(PAR_c, std::integral_constant<bool, true>{}, p);
+        else pass_body(PAR_c, std::integral_constant<bool, false>{}, p);
+        prev_row0 = row0; prev_slot = rslot; st_prev = sx[row0 >> 8];
+        prev_check = (n - row0 < QR_PASS_ROWS) || elig != nullptr;
+        slot = slot + 1 == RING ? 0 : slot + 1;
+        rslot = rslot == RING ? 0 : rslot + 1;
+    };
+    for (int p = 0; p < P; p += 2) {
+        one_pass(std::integral_constant<int, 0>{}, p);
+        one_pass(std::integral_constant<int, 1>{}, p + 1);
+    }
+    // the last pass (parity 1) has no successor to hide its selection under
+    epilogue_plain(acc[1], 1, prev_row0, prev_slot, st_prev, prev_check);
+}
+int flat_scan_qr_steps(int ld8) { return (ld8 == 256 || ld8 == 512 || ld8 == 768) ? ld8 / 128 : 0; }    // K steps per row the register-stationary tile is built for (0: not this one)
+
 // The wide tile on the int8 shadow (more than 64 queries; ld8 a multiple of 256). Q8F: fragment-ordered int8 queries
 // (prep_queries_i8_kernel), sx / sq: tile / query scales. Keys and bounds come out exactly as from the fp16 tile.
 void launch_flat_scan_i8(Ctx* c, int mode, const void* X8, int64_t n, int ld8, const void* Q8F, const void* Q8R, int nq_used, const float* rn, const float* qn,
@@ -780,6 +1085,23 @@ void launch_flat_scan_i8(Ctx* c, int mode, const void* X8, int64_t n, int ld8, c
                             bound, (long)ldB, n_tiles, sx, sq);
         };
         if (mode == 0) gon(flat_scan_f16_n64_kernel<0, true>); else gon(flat_scan_f16_n64_kernel<1, true>);
+        LAUNCH_CHECK();
+        return;
+    }
+    static const int qr_env = [] { const char* e = getenv("COMET_SCAN_QR"); return e ? atoi(e) : 1; }();
+    const char* qr_rt = getenv("COMET_SCAN_QR_RT");            // tools/scan_check.hip switches inside one process
+    const int nks = ((qr_rt ? atoi(qr_rt) : qr_env) != 0) ? flat_scan_qr_steps(ld8) : 0;
+    if (nks) {                  // register-stationary tile: queries in registers, one wave per SIMD, selection under the next pass's MFMAs
+        const long gridr = std::min<long>(round_up(2 * n_tiles, 8), (long)round_up(c->prop.multiProcessorCount, 8));
+        auto gor = [&](auto kernel, size_t lds) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            c->launch_timed("flat_scan_i8", kernel, dim3((unsigned)gridr), dim3(QR_THREADS), lds, (const signed char*)X8, (long)n, (const signed char*)Q8F, rn, qn, (const unsigned char*)elig, S0, (long)ldS,
+                            bound, (long)ldB, n_tiles, sx, sq);
+        };
+#define QR_GO(NKS) do { if (unit_rows == 64) { if (mode == 0) gor(flat_scan_qr_kernel<0, 64, NKS>, QrGeom<NKS>::LDS); else gor(flat_scan_qr_kernel<1, 64, NKS>, QrGeom<NKS>::LDS); } \
+                        else { if (mode == 0) gor(flat_scan_qr_kernel<0, 128, NKS>, QrGeom<NKS>::LDS); else gor(flat_scan_qr_kernel<1, 128, NKS>, QrGeom<NKS>::LDS); } } while (0)
+        if (nks == 2) QR_GO(2); else if (nks == 4) QR_GO(4); else QR_GO(6);
+#undef QR_GO
         LAUNCH_CHECK();
         return;
     }

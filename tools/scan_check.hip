@@ -77,12 +77,15 @@ int main(int argc, char** argv) {
         if (worst > 1.0) { printf("int8 bound VIOLATED\n"); bad_total++; }
         }
     }
-    for (int variant : {0, 1, 8}) {
+    // variant 9: the register-stationary int8 tile (flat_scan_qr_kernel; wide batches, ld8 in {256, 512, 768}); variant 8: the query-stationary one
+    for (int variant : {0, 1, 8, 9}) {
         if (variant == 1 && unit == 64 && B > 64) continue;
+        if (variant == 9 && (B <= 64 || flat_scan_qr_steps(ld8) == 0)) continue;
         setenv("COMET_SCAN_VARIANT_RT", variant == 1 ? "1" : "0", 1);
+        setenv("COMET_SCAN_QR_RT", variant == 9 ? "1" : "0", 1);
         HIP_CHECK(hipMemset(S0, 0xFF, (size_t)256 * ldS * 4)); HIP_CHECK(hipMemset(bound, 0xFF, (size_t)256 * ldB * 4));
         auto run = [&]() {
-            if (variant == 8) launch_flat_scan_i8(&c, 0, X8, n, ld8, Q8F, Q8R, B, rn, qn8, sxd, sqd, nullptr, S0, ldS, bound, ldB, unit);
+            if (variant >= 8) launch_flat_scan_i8(&c, 0, X8, n, ld8, Q8F, Q8R, B, rn, qn8, sxd, sqd, nullptr, S0, ldS, bound, ldB, unit);
             else launch_flat_scan_f16(&c, 0, Xh, n, ldh, Qh, B, rn, qn, nullptr, S0, ldS, bound, ldB, unit);
         };
         run();
@@ -90,12 +93,12 @@ int main(int argc, char** argv) {
         std::vector<float> hS((size_t)256 * ldS), hB((size_t)256 * ldB);
         HIP_CHECK(hipMemcpy(hS.data(), S0, hS.size() * 4, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(hB.data(), bound, hB.size() * 4, hipMemcpyDeviceToHost));
         int bad = 0; double maxerr = 0;
-        if (variant == 8 && X8r.empty()) printf("variant 8: keys not checked at this size\n");
+        if (variant >= 8 && X8r.empty()) printf("variant %d: keys not checked at this size\n", variant);
         else for (int q = 0; q < B && bad < 10; q += 7) for (long u = 0; u < units; u++) {
             std::vector<std::pair<double, int>> d;
             for (int r = 0; r < unit; r++) {
                 const long row = u * unit + r; if (row >= n) break; double s = 0;
-                if (variant == 8) for (int j = 0; j < dim; j++) s += (double)X8r[row * ld8 + j] * Q8r[(size_t)q * ld8 + j];
+                if (variant >= 8) for (int j = 0; j < dim; j++) s += (double)X8r[row * ld8 + j] * Q8r[(size_t)q * ld8 + j];
                 else for (int j = 0; j < dim; j++) s += (double)Xr[row * ld + j] * Qr[q * ld + j];
                 d.push_back({std::max(0.0, 1.0 - s), r});
             }
