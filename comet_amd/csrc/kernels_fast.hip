@@ -802,16 +802,21 @@ template <bool INT> __device__ __forceinline__ void qr_ins3(int& t0, int& t1, in
 // Not the builtin: hipcc's wait-count pass treats a pending LDS-DMA as a FLAT access that may complete on either counter and then turns
 // EVERY lgkmcnt wait into lgkmcnt(0) for as long as it has not seen a vmcnt wait for the DMA (the kernel's counted vmcnt waits are asm and invisible
 // to it): the fragment prefetch (reads for step kk + 1 in flight under step kk's MFMAs) would be drained at every second step. M0 is
-// saved and restored inside the statement (it is compiler-reserved).
+// written and NOT restored (two scalar instructions per piece less): nothing else in flat_scan_qr_kernel uses it — no LDS-DMA builtin, no
+// relative indexing, no message — and the statement that reads M0 is the one that writes it.
+// Operands go through readfirstlane (free for values hipcc already keeps in SGPRs; where it has moved a uniform chain to the vector ALU the
+// v_readfirstlane result needs 5 wait states before a VMEM instruction may read it as base: s_mov + s_nop 3).
 __device__ __forceinline__ void qr_dma16(const char* sbase /*wave-uniform*/, unsigned voff, unsigned lds_addr /*wave-uniform*/) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    const unsigned long long b = (unsigned long long)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32)), la = __builtin_amdgcn_readfirstlane(lds_addr);
+    const unsigned long long bu = ((unsigned long long)hi << 32) | lo;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1 nt" :: "v"(voff), "s"(bu), "s"(la) : "memory");
 }
 __device__ __forceinline__ void qr_dma4(const char* sbase /*wave-uniform*/, unsigned voff, unsigned lds_addr /*wave-uniform*/) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    const unsigned long long b = (unsigned long long)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32)), la = __builtin_amdgcn_readfirstlane(lds_addr);
+    const unsigned long long bu = ((unsigned long long)hi << 32) | lo;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dword %0, %1" :: "v"(voff), "s"(bu), "s"(la) : "memory");
 }
 template <int I, int N, class F> __device__ __forceinline__ void qr_static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); qr_static_for<I + 1, N>(f); }
@@ -840,7 +845,8 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qr_kernel(const signe
                                                                      const float* __restrict__ rn, const float* __restrict__ qn,
                                                                      const unsigned char* __restrict__ elig,
                                                                      float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles,
-                                                                     const float* __restrict__ sx, const float* __restrict__ sq) {
+                                                                     const float* __restrict__ sx, const float* __restrict__ sq,
+                                                                     unsigned long long* __restrict__ trace /*nullable: s_memtime stamps of workgroup 8 (tools/scan_check)*/) {
     using G = QrGeom<NKS>;
     constexpr int NKK = G::NKK, STAGE = G::STAGE, RING = G::RING, PPW = G::PPW;
     constexpr int VMW = PPW + (MODE == 1 ? 1 : 0);              // vector-memory operations a wave issues per pass (pieces + its share of the row norms)
@@ -915,57 +921,62 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qr_kernel(const signe
     // Selection keys. MODE 0 (cosine): the score s_T s_q acc is monotone in the integer sum, so the network runs on EXACT integer keys
     // (acc << 7) | row-in-unit (|acc| <= 127^2 * 768 < 2^24: no overflow; bit 2 of the row = the half-wave, added at the merge) — no
     // conversion, nothing lost to the packing. MODE 1 (L2 family): float keys 2 s - rn with the row in the low 8 mantissa bits, as in
-    // scan_epilogue_q. NONE = "no row yet" (below every key).
+    // scan_epilogue_q. NONE = "no row yet": below every key, and still below every key with the half-wave bit or-ed in.
     constexpr bool IK = MODE == 0;
-    const int NONE = IK ? (int)0x80000000 : __float_as_int(-INF);
+    const int NONE = IK ? (int)0x80000000 : __float_as_int(-3.0e38f);
+    auto is_none = [&](int v) __attribute__((always_inline)) { if constexpr (IK) return v < -2000000000; else return __int_as_float(v) < -1.0e38f; };
     int t0[2], t1[2], t2[2];                                     // running three largest of the current key unit, per query block
 #pragma unroll
     for (int nb = 0; nb < 2; nb++) { t0[nb] = NONE; t1[nb] = NONE; t2[nb] = NONE; }
+    const float sq_lane = khalf ? sqv[1] : sqv[0], qn_lane = khalf ? qnv[1] : qnv[0];     // of the query this lane STORES keys for (block khalf, query l31)
 
-    // unit end: merge the two half-waves (rows + 4), turn the three survivors into keys, store (lanes 0..31: query block 0, lanes 32..63: block 1)
-    auto unit_end = [&](long un, float stv) __attribute__((always_inline)) {
-        int m0[2], m1[2], m2[2];
-#pragma unroll
-        for (int nb = 0; nb < 2; nb++) {
-            const int mybit = 4 * khalf, otherbit = 4 * (khalf ^ 1);
-            auto tag = [&](int v, int bit) __attribute__((always_inline)) { return v == NONE ? v : (v | bit); };
-            auto other = [&](int v) __attribute__((always_inline)) {                          // the value lane ^ 32 holds
-                const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
-                return (int)(khalf ? r[0] : r[1]);
-            };
-            const int o0 = other(t0[nb]), o1 = other(t1[nb]), o2 = other(t2[nb]);
-            int a0 = tag(t0[nb], mybit), a1 = tag(t1[nb], mybit), a2 = tag(t2[nb], mybit);
-            qr_ins3<IK>(a0, a1, a2, tag(o0, otherbit)); qr_ins3<IK>(a0, a1, a2, tag(o1, otherbit)); qr_ins3<IK>(a0, a1, a2, tag(o2, otherbit));
-            m0[nb] = a0; m1[nb] = a1; m2[nb] = a2;
-            t0[nb] = NONE; t1[nb] = NONE; t2[nb] = NONE;
-        }
-        // both half-waves hold the merged triples of both blocks: the lower half stores block 0's, the upper half block 1's
-        const int k0 = khalf ? m0[1] : m0[0], k1 = khalf ? m1[1] : m1[0], k2 = khalf ? m2[1] : m2[0];
-        const float sqs = (khalf ? sqv[1] : sqv[0]) * stv, qns = khalf ? qnv[1] : qnv[0];
-        auto to_key = [&](int v) __attribute__((always_inline)) {
-            if (v == NONE) return INF;
-            float a; unsigned row;
-            if constexpr (IK) { row = (unsigned)v & 0x7Fu; a = 1.0f - sqs * (float)(v >> 7); }
-            else { row = (unsigned)v & 0xFFu; a = qns - __uint_as_float((unsigned)v & 0xFFFFFF00u); }    // the key is -(rn - 2 s)
-            a = fmaxf(a, 0.0f);
-            return __uint_as_float((__float_as_uint(a) & 0xFFFFFF00u) | row);
-        };
-        int q = wid * 64 + lane;                                  // lane = khalf * 32 + l31: query l31 of block khalf
-        asm volatile("" : "+v"(q));                              // (keeps the output addresses out of the loop-carried state)
-        S0[(long)q * ldS + 2 * un] = to_key(k0);
-        S0[(long)q * ldS + 2 * un + 1] = to_key(k1);
-        bound[(long)q * ldB + un] = to_key(k2);
+    // Unit end in eight small stages (issued one per MFMA gap behind the selection): the half-waves trade blocks — after ONE
+    // v_permlane32_swap per value the lower half holds both halves' triples of query block 0 (its own rows in x, the rows + 4 in y) and the
+    // upper half those of block 1 (x: the lower half's rows, y: its own rows + 4) — merge, turn the three survivors into keys, store.
+    int ux0 = 0, ux1 = 0, ux2 = 0, uy0 = 0, uy1 = 0, uy2 = 0; float uk0 = 0.0f, uk1 = 0.0f, uk2 = 0.0f;
+    auto to_key = [&](int v, float stv) __attribute__((always_inline)) {
+        float a; unsigned row;
+        if constexpr (IK) { row = (unsigned)v & 0x7Fu; a = 1.0f - (sq_lane * stv) * (float)(v >> 7); }
+        else { row = (unsigned)v & 0xFFu; a = qn_lane - __uint_as_float((unsigned)v & 0xFFFFFF00u); }    // the key is -(rn - 2 s)
+        a = fmaxf(a, 0.0f);
+        const float k = __uint_as_float((__float_as_uint(a) & 0xFFFFFF00u) | row);
+        return is_none(v) ? INF : k;
     };
+    auto unit_stage = [&](auto S_c, long un, float stv, bool store) __attribute__((always_inline)) {
+        constexpr int S = decltype(S_c)::value;
+        if constexpr (S == 0) {
+            const auto r0 = __builtin_amdgcn_permlane32_swap((unsigned)t0[0], (unsigned)t0[1], false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap((unsigned)t1[0], (unsigned)t1[1], false, false);
+            const auto r2 = __builtin_amdgcn_permlane32_swap((unsigned)t2[0], (unsigned)t2[1], false, false);
+            ux0 = (int)r0[0]; ux1 = (int)r1[0]; ux2 = (int)r2[0];
+            uy0 = (int)r0[1] | 4; uy1 = (int)r1[1] | 4; uy2 = (int)r2[1] | 4;       // y: the rows + 4 of the block (NONE stays below every key)
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) { t0[nb] = NONE; t1[nb] = NONE; t2[nb] = NONE; }
+        } else if constexpr (S == 1) qr_ins3<IK>(ux0, ux1, ux2, uy0);
+        else if constexpr (S == 2) qr_ins3<IK>(ux0, ux1, ux2, uy1);
+        else if constexpr (S == 3) qr_ins3<IK>(ux0, ux1, ux2, uy2);
+        else if constexpr (S == 4) uk0 = to_key(ux0, stv);
+        else if constexpr (S == 5) uk1 = to_key(ux1, stv);
+        else if constexpr (S == 6) uk2 = to_key(ux2, stv);
+        else if (store) {
+            int q = wid * 64 + lane;                              // lane = khalf * 32 + l31: query l31 of block khalf
+            asm volatile("" : "+v"(q));                          // (keeps the output addresses out of the loop-carried state)
+            S0[(long)q * ldS + 2 * un] = uk0;
+            S0[(long)q * ldS + 2 * un + 1] = uk1;
+            bound[(long)q * ldB + un] = uk2;
+        }
+    };
+    constexpr int UNIT_STAGES = 8;
 
     // one element of the selection: block (mb, nb), accumulator register e of the pass with unit half `ppar`
-    auto select_one = [&](const i32x16 (&prev)[2][2], int ppar, int pslot_, float s2_0, float s2_1, int x, bool ok) __attribute__((always_inline)) {
+    auto select_one = [&](const i32x16 (&prev)[2][2], int ppar, int prs, float s2_0, float s2_1, int x, bool ok) __attribute__((always_inline)) {
         // element order: nb fastest (two independent chains), then e, then mb
         const int xnb = x & 1, xe = (x >> 1) & 15, xmb = x >> 5;
         const int rconst = (UR == 128 ? ppar * 64 : 0) + xmb * 32 + (xe & 3) + 8 * (xe >> 2);
         int v_;
         if constexpr (IK) v_ = (prev[xmb][xnb][xe] << 7) | rconst;
         else {
-            const float rnv = rn_ring[pslot_ * 64 + xmb * 32 + (xe & 3) + 8 * (xe >> 2) + 4 * khalf];
+            const float rnv = rn_ring[prs * 64 + xmb * 32 + (xe & 3) + 8 * (xe >> 2) + 4 * khalf];
             const float f = __builtin_fmaf(xnb ? s2_1 : s2_0, (float)prev[xmb][xnb][xe], -rnv);
             v_ = (int)((__float_as_uint(f) & 0xFFFFFF00u) | (unsigned)rconst);
         }
@@ -974,7 +985,7 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qr_kernel(const signe
     };
     // standalone (not interleaved) selection of a finished pass: the workgroup's last pass, and every pass that needs row masks
     // (rows past n, soft deletes, filters)
-    auto epilogue_plain = [&](const i32x16 (&prev)[2][2], int ppar, long prow0, int pslot_, float stv, bool check) __attribute__((always_inline)) {
+    auto epilogue_plain = [&](const i32x16 (&prev)[2][2], int ppar, long prow0, int prs, float stv, bool check) __attribute__((always_inline)) {
         unsigned okm = 0xFFFFFFFFu;
         if (check) {
             okm = 0u;
@@ -987,9 +998,9 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qr_kernel(const signe
         const float s2_0 = 2.0f * (sqv[0] * stv), s2_1 = 2.0f * (sqv[1] * stv);
         qr_static_for<0, 64>([&](auto X) __attribute__((always_inline)) {
             constexpr int x = decltype(X)::value;
-            select_one(prev, ppar, pslot_, s2_0, s2_1, x, (okm >> ((x >> 5) * 16 + ((x >> 1) & 15))) & 1u);
+            select_one(prev, ppar, prs, s2_0, s2_1, x, (okm >> ((x >> 5) * 16 + ((x >> 1) & 15))) & 1u);
         });
-        if (UR == 64 || ppar == 1) unit_end(prow0 / UR, stv);
+        if (UR == 64 || ppar == 1) qr_static_for<0, UNIT_STAGES>([&](auto S) __attribute__((always_inline)) { unit_stage(S, prow0 / UR, stv, true); });
     };
 
     // ---- first pass ready: own pieces of pass 0 landed (the younger passes of the prologue may still be in flight), then everybody's ----
@@ -997,39 +1008,62 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qr_kernel(const signe
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // A fragments, double-buffered: [buffer][mb]
     i32x4v A[2][2];
-    auto lds_frag = [&](int slot, int kk, int mb) __attribute__((always_inline)) {
-        return *reinterpret_cast<const i32x4v*>(smem + slot * STAGE + (kk >> 2) * 8192 + mb * 4096 + sw[kk & 3]);
+    auto lds_frag = [&](unsigned base, int kk, int mb) __attribute__((always_inline)) {
+        return *reinterpret_cast<const i32x4v*>(smem + (kk >> 2) * 8192 + mb * 4096 + base);
     };
-    A[0][0] = lds_frag(0, 0, 0); A[0][1] = lds_frag(0, 0, 1);
+    A[0][0] = lds_frag(sw[0], 0, 0); A[0][1] = lds_frag(sw[0], 0, 1);
 
+    // ---- uniform state of the pipeline ----
     int slot = 0;                                                // ring slot of the current pass
     int rslot = 0;                                               // its slot in the row-norm ring (RING + 1 entries: the norms of pass p - 1 are read by its selection all through pass p)
-    long prev_row0 = 0; int prev_slot = 0; float st_prev = 1.0f; bool prev_check = false;
+    long row0 = row0_of(0);                                      // first row of the current pass
+    float st_cur = sx[row0 >> 8];                                // its tile's scale
+    const char* dsrc = pass_src(RING - 1 < P ? RING - 1 : P - 1); // source of the pass the current pass issues the DMA pieces of (pass p + RING - 1)
+    long prev_row0 = 0; int prev_rslot = 0; float st_prev = 1.0f; bool prev_check = false;
     const i32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // s_memtime stamps of workgroup 8 — compiled in only for tools/scan_check.hip (-DQR_TRACE): even the untaken branches cost issue slots in the pass
+#ifdef QR_TRACE
+    const bool tr = trace != nullptr && blockIdx.x == 8 && lane == 0;
+    auto stamp = [&](int p, int slot_) __attribute__((always_inline)) { if (tr && p < 24) trace[(wid * 24 + p) * 4 + slot_] = __builtin_amdgcn_s_memtime(); };
+#else
+    auto stamp = [&](int, int) __attribute__((always_inline)) {};
+    (void)trace;
+#endif
 
     // The body of pass p with accumulator parity PAR (= p & 1 = the pass's 64-row half of its 128-row unit). INTER: the previous pass's
-    // selection is issued between this pass's MFMAs (spread over the first 7/8 of them; the unit's merge + stores follow). Every index
-    // below is a compile-time constant (static_for): accumulators, fragments and queries stay in registers.
-    auto pass_body = [&](auto PAR_c, auto INTER_c, int p) __attribute__((always_inline)) {
+    // selection is issued between this pass's MFMAs (spread over the first 3/4 of them; the unit's merge + stores follow in eight stages).
+    // DMA: the pieces of pass p + RING - 1 are issued (one per MFMA group, no branch). Every index below is a compile-time constant
+    // (static_for): accumulators, fragments and queries stay in registers. The scalar bookkeeping of pass p + 1 (first row, tile scale, the
+    // next DMA source) is computed in the middle of the pass, so that nothing but register moves sits between two passes' MFMAs.
+    auto pass_body = [&](auto PAR_c, auto INTER_c, auto DMA_c, int p) __attribute__((always_inline)) {
         constexpr int PAR = decltype(PAR_c)::value, PPAR = PAR ^ 1;
-        constexpr bool INTER = decltype(INTER_c)::value;
+        constexpr bool INTER = decltype(INTER_c)::value, DMA = decltype(DMA_c)::value;
+        stamp(p, 0);
         const int nslot = slot + 1 == RING ? 0 : slot + 1;
         const int fslot = slot == 0 ? RING - 1 : slot - 1;   // the slot pass p - 1 has left = where pass p + RING - 1 lands
-        const bool more = p + RING - 1 < P;
-        const char* nsrc = pass_src(more ? p + RING - 1 : p);
+        const unsigned fr0 = sw[0] + slot * STAGE, fr1 = sw[1] + slot * STAGE, fr2 = sw[2] + slot * STAGE, fr3 = sw[3] + slot * STAGE;
+        const unsigned nfr0 = sw[0] + nslot * STAGE;
         const float s2_0 = 2.0f * (sqv[0] * st_prev), s2_1 = 2.0f * (sqv[1] * st_prev);
+        const long un_prev = prev_row0 / UR;
+        const bool store_prev = p > 0;
+        long nrow0 = row0; float nst = st_cur; const char* ndsrc = dsrc;
         qr_static_for<0, NKK>([&](auto KK) __attribute__((always_inline)) {
             constexpr int kk = decltype(KK)::value, ab = kk & 1;
             if constexpr (kk == NKK - 1) {
                 // pass p + 1 readable by all: this wave's pieces of it have landed once only the passes issued after it are outstanding;
                 // this wave's fragment reads of pass p are done (lgkmcnt), so after the barrier pass p's slot may be overwritten
                 if (p + 1 < P) {
+                    stamp(p, 1);
                     qr_wait_passes<VMW, RING - 2>(RING - 2 < P - 2 - p ? RING - 2 : P - 2 - p);
+                    stamp(p, 2);
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    A[ab ^ 1][0] = lds_frag(nslot, 0, 0); A[ab ^ 1][1] = lds_frag(nslot, 0, 1);
+                    stamp(p, 3);
+                    A[ab ^ 1][0] = lds_frag(nfr0, 0, 0); A[ab ^ 1][1] = lds_frag(nfr0, 0, 1);
                 }
             } else {
-                A[ab ^ 1][0] = lds_frag(slot, kk + 1, 0); A[ab ^ 1][1] = lds_frag(slot, kk + 1, 1);
+                constexpr int j = (kk + 1) & 3;
+                const unsigned fb = j == 0 ? fr0 : (j == 1 ? fr1 : (j == 2 ? fr2 : fr3));
+                A[ab ^ 1][0] = lds_frag(fb, kk + 1, 0); A[ab ^ 1][1] = lds_frag(fb, kk + 1, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
             qr_static_for<0, 4>([&](auto J) __attribute__((always_inline)) {
@@ -1037,36 +1071,50 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qr_kernel(const signe
                 if constexpr (kk == 0) acc[PAR][mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ab][mb], Q[nb][kk], zero16, 0, 0, 0);
                 else acc[PAR][mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ab][mb], Q[nb][kk], acc[PAR][mb][nb], 0, 0, 0);
                 if constexpr (INTER) {
-                    constexpr int NM = 4 * NKK, NME = NM - NM / 8;
+                    constexpr int NM = 4 * NKK, NME = NM - UNIT_STAGES - NM / 8;
                     constexpr int e_lo = m * 64 / NME < 64 ? m * 64 / NME : 64, e_hi = (m + 1) * 64 / NME < 64 ? (m + 1) * 64 / NME : 64;
-                    qr_static_for<e_lo, e_hi>([&](auto X) __attribute__((always_inline)) { select_one(acc[PPAR], PPAR, prev_slot, s2_0, s2_1, decltype(X)::value, true); });
-                    if constexpr (m == NME && (UR == 64 || PPAR == 1)) unit_end(prev_row0 / UR, st_prev);
+                    qr_static_for<e_lo, e_hi>([&](auto X) __attribute__((always_inline)) { select_one(acc[PPAR], PPAR, prev_rslot, s2_0, s2_1, decltype(X)::value, true); });
+                    if constexpr (m >= NME && m < NME + UNIT_STAGES && (UR == 64 || PPAR == 1)) unit_stage(std::integral_constant<int, m - NME>{}, un_prev, st_prev, store_prev);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
             // one DMA piece of pass p + RING - 1 per MFMA group, into the slot pass p - 1 has left (free since the barrier of pass p - 1)
-            if constexpr (kk < PPW) { if (more) dma_piece(nsrc, fslot, kk); }
-            else if constexpr (kk == PPW) { if (more) dma_rn(p + RING - 1, rslot + RING - 1 > RING ? rslot - 2 : rslot + RING - 1); }
+            if constexpr (DMA && kk < PPW) dma_piece(dsrc, fslot, kk);
+            else if constexpr (DMA && kk == PPW) dma_rn(p + RING - 1, rslot + RING - 1 > RING ? rslot - 2 : rslot + RING - 1);
+            else if constexpr (kk == PPW + 1) {
+                // the next pass's scalars, a dozen MFMA groups before they are needed
+                if (p + 1 < P) { nrow0 = row0_of(p + 1); nst = sx[nrow0 >> 8]; }
+                ndsrc = pass_src(p + RING < P ? p + RING : P - 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
+        prev_row0 = row0; prev_rslot = rslot; st_prev = st_cur;
+        prev_check = (n - row0 < QR_PASS_ROWS) || elig != nullptr;
+        row0 = nrow0; st_cur = nst; dsrc = ndsrc;
+        slot = nslot;
+        rslot = rslot == RING ? 0 : rslot + 1;
     };
+    // p = 0 has no predecessor: it runs the interleaved body over zeroed "previous" accumulators (their keys are dropped at the unit end: store_prev)
+#pragma unroll
+    for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+        for (int nb = 0; nb < 2; nb++) acc[1][mb][nb] = zero16;
     auto one_pass = [&](auto PAR_c, int p) __attribute__((always_inline)) {
         constexpr int PAR = decltype(PAR_c)::value;
-        const long row0 = row0_of(p);
-        if (p > 0 && prev_check) epilogue_plain(acc[PAR ^ 1], PAR ^ 1, prev_row0, prev_slot, st_prev, true);
-        if (p > 0 && !prev_check) pass_body(PAR_c, std::integral_constant<bool, true>{}, p);
-        else pass_body(PAR_c, std::integral_constant<bool, false>{}, p);
-        prev_row0 = row0; prev_slot = rslot; st_prev = sx[row0 >> 8];
-        prev_check = (n - row0 < QR_PASS_ROWS) || elig != nullptr;
-        slot = slot + 1 == RING ? 0 : slot + 1;
-        rslot = rslot == RING ? 0 : rslot + 1;
+        using T = std::integral_constant<bool, true>; using F = std::integral_constant<bool, false>;
+        const bool dma = p + RING - 1 < P;
+        if (prev_check) {                                        // rare: the previous pass needs row masks — its selection runs on its own, then a plain body
+            if (p > 0) epilogue_plain(acc[PAR ^ 1], PAR ^ 1, prev_row0, prev_rslot, st_prev, true);
+            if (dma) pass_body(PAR_c, F{}, T{}, p); else pass_body(PAR_c, F{}, F{}, p);
+        } else if (dma) pass_body(PAR_c, T{}, T{}, p);
+        else pass_body(PAR_c, T{}, F{}, p);
     };
     for (int p = 0; p < P; p += 2) {
         one_pass(std::integral_constant<int, 0>{}, p);
         one_pass(std::integral_constant<int, 1>{}, p + 1);
     }
     // the last pass (parity 1) has no successor to hide its selection under
-    epilogue_plain(acc[1], 1, prev_row0, prev_slot, st_prev, prev_check);
+    epilogue_plain(acc[1], 1, prev_row0, prev_rslot, st_prev, prev_check);
 }
 int flat_scan_qr_steps(int ld8) { return (ld8 == 256 || ld8 == 512 || ld8 == 768) ? ld8 / 128 : 0; }    // K steps per row the register-stationary tile is built for (0: not this one)
 
@@ -1096,7 +1144,7 @@ void launch_flat_scan_i8(Ctx* c, int mode, const void* X8, int64_t n, int ld8, c
         auto gor = [&](auto kernel, size_t lds) {
             HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             c->launch_timed("flat_scan_i8", kernel, dim3((unsigned)gridr), dim3(QR_THREADS), lds, (const signed char*)X8, (long)n, (const signed char*)Q8F, rn, qn, (const unsigned char*)elig, S0, (long)ldS,
-                            bound, (long)ldB, n_tiles, sx, sq);
+                            bound, (long)ldB, n_tiles, sx, sq, g_scan_trace);
         };
 #define QR_GO(NKS) do { if (unit_rows == 64) { if (mode == 0) gor(flat_scan_qr_kernel<0, 64, NKS>, QrGeom<NKS>::LDS); else gor(flat_scan_qr_kernel<1, 64, NKS>, QrGeom<NKS>::LDS); } \
                         else { if (mode == 0) gor(flat_scan_qr_kernel<0, 128, NKS>, QrGeom<NKS>::LDS); else gor(flat_scan_qr_kernel<1, 128, NKS>, QrGeom<NKS>::LDS); } } while (0)

@@ -136,3 +136,71 @@ def test_config4_hybrid_ivf768_nlist1024_nprobe32_bm25_100k_rrf(ctx):
         want = sorted(zip(os_[:m].tolist(), oi[:m].tolist()), key=lambda t: -t[0])[:k]
         assert sorted(r.score for r in res) == sorted(s for s, _ in want)
         assert {r.id for r in res if r.score > want[-1][0]} == {i for s, i in want if s > want[-1][0]}
+
+
+# ---- the int8 tiles at configs[1]'s own d = 768 / K = 100 / B = 256: EVERY query against the oracle (round-3 review: the only d = 768 / K = 100
+# int8-vs-oracle evidence was bench.py's own parity count; auto mode keeps an index of this size on the fp16 shadow, so the int8 shadow is forced) ----
+def _flat_i8(ctx, d, metric):
+    old = os.environ.get("COMET_FLAT_I8")
+    os.environ["COMET_FLAT_I8"] = "1"                     # read when the index is created
+    try:
+        return FlatIndex(ctx, d, metric)
+    finally:
+        if old is None:
+            os.environ.pop("COMET_FLAT_I8")
+        else:
+            os.environ["COMET_FLAT_I8"] = old
+
+
+@pytest.mark.parametrize("metric", [COSINE, L2_SQUARED])
+def test_config1_int8_wide_tile_768_batch256_k100_every_query(ctx, metric):
+    n, d, B, K = 50_000, 768, 256, 100
+    X = synth(0xC0FFEE + 2, n, d); Q = synth(0xBEEF + 2, B, d)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    g = _flat_i8(ctx, d, metric); g.add_batch(ids, X)
+    o = orc.Flat(d, metric); assert o.add_batch(ids, X) == 0
+    rows = g.search_batch(Q, K, mode=2)                                      # mode 2: fail if the fast path is not taken
+    assert g.stat("i8_slices") == 1 and g.stat("fast_queries") + g.stat("fast_overflows") == B
+    compare_all(rows, lambda q: o.search(q, K), Q)
+
+
+def test_config1_int8_wide_tile_filtered_and_soft_deleted(ctx):
+    """soft deletes + WithDocumentIDs: the scan's eligibility masks (every pass of the register-stationary tile takes its masked selection) and a
+    last tile that is not full"""
+    n, d, B, K = 30_011, 768, 256, 100
+    X = synth(0xC0FFEE + 2, n, d); Q = synth(0xBEEF + 2, B, d)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    g = _flat_i8(ctx, d, COSINE); g.add_batch(ids, X)
+    o = orc.Flat(d, "cosine"); assert o.add_batch(ids, X) == 0
+    rng = np.random.default_rng(11)
+    for i in rng.choice(ids, 700, replace=False):
+        g.remove(int(i)); o.remove(int(i))
+    rows = g.search_batch(Q, K, mode=2)
+    assert g.stat("i8_slices") == 1
+    compare_all(rows, lambda q: o.search(q, K), Q)
+    allowed = np.sort(rng.choice(ids, 9_000, replace=False)).astype(np.uint32)
+    rows = g.search_batch(Q, K, document_ids=allowed, mode=2)
+    assert g.stat("i8_slices") == 1
+    compare_all(rows, lambda q: o.search(q, K, filter_ids=allowed), Q)
+
+
+def test_config4_ivf_int8_scan_768_nlist1024_nprobe32_every_query(ctx):
+    n, d, nlist, B, K = 60_000, 768, 1024, 256, 10
+    old = os.environ.get("COMET_IVF_I8")
+    os.environ["COMET_IVF_I8"] = "1"
+    try:
+        g = IVFIndex(ctx, d, nlist, COSINE)
+    finally:
+        if old is None:
+            os.environ.pop("COMET_IVF_I8")
+        else:
+            os.environ["COMET_IVF_I8"] = old
+    X = synth(0xC0FFEE + 5, n, d)
+    g.train(X[:nlist * 20])
+    g.add_batch(np.arange(1, n + 1, dtype=np.uint32), X)
+    blob = g.to_bytes()
+    o = orc.IVF(d, "cosine", nlist); assert o.from_bytes(blob) == len(blob)
+    Q = synth(0xBEEF + 5, B, d)
+    rows = g.search_batch(Q, K, nprobes=32, mode=2)
+    assert g.stat("fast_queries") == B and g.stat("i8_slices") >= 1
+    compare_all(rows, lambda q: o.search(q, K, 32), Q)

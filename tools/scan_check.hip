@@ -1,7 +1,7 @@
 // scan_check.hip — stand-alone check + timing of the Flat fast-path scan kernels (kernels_fast.hip is compiled into this program).
 // For every COMET_SCAN_VARIANT it runs the scan on random data and compares the emitted unit keys (two smallest approximate
 // distances + the bound of every (query, 128-row unit)) with a float64 host computation on the same fp16-rounded operands.
-// usage: scan_check [rows] [dim] [queries] [iters]        build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/scan_check.hip -o tools/scan_check
+// usage: scan_check [rows] [dim] [queries] [iters]        build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DQR_TRACE] tools/scan_check.hip -o tools/scan_check
 #include "../comet_amd/csrc/kernels_fast.hip"
 
 #include <algorithm>
@@ -90,6 +90,7 @@ int main(int argc, char** argv) {
         };
         run();
         HIP_CHECK(hipStreamSynchronize(c.stream));
+        if (dtrace) { run(); run(); HIP_CHECK(hipStreamSynchronize(c.stream)); }      // the trace of a warm launch
         std::vector<float> hS((size_t)256 * ldS), hB((size_t)256 * ldB);
         HIP_CHECK(hipMemcpy(hS.data(), S0, hS.size() * 4, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(hB.data(), bound, hB.size() * 4, hipMemcpyDeviceToHost));
         int bad = 0; double maxerr = 0;
@@ -111,6 +112,18 @@ int main(int argc, char** argv) {
             }
         }
         printf("variant %d: %s (max |key - float64| = %.2e)\n", variant, bad ? "MISMATCH" : "ok", maxerr);
+        if (dtrace && variant == 9) {
+            std::vector<unsigned long long> t(8 * 32 * 4 + 64);
+            HIP_CHECK(hipMemcpy(t.data(), dtrace, t.size() * 8, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemset(dtrace, 0, (8 * 32 * 4 + 64) * 8));
+            printf("TRACE of variant 9 (register-stationary tile; one pass = 64 rows x %d bytes, %d MFMAs per wave)\n", ld8, ld8 / 32 * 4);
+            for (int w = 0; w < 4; w++)
+                for (int p = 0; p < 23; p++) {
+                    const unsigned long long* q = &t[(w * 24 + p) * 4]; const unsigned long long nxt = t[(w * 24 + p + 1) * 4];
+                    if (!q[0] || !nxt) break;
+                    printf("TRACE wave %d pass %2d: mfma+select to the wait %6llu  vmcnt wait %5llu  barrier %5llu  tail to next pass %5llu  total %6llu\n", w, p, q[1] - q[0], q[2] - q[1], q[3] - q[2], nxt - q[3], nxt - q[0]);
+                }
+        }
         if (dtrace && (variant == 0 || variant == 8) && B > 64) {
             std::vector<unsigned long long> t(8 * 32 * 4 + 64);
             HIP_CHECK(hipMemcpy(t.data(), dtrace, t.size() * 8, hipMemcpyDeviceToHost));
