@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--k", type=int, default=TOPK)
     ap.add_argument("--metric", default="cosine")
     ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 strict exact kernels, 2 fast path")
-    ap.add_argument("--legs", default="flat,flat_l2,ivfpq,ivfpq10m,hnsw,hybrid", help="comma list; flat is always run (it is the headline)")
+    ap.add_argument("--legs", default="flat,c1,flat_l2,ivfpq,ivfpq10m,hnsw,hybrid", help="comma list; flat is always run (it is the headline)")
     ap.add_argument("--nlist", type=int, default=1024)
     ap.add_argument("--nprobe", type=int, default=32)
     ap.add_argument("--M", type=int, default=96)
@@ -452,6 +452,50 @@ def leg_flat_l2(ctx, ca, args, timer, flat2, q_ptrs):
     return out
 
 
+def leg_c1(ctx, ca, args):
+    """configs[0] as a caller of the reference sees it: Flat L2^2 10 000 x 128, K = 10, ONE query per Execute() — host buffers in,
+    host results out (flat_index_search.go:144-150 runs one query per call). Oracle single-thread latency beside the GPU's blocking single-query call."""
+    n, d, K, reps = 10_000, 128, 10, 1000
+    orc = oracle() if not args.no_cpu_baseline else None
+    seedx, seedq = 0xC0FFEE + 1, 0xBEEF + 1
+    idx = ca.FlatIndex(ctx, d, ca.L2_SQUARED)
+    buf = ctx.alloc(n * d * 4)
+    ctx.synth_fill(buf, seedx, 0, n * d)
+    X = ctx.download(buf, (n, d), np.float32)
+    ctx.free(buf)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    idx.add_batch(ids, X)
+    qb = ctx.alloc(reps * d * 4)
+    ctx.synth_fill(qb, seedq, 0, reps * d)
+    Q = ctx.download(qb, (reps, d), np.float32)
+    ctx.free(qb)
+    idx.search_batch(Q[:1], K)
+    t0 = time.perf_counter()
+    g = [idx.search_batch(Q[i:i + 1], K) for i in range(reps)]
+    gpu_s = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    gb = idx.search_batch(Q[:256], K)
+    gpu_b256_s = time.perf_counter() - t0
+    out = {"workload": f"Flat l2_squared {n}x{d}, K={K}, ONE query per call, host buffers (BASELINE configs[0]; {reps} calls)",
+           "gpu_single_query_latency_ms": gpu_s * 1e3, "gpu_single_query_qps": 1.0 / gpu_s,
+           "gpu_batch256_host_buffers_qps": 256 / gpu_b256_s,
+           "what": "comet_index_search with B = 1: upload of the query, the whole search path, download of K results, one host sync — what a Go caller's Execute() costs"}
+    if orc:
+        o = orc.Flat(d, "l2_squared"); o.add_batch(ids, X)
+        o.search(Q[0], K)
+        t0 = time.perf_counter()
+        res = [o.search(Q[i], K) for i in range(reps)]
+        cpu_s = (time.perf_counter() - t0) / reps
+        bad = sum(0 if (g[i][2][0] == res[i][0] and np.array_equal(g[i][0][0, :res[i][0]], res[i][1]) and
+                        np.array_equal(g[i][1][0, :res[i][0]].view(np.uint32), np.asarray(res[i][2], np.float32).view(np.uint32))) else 1 for i in range(reps))
+        bad += sum(0 if (gb[2][i] == res[i][0] and np.array_equal(gb[0][i, :res[i][0]], res[i][1])) else 1 for i in range(256))
+        out.update({"cpu_single_thread_latency_ms": cpu_s * 1e3, "cpu_single_thread_qps": 1.0 / cpu_s, "parity_checked_queries": reps + 256, "parity_mismatches": bad,
+                    "cpu_baseline": {"value": 1.0 / cpu_s, "unit": "queries/s", "cores": 1, "kind": "port", "sample": f"{reps} single-query searches, one thread",
+                                     "parity_checked_queries": reps + 256, "parity_mismatches": bad}})
+    idx.close()
+    return out
+
+
 def adc_lookups_ceiling():
     """random 8-byte LDS gather rate of this GPU, measured by tools/lds_gather_probe (built by __graft_entry__.build())"""
     exe = ROOT / "tools" / "lds_gather_probe"
@@ -723,20 +767,30 @@ def leg_hybrid(ctx, ca, args, timer, q_ptrs, Q0):
                                 "parity_checked_queries": nq, "parity_mismatches": len(bad), "parity_is": "ids and float64 score bit patterns"}
     trec["workload"] = f"BM25 over {nd} documents (Zipf(1.1) token ids, vocabulary {vocab}, 64-256 tokens), batch={B} 3-term queries, K={K} (host-side token lists in, host results out; both indexes built in {tbuild:.0f}s)"
     out["bm25"] = trec
-    # ---- fusion: the reference cuts both legs to k before fusing (hybrid_search_index.go:518,555), ranks on the host ----
-    t0 = time.perf_counter()
-    fused = []
-    for b in range(B):
+    # ---- fusion: the reference cuts both legs to k before fusing (hybrid_search_index.go:518,555) and ranks on the host: one vectorised call for
+    # the batch (comet_amd.hybrid.reciprocal_rank_fusion_batch; checked against the per-query restatement of fusion.go:174-243) ----
+    from comet_amd.hybrid import reciprocal_rank_fusion_batch
+    e2e = {}
+    for tag, vec in (("nprobe1", vec_last), (f"nprobe{args.nprobe}", vec32)):
+        t0 = time.perf_counter()
+        f_ids, f_sc, f_cn = reciprocal_rank_fusion_batch(vec[0], vec[2], tr[0], tr[3], K)
+        fuse_ms = (time.perf_counter() - t0) * 1e3
+        vleg = out["ivf_nprobe1" if tag == "nprobe1" else f"ivf_nprobe{args.nprobe}"]
+        e2e_ms = vleg["ms_per_step"] + trec["ms_per_step"] + fuse_ms
+        e2e[tag] = {"qps": B / (e2e_ms * 1e-3), "ms_per_batch": e2e_ms, "fusion_host_ms_per_batch": fuse_ms}
+    # parity of the fused lists on a sample: the per-query dict form
+    bad_f = 0
+    f_ids, f_sc, f_cn = reciprocal_rank_fusion_batch(vec_last[0], vec_last[2], tr[0], tr[3], K)
+    for b in range(min(B, 64)):
         v = {int(i): float(s) for i, s in zip(vec_last[0][b, :vec_last[2][b]], vec_last[1][b, :vec_last[2][b]])}
         t = {int(i): float(s) for i, s in zip(tr[0][b, :tr[3][b]], tr[2][b, :tr[3][b]])}
-        f = reciprocal_rank_fusion(v, t)
-        fused.append(sorted(f.items(), key=lambda kv: (-kv[1], kv[0]))[:K])
-    fuse_ms = (time.perf_counter() - t0) * 1e3
-    v1 = out["ivf_nprobe1"]
-    e2e_ms = v1["ms_per_step"] + trec["ms_per_step"] + fuse_ms
-    out["rrf"] = {"host_ms_per_batch": fuse_ms, "what": "reciprocalRankFusion.Combine + sort + cut (fusion.go:174-243) on the host for 256 queries, as in the reference (O(k) per query); "
-                                                        "this is the Python mirror's time (dict arithmetic), the Go host's is microseconds"}
-    out["end_to_end"] = {"qps": B / (e2e_ms * 1e-3), "ms_per_batch": e2e_ms, "what": "vector leg (nprobe 1, the hybrid default) + text leg + fusion, run one after the other"}
+        want = sorted(reciprocal_rank_fusion(v, t).items(), key=lambda kv: (-kv[1]))[:K]
+        if [int(x) for x in f_ids[b, :f_cn[b]]] != [d for d, _ in want]:
+            bad_f += 1
+    out["rrf"] = {"host_ms_per_batch": e2e["nprobe1"]["fusion_host_ms_per_batch"], "batch_form_mismatches_vs_per_query_form": bad_f,
+                  "what": "reciprocalRankFusion.Combine + sort + cut (fusion.go:174-243) on the host for the whole batch in one vectorised call (O(k^2) per query)"}
+    out["end_to_end"] = dict(e2e["nprobe1"], what="vector leg (nprobe 1, the hybrid default) + text leg + fusion, run one after the other")
+    out["end_to_end_nprobe32"] = dict(e2e[f"nprobe{args.nprobe}"], what=f"the same with the vector leg at nprobe {args.nprobe}")
     if orc:
         blob = ivf.to_bytes()
         out["cpu_baseline"] = cpu_baseline_from_bytes(lambda: orc.IVF(d, "cosine", nlist), blob, lambda o, q: o.search(q, K, args.nprobe, cap=K), Q0, K, vec32, "IVFX", None)
@@ -822,6 +876,9 @@ def main():
         except Exception as e:        # noqa: BLE001
             import traceback
             return {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc(limit=4)}
+
+    if "c1" in legs and world == 1:
+        line["c1"] = guarded("c1", lambda: leg_c1(ctx, ca, args))
 
     # ---------------------------------------------------------------- clustered 1M corpus: Flat L2^2 (N = 1), IVFPQ (any N), hybrid (N = 1)
     need_mix = legs & ({"flat_l2", "ivfpq", "hybrid"} if world == 1 else {"ivfpq"})

@@ -828,16 +828,14 @@ template <int NKS> struct QrGeom {
     static constexpr int PPW = 2 * NKS;                        // DMA pieces (1 KiB) per wave per pass
     static constexpr int LDS = RING * STAGE + (RING + 1) * 256; // + the row norms of the ring's passes and of the pass whose selection is still running (MODE 1)
 };
-// s_waitcnt vmcnt(K * VMW), K a run-time pass count in 0 .. KMAX (the immediate must be a constant)
+// s_waitcnt vmcnt(min(k, KMAX) * VMW), k a run-time count (the immediate must be a constant: a compare chain over the few possible values)
+template <int VMW, int K> __device__ __forceinline__ void qr_wait_chain(int k) {
+    if constexpr (K <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else { if (k >= K) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K * VMW) : "memory"); else qr_wait_chain<VMW, K - 1>(k); }
+}
 template <int VMW, int KMAX> __device__ __forceinline__ void qr_wait_passes(int k) {
-    static_assert(KMAX * VMW <= 63 && KMAX <= 6, "vmcnt is a 6-bit counter");
-    if (KMAX >= 6 && k >= 6) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KMAX >= 6 ? 6 * VMW : 0) : "memory");
-    else if (KMAX >= 5 && k == 5) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KMAX >= 5 ? 5 * VMW : 0) : "memory");
-    else if (KMAX >= 4 && k == 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KMAX >= 4 ? 4 * VMW : 0) : "memory");
-    else if (KMAX >= 3 && k == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KMAX >= 3 ? 3 * VMW : 0) : "memory");
-    else if (KMAX >= 2 && k == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KMAX >= 2 ? 2 * VMW : 0) : "memory");
-    else if (KMAX >= 1 && k == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KMAX >= 1 ? 1 * VMW : 0) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(KMAX * VMW <= 63, "vmcnt is a 6-bit counter");
+    qr_wait_chain<VMW, KMAX>(k);
 }
 
 template <int MODE, int UR, int NKS>
@@ -1116,6 +1114,235 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qr_kernel(const signe
     // the last pass (parity 1) has no successor to hide its selection under
     epilogue_plain(acc[1], 1, prev_row0, prev_rslot, st_prev, prev_check);
 }
+// ------------------------------------------------------------------------------------------------
+// Register-stationary NARROW tile (at most 64 queries: the reference's API runs ONE query per Execute()): the scan is HBM-bound, so the
+// kernel is built around the row stream. All four waves keep the SAME 64 queries in registers (ld8 / 4 AGPRs) and split the ROWS: a wave
+// owns whole 64-row key units, streams their rows through a PRIVATE LDS ring by LDS-DMA (slabs of 32 rows x 128 bytes, re-issued as soon as
+// their fragments are in registers) and waits on its own vmcnt only — no barrier anywhere, no cross-wave traffic, a quarter of the wide
+// tile's MFMA work per row. The selection of a 32-row pass runs under the next pass's MFMAs exactly as in flat_scan_qr_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int NKS> struct QnGeom {
+    static constexpr int NKK = NKS * 4;
+    static constexpr int C = NKS == 6 ? 1 : 2;                  // passes in a wave's ring
+    static constexpr int RS = C * NKS;                          // slabs (32 rows x 128 B = 4 KiB) in a wave's ring
+    static constexpr int WRB = RS * 4096;                       // ring bytes per wave
+    static constexpr int LDS = 4 * WRB + 4 * (C + 2) * 128;     // + per wave the row norms of C + 2 passes (MODE 1)
+};
+template <int MODE, int NKS>
+__global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qn_kernel(const signed char* __restrict__ X8, long n, const signed char* __restrict__ Q8F,
+                                                                     const float* __restrict__ rn, const float* __restrict__ qn,
+                                                                     const unsigned char* __restrict__ elig,
+                                                                     float* __restrict__ S0, long ldS, float* __restrict__ bound, long ldB, long n_tiles,
+                                                                     const float* __restrict__ sx, const float* __restrict__ sq) {
+    using G = QnGeom<NKS>;
+    constexpr int NKK = G::NKK, C = G::C, RS = G::RS, WRB = G::WRB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* rn_ring = reinterpret_cast<float*>(smem + 4 * WRB) + wid * (C + 2) * 32;
+    // ---- work split: 64-row key units; every XCD owns a contiguous range, its waves take them round robin ----
+    const long nx = 8, xcd = blockIdx.x % nx, WX = (gridDim.x / nx) * 4, wx = (blockIdx.x / nx) * 4 + wid;
+    const long U = n_tiles * 4, uq = U / nx, urem = U % nx;
+    const long xbase = xcd < urem ? xcd * (uq + 1) : urem * (uq + 1) + (xcd - urem) * uq, xcount = xcd < urem ? uq + 1 : uq;
+    const long my_units = wx < xcount ? (xcount - wx + WX - 1) / WX : 0;
+    if (my_units == 0) return;
+    const int P = (int)(my_units * 2);                           // 32-row passes of this wave (even)
+    const int T = P * NKS;                                       // slabs of this wave
+    auto row0_of = [&](int p) __attribute__((always_inline)) { return ((xbase + wx + (long)(p >> 1) * WX) * 2 + (p & 1)) * 32L; };
+    unsigned sw[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) sw[j] = (unsigned)(wid * WRB + l31 * 128 + (((j * 2 + khalf) ^ ((l31 >> 1) & 7)) << 4));
+    // DMA pieces of a slab: piece i = rows 8 i .. 8 i + 7 of the pass (8 rows x 128 B); the lane's source offset inside the K step's slab pair
+    const int prow = lane >> 3, pslot = lane & 7;
+    const int ks_e = pslot ^ ((prow >> 1) & 7), ks_o = pslot ^ ((4 + (prow >> 1)) & 7);
+    const unsigned po_e = (unsigned)((ks_e >> 2) * 16384 + prow * 64 + (ks_e & 3) * 16), po_o = (unsigned)((ks_o >> 2) * 16384 + (8 + prow) * 64 + (ks_o & 3) * 16);
+    const long tile_bytes = (long)NKS * 2 * 16384;
+    auto pass_src = [&](int p) __attribute__((always_inline)) {
+        const long r0 = row0_of(p);
+        return reinterpret_cast<const char*>(X8) + (r0 >> 8) * tile_bytes + (r0 & 255) * 64;
+    };
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto dma_piece = [&](const char* src /*of the pass*/, int ks, int slot, int i) __attribute__((always_inline)) {
+        qr_dma16(src + (long)ks * 32768, ((i & 1) ? po_o : po_e) + (unsigned)((i >> 1) * 1024), lds0 + (unsigned)(wid * WRB + slot * 4096 + i * 1024));
+    };
+    auto dma_rn = [&](int p) __attribute__((always_inline)) {   // MODE 1: the pass's 32 row norms (lanes 0 .. 31 of a 4-byte piece)
+        if constexpr (MODE == 1) {
+            const long r0 = row0_of(p);
+            const long last = n - 1 - r0;
+            const unsigned voff = (unsigned)((long)lane < last ? (long)lane : (last > 0 ? last : 0)) * 4u;
+            if (lane < 32) qr_dma4(reinterpret_cast<const char*>(rn + r0), voff, lds0 + (unsigned)(4 * WRB + (wid * (C + 2) + p % (C + 2)) * 128));
+        }
+    };
+    // ---- prologue: the first RS slabs in flight (passes 0 .. C-1) ----
+#pragma unroll
+    for (int g = 0; g < RS; g++) {
+        if (g < T) {
+            if (g % NKS == 0) dma_rn(g / NKS);
+            const char* src = pass_src(g / NKS);
+#pragma unroll
+            for (int i = 0; i < 4; i++) dma_piece(src, g % NKS, g, i);
+        }
+    }
+    // ---- queries 0 .. 63: fragments [group of 32 queries][kk][lane] 16 bytes, groups 0 and 1; pinned as landed before the loop (see flat_scan_qr_kernel) ----
+    i32x4v Q[2][NKK];
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+        for (int kk = 0; kk < NKK; kk++)
+            Q[nb][kk] = *reinterpret_cast<const i32x4v*>(Q8F + ((long)nb * NKK + kk) * 1024 + lane * 16);
+    float sq_lane = sq[lane], qn_lane = MODE == 1 ? qn[lane] : 0.0f;   // of the query this lane STORES keys for (block khalf, query l31 = query `lane`)
+    float sqv0 = sq[l31], sqv1 = sq[32 + l31];
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+        for (int kk = 0; kk < NKK; kk++) asm volatile("" : "+a"(Q[nb][kk]));
+    asm volatile("" : "+v"(sq_lane), "+v"(qn_lane), "+v"(sqv0), "+v"(sqv1));
+
+    const float INF = __builtin_inff();
+    i32x16 acc[2][2];                                            // [parity][nb]
+    constexpr bool IK = MODE == 0;
+    const int NONE = IK ? (int)0x80000000 : __float_as_int(-3.0e38f);
+    auto is_none = [&](int v) __attribute__((always_inline)) { if constexpr (IK) return v < -2000000000; else return __int_as_float(v) < -1.0e38f; };
+    int t0[2], t1[2], t2[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) { t0[nb] = NONE; t1[nb] = NONE; t2[nb] = NONE; }
+    int ux0 = 0, ux1 = 0, ux2 = 0, uy0 = 0, uy1 = 0, uy2 = 0; float uk0 = 0.0f, uk1 = 0.0f, uk2 = 0.0f;
+    auto to_key = [&](int v, float stv) __attribute__((always_inline)) {
+        float a; unsigned row;
+        if constexpr (IK) { row = (unsigned)v & 0x7Fu; a = 1.0f - (sq_lane * stv) * (float)(v >> 7); }
+        else { row = (unsigned)v & 0xFFu; a = qn_lane - __uint_as_float((unsigned)v & 0xFFFFFF00u); }
+        a = fmaxf(a, 0.0f);
+        const float k = __uint_as_float((__float_as_uint(a) & 0xFFFFFF00u) | row);
+        return is_none(v) ? INF : k;
+    };
+    auto unit_stage = [&](auto S_c, long un, float stv, bool store) __attribute__((always_inline)) {
+        constexpr int S = decltype(S_c)::value;
+        if constexpr (S == 0) {
+            const auto r0 = __builtin_amdgcn_permlane32_swap((unsigned)t0[0], (unsigned)t0[1], false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap((unsigned)t1[0], (unsigned)t1[1], false, false);
+            const auto r2 = __builtin_amdgcn_permlane32_swap((unsigned)t2[0], (unsigned)t2[1], false, false);
+            ux0 = (int)r0[0]; ux1 = (int)r1[0]; ux2 = (int)r2[0];
+            uy0 = (int)r0[1] | 4; uy1 = (int)r1[1] | 4; uy2 = (int)r2[1] | 4;
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) { t0[nb] = NONE; t1[nb] = NONE; t2[nb] = NONE; }
+        } else if constexpr (S == 1) qr_ins3<IK>(ux0, ux1, ux2, uy0);
+        else if constexpr (S == 2) qr_ins3<IK>(ux0, ux1, ux2, uy1);
+        else if constexpr (S == 3) qr_ins3<IK>(ux0, ux1, ux2, uy2);
+        else if constexpr (S == 4) uk0 = to_key(ux0, stv);
+        else if constexpr (S == 5) uk1 = to_key(ux1, stv);
+        else if constexpr (S == 6) uk2 = to_key(ux2, stv);
+        else if (store) {
+            int q = lane;                                         // lane = khalf * 32 + l31: query l31 of block khalf
+            asm volatile("" : "+v"(q));
+            S0[(long)q * ldS + 2 * un] = uk0;
+            S0[(long)q * ldS + 2 * un + 1] = uk1;
+            bound[(long)q * ldB + un] = uk2;
+        }
+    };
+    constexpr int UNIT_STAGES = 8;
+    auto select_one = [&](const i32x16 (&prev)[2], int ppar, int prs, float s2_0, float s2_1, int x, bool ok) __attribute__((always_inline)) {
+        const int xnb = x & 1, xe = x >> 1;
+        const int rconst = ppar * 32 + (xe & 3) + 8 * (xe >> 2);
+        int v_;
+        if constexpr (IK) v_ = (prev[xnb][xe] << 7) | rconst;
+        else {
+            const float rnv = rn_ring[prs * 32 + (xe & 3) + 8 * (xe >> 2) + 4 * khalf];
+            const float f = __builtin_fmaf(xnb ? s2_1 : s2_0, (float)prev[xnb][xe], -rnv);
+            v_ = (int)((__float_as_uint(f) & 0xFFFFFF00u) | (unsigned)rconst);
+        }
+        if (!ok) v_ = NONE;
+        qr_ins3<IK>(t0[xnb], t1[xnb], t2[xnb], v_);
+    };
+    auto epilogue_plain = [&](const i32x16 (&prev)[2], int ppar, long prow0, int prs, float stv, bool check) __attribute__((always_inline)) {
+        unsigned okm = 0xFFFFu;
+        if (check) {
+            okm = 0u;
+            for (int e = 0; e < 16; e++) {
+                const long r = prow0 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
+                if (r < n && (!elig || elig[r])) okm |= 1u << e;
+            }
+        }
+        const float s2_0 = 2.0f * (sqv0 * stv), s2_1 = 2.0f * (sqv1 * stv);
+        qr_static_for<0, 32>([&](auto X) __attribute__((always_inline)) {
+            constexpr int x = decltype(X)::value;
+            select_one(prev, ppar, prs, s2_0, s2_1, x, (okm >> (x >> 1)) & 1u);
+        });
+        if (ppar == 1) qr_static_for<0, UNIT_STAGES>([&](auto S) __attribute__((always_inline)) { unit_stage(S, prow0 / 64, stv, true); });
+    };
+
+    // ---- slab 0 landed (only the RS - 1 younger slabs of the prologue may still be in flight) ----
+    qr_wait_passes<4, RS - 1>(RS - 1 < T - 1 ? RS - 1 : T - 1);
+    i32x4v F[2][4];                                              // fragments of a slab (kk & 3 = 0..3), double-buffered by slab
+    auto lds_frag = [&](int slot, int j) __attribute__((always_inline)) { return *reinterpret_cast<const i32x4v*>(smem + slot * 4096 + sw[j]); };
+#pragma unroll
+    for (int j = 0; j < 4; j++) F[0][j] = lds_frag(0, j);
+
+    long row0 = row0_of(0); float st_cur = sx[row0 >> 8];
+    const char* dsrc = pass_src(C < P ? C : P - 1);              // source of the pass whose slabs the current pass issues (pass p + C)
+    long prev_row0 = 0; float st_prev = 1.0f; bool prev_check = false;
+    const i32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) acc[1][nb] = zero16;
+
+    auto pass_body = [&](auto PAR_c, auto INTER_c, int p) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_c)::value, PPAR = PAR ^ 1;
+        constexpr bool INTER = decltype(INTER_c)::value;
+        const float s2_0 = 2.0f * (sqv0 * st_prev), s2_1 = 2.0f * (sqv1 * st_prev);
+        const long un_prev = prev_row0 / 64;
+        const bool store_prev = p > 0;
+        const int prs = (p + C + 1) % (C + 2);                   // (p - 1) mod (C + 2)
+        const int sbase = C == 1 ? 0 : (p & 1) * NKS;            // ring slot of the pass's first slab
+        long nrow0 = row0; float nst = st_cur; const char* ndsrc = dsrc;
+        const bool dma = p + C < P;
+        qr_static_for<0, NKS>([&](auto KS) __attribute__((always_inline)) {
+            constexpr int ks = decltype(KS)::value, fb = ks & 1;   // NKS is even: the fragment buffer of a slab is its K step's parity
+            const int g = p * NKS + ks;
+            // slab g + 1 (this pass's next K step, or the next pass's first) has landed once only the slabs issued after it are outstanding
+            if (g + 1 < T) {
+                qr_wait_passes<4, RS - 2>(RS - 2 < T - 2 - g ? RS - 2 : T - 2 - g);
+                const int nslot = ks + 1 < NKS ? sbase + ks + 1 : (C == 1 ? 0 : (sbase ? 0 : NKS));
+#pragma unroll
+                for (int j = 0; j < 4; j++) F[fb ^ 1][j] = lds_frag(nslot, j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            qr_static_for<0, 8>([&](auto J) __attribute__((always_inline)) {
+                constexpr int j = decltype(J)::value >> 1, nb = decltype(J)::value & 1, kk = ks * 4 + j, m = ks * 8 + decltype(J)::value;
+                if constexpr (kk == 0) acc[PAR][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[fb][j], Q[nb][kk], zero16, 0, 0, 0);
+                else acc[PAR][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[fb][j], Q[nb][kk], acc[PAR][nb], 0, 0, 0);
+                if constexpr (INTER) {
+                    constexpr int NM = 2 * NKK, NME = NM - UNIT_STAGES - NM / 8;
+                    constexpr int e_lo = m * 32 / NME < 32 ? m * 32 / NME : 32, e_hi = (m + 1) * 32 / NME < 32 ? (m + 1) * 32 / NME : 32;
+                    qr_static_for<e_lo, e_hi>([&](auto X) __attribute__((always_inline)) { select_one(acc[PPAR], PPAR, prs, s2_0, s2_1, decltype(X)::value, true); });
+                    if constexpr (m >= NME && m < NME + UNIT_STAGES && PPAR == 1) unit_stage(std::integral_constant<int, m - NME>{}, un_prev, st_prev, store_prev);
+                }
+                // the slab's fragments are in registers (the MFMAs above waited for them): its slot takes slab g + RS = K step ks of pass p + C
+                if constexpr ((decltype(J)::value & 1) == 1) { if (dma) dma_piece(dsrc, ks, sbase + ks, decltype(J)::value >> 1); }
+                if constexpr (decltype(J)::value == 0 && ks == 0) { if (dma) dma_rn(p + C); }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (ks == NKS / 2) {
+                if (p + 1 < P) { nrow0 = row0_of(p + 1); nst = sx[nrow0 >> 8]; }
+                ndsrc = pass_src(p + 1 + C < P ? p + 1 + C : P - 1);
+            }
+        });
+        prev_row0 = row0; st_prev = st_cur;
+        prev_check = (n - row0 < 32) || elig != nullptr;
+        row0 = nrow0; st_cur = nst; dsrc = ndsrc;
+    };
+    auto one_pass = [&](auto PAR_c, int p) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_c)::value;
+        using TT = std::integral_constant<bool, true>; using FF = std::integral_constant<bool, false>;
+        if (prev_check) {
+            if (p > 0) epilogue_plain(acc[PAR ^ 1], PAR ^ 1, prev_row0, (p + C + 1) % (C + 2), st_prev, true);
+            pass_body(PAR_c, FF{}, p);
+        } else pass_body(PAR_c, TT{}, p);
+    };
+    for (int p = 0; p < P; p += 2) {
+        one_pass(std::integral_constant<int, 0>{}, p);
+        one_pass(std::integral_constant<int, 1>{}, p + 1);
+    }
+    epilogue_plain(acc[1], 1, prev_row0, (P - 1) % (C + 2), st_prev, prev_check);
+}
 int flat_scan_qr_steps(int ld8) { return (ld8 == 256 || ld8 == 512 || ld8 == 768) ? ld8 / 128 : 0; }    // K steps per row the register-stationary tile is built for (0: not this one)
 
 // The wide tile on the int8 shadow (more than 64 queries; ld8 a multiple of 256). Q8F: fragment-ordered int8 queries
@@ -1124,7 +1351,24 @@ void launch_flat_scan_i8(Ctx* c, int mode, const void* X8, int64_t n, int ld8, c
                          const float* sx, const float* sq, const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB, int unit_rows) {
     if ((ld8 & 255) != 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "int8 shadow rows are padded to 256 bytes");
     const long n_tiles = ceil_div(n, FB_M);
-    if (nq_used <= FN_N) {      // the narrow tile (64-row units), row-major queries through LDS
+    if (nq_used <= FN_N) {      // the narrow tile (64-row units)
+        static const int qn_env = [] { const char* e = getenv("COMET_SCAN_QR"); return e ? atoi(e) : 1; }();
+        const char* qn_rt = getenv("COMET_SCAN_QR_RT");
+        const int nksn = ((qn_rt ? atoi(qn_rt) : qn_env) != 0) ? flat_scan_qr_steps(ld8) : 0;
+        if (nksn) {             // register-stationary: queries in registers, the waves split the rows, private LDS rings, no barrier
+            const long waves = ceil_div(n_tiles * 4, 1);          // one 64-row unit per wave at least
+            const long gridw = std::max<long>(8, std::min<long>(round_up(ceil_div(waves, 4), 8), (long)round_up(c->prop.multiProcessorCount, 8)));
+            auto gow = [&](auto kernel, size_t lds) {
+                HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                c->launch_timed("flat_scan_i8_n64", kernel, dim3((unsigned)gridw), dim3(QR_THREADS), lds, (const signed char*)X8, (long)n, (const signed char*)Q8F, rn, qn, (const unsigned char*)elig, S0, (long)ldS,
+                                bound, (long)ldB, n_tiles, sx, sq);
+            };
+#define QN_GO(NKS) do { if (mode == 0) gow(flat_scan_qn_kernel<0, NKS>, QnGeom<NKS>::LDS); else gow(flat_scan_qn_kernel<1, NKS>, QnGeom<NKS>::LDS); } while (0)
+            if (nksn == 2) QN_GO(2); else if (nksn == 4) QN_GO(4); else QN_GO(6);
+#undef QN_GO
+            LAUNCH_CHECK();
+            return;
+        }
         const size_t ldsn = 2 * FN_STAGE;
         const long gridn = round_up(n_tiles, 8);
         auto gon = [&](auto kernel) {

@@ -45,6 +45,35 @@ def reciprocal_rank_fusion(vector: dict[int, float], text: dict[int, float], k: 
     return out
 
 
+def reciprocal_rank_fusion_batch(v_ids, v_counts, t_ids, t_counts, k_out: int, k: float = 60.0):
+    """reciprocalRankFusion.Combine + the descending sort and the cut to k of hybridSearch.Execute (fusion.go:174-203,
+    hybrid_search_index.go:603-611) for a whole BATCH of queries at once, vectorised: v_ids[b, :v_counts[b]] are query b's vector hits
+    best first (ascending distance), t_ids[b, :t_counts[b]] its text hits best first (descending relevance) — a hit's 0-based rank is its
+    position, exactly what score_map_to_ranks() gives for lists that arrive sorted. Same float64 arithmetic in the same order as the
+    per-query form (vector term first, text term added), ties in insertion order (vector hits, then text-only hits).
+    Returns (ids uint32 [B, k_out], scores float64 [B, k_out], counts int32 [B])."""
+    import numpy as np
+    v_ids = np.asarray(v_ids); t_ids = np.asarray(t_ids)
+    v_counts = np.asarray(v_counts, np.int64); t_counts = np.asarray(t_counts, np.int64)
+    B, kv = v_ids.shape
+    kt = t_ids.shape[1]
+    rv = 1.0 / (k + np.arange(kv, dtype=np.float64))
+    rt = 1.0 / (k + np.arange(kt, dtype=np.float64))
+    v_ok = np.arange(kv)[None, :] < v_counts[:, None]
+    t_ok = np.arange(kt)[None, :] < t_counts[:, None]
+    eq = (v_ids[:, :, None] == t_ids[:, None, :]) & v_ok[:, :, None] & t_ok[:, None, :]         # [B, kv, kt]; ids are unique inside a list
+    hit_t = eq.argmax(2); has_t = eq.any(2)
+    sv = np.where(has_t, rv[None, :] + rt[hit_t], rv[None, :])                                  # existing + rrfScore
+    t_only = t_ok & ~eq.any(1)
+    ids = np.concatenate([v_ids, t_ids], axis=1)
+    sc = np.concatenate([np.where(v_ok, sv, -np.inf), np.where(t_only, rt[None, :], -np.inf)], axis=1)
+    order = np.argsort(-sc, axis=1, kind="stable")[:, :k_out]
+    out_ids = np.take_along_axis(ids, order, 1).astype(np.uint32)
+    out_sc = np.take_along_axis(sc, order, 1)
+    counts = np.minimum(k_out, v_ok.sum(1) + t_only.sum(1)).astype(np.int32)
+    return out_ids, out_sc, counts
+
+
 def weighted_sum_fusion(vector: dict[int, float], text: dict[int, float], wv: float = 1.0, wt: float = 1.0) -> dict[int, float]:
     """weightedSumFusion.Combine (the reference's default, hybrid_search_index.go:237): wv*vector + wt*text."""
     out = {d: wv * s for d, s in vector.items()}

@@ -75,3 +75,24 @@ def test_constructor_validation_and_defaults():
         with pytest.raises(ValueError):
             _validate_pq(*bad)                                                  # pq_index.go:135-155
     _validate_pq(8, 4, 16)
+
+
+def test_rrf_batch_equals_per_query_form():
+    """the vectorised batch form of RRF + sort + cut returns what the per-query dict form (the restatement of fusion.go:174-243) returns, bit for bit"""
+    import numpy as np
+    from comet_amd.hybrid import reciprocal_rank_fusion, reciprocal_rank_fusion_batch
+    rng = np.random.default_rng(4)
+    B, k = 64, 10
+    v_ids = np.stack([rng.choice(40, k, replace=False) for _ in range(B)]).astype(np.uint32) + 1
+    t_ids = np.stack([rng.choice(40, k, replace=False) for _ in range(B)]).astype(np.uint32) + 1
+    v_cnt = rng.integers(0, k + 1, B); t_cnt = rng.integers(0, k + 1, B)
+    v_cnt[0] = 0; t_cnt[1] = 0; v_cnt[2] = t_cnt[2] = k
+    ids, sc, cnt = reciprocal_rank_fusion_batch(v_ids, v_cnt, t_ids, t_cnt, k)
+    for b in range(B):
+        v = {int(i): float(r) for r, i in enumerate(v_ids[b, :v_cnt[b]])}          # any ascending scores: only the order matters
+        t = {int(i): float(-r) for r, i in enumerate(t_ids[b, :t_cnt[b]])}
+        f = reciprocal_rank_fusion(v, t)
+        want = sorted(f.items(), key=lambda kv: -kv[1])[:k]
+        assert cnt[b] == len(want)
+        assert [int(x) for x in ids[b, :cnt[b]]] == [d for d, _ in want]
+        assert np.array_equal(sc[b, :cnt[b]].view(np.uint64), np.array([s for _, s in want], np.float64).view(np.uint64))
