@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--k", type=int, default=TOPK)
     ap.add_argument("--metric", default="cosine")
     ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 strict exact kernels, 2 fast path")
-    ap.add_argument("--legs", default="flat,c1,flat_l2,ivfpq,ivfpq10m,hnsw,hybrid", help="comma list; flat is always run (it is the headline)")
+    ap.add_argument("--legs", default="flat,c1,flat_l2,ivfpq,ivfpq_uniform,ivfpq10m,hnsw,hybrid", help="comma list; flat is always run (it is the headline)")
     ap.add_argument("--nlist", type=int, default=1024)
     ap.add_argument("--nprobe", type=int, default=32)
     ap.add_argument("--M", type=int, default=96)
@@ -506,15 +506,16 @@ def adc_lookups_ceiling():
         return {"error": f"tools/lds_gather_probe did not run: {e}"}
 
 
-def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, comm=None, rank=0, world=1, every_candidate=True, nsub=MIX_SUB):
+def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, comm=None, rank=0, world=1, every_candidate=True, nsub=MIX_SUB, fill=None, corpus="clustered corpus"):
     """world > 1: every rank trains on the same vectors (deterministic GPU k-means: replicated quantisers), owns the inverted lists
     l % world == rank (comet_index_set_shard) and adds every row (foreign members are dropped); searches go through the in-library
     RCCL exchange, so every rank ends up with the merged global top-K."""
     B, K, d, n = args.batch, args.ivfpq_k, args.dim, rows
     idx = ca.IVFPQIndex(ctx, d, ca.L2_SQUARED, nlist, args.M, args.nbits)
     ntrain = min(n, nlist * 100)
+    fill = fill or mix_fill(ctx, d, nsub)
     tbuf = ctx.alloc(ntrain * d * 4)
-    mix_fill(ctx, d, nsub)(tbuf, 0, ntrain)
+    fill(tbuf, 0, ntrain)
     t0 = time.time()
     idx.train_dev(tbuf, ntrain)
     train_s = time.time() - t0
@@ -522,7 +523,7 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
     if world > 1:
         idx.set_shard(rank, world)
     t0 = time.time()
-    add_rows(ctx, idx, 0, n, d, mix_fill(ctx, d, nsub))
+    add_rows(ctx, idx, 0, n, d, fill)
     ctx.sync()
     add_s = time.time() - t0
     pipe = Pipe(ctx, idx, q_ptrs, B, K, comm, depth=4, nprobes=args.nprobe)     # no kernel of an IVFPQ step fills the GPU: four searches in flight on four lanes
@@ -537,7 +538,7 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
     idx.stat("adc_stats_off")
     rec, prof, med, times = measure(ctx, timer, args, pipe.step, "adc_scan", B)
     g = pipe.results_of(0)
-    out = {"workload": f"IVFPQ l2_squared {n}x{d} (clustered corpus), nlist={nlist} nprobe={args.nprobe} M={args.M} nbits={args.nbits}, batch={B}, K={K}"
+    out = {"workload": f"IVFPQ l2_squared {n}x{d} ({corpus}), nlist={nlist} nprobe={args.nprobe} M={args.M} nbits={args.nbits}, batch={B}, K={K}"
                        + (f"; inverted lists sharded over {world} ranks" if world > 1 else ""), **rec,
            "train_vectors": ntrain, "train_s": round(train_s, 2), "add_s": round(add_s, 2)}
     alive, behind = stat1[0] - stat0[0], stat1[1] - stat0[1]
@@ -881,7 +882,7 @@ def main():
         line["c1"] = guarded("c1", lambda: leg_c1(ctx, ca, args))
 
     # ---------------------------------------------------------------- clustered 1M corpus: Flat L2^2 (N = 1), IVFPQ (any N), hybrid (N = 1)
-    need_mix = legs & ({"flat_l2", "ivfpq", "hybrid"} if world == 1 else {"ivfpq"})
+    need_mix = legs & ({"flat_l2", "ivfpq", "ivfpq_uniform", "hybrid"} if world == 1 else {"ivfpq"})
     if need_mix:
         flat2 = None
         if rank == 0 or world == 1:
@@ -901,6 +902,21 @@ def main():
                     line["recall_at_10"]["ivfpq_vs_exact_flat"] = iv["recall_at_10_vs_exact_flat"]
                 if "recall_at_10_vs_oracle_ivfpq" in iv:
                     line["recall_at_10"]["ivfpq_vs_oracle_ivfpq"] = iv["recall_at_10_vs_oracle_ivfpq"]
+        if "ivfpq_uniform" in legs and world == 1:
+            # SURVEY 8(d)'s primary input: i.i.d. SplitMix64 rows — no cluster structure, the two-stage lower bound has nothing to remove: the honest worst case
+            def uni():
+                useed, qseed = 0xC0FFEE + 3, 0xBEEF + 3
+                ufill = lambda buf, lo, m: ctx.synth_fill(buf, useed, lo * args.dim, m * args.dim)
+                fu = ca.FlatIndex(ctx, args.dim, ca.L2_SQUARED)
+                add_rows(ctx, fu, 0, args.rows, args.dim, ufill)
+                qu = query_batches(ctx, B, args.dim, lambda p, i: ctx.synth_fill(p, qseed, i * B * args.dim, B * args.dim))
+                Qu = ctx.download(qu[0], (B, args.dim), np.float32)
+                r = leg_ivfpq(ctx, ca, args, timer, fu, qu, Qu, args.rows, args.nlist, "ivfpq_uniform", None, 0, 1, fill=ufill, corpus="UNIFORM SplitMix64 rows, SURVEY 8d")
+                fu.close(); ctx.free(qu[0])
+                return r
+            line["ivfpq_uniform"] = guarded("ivfpq_uniform", uni)
+            if "recall_at_10_vs_exact_flat" in line["ivfpq_uniform"]:
+                line["recall_at_10"]["ivfpq_uniform_vs_exact_flat"] = line["ivfpq_uniform"]["recall_at_10_vs_exact_flat"]
         if "hybrid" in legs and world == 1:
             line["hybrid"] = guarded("hybrid", lambda: leg_hybrid(ctx, ca, args, timer, q2, Q2))
         if flat2 is not None:

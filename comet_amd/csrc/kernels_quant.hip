@@ -384,7 +384,13 @@ void launch_finalize_probe(Ctx* c, const uint32_t* pos, int B, int k_cap, const 
 //                     LUT[m][code[m]] in m order (the reference's serial sum), takes the correctly-rounded sqrt and
 //                     writes both queries' distances.
 // ------------------------------------------------------------------------------------------------
-constexpr int ADC_THREADS = 1024;
+#ifndef ADC_THREADS_N
+#define ADC_THREADS_N 1024
+#endif
+#ifndef ADC_BUF_KB
+#define ADC_BUF_KB 64
+#endif
+constexpr int ADC_THREADS = ADC_THREADS_N;
 constexpr int ADC_WAVES = ADC_THREADS / 64;
 constexpr int ADC_CHAINS = 4;
 constexpr int ADC_PASS_CODES = ADC_WAVES * ADC_CHAINS * 64;    // codes one workgroup scans per pass (one block per chain per wave)
@@ -392,7 +398,7 @@ constexpr int ADC_SEG_PASSES = 2;
 constexpr int ADC_SEG_CODES = ADC_PASS_CODES * ADC_SEG_PASSES;  // codes per item: their partial sums live in registers across the phases
 constexpr int ADC_XCD_CHUNK = 4;                               // adjacent duos kept on one XCD
 constexpr int ADC_G = 2;                                       // code words (4 subspaces each) per software-pipelined group
-constexpr int ADC_BUF_BYTES = 64 * 1024;                       // one phase buffer; two of them in LDS
+constexpr int ADC_BUF_BYTES = ADC_BUF_KB * 1024;                       // one phase buffer; two of them in LDS
 constexpr unsigned ADC_HOLE = 0xFFFFFFFFu;
 constexpr int LUT_PAIRS_PER_WG = 32;
 constexpr int ORDER_MAX_LISTS = 36 * 1024;                     // counting-sort bins that fit in LDS
@@ -1367,7 +1373,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
             }
             {   // (timed through Ctx::launch_timed: no event-record packets around the kernel when a bench times this scope)
                 const long n_items = (long)(n_slots / 2) * segs;
-                long g = std::min<long>(n_items, (long)c->prop.multiProcessorCount);
+                long g = std::min<long>(n_items, (long)c->prop.multiProcessorCount * (160 / (2 * ADC_BUF_KB + 2)));    // as many workgroups per CU as their LDS allows
                 g = std::max<long>(8, (g + 7) / 8 * 8);          // a multiple of the XCD count so that blockIdx % 8 is the XCD of every slot
                 static const bool prune_on = getenv("COMET_ADC_NO_PRUNE") == nullptr;
                 AdcArgs a{lut, codes, (const long*)list_base, list_len, so, elig, order, slist, qitems, qcount, queues, D ? D + (size_t)b0 * ldD : nullptr, (long)ldD, M, KL, mp, M4, np, (int)qcap,
