@@ -475,6 +475,7 @@ int comet_index_set_shard(comet_index* idx, int32_t rank, int32_t world) {
         if (idx->size() != 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "set the shard before adding vectors");
         std::lock_guard<std::recursive_mutex> lk(idx->c->mu);
         idx->shard_rank = rank; idx->shard_world = world;
+        idx->assign_list_owners();          // trained already: lists dealt by their training-set lengths (before training: at the end of Train)
         return (int)COMET_OK;
     });
 }
@@ -540,6 +541,7 @@ int comet_index_export(const comet_index* idx, uint32_t* out_ids, int32_t* out_l
 int comet_index_get_stat(const comet_index* idx, const char* name, double* out) {
     return guarded([&] {
         std::lock_guard<std::recursive_mutex> lk(idx->c->mu); idx->c->bind();      // some statistics are read back from the device
+        if (idx->shard_stat(name, out)) return (int)COMET_OK;
         if (!idx->get_stat(name, out)) COMET_FAIL(COMET_ERR_INVALID_ARG, "unknown stat '%s'", name);
         return (int)COMET_OK;
     });

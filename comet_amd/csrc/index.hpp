@@ -25,6 +25,44 @@ struct comet_index {
     // centroids / codebooks stay replicated, every rank ranks ALL centroids and probes the same lists, and the lists it does
     // not own are simply empty here — table build, scan and selection all shrink with the rank count.
     int shard_rank = 0, shard_world = 1;
+    // Which rank owns which list. Lists are dealt by LENGTH, not by index: the members per list seen in training (`train_counts`, the same on every
+    // rank: training is deterministic and replicated) estimate the lists' final lengths, and the lists go longest first to the rank with the
+    // least estimated rows (LPT; ties: fewer lists, then the lower rank) — a corpus with a few giant lists (the bench's clustered corpus: longest
+    // list 23 x the mean) no longer piles them on the ranks their indices happen to name. Empty until trained: l % world then.
+    std::vector<int32_t> train_counts, list_owner;
+    int owner_of(int32_t l) const { return list_owner.empty() ? l % shard_world : list_owner[(size_t)l]; }
+    void assign_list_owners() {
+        list_owner.clear();
+        if (shard_world <= 1 || train_counts.empty()) return;
+        const int nl = (int)train_counts.size();
+        std::vector<int32_t> order(nl);
+        for (int l = 0; l < nl; l++) order[l] = l;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return train_counts[a] > train_counts[b]; });
+        std::vector<int64_t> load(shard_world, 0); std::vector<int32_t> cnt(shard_world, 0);
+        list_owner.assign(nl, 0);
+        for (int32_t l : order) {
+            int best = 0;
+            for (int r = 1; r < shard_world; r++) if (load[r] < load[best] || (load[r] == load[best] && cnt[r] < cnt[best])) best = r;
+            list_owner[l] = best; load[best] += train_counts[l]; cnt[best]++;
+        }
+    }
+    // "shard_est_rows" (training-set members of this rank's lists), "shard_est_rows_max" / "_mean" over the ranks, "shard_lists" (lists owned)
+    bool shard_stat(const char* name, double* out) const {
+        if (std::strncmp(name, "shard_", 6) != 0) return false;
+        std::vector<double> load(std::max(1, shard_world), 0.0); double lists = 0;
+        for (size_t l = 0; l < train_counts.size(); l++) { const int o = owner_of((int32_t)l); load[o] += train_counts[l]; if (o == shard_rank) lists += 1; }
+        double mx = 0, sum = 0; for (double v : load) { mx = std::max(mx, v); sum += v; }
+        if (!std::strcmp(name, "shard_est_rows")) { *out = load[shard_rank]; return true; }
+        if (!std::strcmp(name, "shard_est_rows_max")) { *out = mx; return true; }
+        if (!std::strcmp(name, "shard_est_rows_mean")) { *out = sum / load.size(); return true; }
+        if (!std::strcmp(name, "shard_lists")) { *out = lists; return true; }
+        return false;
+    }
+    void note_training_assignment(const std::vector<int32_t>& assign, int nl) {
+        train_counts.assign(nl, 0);
+        for (int32_t a : assign) if (a >= 0 && a < nl) train_counts[a]++;
+        assign_list_owners();
+    }
     // set by comet_index_search_sharded_async for the duration of the call: all-reduce(min) of n floats on the context's stream across the
     // ranks of the communicator (the stage-1 bound exchange of the sharded two-stage IVFPQ search); null outside a sharded search
     void (*bound_exchange)(void* user, uint32_t* tq, int n) = nullptr; void* bound_exchange_user = nullptr;

@@ -191,10 +191,17 @@ static float* pad_raw(Ctx* c, const float* vecs_dev, int64_t n, int dim, int ld)
 }
 
 // list sharding: positions (within a batch) of the rows whose list this rank owns
-static std::vector<int32_t> owned_rows(const std::vector<int32_t>& lists, int rank, int world) {
+static std::vector<int32_t> owned_rows(const std::vector<int32_t>& lists, const comet_index* ix) {
     std::vector<int32_t> keep;
-    for (size_t i = 0; i < lists.size(); i++) if (lists[i] % world == rank) keep.push_back((int32_t)i);
+    for (size_t i = 0; i < lists.size(); i++) if (ix->owner_of(lists[i]) == ix->shard_rank) keep.push_back((int32_t)i);
     return keep;
+}
+// members per list of the training set (host copy of the device assignment): the length estimate the list -> rank assignment is made from
+static void note_training(comet_index* ix, Ctx* c, const int32_t* assign_dev, int64_t n, int nlist) {
+    std::vector<int32_t> h((size_t)n);
+    c->d2h(h.data(), assign_dev, (size_t)n * sizeof(int32_t));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    ix->note_training_assignment(h, nlist);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -368,6 +375,8 @@ struct IVFIndex : comet_index {
         centroids.reserve((size_t)nlist * ld * sizeof(float), c->stream, 0);
         int32_t* assign = c->salloc<int32_t>(n);
         if (kmeans_device(c, metric, Vt, n, ld, nlist, 20, centroids.as<float>(), assign) == 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "k-means clustering failed");
+        assign_nearest(c, metric, Vt, n, ld, centroids.as<float>(), nlist, assign);     // against the FINAL centroids (what Add will do): the list-length estimate of the shard assignment
+        note_training(this, c, assign, n, nlist);
         trained = true;
     }
     // IVFIndex.Add ivf_index.go:251-280
@@ -395,7 +404,7 @@ struct IVFIndex : comet_index {
             if (normalized_dev) launch_unpad_rows(c, dst, added, ld, normalized_dev, dim);
             HIP_CHECK(hipStreamSynchronize(c->stream));
             if (sharded) {     // keep the rows of the lists this rank owns
-                const std::vector<int32_t> keep = owned_rows(ah, shard_rank, shard_world);
+                const std::vector<int32_t> keep = owned_rows(ah, this);
                 if (!keep.empty()) {
                     int32_t* kd = c->salloc<int32_t>(keep.size());
                     c->h2d(kd, keep.data(), keep.size() * 4);
@@ -729,6 +738,7 @@ struct PQFamilyIndex : comet_index {
             int32_t* assign = c->salloc<int32_t>(n);
             if (kmeans_device(c, metric, Vt, n, ld, nlist, 20, centroids.as<float>(), assign) == 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "IVF k-means failed");
             assign_nearest(c, metric, Vt, n, ld, centroids.as<float>(), nlist, assign);       // STEP 2 (:205-208)
+            note_training(this, c, assign, n, nlist);
             float* R = c->salloc<float>((size_t)n * ld);
             launch_residual_rows(c, Vt, ld, n, centroids.as<float>(), assign, R);              // STEP 3 (:213-224)
             train_codebooks(R, n);                                                              // STEP 4
@@ -767,7 +777,7 @@ struct PQFamilyIndex : comet_index {
             c->d2h(ah.data(), a, added * sizeof(int32_t));
             HIP_CHECK(hipStreamSynchronize(c->stream));
             if (shard_world > 1) {                         // encode only the members of the lists this rank owns
-                const std::vector<int32_t> keep = owned_rows(ah, shard_rank, shard_world);
+                const std::vector<int32_t> keep = owned_rows(ah, this);
                 kept = (int64_t)keep.size();
                 if (kept == 0) return added;
                 int32_t* kd = c->salloc<int32_t>(kept);
