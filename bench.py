@@ -508,7 +508,7 @@ def adc_lookups_ceiling():
 
 def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, comm=None, rank=0, world=1, every_candidate=True, nsub=MIX_SUB, fill=None, corpus="clustered corpus"):
     """world > 1: every rank trains on the same vectors (deterministic GPU k-means: replicated quantisers), owns the inverted lists
-    l % world == rank (comet_index_set_shard) and adds every row (foreign members are dropped); searches go through the in-library
+    dealt to it (comet_index_set_shard: by list length, identically on every rank) and adds every row (foreign members are dropped); searches go through the in-library
     RCCL exchange, so every rank ends up with the merged global top-K."""
     B, K, d, n = args.batch, args.ivfpq_k, args.dim, rows
     idx = ca.IVFPQIndex(ctx, d, ca.L2_SQUARED, nlist, args.M, args.nbits)

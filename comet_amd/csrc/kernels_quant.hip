@@ -484,11 +484,23 @@ __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ Q
 // serial float32 sum of a pair's row minima as a lower bound on every candidate of that (query, list) — float32 addition is
 // monotone, so summing the minima in the scan's order can never exceed a candidate's own sum. Workgroup = the LUT kernel's
 // (mw subspaces x KL codewords) over `ppw` consecutive PAIRS.
+// Which pair of a query is scanned in stage 1 of the two-stage search (it seeds the query's bound), from the query's segment offsets `sor`
+// (np + 1 prefix sums of its probed lists' local lengths). Default: the first probed list that holds anything HERE. `strict` (a sharded search
+// whose ranks all-reduce their stage-1 bounds): probe 0 only — the query's globally nearest list, on the one rank that owns it; the other
+// ranks seed nothing for the query (+inf) and receive the bound through the exchange. Without it every rank of an N-rank job scans one whole list
+// per query in stage 1 — the nearest one it owns — and stage 1, the bulk of a pruned search, does not shrink with N at all.
+__device__ __forceinline__ bool adc_is_first(const int* __restrict__ sor, int pi, int strict) {
+    const bool nonempty = sor[pi + 1] != sor[pi];
+    return nonempty && (strict ? pi == 0 : sor[pi] == sor[0]);
+}
+__device__ __forceinline__ bool adc_is_behind(const int* __restrict__ sor, int pi, int strict) {
+    return sor[pi + 1] != sor[pi] && !adc_is_first(sor, pi, strict);
+}
 template <bool HAS_CENTROID, int DSUB>
 __global__ __launch_bounds__(256) void pq_rowmin_kernel(const float* __restrict__ Qp, int ld, const float* __restrict__ centroids,
                                                         const float* __restrict__ codebooks, int M, int Ksub, int KL, int kl_shift, int dsub,
                                                         const unsigned* __restrict__ probe_list, int ldp, int np,
-                                                        const int* __restrict__ seg_off, int n_pairs, int ppw, float* __restrict__ rowmin) {
+                                                        const int* __restrict__ seg_off, int n_pairs, int ppw, float* __restrict__ rowmin, int strict) {
     extern __shared__ __attribute__((aligned(16))) float rs[];  // [ppw][mw * d] residual slices, [ppw] live flags, [ppw][mw][nwv] partial minima
     const int d = DSUB > 0 ? DSUB : dsub;
     const int mw = 256 >> kl_shift, nwv = KL > 64 ? KL >> 6 : 1;
@@ -501,7 +513,7 @@ __global__ __launch_bounds__(256) void pq_rowmin_kernel(const float* __restrict_
         const int pl = e / wcols, col = e - pl * wcols;
         const int pr = p0 + pl, q = pr / np, pi = pr - q * np;
         const int* so = seg_off + (long)q * (np + 1) + pi;
-        const bool lv = so[1] != so[0] && so[0] != so[-pi];      // the query's first non-empty list was scanned in stage 1; empty lists have nothing to bound
+        const bool lv = adc_is_behind(so - pi, pi, strict);      // the pair scanned in stage 1 and empty lists have nothing to bound
         float r = 0.0f;
         if (lv) {
             const float qv = Qp[(long)q * ld + m_base * d + col];
@@ -565,7 +577,7 @@ __global__ __launch_bounds__(256) void pq_rowmin_kernel(const float* __restrict_
 // dead[pair] = 1 when no candidate of the pair's list can pass the query's bound: the serial float32 sum (the scan's order, m = 0 ..
 // M-1) of the row minima is above it (with the 4 ulp of slack of the scan's own test). Stage-1 pairs and empty lists are "dead" for stage 2.
 __global__ __launch_bounds__(256) void pq_lb_kernel(const float* __restrict__ rowmin, int M, int n_pairs, int np, const int* __restrict__ seg_off,
-                                                    const unsigned* __restrict__ tq, unsigned char* __restrict__ dead, int* __restrict__ stats /*nullable: [pairs alive]*/) {
+                                                    const unsigned* __restrict__ tq, unsigned char* __restrict__ dead, int* __restrict__ stats /*nullable: [pairs alive]*/, int strict) {
     extern __shared__ __attribute__((aligned(16))) float rml[];     // [64][M + 1]: the row minima of this workgroup's 64 pairs (coalesced loads; the sum itself is serial)
     const int i0 = blockIdx.x * 64, cnt = min(64, n_pairs - i0);
     for (int e = threadIdx.x; e < cnt * M; e += 256) { const int pl = e / M, m = e - pl * M; rml[pl * (M + 1) + m] = rowmin[(long)i0 * M + e]; }
@@ -575,7 +587,7 @@ __global__ __launch_bounds__(256) void pq_lb_kernel(const float* __restrict__ ro
     const int q = i / np, pi = i - q * np;
     const int* so = seg_off + (long)q * (np + 1) + pi;
     unsigned char dd = 1;
-    const bool behind = so[1] != so[0] && so[0] != so[-pi];      // a non-empty list behind the query's first non-empty one
+    const bool behind = adc_is_behind(so - pi, pi, strict);      // a non-empty list that stage 1 did not scan
     if (behind) {
         const float* r = rml + threadIdx.x * (M + 1);
         float lb = 0.0f;
@@ -613,7 +625,7 @@ __global__ __launch_bounds__(64) void pq_bound_kernel(const float* __restrict__ 
                                                       const float* __restrict__ codebooks, int M, int Ksub,
                                                       const unsigned* __restrict__ probe_list, int ldp, int np, const int* __restrict__ seg_off, int n_q,
                                                       const unsigned* __restrict__ tq, unsigned char* __restrict__ dead, int* __restrict__ stats,
-                                                      const float* __restrict__ list_rmax /*nullable: per list, an upper bound on the norm of its members' decoded residuals*/) {
+                                                      const float* __restrict__ list_rmax /*nullable: per list, an upper bound on the norm of its members' decoded residuals*/, int strict) {
     extern __shared__ __attribute__((aligned(16))) float res[];     // [BND_GP][M * DSUB] residuals of the group's pairs
     const int ng = (np + BND_GP - 1) / BND_GP;                       // groups per query
     const int q = blockIdx.x / ng, j0 = blockIdx.x - q * ng;
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(64) void pq_bound_kernel(const float* __restrict__ 
 #pragma unroll
     for (int t = 0; t < BND_GP; t++) {
         const int pi = j0 + t * ng;
-        if (pi < np && sor[pi + 1] != sor[pi] && sor[pi] != sor[0]) mask |= 1u << t;
+        if (pi < np && adc_is_behind(sor, pi, strict)) mask |= 1u << t;
     }
     const unsigned behind = mask;
     const unsigned T = tq[q];
@@ -813,7 +825,7 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
                                                          unsigned* __restrict__ order, unsigned* __restrict__ slist, AdcRec* __restrict__ qitems, int qcap,
                                                          int* __restrict__ qcount, int* __restrict__ queues, unsigned* __restrict__ tq, int* __restrict__ cursor, int n_q, int lead,
                                                          const long* __restrict__ list_base, int stage, const unsigned char* __restrict__ dead, int* __restrict__ used,
-                                                         int* __restrict__ gstats /*nullable: [2] += 64-code blocks the items cover, [3] += items, [4] += (query, block) pairs, [5] += searches*/) {
+                                                         int* __restrict__ gstats /*nullable: [2] += 64-code blocks the items cover, [3] += items, [4] += (query, block) pairs, [5] += searches*/, int strict) {
     // stage (two-stage fused search, see launch_adc_scan): 0 = every pair; 1 = only every query's nearest non-empty list, which seeds the
     // bounds; 2 = the other pairs that the lower-bound test (pq_lb_kernel) left alive. Pairs outside the stage take no slot at all.
     // lead (fused filter, np >= 2): every query's NEAREST list (probe 0) gets a duo of its own in the first 2 * n_q slots, so that
@@ -830,7 +842,7 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
         const int s0 = so[0], s1 = so[1], sr = so[-pi];
         const unsigned pl = probe_list[(long)q * ldp + pi];
         const unsigned char dd = stage == 2 ? dead[i] : (unsigned char)0;
-        const bool first = s0 == sr && s1 != s0;     // the query's nearest list that holds anything here (probe 0, or — on a rank that does not own it — the nearest owned list)
+        const bool first = s1 != s0 && (strict ? pi == 0 : s0 == sr);     // the pair stage 1 scans (adc_is_first)
         const bool out = (stage == 1 && !first) || (stage == 2 && (first || dd)) || s1 == s0;
         return out ? nlist : (int)min(pl, (unsigned)(nlist - 1));
     };
@@ -1339,6 +1351,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
     // Exact: a removed candidate's sum is above a bound that only ever tightens. On clustered data almost everything behind the
     // nearest lists goes (bench corpus: 98.6 % of the candidates); on unclustered data the cost is the row-minima kernel.
     const bool two_stage = adc_two_stage(flt, np, nlist);
+    const int strict = (two_stage && flt->exchange) ? 1 : 0;     // sharded search with a bound exchange: stage 1 = probe 0 on its owner only (adc_is_first)
     int32_t* used = c->salloc<int32_t>(4);
     float* rowmin = two_stage ? c->salloc<float>((size_t)qc * np * M) : nullptr;
     uint8_t* dead = two_stage ? c->salloc<uint8_t>((size_t)qc * np) : nullptr;
@@ -1350,13 +1363,13 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
         const uint32_t* pl = probe_list + (size_t)b0 * ldp;
         const int32_t* so = seg_off + (size_t)b0 * (np + 1);
         auto run_stage = [&](int stage) {
-            const int n_slots = (int)(stage == 0 ? slots_for(n_pairs) : round_up((stage == 1 ? bn : n_pairs - bn) + std::min<int64_t>(nlist, n_pairs), 2));
+            const int n_slots = (int)(stage == 0 ? slots_for(n_pairs) : round_up((stage == 1 ? bn : (strict ? n_pairs : n_pairs - bn)) + std::min<int64_t>(nlist, n_pairs), 2));
             {
                 ProfScope ps(c, "adc_order");
                 adc_order_kernel<<<dim3(1), dim3(1024), identity ? 0 : (size_t)(nlist + 1) * 4, c->stream>>>(pl, ldp, np, so, n_pairs, nlist, identity ? 1 : 0, list_len,
                                                                                                            n_slots, order, slist, qitems, (int)qcap, qcount, queues,
                                                                                                            flt ? flt->tq + b0 : nullptr, flt ? flt->cursor + b0 : nullptr, bn, (lead && stage == 0) ? 1 : 0, (const long*)list_base,
-                                                                                                           stage, dead, used, flt ? flt->stats : nullptr);
+                                                                                                           stage, dead, used, flt ? flt->stats : nullptr, strict);
                 LAUNCH_CHECK();
             }
             {
@@ -1391,7 +1404,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
             {
             ProfScope ps(c, "pq_bound");
             const unsigned groups = (unsigned)(bn * ceil_div(np, BND_GP));
-#define BND_LAUNCH(HC, DS) pq_bound_kernel<HC, DS><<<dim3(groups), dim3(64), bnd_lds, c->stream>>>(Qb, ld, centroids, codebooks, M, Ksub, pl, ldp, np, so, bn, flt->tq + b0, dead, flt->stats, flt->list_rmax)
+#define BND_LAUNCH(HC, DS) pq_bound_kernel<HC, DS><<<dim3(groups), dim3(64), bnd_lds, c->stream>>>(Qb, ld, centroids, codebooks, M, Ksub, pl, ldp, np, so, bn, flt->tq + b0, dead, flt->stats, flt->list_rmax, strict)
 #define BND_DS(HC) do { switch (dsub) { case 4: BND_LAUNCH(HC, 4); break; case 8: BND_LAUNCH(HC, 8); break; default: BND_LAUNCH(HC, 16); break; } } while (0)
             if (centroids) BND_DS(true); else BND_DS(false);
 #undef BND_DS
@@ -1405,7 +1418,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
             ProfScope ps(c, "pq_rowmin");
             dim3 grid((unsigned)ceil_div(M, mw), (unsigned)ceil_div(n_pairs, ppw)), blk(256);
 #define RM_LAUNCH(HC, DS) do { if (rm_lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)pq_rowmin_kernel<HC, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rm_lds)); \
-        pq_rowmin_kernel<HC, DS><<<grid, blk, rm_lds, c->stream>>>(Qb, ld, centroids, codebooks, M, Ksub, KL, kl_shift, dsub, pl, ldp, np, so, n_pairs, ppw, rowmin); } while (0)
+        pq_rowmin_kernel<HC, DS><<<grid, blk, rm_lds, c->stream>>>(Qb, ld, centroids, codebooks, M, Ksub, KL, kl_shift, dsub, pl, ldp, np, so, n_pairs, ppw, rowmin, strict); } while (0)
 #define RM_DS(HC) do { switch (dsub) { case 2: RM_LAUNCH(HC, 2); break; case 4: RM_LAUNCH(HC, 4); break; case 8: RM_LAUNCH(HC, 8); break; \
                                       case 16: RM_LAUNCH(HC, 16); break; default: RM_LAUNCH(HC, 0); break; } } while (0)
             if (centroids) RM_DS(true); else RM_DS(false);
@@ -1416,7 +1429,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
         {
             ProfScope ps(c, "pq_lb");
             if (64 * (M + 1) * 4 > 64 * 1024) COMET_FAIL(COMET_ERR_UNSUPPORTED, "too many PQ subspaces for the lower-bound kernel (%d)", M);
-            pq_lb_kernel<<<dim3((unsigned)ceil_div(n_pairs, 64)), dim3(256), (size_t)64 * (M + 1) * 4, c->stream>>>(rowmin, M, n_pairs, np, so, flt->tq + b0, dead, flt->stats);
+            pq_lb_kernel<<<dim3((unsigned)ceil_div(n_pairs, 64)), dim3(256), (size_t)64 * (M + 1) * 4, c->stream>>>(rowmin, M, n_pairs, np, so, flt->tq + b0, dead, flt->stats, strict);
             LAUNCH_CHECK();
         }
         run_stage(2);

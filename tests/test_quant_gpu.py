@@ -354,7 +354,7 @@ def test_merge_topk(ctx):
 def test_sharded_lists_merge_equals_unsharded(ctx, kind, policy):
     """SURVEY §8(e) for the inverted-list indexes: every rank trains on the same vectors (the GPU k-means is deterministic,
     so centroids / codebooks are replicated bit for bit), holds a round-robin share of the members ("members") or the whole
-    lists l % R == r ("lists", comet_index_set_shard), probes the same lists,
+    lists dealt to it ("lists", comet_index_set_shard: balanced by list length), probes the same lists,
     and the per-shard top-K merged by comet_merge_topk_dev equal the unsharded search (scores bit for bit; ids wherever the
     score is unique — inside runs of equal scores the merged order is (shard, position) instead of scan position)."""
     import ctypes as C
@@ -371,17 +371,21 @@ def test_sharded_lists_merge_equals_unsharded(ctx, kind, policy):
     full = make(); full.add_batch(ids, X)
     f_ids, f_sc, f_cn = full.search_batch(Q, k, nprobes=5)
     all_ids = np.zeros((R, B, k), np.uint32); all_sc = np.zeros((R, B, k), np.float32); all_cn = np.zeros((R, B), np.int32)
+    owned = np.zeros((R, nlist), np.int64)
     for r in range(R):
         sh = make()
         assert np.array_equal(sh.centroids(nlist), full.centroids(nlist))          # replicated quantiser
         if policy == "members":
             sh.add_batch(ids[r::R], X[r::R])
-        else:                                          # comet_index_set_shard: handed every vector, keeps the lists l % R == r
+        else:                                          # comet_index_set_shard: handed every vector, keeps the lists dealt to rank r (by length: LPT on the training set's list sizes)
             sh.set_shard(r, R)
             sh.add_batch(ids, X)
-            sizes = [sh.list_size(l) for l in range(nlist)]
-            assert all(sizes[l] == (full.list_size(l) if l % R == r else 0) for l in range(nlist))
+            owned[r] = [sh.list_size(l) for l in range(nlist)]
+            assert sh.stat("shard_est_rows_max") <= 1.25 * sh.stat("shard_est_rows_mean")          # balanced by estimated rows, whatever the lists' indices
         all_ids[r], all_sc[r], all_cn[r] = sh.search_batch(Q, k, nprobes=5)
+    if policy == "lists":                              # every list whole on exactly one rank
+        for l in range(nlist):
+            assert sorted(owned[:, l].tolist()) == [0] * (R - 1) + [full.list_size(l)], (l, owned[:, l])
     bufs = [ctx.alloc(a.nbytes) for a in (all_ids, all_sc, all_cn)]
     for p, a in zip(bufs, (all_ids, all_sc, all_cn)):
         ctx.upload(p, a)
