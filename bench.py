@@ -678,6 +678,53 @@ def leg_hnsw(ctx, ca, args, timer):
         orc = oracle()
         blob = g.to_bytes()
         out["cpu_baseline"] = cpu_baseline_from_bytes(lambda: orc.HNSW(d, "l2", M, efc, efs), blob, lambda o, q: o.search(q, K, efs), Q0, K, gr, "HNSW")
+    # ---- the same kernel on a NAVIGABLE graph (clearly not the reference's build): layer 0 only, every node linked to its 16 exact nearest
+    # neighbours (Flat search on the GPU) + 16 random nodes, loaded through comet_hnsw_load_graph — the reference's own insertNode leaves a graph
+    # whose searches stop after ~33 expansions; here a search runs its ~efSearch expansions, which is what the kernel is for ----
+    def navigable():
+        nn = min(n, 100_000)
+        buf = ctx.alloc(nn * d * 4); fill(buf, 0, nn); Xh = ctx.download(buf, (nn, d), np.float32); ctx.free(buf)
+        fl = ca.FlatIndex(ctx, d, ca.EUCLIDEAN)
+        ids_n = np.arange(1, nn + 1, dtype=np.uint32)
+        fl.add_batch(ids_n, Xh)
+        t0 = time.time()
+        knn = np.zeros((nn, 17), np.uint32)
+        for lo in range(0, nn, 4096):
+            knn[lo:lo + 4096] = fl.search_batch(Xh[lo:lo + 4096], 17)[0]
+        fl.close()
+        rng = np.random.default_rng(5)
+        edges = np.concatenate([knn[:, 1:17], rng.integers(1, nn + 1, (nn, 16), dtype=np.uint32)], axis=1)      # node IDS; a self / duplicate edge is harmless (visited set)
+        gn = ca.HNSWIndex(ctx, d, ca.EUCLIDEAN, M, efc, efs)
+        gn.load_graph(ids_n, np.zeros(nn, np.int32), Xh, np.arange(0, (nn + 1) * 32, 32, dtype=np.int64), edges.reshape(-1), 1, 0)
+        build_nav_s = time.time() - t0
+        qn_ = query_batches(ctx, B, d, lambda p, i: ctx.synth_mixture(p, MIX_SEED + 1, MIX_CENTERS, MIX_SIGMA, nsub, MIX_NOISE, n + 7 + i * B, B, d))
+        Qn = ctx.download(qn_[0], (B, d), np.float32)
+        pn = Pipe(ctx, gn, qn_, B, K, None, depth=4, **params)
+        pn.step(2)
+        recn, profn, _m, _t = measure(ctx, timer, args, pn.step, "hnsw_search", B)
+        grn = pn.results_of(0)
+        ev, ex = gn.stat("hnsw_distance_evals"), gn.stat("hnsw_expansions")
+        pn.free()
+        a_ms, a_n = one_lane_stats(profn, "hnsw_search")
+        algn = ev * d * 4 + ex * 2 * M * 4
+        achn = algn / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
+        fl2 = ca.FlatIndex(ctx, d, ca.EUCLIDEAN); fl2.add_batch(ids_n, Xh)
+        f2 = fl2.search_batch(Qn, K)[0]; fl2.close()
+        r = {"workload": f"HNSW l2 {nn}x{d} on a NAVIGABLE layer-0 graph (16 exact nearest neighbours + 16 random edges per node, built in {build_nav_s:.1f}s on the GPU, loaded through "
+                         f"comet_hnsw_load_graph): NOT the reference's construction — shown to time the search kernel at ~efSearch expansions", **recn,
+             "distance_evals_per_query": ev / B, "expansions_per_query": ex / B, "recall_at_10_vs_exact_flat": recall_of(f2, grn[0], grn[2], K),
+             "roofline": {"bound": "hbm", "kernel": "hnsw_search", "achieved": achn, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achn / HBM_PEAK_GBS, "traffic": None,
+                          "avg_kernel_ms": a_ms, "launches": a_n, "algorithmic_bytes_per_launch": algn}}
+        if not args.no_cpu_baseline:
+            orc = oracle()
+            r["cpu_baseline"] = cpu_baseline_from_bytes(lambda: orc.HNSW(d, "l2", M, efc, efs), gn.to_bytes(), lambda o, q: o.search(q, K, efs), Qn, K, grn, "HNSW")
+        gn.close(); ctx.free(qn_[0])
+        return r
+    try:
+        out["navigable"] = navigable()
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        out["navigable"] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc(limit=3)}
     ctx.free(q_ptrs[0])
     return out
 
@@ -1016,7 +1063,7 @@ def _leg(rec):
     if isinstance(c, dict):
         out["cpu_qps"] = _rnd(c.get("value")); out["cpu_cores"] = c.get("cores"); out["parity_mismatches"] = c.get("parity_mismatches")
         out["parity_checked"] = c.get("parity_checked_queries")
-    for k in ("recall_at_10_vs_exact_flat", "recall_at_10_vs_oracle_ivfpq", "rows", "build_s", "train_s", "add_s", "identical_to_exact_kernels"):
+    for k in ("recall_at_10_vs_exact_flat", "recall_at_10_vs_oracle_ivfpq", "rows", "build_s", "train_s", "add_s", "identical_to_exact_kernels", "expansions_per_query"):
         if k in rec:
             out[k] = _rnd(rec[k])
     return out
@@ -1044,6 +1091,9 @@ def compact_line(full):
         out["host_buffers_qps"] = _rnd(full["host_buffers"].get("qps"))
     out["recall_at_10"] = {k: _rnd(v) for k, v in (full.get("recall_at_10") or {}).items()}
     legs = {}
+    full = dict(full)
+    if isinstance(full.get("hnsw"), dict) and isinstance(full["hnsw"].get("navigable"), dict):
+        full["hnsw_navigable"] = full["hnsw"]["navigable"]
     for name in ("c1", "flat_l2", "ivfpq", "ivfpq_uniform", "ivfpq10m", "hnsw", "hnsw_navigable", "hybrid"):
         rec = full.get(name)
         if not isinstance(rec, dict):

@@ -1043,12 +1043,26 @@ struct AdcArgs {
     unsigned long long* cand; int* cursor; unsigned* tq; int K; float thr;
     int prune;                  // fused filter: waves skip the remaining phases of an item once all their partial sums exceed the bounds
 };
+// The table slabs' LDS-DMA pieces are issued from inline asm (16 bytes per lane from sbase + voff to LDS byte address lds_addr + lane * 16,
+// non-temporal): with the builtin, hipcc's wait-count pass sees a pending access that may complete on either counter and turns EVERY wait of the
+// item — each group's code words, each batch of table gathers — into vmcnt(0) / lgkmcnt(0) (119 + 138 of them in the round-3 binary): no gather stayed
+// in flight under the add chains, and every code-word wait drained the slab as well. The kernel waits for a slab itself (ADC_TABLE_WAIT) in front
+// of the phase barrier. M0 is saved and restored inside the statement.
+__device__ __forceinline__ void adc_dma16(const void* sbase /*wave-uniform*/, unsigned voff, unsigned lds_addr /*wave-uniform*/) {
+    const unsigned long long b = (unsigned long long)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32)), la = __builtin_amdgcn_readfirstlane(lds_addr);
+    const unsigned long long bu = ((unsigned long long)hi << 32) | lo;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(bu), "s"(la) : "memory");
+}
+#define ADC_TABLE_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 __device__ __forceinline__ unsigned adc_f2key(unsigned u) { return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // two phase buffers of ADC_BUF_BYTES
     __shared__ int s_ticket[2][2];                                  // [item parity][0] queue, [1] ticket (-1: all queues drained)
     const unsigned lane = threadIdx.x & 63u, voff = lane * 4u;
     const int wid = RFL((int)(threadIdx.x >> 6));
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
     const int M = a.M, KL = a.KL, mp = a.mp, M4 = a.M4;
     const long n_ent = (long)M * KL;                                // float2 entries of a duo's table
     const int P = (M + mp - 1) / mp;
@@ -1096,11 +1110,9 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
     auto issue_table = [&](const AdcItem& it, int ph, int buf) {
         const float* __restrict__ src = a.lutg + (it.duo * n_ent + (long)ph * mp * KL) * 2;
         const int cnt = (min(M, (ph + 1) * mp) - ph * mp) * KL * 2;  // floats; a multiple of 4
-        float* dst = lds + (long)buf * (ADC_BUF_BYTES / 4);
+        const unsigned dst = lds0 + (unsigned)buf * ADC_BUF_BYTES;
         for (int e = wid * 256; e < cnt; e += ADC_THREADS * 4) {     // LDS-DMA: each wave moves 1 KiB per instruction, lane-linear destination
-            if (e + (int)lane * 4 < cnt)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + e + lane * 4),
-                                                 (__attribute__((address_space(3))) void*)(dst + e), 16, 0, 2);   // nt: a table is read by exactly one workgroup, once
+            if (e + (int)lane * 4 < cnt) adc_dma16(src + e, lane * 16u, dst + (unsigned)e * 4u);   // nt: a table is read by exactly one workgroup, once
         }
     };
     int my_q = blockIdx.x & 7, parity = 0;
@@ -1138,7 +1150,8 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
             pTb = cur.qB >= 0 ? (unsigned)RFL((int)slack(__builtin_nontemporal_load(&a.tq[cur.qB]))) : 0u;
         }
         for (int ph = 0; ph < P; ph++, stage++) {
-            __syncthreads();        // table (cur, ph) has landed (the barrier drains vmcnt); nobody still reads the other buffer; ticket visible
+            ADC_TABLE_WAIT();       // this wave's pieces of table (cur, ph) have landed ...
+            __syncthreads();        // ... everybody's have; nobody still reads the other buffer; ticket visible
             if (a.prune && ph > 0 && !dead && na0 > 0) {
                 const unsigned sa = pTa, sb = pTb;
                 bool alive = false;
