@@ -826,7 +826,7 @@ template <int NKS> struct QrGeom {
     static constexpr int STAGE = NKS * 8192;                   // bytes of one pass in LDS: [K step][64 rows][128 B]
     static constexpr int RING = (144 * 1024) / STAGE > 8 ? 8 : (144 * 1024) / STAGE;   // passes in the ring (3 at 768, 4 at 512, 8 at 256)
     static constexpr int PPW = 2 * NKS;                        // DMA pieces (1 KiB) per wave per pass
-    static constexpr int LDS = RING * STAGE + (RING + 1) * 256; // + the row norms of the ring's passes and of the pass whose selection is still running (MODE 1)
+    static constexpr int LDS = RING * STAGE + (RING + 1) * (256 + 64); // + the row norms (MODE 1) and the eligibility bytes of the ring's passes and of the pass whose selection is still running
 };
 // s_waitcnt vmcnt(min(k, KMAX) * VMW), k a run-time count (the immediate must be a constant: a compare chain over the few possible values)
 template <int VMW, int K> __device__ __forceinline__ void qr_wait_chain(int k) {
@@ -847,9 +847,10 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qr_kernel(const signe
                                                                      unsigned long long* __restrict__ trace /*nullable: s_memtime stamps of workgroup 8 (tools/scan_check)*/) {
     using G = QrGeom<NKS>;
     constexpr int NKK = G::NKK, STAGE = G::STAGE, RING = G::RING, PPW = G::PPW;
-    constexpr int VMW = PPW + (MODE == 1 ? 1 : 0);              // vector-memory operations a wave issues per pass (pieces + its share of the row norms)
+    constexpr int VMW = PPW + (MODE == 1 ? 1 : 0) + 1;          // vector-memory operations a wave issues per pass (pieces + its share of the row norms + its share of the eligibility bytes)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* rn_ring = reinterpret_cast<float*>(smem + RING * STAGE);
+    const unsigned* el_ring = reinterpret_cast<const unsigned*>(smem + RING * STAGE + (RING + 1) * 256);     // 16 dwords (64 eligibility bytes) per pass
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- work split: 128-row halves; every XCD owns a contiguous range, its workgroups take them round robin ----
@@ -886,6 +887,17 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qr_kernel(const signe
             if ((lane >> 4) == wid) qr_dma4(reinterpret_cast<const char*>(rn + r0), voff, lds0 + (unsigned)(RING * STAGE + slot * 256));
         }
     };
+    // The pass's 64 eligibility bytes (soft deletes / WithDocumentIDs) ride the same DMA stream into LDS, 16 bytes per wave (lanes 4 w .. 4 w + 3 of a
+    // 4-byte piece): the masked selection never issues a vector-memory load of its own (a compiler-visible load in the loop would make hipcc wait
+    // vmcnt(0) and drain the ring once per pass). Issued for every pass, filter or not (from the shadow when there is none: the bytes are
+    // ignored), so that every wave's per-pass operation count — what the counted waits rely on — is one compile-time constant.
+    auto dma_el = [&](int p, int slot) __attribute__((always_inline)) {
+        const long r0 = row0_of(p);
+        const long lastdw = ((n - 1 - r0) > 0 ? (n - 1 - r0) : 0) & ~3l;           // rows past n are masked by their index: read the last valid dword instead
+        const unsigned voff = (unsigned)((long)lane * 4 < lastdw ? (long)lane * 4 : lastdw);
+        const char* src = elig ? reinterpret_cast<const char*>(elig) + r0 : reinterpret_cast<const char*>(X8);
+        if ((lane >> 2) == wid) qr_dma4(src, elig ? voff : (unsigned)lane * 4u, lds0 + (unsigned)(RING * STAGE + (RING + 1) * 256 + slot * 64));
+    };
     // ---- prologue: passes 0 .. RING-2 in flight ----
 #pragma unroll
     for (int pp = 0; pp < RING - 1; pp++) {
@@ -894,6 +906,7 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qr_kernel(const signe
 #pragma unroll
             for (int i = 0; i < PPW; i++) dma_piece(src, pp, i);
             dma_rn(pp, pp);
+            dma_el(pp, pp);
         }
     }
     // ---- queries: fragments [group of 32 queries][kk][lane] 16 bytes (prep_queries_i8_kernel), groups 2 w and 2 w + 1 ----
@@ -987,10 +1000,16 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qr_kernel(const signe
         unsigned okm = 0xFFFFFFFFu;
         if (check) {
             okm = 0u;
+#pragma unroll
             for (int mb = 0; mb < 2; mb++)
-                for (int e = 0; e < 16; e++) {
-                    const long r = prow0 + mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
-                    if (r < n && (!elig || elig[r])) okm |= 1u << (mb * 16 + e);
+#pragma unroll
+                for (int e4 = 0; e4 < 4; e4++) {
+                    const unsigned dw = elig ? el_ring[prs * 16 + mb * 8 + e4 * 2 + khalf] : 0x01010101u;      // the 4 consecutive rows e & 3 = 0 .. 3
+#pragma unroll
+                    for (int e1 = 0; e1 < 4; e1++) {
+                        const long r = prow0 + mb * 32 + e1 + 8 * e4 + 4 * khalf;
+                        if (r < n && ((dw >> (8 * e1)) & 0xFFu)) okm |= 1u << (mb * 16 + e4 * 4 + e1);
+                    }
                 }
         }
         const float s2_0 = 2.0f * (sqv[0] * stv), s2_1 = 2.0f * (sqv[1] * stv);
@@ -1079,7 +1098,8 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qr_kernel(const signe
             // one DMA piece of pass p + RING - 1 per MFMA group, into the slot pass p - 1 has left (free since the barrier of pass p - 1)
             if constexpr (DMA && kk < PPW) dma_piece(dsrc, fslot, kk);
             else if constexpr (DMA && kk == PPW) dma_rn(p + RING - 1, rslot + RING - 1 > RING ? rslot - 2 : rslot + RING - 1);
-            else if constexpr (kk == PPW + 1) {
+            else if constexpr (DMA && kk == PPW + 1) dma_el(p + RING - 1, rslot + RING - 1 > RING ? rslot - 2 : rslot + RING - 1);
+            else if constexpr (kk == PPW + 2) {
                 // the next pass's scalars, a dozen MFMA groups before they are needed
                 if (p + 1 < P) { nrow0 = row0_of(p + 1); nst = sx[nrow0 >> 8]; }
                 ndsrc = pass_src(p + RING < P ? p + RING : P - 1);
@@ -1126,7 +1146,7 @@ template <int NKS> struct QnGeom {
     static constexpr int C = NKS == 6 ? 1 : 2;                  // passes in a wave's ring
     static constexpr int RS = C * NKS;                          // slabs (32 rows x 128 B = 4 KiB) in a wave's ring
     static constexpr int WRB = RS * 4096;                       // ring bytes per wave
-    static constexpr int LDS = 4 * WRB + 4 * (C + 2) * 128;     // + per wave the row norms of C + 2 passes (MODE 1)
+    static constexpr int LDS = 4 * WRB + 4 * (C + 2) * (128 + 32);   // + per wave the row norms (MODE 1) and the eligibility bytes of C + 2 passes
 };
 template <int MODE, int NKS>
 __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qn_kernel(const signed char* __restrict__ X8, long n, const signed char* __restrict__ Q8F,
@@ -1140,6 +1160,7 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qn_kernel(const signe
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* rn_ring = reinterpret_cast<float*>(smem + 4 * WRB) + wid * (C + 2) * 32;
+    const unsigned* el_ring = reinterpret_cast<const unsigned*>(smem + 4 * WRB + 4 * (C + 2) * 128) + wid * (C + 2) * 8;     // 8 dwords (32 eligibility bytes) per pass
     // ---- work split: 64-row key units; every XCD owns a contiguous range, its waves take them round robin ----
     const long nx = 8, xcd = blockIdx.x % nx, WX = (gridDim.x / nx) * 4, wx = (blockIdx.x / nx) * 4 + wid;
     const long U = n_tiles * 4, uq = U / nx, urem = U % nx;
@@ -1173,11 +1194,19 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qn_kernel(const signe
             if (lane < 32) qr_dma4(reinterpret_cast<const char*>(rn + r0), voff, lds0 + (unsigned)(4 * WRB + (wid * (C + 2) + p % (C + 2)) * 128));
         }
     };
+    auto dma_el = [&](int p) __attribute__((always_inline)) {   // the pass's 32 eligibility bytes (lanes 0 .. 7 of a 4-byte piece), only when there is a filter
+        if (elig) {
+            const long r0 = row0_of(p);
+            const long lastdw = ((n - 1 - r0) > 0 ? (n - 1 - r0) : 0) & ~3l;
+            const unsigned voff = (unsigned)((long)lane * 4 < lastdw ? (long)lane * 4 : lastdw);
+            if (lane < 8) qr_dma4(reinterpret_cast<const char*>(elig) + r0, voff, lds0 + (unsigned)(4 * WRB + 4 * (C + 2) * 128 + (wid * (C + 2) + p % (C + 2)) * 32));
+        }
+    };
     // ---- prologue: the first RS slabs in flight (passes 0 .. C-1) ----
 #pragma unroll
     for (int g = 0; g < RS; g++) {
         if (g < T) {
-            if (g % NKS == 0) dma_rn(g / NKS);
+            if (g % NKS == 0) { dma_rn(g / NKS); dma_el(g / NKS); }
             const char* src = pass_src(g / NKS);
 #pragma unroll
             for (int i = 0; i < 4; i++) dma_piece(src, g % NKS, g, i);
@@ -1257,9 +1286,14 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qn_kernel(const signe
         unsigned okm = 0xFFFFu;
         if (check) {
             okm = 0u;
-            for (int e = 0; e < 16; e++) {
-                const long r = prow0 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
-                if (r < n && (!elig || elig[r])) okm |= 1u << e;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; e4++) {
+                const unsigned dw = elig ? el_ring[prs * 8 + e4 * 2 + khalf] : 0x01010101u;
+#pragma unroll
+                for (int e1 = 0; e1 < 4; e1++) {
+                    const long r = prow0 + e1 + 8 * e4 + 4 * khalf;
+                    if (r < n && ((dw >> (8 * e1)) & 0xFFu)) okm |= 1u << (e4 * 4 + e1);
+                }
             }
         }
         const float s2_0 = 2.0f * (sqv0 * stv), s2_1 = 2.0f * (sqv1 * stv);
@@ -1317,7 +1351,7 @@ __global__ __launch_bounds__(QR_THREADS, 1) void flat_scan_qn_kernel(const signe
                 }
                 // the slab's fragments are in registers (the MFMAs above waited for them): its slot takes slab g + RS = K step ks of pass p + C
                 if constexpr ((decltype(J)::value & 1) == 1) { if (dma) dma_piece(dsrc, ks, sbase + ks, decltype(J)::value >> 1); }
-                if constexpr (decltype(J)::value == 0 && ks == 0) { if (dma) dma_rn(p + C); }
+                if constexpr (decltype(J)::value == 0 && ks == 0) { if (dma) { dma_rn(p + C); dma_el(p + C); } }
                 __builtin_amdgcn_sched_barrier(0);
             });
             if constexpr (ks == NKS / 2) {
