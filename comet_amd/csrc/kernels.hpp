@@ -130,6 +130,10 @@ void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const fl
 // int8 shadow of the wide tile (round 3): rows [256-row tile][64-byte slab][row][64 codes] + one scale per TILE. Quantises every row of
 // tiles tile0 .. ceil(n / 256) - 1 (X: row 0 of the index, n: its rows); stats[2] = max ||x - s c||^2 bits (atomicMax)
 void launch_to_i8_tiles(Ctx* c, const float* X, int64_t n, int ld, void* X8, int ld8, int64_t tile0, float* st, uint32_t* stats);
+// kernels_scanq.hip: the register-stationary tiles (int8 shadow rows of 256 / 512 / 768 bytes); false: not handled, use the older tiles
+int flat_scan_qr_steps(int ld8);
+bool launch_flat_scan_qr(Ctx* c, int mode, const void* X8, int64_t n, int ld8, const void* Q8F, int nq_used, const float* rn, const float* qn,
+                         const float* sx, const float* sq, const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB, int unit_rows);
 void launch_flat_scan_i8(Ctx* c, int mode, const void* X8, int64_t n, int ld8, const void* Q8F, const void* Q8R, int nq_used, const float* rn, const float* qn,
                          const float* sx, const float* sq, const uint8_t* elig, float* S0, int64_t ldS, float* bound, int64_t ldB, int unit_rows);
 bool prep_queries_i8_ok(int dim);

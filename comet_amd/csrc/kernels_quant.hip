@@ -397,7 +397,10 @@ constexpr int ADC_PASS_CODES = ADC_WAVES * ADC_CHAINS * 64;    // codes one work
 constexpr int ADC_SEG_PASSES = 2;
 constexpr int ADC_SEG_CODES = ADC_PASS_CODES * ADC_SEG_PASSES;  // codes per item: their partial sums live in registers across the phases
 constexpr int ADC_XCD_CHUNK = 4;                               // adjacent duos kept on one XCD
-constexpr int ADC_G = 2;                                       // code words (4 subspaces each) per software-pipelined group
+#ifndef ADC_G_N
+#define ADC_G_N 2
+#endif
+constexpr int ADC_G = ADC_G_N;                                       // code words (4 subspaces each) per software-pipelined group
 constexpr int ADC_BUF_BYTES = ADC_BUF_KB * 1024;                       // one phase buffer; two of them in LDS
 constexpr unsigned ADC_HOLE = 0xFFFFFFFFu;
 constexpr int LUT_PAIRS_PER_WG = 32;

@@ -3,6 +3,8 @@
 // distances + the bound of every (query, 128-row unit)) with a float64 host computation on the same fp16-rounded operands.
 // usage: scan_check [rows] [dim] [queries] [iters]        build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DQR_TRACE] tools/scan_check.hip -o tools/scan_check
 #include "../comet_amd/csrc/kernels_fast.hip"
+#include "../comet_amd/csrc/kernels_scanq.hip"
+#include "../comet_amd/csrc/kernels_scanq_l2.hip"
 
 #include <algorithm>
 #include <cmath>
