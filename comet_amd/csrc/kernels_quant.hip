@@ -390,8 +390,15 @@ void launch_finalize_probe(Ctx* c, const uint32_t* pos, int B, int k_cap, const 
 #ifndef ADC_BUF_KB
 #define ADC_BUF_KB 64
 #endif
+// ADC_LOADERS_N of the workgroup's waves only stream table slabs (LDS-DMA); the others only gather. Vector-memory operations return in order per wave:
+// with every wave issuing its share of a 64 KB slab, a wave's next 256-byte group of code words queued up behind the slab (~1 800 clocks per group,
+// four groups per phase, s_memtime trace) — on short lists, where an item is a chain of such waits, that was most of an item's 30 us.
+#ifndef ADC_LOADERS_N
+#define ADC_LOADERS_N 2
+#endif
 constexpr int ADC_THREADS = ADC_THREADS_N;
-constexpr int ADC_WAVES = ADC_THREADS / 64;
+constexpr int ADC_LOADERS = ADC_LOADERS_N;
+constexpr int ADC_WAVES = ADC_THREADS / 64 - ADC_LOADERS;       // the gathering waves (chains, code blocks and the epilogue are laid out over these)
 constexpr int ADC_CHAINS = 4;
 constexpr int ADC_PASS_CODES = ADC_WAVES * ADC_CHAINS * 64;    // codes one workgroup scans per pass (one block per chain per wave)
 constexpr int ADC_SEG_PASSES = 2;
@@ -1103,7 +1110,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
         const int pstart = it.start + ps * ADC_PASS_CODES;
         if (!it.live || pstart >= it.seg_end) return 0;
         const int nblk = (min(it.seg_end, pstart + ADC_PASS_CODES) - pstart + 63) >> 6;
-        return wid < nblk ? (nblk - wid + ADC_WAVES - 1) / ADC_WAVES : 0;
+        return (wid < ADC_WAVES && wid < nblk) ? (nblk - wid + ADC_WAVES - 1) / ADC_WAVES : 0;     // loader waves hold no chains
     };
     auto rsrc_of = [&](const AdcItem& it) -> adc_rsrc_t {           // the segment's first block
         const unsigned* b = a.codes + (it.base_blk + (it.start >> 6)) * (long)M4 * 64;
@@ -1114,7 +1121,10 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
         const float* __restrict__ src = a.lutg + (it.duo * n_ent + (long)ph * mp * KL) * 2;
         const int cnt = (min(M, (ph + 1) * mp) - ph * mp) * KL * 2;  // floats; a multiple of 4
         const unsigned dst = lds0 + (unsigned)buf * ADC_BUF_BYTES;
-        for (int e = wid * 256; e < cnt; e += ADC_THREADS * 4) {     // LDS-DMA: each wave moves 1 KiB per instruction, lane-linear destination
+        constexpr int NL = ADC_LOADERS > 0 ? ADC_LOADERS : ADC_WAVES;              // the waves that move slabs: the loaders, or (ADC_LOADERS_N = 0) every wave
+        const int lw = ADC_LOADERS > 0 ? wid - ADC_WAVES : wid;
+        if (lw < 0) return;
+        for (int e = lw * 256; e < cnt; e += NL * 256) {             // LDS-DMA: a wave moves 1 KiB per instruction, lane-linear destination
             if (e + (int)lane * 4 < cnt) adc_dma16(src + e, lane * 16u, dst + (unsigned)e * 4u);   // nt: a table is read by exactly one workgroup, once
         }
     };
