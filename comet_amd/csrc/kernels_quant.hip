@@ -1067,6 +1067,14 @@ __device__ __forceinline__ void adc_dma16(const void* sbase /*wave-uniform*/, un
 }
 #define ADC_TABLE_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 __device__ __forceinline__ unsigned adc_f2key(unsigned u) { return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+#ifdef ADC_TRACE
+// s_memtime stamps of workgroup 8's thread 0 (build with -DADC_TRACE; tools/adc_trace.py reads them): per item [start, then per phase: after the barrier,
+// after the gathers ..., epilogue done]
+__device__ unsigned long long adc_trace_buf[32 * 16];
+#define ADC_STAMP(ITEM, SLOT) do { if (blockIdx.x == 8 && threadIdx.x == 0 && (ITEM) < 32) adc_trace_buf[(ITEM) * 16 + (SLOT)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ADC_STAMP(ITEM, SLOT) do { } while (0)
+#endif
 __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // two phase buffers of ADC_BUF_BYTES
     __shared__ int s_ticket[2][2];                                  // [item parity][0] queue, [1] ticket (-1: all queues drained)
@@ -1141,6 +1149,9 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
 #pragma unroll
         for (int i = 0; i < ADC_G; i++) cw_cur[c][i] = adc_ldw(rs_cur, voff, off_of(0) + c * stride16b + min(i, M4 - 1) * 256);
     int stage = 0;
+#ifdef ADC_TRACE
+    int trace_item = 0;
+#endif
     while (true) {
         if (wid == 0) { const int t = take(my_q); if (lane == 0u) { s_ticket[parity ^ 1][0] = my_q; s_ticket[parity ^ 1][1] = t; } }   // next item's ticket
         AdcItem nxt = decode(0, -1);
@@ -1151,6 +1162,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
 #pragma unroll
             for (int c = 0; c < ADC_CHAINS; c++) { acc[ps][c][0] = 0.0f; acc[ps][c][1] = 0.0f; }
         const int na0 = chains_of(cur, 0), na1 = chains_of(cur, 1);
+        ADC_STAMP(trace_item, 0);
         // Fused filter: the terms of a sum are squares, so a candidate's partial sum over the first phases never exceeds its sum
         // (float32 addition of non-negative terms is monotone). A wave whose candidates are ALL above their query's bound after a
         // phase cannot deliver a survivor: it skips the gathers of the item's remaining phases (the far lists of a query, mostly).
@@ -1165,6 +1177,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
         for (int ph = 0; ph < P; ph++, stage++) {
             ADC_TABLE_WAIT();       // this wave's pieces of table (cur, ph) have landed ...
             __syncthreads();        // ... everybody's have; nobody still reads the other buffer; ticket visible
+            ADC_STAMP(trace_item, 1 + 2 * ph);
             if (a.prune && ph > 0 && !dead && na0 > 0) {
                 const unsigned sa = pTa, sb = pTb;
                 bool alive = false;
@@ -1208,6 +1221,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
                     default: adc_chains2<4>(lut, w_lo, m_hi, M4, KL, rs_cur, off_of(ps), stride16b, nrs, nx_off, nxw, voff, cw_cur, acc[ps]); break;
                 }
             }
+            ADC_STAMP(trace_item, 2 + 2 * ph);
         }
         if (a.cand == nullptr) {
 #pragma unroll
@@ -1290,8 +1304,12 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
                 }
             }
         }
+        ADC_STAMP(trace_item, 15);
         if (!nxt.live) break;
         cur = nxt; rs_cur = rs_nxt; parity ^= 1;
+#ifdef ADC_TRACE
+        trace_item++;
+#endif
     }
 }
 // pairs of a (sub-)batch grouped by probed list; falls back to the identity order when the list count does not fit in LDS
@@ -1463,3 +1481,9 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
 }
 
 }  // namespace comet
+
+#ifdef ADC_TRACE
+extern "C" __attribute__((visibility("default"))) int comet_debug_adc_trace(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(comet::adc_trace_buf), (size_t)n * 8);
+}
+#endif
