@@ -1119,14 +1119,26 @@ __device__ __forceinline__ void post_bitonic(T* sm, int n2) {
 template <typename T>
 __device__ __forceinline__ void post_sort(T* sm, int n, int n2, T* tmp) {
     if (n <= 1024) {
+        // every value's rank = the number of smaller values (all distinct). The n * n comparisons are spread over ALL 1024 threads: P = 1024 / n2s
+        // threads per value (n2s = n rounded up to a power of two, >= 64), each over 1 / P of the list (broadcast LDS reads, 16 values requested
+        // at a time); the partial ranks meet in an LDS counter per value (tmp[1024 ..]: `tmp` holds >= 2048 values at every call site).
         const int t = threadIdx.x;
-        T me = 0; int rank = 0;
-        if (t < n) {
-            me = sm[t];
-            for (int j = 0; j < n; j++) rank += (sm[j] < me) ? 1 : 0;
+        int n2s = 64; while (n2s < n) n2s <<= 1;
+        const int P = POST_THREADS / n2s, e = t & (n2s - 1), part = t / n2s;
+        int* rk = reinterpret_cast<int*>(tmp + 1024);
+        if (t < n) rk[t] = 0;
+        __syncthreads();
+        T me = 0;
+        if (e < n) {
+            me = sm[e];
+            const int j0 = (int)((long)n * part / P), j1 = (int)((long)n * (part + 1) / P);
+            int rank = 0;
+#pragma unroll 16
+            for (int j = j0; j < j1; j++) rank += (sm[j] < me) ? 1 : 0;
+            if (P == 1) rk[e] = rank; else if (rank) atomicAdd(&rk[e], rank);
         }
         __syncthreads();
-        if (t < n) tmp[rank] = me;
+        if (t < n) tmp[rk[t]] = me;          // (part 0: e == t)
         __syncthreads();
         if (t < n) sm[t] = tmp[t];
         __syncthreads();
@@ -1201,20 +1213,22 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
     const long n_tiles = geom.units();
     const int unit_rows = geom.urows();
     unsigned long long tr_prev = trace ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long tf_prev = tr_prev;
+    auto TF = [&](int ph) { if (trace && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); atomicAdd(&trace[8 + ph], now - tf_prev); tf_prev = now; } };   // fine stamps (COMET_POST_TRACE)
     auto TR = [&](int ph) { if (trace && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); atomicAdd(&trace[ph], now - tr_prev); tr_prev = now; } };
     unsigned* hist = reinterpret_cast<unsigned*>(psm) + POST_MAXKEYS;       // [4096]; the 64 KiB in front: rescoring slices, then the sort buffer
     unsigned* lst = hist + 4096;                                             // [POST_CAP] candidate rows
     float* sc = reinterpret_cast<float*>(lst + POST_CAP);                    // [POST_CAP] exact scores
     unsigned* slotv = reinterpret_cast<unsigned*>(sc + POST_CAP);            // [POST_CAP] slot of every candidate (GEOM::kSlots only: the launcher adds the 16 KiB)
     __shared__ unsigned wsum[16];
-    __shared__ int s_bin, s_before, s_cnt, s_exp, s_valid;
+    __shared__ int s_bin, s_before, s_cnt, s_exp;
     const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
     constexpr bool DENSE = GEOM::kDense;
     const int nkeys = DENSE ? (int)(n_tiles * unit_rows) : (int)(2 * n_tiles);
     const float* s0 = S0 + (long)q * ldS;
     const float* bd = DENSE ? nullptr : bound + (long)q * ldB;
     const float INF = __builtin_inff();
-    if (t == 0) { s_cnt = 0; s_exp = 0; s_valid = 0; }
+    if (t == 0) { s_cnt = 0; s_exp = 0; }
     float tau = INF;
     float kappa_v = INF; bool kappa_ok = false;          // the K-th smallest emitted key (general path), for the anchored threshold below
     bool hier_done = false;
@@ -1325,11 +1339,19 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
                 const long tl = (long)j * POST_THREADS + t;
                 const bool lv = tl < n_tiles;
                 kreg[j] = lv ? *reinterpret_cast<const f32x2v*>(s0 + 2 * tl) : f32x2v{INF, INF};
-                breg[j] = lv ? bd[tl] : INF;
             }
         }
     };
+    // the unit bounds are wanted by the LAST collection only (expansions): loaded right before it — held from the start they cost eight registers across
+    // the kappa stage, which the allocator paid for with spills AND a full wait after every bound load (eight serial memory round trips at entry)
+    auto load_bounds = [&]() {
+        if constexpr (!DENSE) {
+#pragma unroll
+            for (int j = 0; j < POST_RU; j++) { const long tl = (long)j * POST_THREADS + t; breg[j] = tl < n_tiles ? bd[tl] : INF; }
+        }
+    };
     if (reg && !hier_done) load_keys();
+    TF(0);
     // dense rows beyond the registers: streamed per pass, 4 x 16 bytes per thread in flight (a one-load-per-iteration loop pays the
     // L2 / HBM latency once per value: ~300 iterations for a query that probes a 40 k-row list); every thread makes the same
     // number of calls (absent values arrive as +inf), so f may use wave-wide ballots
@@ -1377,6 +1399,7 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
         int valid = 0;
         for (int w = 0; w < POST_WAVES; w++) { lo = fminf(lo, wlo[w]); hi = fmaxf(hi, whi[w]); valid += wct[w]; }
         __syncthreads();
+        TF(1);
         unsigned kap = 0; bool have_kap = false;
         if constexpr (DENSE) {
             // Dense rows hold tens of thousands of values for the sake of the K smallest, and most of them share a few histogram bins
@@ -1437,6 +1460,7 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
             post_find_bin(hist, kappa_rank, wsum, &s_bin, &s_before);
             const int kbin = s_bin, rank_in = kappa_rank - s_before, members = (int)hist[kbin];
             __syncthreads();
+            TF(2);
             if (members <= 1024) {
                 unsigned* mem = lst;                      // the candidate list is not in use yet
                 if (t == 0) s_cnt = 0;
@@ -1502,12 +1526,12 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
             anchor = tot > 2 * kappa_rank + 64 ? 1 : 0;
         }
     }
-    TR(0);
+    TF(3); TR(0);
     int cnt = 0, cnt_anchor = 0;
     // ---- 2. candidates ----
     // rows with key <= tau_c, except the emitted rows with key <= key_lo (phase 0 holds those already, -1: none); at most cap of them
     auto collect = [&](const float tau_c, const bool expand_ok, const float key_lo, const int cap) {
-    auto candidates_of = [&](long t0, float bnd, float k0, float k1) {
+    auto candidates_of = [&](long t0, float bnd, float k0, float k1, float x0, float x1) {      // (x0, x1: the unit's emitted keys, for the expansion; k0, k1: the keys offered)
         const long tl = t0 + t;
         const bool live = tl < n_tiles;
         const bool expand = live && expand_ok && bnd <= tau_c;
@@ -1518,7 +1542,7 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
             const long te = t0 + (t & ~63) + src;      // tile of lane `src`
             if (lane == src) atomicAdd(&s_exp, 1);
             const typename GEOM::Unit U = geom.unit(te);
-            const float e0 = __shfl(k0, src, 64), e1 = __shfl(k1, src, 64);     // the unit's emitted keys: phase 0 took those <= key_lo
+            const float e0 = __shfl(x0, src, 64), e1 = __shfl(x1, src, 64);     // the unit's emitted keys: phase 0 took those <= key_lo
             const int r0 = e0 <= key_lo ? (int)(__float_as_uint(e0) & (unsigned)(unit_rows - 1)) : -1;
             const int r1 = e1 <= key_lo ? (int)(__float_as_uint(e1) & (unsigned)(unit_rows - 1)) : -1;
             for (int j = lane; j < unit_rows; j += 64)
@@ -1534,13 +1558,48 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
     } else if constexpr (DENSE) {                        // every position whose approximate distance is within tau
         for_keys_idx([&](float v, int i) { post_append(v <= tau_c && v != INF, (unsigned)i, lst, &s_cnt, cap); });
     } else if (reg) {
+        // keys in registers: the wave counts its takers first (16 ballots, wave-uniform), reserves their slots with ONE LDS atomic and then writes
+        // them — an atomic round trip per key register (three of four have a taker at 1M rows) was most of this stage. Expansions (rare) go through
+        // candidates_of's path, one unit at a time.
+        unsigned long long bm[POST_RU][2];
+        int total = 0;
 #pragma unroll
-        for (int j = 0; j < POST_RU; j++) if ((long)j * POST_THREADS < n_tiles) candidates_of((long)j * POST_THREADS, breg[j], kreg[j][0], kreg[j][1]);
+        for (int j = 0; j < POST_RU; j++) {
+            const long tl = (long)j * POST_THREADS + t;
+            const bool live = tl < n_tiles;
+            const bool expand = live && expand_ok && breg[j] <= tau_c;
+            if (__ballot(expand)) candidates_of((long)j * POST_THREADS, breg[j], INF, INF, kreg[j][0], kreg[j][1]);   // the expansions only (keys +inf: no takers)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const float key = (live && !expand) ? kreg[j][e] : INF;
+                bm[j][e] = __ballot(key <= tau_c && key > key_lo && key != INF);
+                total += (int)__builtin_popcountll(bm[j][e]);
+            }
+        }
+        int base = 0;
+        if (total) {                                   // wave-uniform
+            if (lane == 0) base = atomicAdd(&s_cnt, total);
+            base = __shfl(base, 0, 64);
+            const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int j = 0; j < POST_RU; j++)
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const unsigned long long m = bm[j][e];
+                    if ((m >> lane) & 1ull) {
+                        const int sl = base + (int)__builtin_popcountll(m & below);
+                        const long tl = (long)j * POST_THREADS + t;
+                        if (sl < cap) lst[sl] = (unsigned)(tl * unit_rows + (__float_as_uint(kreg[j][e]) & (unsigned)(unit_rows - 1)));
+                    }
+                    base += (int)__builtin_popcountll(m);
+                }
+        }
     } else {
         for (long t0 = 0; t0 < n_tiles; t0 += POST_THREADS) {
             const long tl = t0 + t;
             const bool lv = tl < n_tiles;
-            candidates_of(t0, lv ? bd[tl] : INF, lv ? s0[2 * tl] : INF, lv ? s0[2 * tl + 1] : INF);
+            const float k0 = lv ? s0[2 * tl] : INF, k1 = lv ? s0[2 * tl + 1] : INF;
+            candidates_of(t0, lv ? bd[tl] : INF, k0, k1, k0, k1);
         }
     }
     __syncthreads();
@@ -1642,18 +1701,23 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
     constexpr int POST_ACAP = 2048;
     unsigned* lstA = slotv; float* scA = reinterpret_cast<float*>(slotv + POST_ACAP);
     float key_lo = -1.0f;                                // keys are >= 0
+    float u_score = INF;                                 // phase 0's largest exact score (the final order's cut)
     if (anchor) {                                        // phase 0: the rows under kappa, exactly (no order needed, no expansions)
         collect(kappa_v, false, -1.0f, POST_CAP);
         cnt = s_cnt;
+        TF(4);
         if (cnt <= POST_ACAP && cnt >= kappa_rank) {     // (more: mass ties at kappa — the plain threshold decides)
         if constexpr (GEOM::kSlots) {
             for (int i = t; i < cnt; i += POST_THREADS) slotv[i] = (unsigned)geom.slot_of(lst[i]);
             __syncthreads();
         }
         stage_query();
+        TF(5);
         rescore_all();
+        TF(6);
         // U = the largest exact distance among the (at least K) rows under kappa, in the keys' space (squared for the L2 family:
         // sqrt is monotone, and U^2 (1 + 2^-21) is no smaller than the sum the largest score was rooted from)
+        if (reg) { load_keys(); load_bounds(); }          // requested now: the 48 MB of key rows (all queries) arrive under the reduction and the copies below
         float u = 0.0f;
         for (int i = t; i < cnt; i += POST_THREADS) u = fmaxf(u, sc[i]);
 #pragma unroll
@@ -1662,6 +1726,7 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
         if (lane == 0) wmx[wid] = u;
         __syncthreads();
         for (int w = 0; w < POST_WAVES; w++) u = fmaxf(u, wmx[w]);
+        u_score = u;
         if constexpr (METRIC == COMET_L2) u = u * u * 1.0000005f;
         const float tau_a = u + err_abs[q] + 1.0e-4f * fabsf(u) + 1e-30f;
         if (tau_a < tau) tau = tau_a;
@@ -1670,13 +1735,15 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
         }
         __syncthreads();
         if (t == 0) s_cnt = 0;
-        // the key registers are loaded again (L2 hits) rather than kept alive across the rescoring above: 24 registers the
-        // 128-register budget of a 1024-thread workgroup does not have
-        if (reg) load_keys();
+        // the key registers are loaded again rather than kept alive across the rescoring above (24 registers the 128-register budget of a
+        // 1024-thread workgroup does not have): inside the branch above when phase 0 ran, here when it was abandoned (mass ties at kappa)
+        if (reg && cnt_anchor == 0) load_keys();
         __syncthreads();
     }
+    if (reg && cnt_anchor == 0) load_bounds();
+    TF(7);
     collect(tau, true, key_lo, POST_CAP - cnt_anchor);
-    TR(1);
+    TF(8); TR(1);
     cnt = s_cnt;
     if (cnt > POST_CAP - cnt_anchor) {                 // empty row; the host re-runs this query on the strict path
         for (int i = t; i < k_cap; i += POST_THREADS) { out_ids[(long)q * k_cap + i] = 0u; out_scores[(long)q * k_cap + i] = 0.0f; }
@@ -1686,38 +1753,56 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
     int n2 = 64; while (n2 < cnt) n2 <<= 1;
     for (int i = cnt + t; i < n2; i += POST_THREADS) lst[i] = 0xFFFFFFFFu;
     __syncthreads();
-    post_sort(lst, cnt, n2, hist);                     // ascending row = canonical tie order of the strict path (hist: 16 KiB scratch)
+    // slot geometries: ascending position = canonical tie order of the strict path, carried by the INDEX into the sorted list (hist: 16 KiB scratch).
+    // Unit keys: the final composites carry the row itself, so the order of lst[] is immaterial and is left as collected.
+    if constexpr (GEOM::kSlots) post_sort(lst, cnt, n2, hist);
     if constexpr (GEOM::kSlots) {                      // position -> slot, once per candidate
         for (int i = t; i < cnt; i += POST_THREADS) slotv[i] = (unsigned)geom.slot_of(lst[i]);
         __syncthreads();
     }
-    TR(2);
+    TF(9); TR(2);
     stage_query();
+    TF(10);
     rescore_all();
-    TR(3);
+    TF(11); TR(3);
     // ---- 4. final order: (score, row position) ----
     // unit-key geometries: the composite's low word is the ROW (= position; ascending row is what the index in the row-sorted list stood
     // for), so that phase 0's rows merge in; slot geometries keep the index (their slot sits in slotv[index])
     unsigned long long* comp = reinterpret_cast<unsigned long long*>(psm);   // POST_CAP composites (32 KiB) over the slices
     const int tot = cnt + cnt_anchor;
-    int n3 = n2; while (n3 < tot) n3 <<= 1;
-    int mine = 0;
-    for (int i = t; i < n3; i += POST_THREADS) {
-        unsigned long long v = ~0ull;
+    // Only the K smallest leave, and phase 0 measured a bound on them: at least cnt_anchor >= K candidates have an exact score <= u_score, so a
+    // candidate above it is not among the K best — it does not enter the final order (the order's n^2 comparisons are LDS-return-bound: ~270
+    // composites cost ~9 k clocks, the ~120 at or under u_score a fifth). A threshold below u_score leaves only scores the cut keeps anyway, one at
+    // or above it leaves phase 0's rows all valid: min(K, valid) is the same number with and without the cut.
+    const bool cut = cnt_anchor > 0 && K > 0 && cnt_anchor >= K;
+    if (t == 0) s_cnt = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < tot; i0 += POST_THREADS) {                          // (workgroup-uniform trip count: the appends ballot)
+        const int i = i0 + t;
+        bool keep = false; unsigned long long v = ~0ull;
         if (i < tot) {
             const float sv = i < cnt ? sc[i] : scA[i - cnt];
             const unsigned low = GEOM::kSlots ? (unsigned)i : (i < cnt ? lst[i] : lstA[i - cnt]);
-            const bool ok = !(thr > 0.0f && sv > thr);                       // `s.threshold > 0 && dist > s.threshold`
-            if (ok) { v = ((unsigned long long)pf2key(__float_as_uint(sv)) << 32) | low; mine++; }
+            keep = !(thr > 0.0f && sv > thr) && !(cut && sv > u_score);     // `s.threshold > 0 && dist > s.threshold`
+            v = ((unsigned long long)pf2key(__float_as_uint(sv)) << 32) | low;
         }
-        comp[i] = v;
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            const int leader = __builtin_ctzll(m);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&s_cnt, (int)__builtin_popcountll(m));
+            base = __shfl(base, leader, 64);
+            if (keep) comp[base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = v;
+        }
     }
-    if (t == 0) s_valid = 0;
     __syncthreads();
-    if (mine) atomicAdd(&s_valid, mine);
+    const int valid = s_cnt;                                                  // every composite kept is a valid result
+    int n3 = 64; while (n3 < valid) n3 <<= 1;
+    for (int i = valid + t; i < n3; i += POST_THREADS) comp[i] = ~0ull;
     __syncthreads();
-    post_sort(comp, tot, n3, comp + POST_CAP);           // second half of the 64 KiB key area as scratch
-    const int valid = s_valid;
+    TF(12);
+    post_sort(comp, valid, n3, comp + POST_CAP);         // second half of the 64 KiB key area as scratch
+    TF(13);
     const int kq = (K <= 0 || K > valid) ? valid : K;                          // sanitizeK limiter.go:12-17
     const int nw = kq < k_cap ? kq : k_cap;
     for (int i = t; i < k_cap; i += POST_THREADS) {
@@ -1738,7 +1823,7 @@ __global__ __launch_bounds__(POST_THREADS) void fast_post_kernel(GEOM geom, cons
         overflow[q] = 0;
         if (stats) { atomicAdd(&stats[0], cnt + cnt_anchor); atomicAdd(&stats[2], s_exp); }      // rows rescored exactly (both phases)
     }
-    TR(4);
+    TF(14); TR(4);
     if (trace && threadIdx.x == 0) { atomicAdd(&trace[5], (unsigned long long)(cnt + cnt_anchor)); atomicAdd(&trace[6], 1ull); }
 }
 void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const float* bound, int64_t ldB, int64_t n_tiles, int unit_rows, int64_t n, const uint8_t* elig,
@@ -1746,7 +1831,7 @@ void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const fl
                       const uint32_t* ids_table, const int32_t* zflag, uint32_t* out_ids, float* out_scores, int32_t* out_counts, int k_cap,
                       int32_t* overflow, int32_t* stats) {
     if (B <= 0) return;
-    static unsigned long long* trace = [] { unsigned long long* p = nullptr; if (getenv("COMET_POST_TRACE")) { HIP_CHECK(hipMalloc(&p, 64)); HIP_CHECK(hipMemset(p, 0, 64)); } return p; }();
+    static unsigned long long* trace = [] { unsigned long long* p = nullptr; if (getenv("COMET_POST_TRACE")) { HIP_CHECK(hipMalloc(&p, 256)); HIP_CHECK(hipMemset(p, 0, 256)); } return p; }();
     ProfScope ps(c, "flat_post");
     const FlatGeom geom{(long)n_tiles, unit_rows, (long)n, (const unsigned char*)elig, ids_table};
     const size_t lds_flat = POST_LDS + (size_t)POST_CAP * 4;     // + phase 0's rows and scores
@@ -1759,8 +1844,11 @@ void launch_flat_post(Ctx* c, int metric, const float* S0, int64_t ldS, const fl
     if (trace) {          // COMET_POST_TRACE: cumulative s_memtime ticks (100 MHz) per phase, printed every 64 launches
         static int calls = 0;
         if ((++calls & 63) == 0) {
-            unsigned long long h[8]; HIP_CHECK(hipStreamSynchronize(c->stream)); HIP_CHECK(hipMemcpy(h, trace, 64, hipMemcpyDeviceToHost));
+            unsigned long long h2[32]; HIP_CHECK(hipStreamSynchronize(c->stream)); HIP_CHECK(hipMemcpy(h2, trace, 256, hipMemcpyDeviceToHost));
+            const unsigned long long* h = h2;
             const double wg = (double)h[6];
+            fprintf(stderr, "[post trace fine] clocks per query: keys %.0f minmax %.0f hist+bin %.0f kappa-rank+anchor? %.0f | A.collect %.0f A.stage %.0f A.rescore %.0f A.U+reload %.0f | collect %.0f sort %.0f stage %.0f rescore %.0f | comp %.0f sort %.0f out %.0f\n",
+                    h2[8] / wg, h2[9] / wg, h2[10] / wg, h2[11] / wg, h2[12] / wg, h2[13] / wg, h2[14] / wg, h2[15] / wg, h2[16] / wg, h2[17] / wg, h2[18] / wg, h2[19] / wg, h2[20] / wg, h2[21] / wg, h2[22] / wg);
             fprintf(stderr, "[post trace] per query, us: kappa %.1f  candidates %.1f  sort %.1f  rescoring %.1f  final %.1f   (%.0f candidates)\n", h[0] / wg / 100.0, h[1] / wg / 100.0,
                     h[2] / wg / 100.0, h[3] / wg / 100.0, h[4] / wg / 100.0, h[5] / wg);
         }
@@ -1773,7 +1861,7 @@ void launch_ivf_post(Ctx* c, int metric, const float* D, int64_t ldD, const floa
                      const float* err_abs, int K, float thr, const float* X, int ld, const float* Qp, int B, const int32_t* zflag,
                      uint32_t* out_ids, float* out_scores, int32_t* out_counts, int k_cap, int32_t* overflow, int32_t* stats) {
     if (B <= 0) return;
-    static unsigned long long* trace = [] { unsigned long long* p = nullptr; if (getenv("COMET_POST_TRACE")) { HIP_CHECK(hipMalloc(&p, 64)); HIP_CHECK(hipMemset(p, 0, 64)); } return p; }();
+    static unsigned long long* trace = [] { unsigned long long* p = nullptr; if (getenv("COMET_POST_TRACE")) { HIP_CHECK(hipMalloc(&p, 256)); HIP_CHECK(hipMemset(p, 0, 256)); } return p; }();
     ProfScope ps(c, "ivf_post");
     const IvfGeom geom{uoff, np, probe_list, ldp, (const long*)list_base, list_len, row_of_slot, ids_slot, (const unsigned char*)elig, umin, (long)ldu};
     const size_t lds = POST_LDS + (size_t)POST_CAP * 4;
