@@ -1045,7 +1045,7 @@ def _leg(rec):
     if "error" in rec:
         return {"error": str(rec["error"])[:200]}
     out = {}
-    for k in ("qps", "ms_per_step", "execution_lanes", "batches_in_flight"):
+    for k in ("qps", "ms_per_step"):
         if k in rec:
             out[k] = _rnd(rec[k])
     if isinstance(rec.get("sustained"), dict):
@@ -1056,14 +1056,14 @@ def _leg(rec):
         out["host_buffers_qps"] = _rnd(rec["host_buffers"].get("qps"))
     r = rec.get("roofline")
     if isinstance(r, dict):
-        out["roofline"] = {k: _rnd(r.get(k)) for k in ("kernel", "frac", "avg_kernel_ms", "traffic") if k in r}
+        out["roofline"] = {k: _rnd(r.get(k)) for k in ("kernel", "frac", "avg_kernel_ms", "traffic") if r.get(k) is not None}
         if "lds_frac_of_measured_ceiling" in r:
             out["roofline"]["lds_frac"] = _rnd(r["lds_frac_of_measured_ceiling"])
     c = rec.get("cpu_baseline")
     if isinstance(c, dict):
-        out["cpu_qps"] = _rnd(c.get("value")); out["cpu_cores"] = c.get("cores"); out["parity_mismatches"] = c.get("parity_mismatches")
+        out["cpu_qps"] = _rnd(c.get("value")); out["parity_mismatches"] = c.get("parity_mismatches")
         out["parity_checked"] = c.get("parity_checked_queries")
-    for k in ("recall_at_10_vs_exact_flat", "recall_at_10_vs_oracle_ivfpq", "rows", "build_s", "train_s", "add_s", "identical_to_exact_kernels", "expansions_per_query"):
+    for k in ("recall_at_10_vs_exact_flat", "recall_at_10_vs_oracle_ivfpq", "rows", "identical_to_exact_kernels", "expansions_per_query"):
         if k in rec:
             out[k] = _rnd(rec[k])
     return out
@@ -1082,7 +1082,7 @@ def compact_line(full):
     out["roofline"] = _roof(full.get("roofline"))
     out["cpu_baseline"] = _cpu(full.get("cpu_baseline"))
     out["lanes"] = full.get("execution_lanes"); out["batches_in_flight"] = full.get("batches_in_flight")
-    out["note_overlap"] = "value is measured with `batches_in_flight` batches on `lanes` streams (kernels of different batches overlap: per-kernel sums can exceed ms_per_step); single_stream_qps = 1 lane, 1 batch in flight"
+    out["note_overlap"] = "value: `batches_in_flight` batches on `lanes` streams (kernels of different batches overlap); single_stream_qps: 1 lane, 1 batch in flight"
     if isinstance(full.get("single_stream"), dict):
         out["single_stream_qps"] = _rnd(full["single_stream"].get("qps"))
     if isinstance(full.get("sustained"), dict):
@@ -1104,7 +1104,8 @@ def compact_line(full):
         if name == "flat_l2":
             legs[name] = {b: _leg(rec[b]) for b in ("batch1", "batch64", "batch256") if b in rec}
         elif name == "hybrid":
-            legs[name] = {b: _leg(rec[b]) for b in rec if b.startswith("ivf_nprobe") or b == "bm25"}
+            legs[name] = {b: {k: v for k, v in _leg(rec[b]).items() if k in ("qps", "single_stream_qps", "cpu_qps", "parity_mismatches", "parity_checked")}
+                          for b in rec if b.startswith("ivf_nprobe") or b == "bm25"}
             for b in ("rrf", "end_to_end", "end_to_end_nprobe32"):
                 if isinstance(rec.get(b), dict):
                     legs[name][b] = {k: _rnd(v) for k, v in rec[b].items() if isinstance(v, (int, float))}
