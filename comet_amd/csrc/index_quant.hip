@@ -706,6 +706,7 @@ struct PQFamilyIndex : comet_index {
     DevBuf codes_il;    // compiled, block-interleaved
     DevBuf adc_stats;   // two-stage search counters (AdcFilter::stats), read by get_stat
     mutable bool stats_on = false;   // adc_* counters are collected (get_stat "adc_stats_on" / "adc_stats_off")
+    DevBuf bound_tab3, bound_cmax2;   // the lower bound's transposed codebook (IVFPQ, Ksub == 256; rebuilt with the interleaved codes)
     DevBuf list_rmax;   // per list: upper bound on the norm of its members' decoded residuals (IVFPQ; rebuilt with the interleaved codes)
     bool il_dirty = true;
     ListLayout lay;
@@ -820,6 +821,10 @@ struct PQFamilyIndex : comet_index {
         il_dirty = false;
         codes_il.reserve((size_t)(lay.nslots + adc_codes_pad()) * M4 * 4 + 4, c->stream, 0);   // + the scan's read-ahead past the last block
         launch_interleave_codes(c, codes_arr.as<uint32_t>(), M4, lay.row_of_slot.as<uint32_t>(), lay.nslots, codes_il.as<uint32_t>());
+        if (ivf && Ksub == 256) {
+            bound_tab3.reserve((size_t)64 * (dsub + 1) * M * 4 * 4, c->stream, 0); bound_cmax2.reserve((size_t)M * 4, c->stream, 0);
+            launch_pq_bound_tab3(c, codebooks.as<float>(), M, dsub, bound_tab3.as<float>(), bound_cmax2.as<float>());
+        }
         if (ivf) {      // R(list) for the table-free lower bound of the two-stage search
             list_rmax.reserve((size_t)nlist * 4, c->stream, 0);
             launch_pq_list_rmax(c, codebooks.as<float>(), M, Ksub, dsub, codes_arr.as<uint32_t>(), M4, lay.row_of_slot.as<uint32_t>(), lay.list_base.as<int64_t>(),
@@ -885,6 +890,7 @@ struct PQFamilyIndex : comet_index {
                 afl.exchange = shard_world > 1 ? bound_exchange : nullptr; afl.exchange_user = bound_exchange_user;
                 static const bool norm_bound_off = getenv("COMET_ADC_NO_NORM_BOUND") != nullptr;
                 afl.list_rmax = (ivf && !norm_bound_off && list_rmax.p) ? list_rmax.as<float>() : nullptr;
+                afl.bound_tab3 = (ivf && Ksub == 256 && bound_tab3.p) ? bound_tab3.as<float>() : nullptr; afl.bound_cmax2 = afl.bound_tab3 ? bound_cmax2.as<float>() : nullptr;
                 afl.one_stage = (p.mode == 1 || (shard_world > 2 && !afl.exchange)) ? 1 : 0;
             }
             for (int b0 = 0; b0 < B; b0 += qb) {

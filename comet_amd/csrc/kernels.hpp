@@ -79,6 +79,7 @@ void launch_extract_sub(Ctx* c, const float* src, int ld_src, int64_t n, int col
 void launch_residual_rows(Ctx* c, const float* V, int ld, int64_t n, const float* C, const int32_t* assign, float* R);
 void launch_pq_encode(Ctx* c, const float* R, int ld, int64_t n, const float* codebooks, int M, int Ksub, int dsub,
                       uint8_t* codes, int code_stride);
+void launch_pq_bound_tab3(Ctx* c, const float* codebooks, int M, int dsub, float* btab3 /*64 * (dsub + 1) * M * 4 floats*/, float* cmax2 /*M*/);   // Ksub == 256
 void launch_pq_list_rmax(Ctx* c, const float* codebooks, int M, int Ksub, int dsub, const uint32_t* codes_arr, int M4, const uint32_t* row_of_slot,
                          const int64_t* list_base, const int32_t* list_len, int nlist, float* rmax);
 void launch_interleave_codes(Ctx* c, const uint32_t* src_words, int M4, const uint32_t* row_of_slot, int64_t nslots, uint32_t* dst);
@@ -101,6 +102,7 @@ struct AdcFilter { unsigned long long* cand; int32_t* cursor; uint32_t* tq; int 
                    // this rank scanned nothing for the query) — an all-reduce(min) over the ranks makes every rank prune with the tightest bound. A rank's
                    // bound is the K-th smallest sum of SOME candidates, i.e. an upper bound on the global K-th smallest, and so is the minimum.
                    void (*exchange)(void* user, uint32_t* tq, int n); void* exchange_user;
+                   const float* bound_tab3; const float* bound_cmax2;   // nullable: the codebook as [k / 4][dimension | norm][subspace][k % 4] and the largest squared codeword norm per subspace (launch_pq_bound_tab3): pq_bound3_kernel
                    const float* list_rmax;   // nullable: per list an upper bound on the norm of its members' decoded residuals (launch_pq_list_rmax): the table-free lower bound
                    int32_t* stats;   // nullable, 8 ints: [0] += pairs behind the nearest lists the lower bound left alive, [1] += pairs behind the nearest lists (two-stage search),
                                      // [2] += 64-code blocks the scan's items cover, [3] += items (each streams one duo table), [4] += (query, block) pairs, [5] += searches

@@ -252,7 +252,7 @@ void launch_interleave_codes(Ctx* c, const uint32_t* src_words, int M4, const ui
 
 // ------------------------------------------------------------------------------------------------
 // R(list) = an upper bound on the Euclidean norm of the decoded residuals (concatenated codewords) of a list's members: feeds the
-// table-free lower bound of pq_bound_kernel. cbn2[m][k] = |codeword|^2 in float64, rounded up; per list the maximum over its members of
+// table-free lower bound of pq_bound_prep_kernel. cbn2[m][k] = |codeword|^2 in float64, rounded up; per list the maximum over its members of
 // sqrt(sum_m cbn2[m][code_m]) with a 1e-5 margin (the float32 sum of M non-negative terms is within M 2^-24 of the real one).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pq_cb_norms_kernel(const float* __restrict__ codebooks, int M, int Ksub, int dsub, float* __restrict__ cbn2) {
@@ -610,179 +610,245 @@ __global__ __launch_bounds__(256) void pq_lb_kernel(const float* __restrict__ ro
     if (stats) { if (!dd) atomicAdd(&stats[0], 1); if (behind) atomicAdd(&stats[1], 1); }
 }
 
-// The lower bound in one kernel, for 8-bit codebooks (KL = 256) and DSUB known at compile time: ONE WAVE per group of BND_GP pairs of
-// a query walks the subspaces IN ORDER, keeps every pair's running serial sum of row minima, and stops computing for a pair the
-// moment that sum passes the query's bound — on the bench corpus a pair dies after 37 of 96 subspaces on average (tools/prune_probe.py),
-// so 60 % of the entry arithmetic that bounds pq_rowmin_kernel is never done, and neither the M floats per pair nor a second
-// kernel are needed. A lane holds four codewords (k = lane + 64 j); an entry is formed exactly as pq_lut_kernel forms it; the
-// minimum over the wave is a reduce-scatter butterfly over the pairs; no LDS traffic besides the residual slices, no barrier.
-// A group takes every ng-th pair of its query (ng groups per query), so every wave holds a nearer and a farther list.
-// Group size (same box, 1M x 768, nprobe 32, B = 256; the two-kernel form takes 0.137 ms): 8 pairs 0.180 ms, 4 pairs 0.136,
-// 2 pairs 0.106, 1 pair 0.148 — a wave's subspace step is short, so few large groups (one wave per SIMD) cannot hide the latency
-// of the next subspace's codewords, while many small ones re-read the 8 KB codebook slice of every subspace from L2 once per wave
-// (2 pairs: ~1.8 GB per batch). Built and measured as well: four such waves per workgroup sharing the slice through a three-stage
-// LDS-DMA ring two subspaces ahead, one voting barrier per subspace — 0.194 ms: a subspace step (~0.3 us) is far shorter than the
-// DMA's round trip, the ring would have to be six or more slices deep, and the workgroup lives as long as its slowest pair.
-// Round 3, measured on the same corpus (pq_bound 0.131 ms per batch at the start): the per-pair statistics atomics (8 k same-address atomics per
-// batch, ~12 ns each in the L2) were 0.025 ms of it — now opt-in; a table-free norm bound in front of the walk removes 22 % of the pairs at nlist 1024
-// and 97 % at nlist 4096 (lists finer than the clusters) for one pass over the residual; what remains, 0.10 ms, is the walk of the pairs that SURVIVE —
-// all M dependent steps at ~0.8 us each (a step's chain: 8-term sums, a 64-lane minimum, a ballot), whatever the other pairs do. Tried against it: two
-// slices of codewords in flight instead of one (0.125 ms: the step is not waiting for its loads), stopping the walk after 80 / 64 / 48 subspaces and
-// keeping what is still alive (pq_bound 0.099 / 0.093 / 0.077 ms, but the pairs that die late then reach the scan: step 0.362 / 0.419 / 0.547 ms).
-constexpr int BND_GP = 2;
-template <bool HAS_CENTROID, int DSUB>
-__global__ __launch_bounds__(64) void pq_bound_kernel(const float* __restrict__ Qp, int ld, const float* __restrict__ centroids,
-                                                      const float* __restrict__ codebooks, int M, int Ksub,
-                                                      const unsigned* __restrict__ probe_list, int ldp, int np, const int* __restrict__ seg_off, int n_q,
-                                                      const unsigned* __restrict__ tq, unsigned char* __restrict__ dead, int* __restrict__ stats,
-                                                      const float* __restrict__ list_rmax /*nullable: per list, an upper bound on the norm of its members' decoded residuals*/, int strict) {
-    extern __shared__ __attribute__((aligned(16))) float res[];     // [BND_GP][M * DSUB] residuals of the group's pairs
-    const int ng = (np + BND_GP - 1) / BND_GP;                       // groups per query
-    const int q = blockIdx.x / ng, j0 = blockIdx.x - q * ng;
-    if (q >= n_q) return;
-    const int lane = threadIdx.x, dimc = M * DSUB;
-    const int* sor = seg_off + (long)q * (np + 1);
-    // pair t of the group: probe pi = j0 + t * ng; "behind" = a non-empty list behind the query's first non-empty one
-    unsigned mask = 0u;
+// The lower bound in ONE kernel family, for 8-bit codebooks (KL = 256) and DSUB known at compile time (rounds 2-3: pq_bound_kernel, a wave per two pairs of a
+// query walking the subspaces in order with entries formed exactly as the table forms them, the wave minimum through six LDS-crossbar shuffles; 0.10 ms per
+// batch at 1M x 768, nprobe 32, B = 256. History of what was tried against it — group sizes 1 / 2 / 4 / 8 pairs (0.148 / 0.106 / 0.136 / 0.180 ms), four waves
+// sharing the codeword slice through an LDS-DMA ring (0.194), two slices in flight (0.125), stopping the walk early (the pairs that die late then reach the
+// scan) — is in DESIGN.md 3.5; the round-4 forms below replaced it.)
+// ------------------------------------------------------------------------------------------------
+// Round 4: the lower bound WITHOUT a walk. The round-3 kernel's time was its critical path — a pair that survives took 96 dependent steps of ~1 500 clocks
+// (200 VALU instructions forming every entry as the table forms it + six waited-for LDS-crossbar shuffles per wave minimum): 45-60 us of walk behind ~15 us of
+// set-up, whatever the other 8 000 pairs did (tools/bnd_trace.py measured the same shape on a cheaper-step walk, 0.077 / 0.107 ms at 1M / 10M), while all of
+// the arithmetic is ~20 us of the chip. Two observations remove the chain:
+//   * a lower bound does not have to be the table's value, only never above it. An entry's real value is |r|^2 + (|c|^2 - 2 r.c); w_k = fma-chain(-2 r_i, c_ki,
+//     |c_k|^2) costs DSUB fused multiply-adds per codeword, two codewords per instruction (v_pk_fma_f32). Float32 against real arithmetic (u = 2^-24): the
+//     table's entry e_k >= d_k (1 - 10 u) (one rounding per subtraction, square and addition of non-negative terms, DSUB = 8; 18 u for 16);
+//     |w_k - (|c_k|^2 - 2 r.c_k)| <= (DSUB + 3) u (2 |c_k|^2 + |r|^2) (every fma rounds once on a partial sum bounded by |c|^2 + 2 sum |r_i c_i|; the stored norm
+//     is the float64 sum rounded); |r_m|^2 is a float32 sum of squares (relative (DSUB + 1) u). All of it is below 60 u (2 max_k |c_k|^2 + |r_m|^2) = 3.6e-6 (..);
+//     the term subtracts 1e-5 (2 cmax2_m + |r_m|^2) + 1e-30 and clamps at zero, so  term_m <= min_k e_k  always;
+//   * the row minima of different subspaces do not depend on each other, and the sum does not have to be the serial one: any float32 sum of the (non-negative)
+//     terms is within 100 u of their real sum, which is below the real sum of the table's entries, which is within 96 u of the table's serial sum — a factor
+//     (1 - 2e-5) on the total covers both.
+// So:
+//   pq_bound_prep_kernel  one wave per pair: is the pair behind stage 1, the residual's norm against R(list) (the table-free bound); survivors go to a compact
+//                         list (one atomic per 16 pairs);
+//   pq_bound3_kernel      four waves per BND3_P surviving pairs (a quarter of the codewords each), LANE = SUBSPACE (64 per round, ceil(M / 64) rounds): a lane
+//                         keeps -2 r_m of its pairs in registers and runs over its codewords, four per 16-byte load (table [k / 4][dimension | norm][m][k % 4]:
+//                         a load instruction is 1 KB contiguous), two per v_pk_fma_f32; no LDS and no cross-lane traffic inside the loop. After a round the
+//                         waves' minima meet in LDS, then per pair a DPP sum over the lanes and the test; a group leaves when none of its pairs is alive.
+// Measured (same box, B = 256, nprobe 32): 1M x nlist 1024 (6 400 of 8 192 pairs survive the table-free tests) 0.100 -> 0.072 ms; 10M x nlist 4096 (~400 survive)
+// 0.100 -> 0.032 ms. (A single wave per group — 64 dependent load-then-compute iterations, 9 KB in flight — took 0.13 ms at 10M: four waves quarter the chain.)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pq_bound_tab3_kernel(const float* __restrict__ codebooks, int M, int dsub, float* __restrict__ btab3, float* __restrict__ cmax2) {
+    __shared__ float part[4];
+    const int m = blockIdx.x, k = threadIdx.x;                                      // Ksub == 256
+    const float* p = codebooks + ((long)m * 256 + k) * dsub;
+    float* o = btab3 + ((long)(k >> 2) * (dsub + 1) * M + m) * 4 + (k & 3);          // row stride M * 4 floats
+    double sq = 0.0;
+    for (int i = 0; i < dsub; i++) { o[(long)i * M * 4] = p[i]; sq += (double)p[i] * (double)p[i]; }
+    o[(long)dsub * M * 4] = (float)sq;
+    float mx = (float)(sq * 1.000001);                                               // cmax2[m] = the largest squared codeword norm of the subspace, rounded up
 #pragma unroll
-    for (int t = 0; t < BND_GP; t++) {
-        const int pi = j0 + t * ng;
-        if (pi < np && adc_is_behind(sor, pi, strict)) mask |= 1u << t;
-    }
-    const unsigned behind = mask;
-    const unsigned T = tq[q];
-    if (mask == 0u) {                                               // nothing behind the nearest list in this group
-        if (lane < BND_GP) { const int pi = j0 + lane * ng; if (pi < np) dead[(long)q * np + pi] = 1; }
-        return;
-    }
-    // residuals of the group's pairs -> LDS, and their squared norms. All row pieces (query + the pairs' centroids, 16 bytes per lane and
-    // piece) are requested before any is used (a load per loop iteration pays the L2 round trip twelve times per pair).
-    constexpr int NV = 6;                                           // 16-byte pieces per lane and row: rows up to 1536 floats
-    float rn2[BND_GP];
-    unsigned Lt[BND_GP];
-#pragma unroll
-    for (int t = 0; t < BND_GP; t++) { rn2[t] = 0.0f; const int pi = j0 + t * ng; Lt[t] = ((mask >> t) & 1u) ? probe_list[(long)q * ldp + pi] : 0u; }
-    if (dimc <= NV * 256 && (dimc & 3) == 0) {
-        f32x4q qv[NV], cv[BND_GP][NV];
-#pragma unroll
-        for (int i = 0; i < NV; i++) { const int c4 = (i * 64 + lane) * 4; if (c4 < dimc) qv[i] = *reinterpret_cast<const f32x4q*>(Qp + (long)q * ld + c4); }
-#pragma unroll
-        for (int t = 0; t < BND_GP; t++)
-#pragma unroll
-            for (int i = 0; i < NV; i++) {
-                const int c4 = (i * 64 + lane) * 4;
-                if (HAS_CENTROID && ((mask >> t) & 1u) && c4 < dimc) cv[t][i] = *reinterpret_cast<const f32x4q*>(centroids + (long)Lt[t] * ld + c4);
-            }
-#pragma unroll
-        for (int t = 0; t < BND_GP; t++) {
-            if (!((mask >> t) & 1u)) continue;
-#pragma unroll
-            for (int i = 0; i < NV; i++) {
-                const int c4 = (i * 64 + lane) * 4;
-                if (c4 < dimc) {
-                    f32x4q r = qv[i];
-                    if (HAS_CENTROID) { r[0] = r[0] - cv[t][i][0]; r[1] = r[1] - cv[t][i][1]; r[2] = r[2] - cv[t][i][2]; r[3] = r[3] - cv[t][i][3]; }
-                    *reinterpret_cast<f32x4q*>(res + t * dimc + c4) = r;
-                    rn2[t] += r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
-                }
-            }
-        }
-    } else {
-        for (int t = 0; t < BND_GP; t++) {
-            if (!((mask >> t) & 1u)) continue;
-            const float* cen = HAS_CENTROID ? centroids + (long)Lt[t] * ld : nullptr;
-            for (int col = lane; col < dimc; col += 64) {
-                const float qv = Qp[(long)q * ld + col];
-                const float r = HAS_CENTROID ? qv - cen[col] : qv;
-                res[t * dimc + col] = r;
-                rn2[t] += r * r;
-            }
-        }
-    }
-    // A bound that needs no table entry: a candidate's sum is the float32 value of |r - x|^2 for its decoded residual x, and
-    // |r - x| >= |r| - |x| >= |r| - R(list). Float32 against real arithmetic: every term (fl(fl(r_i - x_i)^2)) and every addition of the
-    // non-negative terms loses at most one rounding, so the computed sum is >= (1 - (d + M + 3) 2^-24) times the real one (< 1 - 1e-4 for
-    // d <= 1500); the norm below is a float32 sum in another order (same relative bound) and R carries its own margin. The test is made
-    // with 1e-4 margins on every factor, so a pair it removes cannot hold a candidate at or under the query's bound — pairs the walk over
-    // the subspaces would remove later, found after one pass over the residual instead of ~40 % of the table arithmetic.
-    if (list_rmax && T < 0x7F800000u && dimc <= 1400) {
-#pragma unroll
-        for (int t = 0; t < BND_GP; t++) {
-            if (!((mask >> t) & 1u)) continue;                      // wave-uniform
-            float v = rn2[t];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            const float gap = sqrtf(v * 0.9999f) * 0.9999f - list_rmax[Lt[t]] * 1.0001f;
-            if (gap > 0.0f && gap * gap * 0.9998f > __uint_as_float(T) * 1.0001f) { mask &= ~(1u << t); if (stats && lane == 0) atomicAdd(&stats[6], 1); }
-        }
-    }
-    if (mask == 0u) {                                               // every pair of the group is out: no codeword is fetched
-        if (lane < BND_GP) {
-            const int pi = j0 + lane * ng;
-            if (pi < np) { dead[(long)q * np + pi] = 1; if (stats && ((behind >> lane) & 1u)) atomicAdd(&stats[1], 1); }
-        }
-        return;
-    }
-    const unsigned Ts = T >= 0x7F800000u ? 0xFFFFFFFFu : __float_as_uint(__uint_as_float(T) * 1.0000005f);
-    float lb = 0.0f;                                                 // lanes 0 .. BND_GP-1: the running sum of pair `lane`
-    float cb[4][DSUB], cbn[4][DSUB];
-    auto load_cb = [&](int m, float (&dst)[4][DSUB]) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float* p = codebooks + ((long)m * Ksub + lane + 64 * j) * DSUB;
-#pragma unroll
-            for (int i = 0; i < DSUB; i++) dst[j][i] = p[i];
-        }
-    };
-    load_cb(0, cb);
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((k & 63) == 0) part[k >> 6] = mx;
     __syncthreads();
-    for (int m = 0; m < M && mask; m++) {
-        if (m + 1 < M) load_cb(m + 1, cbn);
-        float v[BND_GP];
+    if (k == 0) cmax2[m] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+}
+void launch_pq_bound_tab3(Ctx* c, const float* codebooks, int M, int dsub, float* btab3, float* cmax2) {
+    pq_bound_tab3_kernel<<<dim3((unsigned)M), dim3(256), 0, c->stream>>>(codebooks, M, dsub, btab3, cmax2);
+    LAUNCH_CHECK();
+}
+#ifndef BND3_P_N
+#define BND3_P_N 4
+#endif
+constexpr int BND3_P = BND3_P_N;      // pairs per workgroup of pq_bound3_kernel
+constexpr int PREP_WAVES = 16;        // pairs per workgroup: ONE atomic per workgroup reserves its survivors' slots (an atomic per survivor — 6 400 same-address
+                                      // atomics with a return value at 1M x nlist 1024 — cost 0.07 ms: they retire one per ~12 ns in the L2)
+template <bool HAS_CENTROID>
+__global__ __launch_bounds__(PREP_WAVES * 64) void pq_bound_prep_kernel(const float* __restrict__ Qp, int ld, const float* __restrict__ centroids, int dimc,
+                                                            const unsigned* __restrict__ probe_list, int ldp, int np, const int* __restrict__ seg_off, int n_pairs,
+                                                            const unsigned* __restrict__ tq, unsigned char* __restrict__ dead, int* __restrict__ stats,
+                                                            const float* __restrict__ list_rmax, int strict, unsigned* __restrict__ plist, int* __restrict__ pcount) {
+    __shared__ int s_keep[PREP_WAVES]; __shared__ int s_base;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, i = blockIdx.x * PREP_WAVES + wid;
+    bool keep = false;
+    if (i < n_pairs) {
+        const int q = i / np, pi = i - q * np;
+        if (!adc_is_behind(seg_off + (long)q * (np + 1), pi, strict)) { if (lane == 0) dead[i] = 1; }     // scanned in stage 1, or nothing to scan
+        else {
+            const unsigned T = tq[q];
+            bool out = false;
+            // A bound that needs no table entry: a candidate's sum is the float32 value of |r - x|^2 for its decoded residual x, and |r - x| >= |r| - |x| >=
+            // |r| - R(list). Float32 against real arithmetic: every term and every addition of the non-negative terms loses at most one rounding, so the
+            // computed sum is >= (1 - (d + M + 3) 2^-24) times the real one (< 1 - 1e-4 for d <= 1500); the norm below is a float32 sum in another order
+            // (same relative bound) and R carries its own margin. The test is made with 1e-4 margins on every factor.
+            if (list_rmax && T < 0x7F800000u && dimc <= 1400) {
+                const unsigned L = probe_list[(long)q * ldp + pi];
+                const float* qr = Qp + (long)q * ld; const float* cr = HAS_CENTROID ? centroids + (long)L * ld : nullptr;
+                float v = 0.0f;
+                if ((dimc & 3) == 0) {
+                    for (int c4 = lane * 4; c4 < dimc; c4 += 256) {
+                        f32x4q r = *reinterpret_cast<const f32x4q*>(qr + c4);
+                        if (HAS_CENTROID) { const f32x4q cv = *reinterpret_cast<const f32x4q*>(cr + c4); r[0] = r[0] - cv[0]; r[1] = r[1] - cv[1]; r[2] = r[2] - cv[2]; r[3] = r[3] - cv[3]; }
+                        v += r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+                    }
+                } else {
+                    for (int col = lane; col < dimc; col += 64) { const float r = HAS_CENTROID ? qr[col] - cr[col] : qr[col]; v += r * r; }
+                }
 #pragma unroll
-        for (int t = 0; t < BND_GP; t++) {
-            v[t] = __builtin_inff();
-            if (!((mask >> t) & 1u)) continue;                       // wave-uniform
-            const float* r = res + t * dimc + m * DSUB;
-            float rr[DSUB];
-#pragma unroll
-            for (int i = 0; i < DSUB; i++) rr[i] = r[i];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float dsum = 0.0f;
-#pragma unroll
-                for (int i = 0; i < DSUB; i++) { const float diff = rr[i] - cb[j][i]; const float sq = diff * diff; dsum = dsum + sq; }
-                v[t] = fminf(v[t], dsum);
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                const float gap = sqrtf(v * 0.9999f) * 0.9999f - list_rmax[L] * 1.0001f;
+                out = gap > 0.0f && gap * gap * 0.9998f > __uint_as_float(T) * 1.0001f;
             }
-        }
-#define BND_STEP(O) { const bool up = (lane & O) != 0; _Pragma("unroll") for (int t = 0; t < O; t++) { \
-            const float send = up ? v[t] : v[t + O], keep = up ? v[t + O] : v[t]; v[t] = fminf(keep, __shfl_xor(send, O, 64)); } }
-        if constexpr (BND_GP >= 8) BND_STEP(4)
-        if constexpr (BND_GP >= 4) BND_STEP(2)
-        if constexpr (BND_GP >= 2) BND_STEP(1)
-#undef BND_STEP
-        float mn = v[0];                                             // pair (lane & (BND_GP - 1)), minimum over this lane's group of BND_GP lanes
-#pragma unroll
-        for (int o = BND_GP; o < 64; o <<= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
-        bool alive = false;
-        if (lane < BND_GP && ((mask >> lane) & 1u)) { lb = lb + mn; alive = __float_as_uint(lb) <= Ts; }
-        mask = (unsigned)__ballot(alive) & ((1u << BND_GP) - 1u);
-        if (m + 1 < M) {
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int i = 0; i < DSUB; i++) cb[j][i] = cbn[j][i];
+            if (out) { if (lane == 0) { dead[i] = 1; if (stats) { atomicAdd(&stats[6], 1); atomicAdd(&stats[1], 1); } } }
+            else keep = true;
         }
     }
-    // pairs still in the mask passed every subspace: their lower bound is within the query's bound — alive
-    if (lane < BND_GP) {
-        const int pi = j0 + lane * ng;
-        if (pi < np) {
-            const bool al = (mask >> lane) & 1u;
-            dead[(long)q * np + pi] = al ? 0 : 1;
-            if (stats) { if (al) atomicAdd(&stats[0], 1); if ((behind >> lane) & 1u) atomicAdd(&stats[1], 1); }
-        }
+    if (lane == 0) s_keep[wid] = keep ? 1 : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int w = 0; w < PREP_WAVES; w++) { const int k = s_keep[w]; s_keep[w] = n; n += k; }     // exclusive ranks
+        s_base = n ? atomicAdd(pcount, n) : 0;
     }
+    __syncthreads();
+    if (keep && lane == 0) plist[s_base + s_keep[wid]] = (unsigned)i;
+}
+// sum over the wave as a wave-uniform value (DPP: quad swaps, half-row and row mirrors — every lane of a group holds the group's sum, so a mirror adds the other
+// group's — then the two row broadcasts; lane 63 holds the total)
+__device__ __forceinline__ float bnd_wave_sum(float a) {
+    int ra;
+    asm volatile(
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_readlane_b32 %1, %0, 63\n"
+        : "+v"(a), "=s"(ra));
+    return __int_as_float(ra);
+}
+template <bool HAS_CENTROID, int DSUB, int P>
+__device__ __forceinline__ void pq_bound3_body(const float* __restrict__ Qp, int ld, const float* __restrict__ centroids, const float* __restrict__ btab3,
+                                               const float* __restrict__ cmax2, int M, const unsigned* __restrict__ probe_list, int ldp, int np,
+                                               const unsigned* __restrict__ tq, unsigned char* __restrict__ dead, int* __restrict__ stats,
+                                               const unsigned* __restrict__ plist, int cnt, int first) {
+    // four waves per group of P pairs: wave w runs over codewords 64 w .. 64 w + 63 (16 loads of four), the minima meet in LDS once per round — a
+    // single wave's 64 dependent load-then-compute iterations were the whole kernel time (9 KB in flight per wave: 45 us for a lone wave)
+    __shared__ float xch[2][4][P][64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int pr[P]; unsigned Ts[P]; float lbs[P];
+    const float* qrow[P]; const float* crow[P];
+    unsigned alive = 0u;
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const bool have = first + p < cnt;                          // wave-uniform
+        pr[p] = have ? (int)plist[first + p] : (int)plist[first];
+        const int q = pr[p] / np, pi = pr[p] - q * np;
+        const unsigned T = tq[q];
+        Ts[p] = T >= 0x7F800000u ? 0xFFFFFFFFu : __float_as_uint(__uint_as_float(T) * 1.0000005f);
+        qrow[p] = Qp + (long)q * ld;
+        crow[p] = HAS_CENTROID ? centroids + (long)probe_list[(long)q * ldp + pi] * ld : nullptr;
+        lbs[p] = 0.0f;
+        if (have) alive |= 1u << p;
+    }
+    alive = (unsigned)__builtin_amdgcn_readfirstlane((int)alive);
+    const unsigned had = alive;
+    int par = 0;
+    for (int m0 = 0; m0 < M && alive; m0 += 64, par ^= 1) {
+        const bool valid = m0 + lane < M;
+        const int m = valid ? m0 + lane : M - 1;
+        // this lane's subspace of every pair: -2 x residual, and what the smallest w_k is added to (|r_m|^2 minus the margin: see the head comment)
+        f32x4q qv[P][DSUB / 4], cv[P][DSUB / 4];
+#pragma unroll
+        for (int p = 0; p < P; p++)
+#pragma unroll
+            for (int i4 = 0; i4 < DSUB / 4; i4++) {
+                qv[p][i4] = *reinterpret_cast<const f32x4q*>(qrow[p] + m * DSUB + i4 * 4);
+                if (HAS_CENTROID) cv[p][i4] = *reinterpret_cast<const f32x4q*>(crow[p] + m * DSUB + i4 * 4);
+            }
+        const float cm2 = cmax2[m];
+        float r2[P][DSUB], adjv[P], rm[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            float s2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < DSUB; i++) {
+                float r = qv[p][i >> 2][i & 3];
+                if (HAS_CENTROID) r = r - cv[p][i >> 2][i & 3];
+                s2 = s2 + r * r;
+                r2[p][i] = -2.0f * r;
+            }
+            adjv[p] = s2 - (1.0e-5f * (2.0f * cm2 + s2) + 1.0e-30f);
+            rm[p] = __builtin_inff();
+        }
+        const f32x4q* tab = reinterpret_cast<const f32x4q*>(btab3) + m;      // row (k4, i) at tab[(k4 * (DSUB + 1) + i) * M]
+        auto load_cw = [&](int k4, f32x4q (&dst)[DSUB + 1]) {
+            const f32x4q* t4 = tab + (long)min(wid * 16 + k4, 63) * (DSUB + 1) * M;
+#pragma unroll
+            for (int i = 0; i <= DSUB; i++) dst[i] = t4[(long)i * M];
+        };
+        auto quad = [&](const f32x4q (&cur)[DSUB + 1]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                f32x2q a01 = {cur[DSUB][0], cur[DSUB][1]}, a23 = {cur[DSUB][2], cur[DSUB][3]};
+#pragma unroll
+                for (int i = 0; i < DSUB; i++) {
+                    const f32x2q rr = {r2[p][i], r2[p][i]};
+                    a01 = __builtin_elementwise_fma(rr, f32x2q{cur[i][0], cur[i][1]}, a01);
+                    a23 = __builtin_elementwise_fma(rr, f32x2q{cur[i][2], cur[i][3]}, a23);
+                }
+                rm[p] = fminf(rm[p], fminf(fminf(a01[0], a01[1]), fminf(a23[0], a23[1])));
+            }
+        };
+        f32x4q cwA[DSUB + 1], cwB[DSUB + 1];
+        load_cw(0, cwA);
+        for (int k4 = 0; k4 < 16; k4 += 2) {
+            load_cw(k4 + 1, cwB);
+            quad(cwA);
+            load_cw(k4 + 2, cwA);
+            quad(cwB);
+        }
+#pragma unroll
+        for (int p = 0; p < P; p++) xch[par][wid][p][lane] = rm[p];
+        __syncthreads();                                             // (the buffer of the round before last is free again: every wave passed this barrier since)
+#pragma unroll
+        for (int p = 0; p < P; p++) rm[p] = fminf(fminf(xch[par][0][p][lane], xch[par][1][p][lane]), fminf(xch[par][2][p][lane], xch[par][3][p][lane]));
+        unsigned al = 0u;
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const float term = valid ? fmaxf(rm[p] + adjv[p], 0.0f) : 0.0f;
+            lbs[p] = lbs[p] + bnd_wave_sum(term);
+            al |= (__float_as_uint(lbs[p] * 0.99998f) <= Ts[p]) ? (1u << p) : 0u;
+        }
+        alive &= (unsigned)__builtin_amdgcn_readfirstlane((int)al);
+    }
+    if (wid == 0 && lane < P && ((had >> lane) & 1u)) {
+        int mine = pr[0];
+#pragma unroll
+        for (int p = 1; p < P; p++) if (lane == p) mine = pr[p];
+        const bool al = (alive >> lane) & 1u;
+        dead[mine] = al ? 0 : 1;
+        if (stats) { if (al) atomicAdd(&stats[0], 1); atomicAdd(&stats[1], 1); }
+    }
+}
+template <bool HAS_CENTROID, int DSUB, int P>
+__global__ __launch_bounds__(256) void pq_bound3_kernel(const float* __restrict__ Qp, int ld, const float* __restrict__ centroids, const float* __restrict__ btab3,
+                                                       const float* __restrict__ cmax2, int M, const unsigned* __restrict__ probe_list, int ldp, int np,
+                                                       const unsigned* __restrict__ tq, unsigned char* __restrict__ dead, int* __restrict__ stats,
+                                                       const unsigned* __restrict__ plist, const int* __restrict__ pcount) {
+    const int cnt = *pcount;
+    const int first = (int)blockIdx.x * P;
+    if (first >= cnt) return;
+    pq_bound3_body<HAS_CENTROID, DSUB, P>(Qp, ld, centroids, btab3, cmax2, M, probe_list, ldp, np, tq, dead, stats, plist, cnt, first);
 }
 
 // order[] = the pair indices grouped by probed list (counting sort in LDS; pairs with nothing to scan go last; the
@@ -1443,12 +1509,17 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
         run_stage(1);
         if (flt->exchange) flt->exchange(flt->exchange_user, flt->tq + b0, bn);     // list shards: the global bound (one small all-reduce per sub-batch)
         static const bool bound_off = getenv("COMET_ADC_ROWMIN") != nullptr;      // the two-kernel form (row minima of every subspace, then the sums)
-        const size_t bnd_lds = (size_t)BND_GP * M * dsub * 4;
-        if (!bound_off && KL == 256 && Ksub == 256 && (dsub == 4 || dsub == 8 || dsub == 16) && bnd_lds <= 64 * 1024) {
+        // 8-bit codebooks, DSUB 4 / 8 / 16: the survivors of the table-free tests are compacted (pq_bound_prep_kernel) and bounded without a walk (pq_bound3_kernel)
+        if (!bound_off && flt->bound_tab3 && KL == 256 && Ksub == 256 && (dsub == 4 || dsub == 8 || dsub == 16) && (size_t)M * dsub <= (size_t)ld) {
             {
             ProfScope ps(c, "pq_bound");
-            const unsigned groups = (unsigned)(bn * ceil_div(np, BND_GP));
-#define BND_LAUNCH(HC, DS) pq_bound_kernel<HC, DS><<<dim3(groups), dim3(64), bnd_lds, c->stream>>>(Qb, ld, centroids, codebooks, M, Ksub, pl, ldp, np, so, bn, flt->tq + b0, dead, flt->stats, flt->list_rmax, strict)
+            unsigned* plist = c->salloc<unsigned>((size_t)n_pairs + 8);
+            int* pcount = c->salloc<int>(4);
+            HIP_CHECK(hipMemsetAsync(pcount, 0, 4, c->stream));
+            const dim3 pg((unsigned)ceil_div(n_pairs, PREP_WAVES));
+            if (centroids) pq_bound_prep_kernel<true><<<pg, dim3(PREP_WAVES * 64), 0, c->stream>>>(Qb, ld, centroids, M * dsub, pl, ldp, np, so, n_pairs, flt->tq + b0, dead, flt->stats, flt->list_rmax, strict, plist, pcount);
+            else pq_bound_prep_kernel<false><<<pg, dim3(PREP_WAVES * 64), 0, c->stream>>>(Qb, ld, centroids, M * dsub, pl, ldp, np, so, n_pairs, flt->tq + b0, dead, flt->stats, flt->list_rmax, strict, plist, pcount);
+#define BND_LAUNCH(HC, DS) pq_bound3_kernel<HC, DS, BND3_P><<<dim3((unsigned)ceil_div(n_pairs, BND3_P)), dim3(256), 0, c->stream>>>(Qb, ld, centroids, flt->bound_tab3, flt->bound_cmax2, M, pl, ldp, np, flt->tq + b0, dead, flt->stats, plist, pcount)
 #define BND_DS(HC) do { switch (dsub) { case 4: BND_LAUNCH(HC, 4); break; case 8: BND_LAUNCH(HC, 8); break; default: BND_LAUNCH(HC, 16); break; } } while (0)
             if (centroids) BND_DS(true); else BND_DS(false);
 #undef BND_DS
