@@ -661,6 +661,9 @@ void launch_pq_bound_tab3(Ctx* c, const float* codebooks, int M, int dsub, float
 #ifndef BND3_P_N
 #define BND3_P_N 4
 #endif
+#ifndef BND3_WPE
+#define BND3_WPE 2                    // waves per SIMD the register allocation aims at (218 VGPRs at four pairs; forcing three spills 38 registers: 0.073 -> 0.091 ms)
+#endif
 constexpr int BND3_P = BND3_P_N;      // pairs per workgroup of pq_bound3_kernel
 constexpr int PREP_WAVES = 16;        // pairs per workgroup: ONE atomic per workgroup reserves its survivors' slots (an atomic per survivor — 6 400 same-address
                                       // atomics with a return value at 1M x nlist 1024 — cost 0.07 ms: they retire one per ~12 ns in the L2)
@@ -751,12 +754,12 @@ __device__ __forceinline__ void pq_bound3_body(const float* __restrict__ Qp, int
 #pragma unroll
     for (int p = 0; p < P; p++) {
         const bool have = first + p < cnt;                          // wave-uniform
-        pr[p] = have ? (int)plist[first + p] : (int)plist[first];
+        pr[p] = __builtin_amdgcn_readfirstlane((int)plist[have ? first + p : first]);       // wave-uniform: the pair's rows, bound and sums live in SGPRs
         const int q = pr[p] / np, pi = pr[p] - q * np;
-        const unsigned T = tq[q];
+        const unsigned T = (unsigned)__builtin_amdgcn_readfirstlane((int)tq[q]);
         Ts[p] = T >= 0x7F800000u ? 0xFFFFFFFFu : __float_as_uint(__uint_as_float(T) * 1.0000005f);
         qrow[p] = Qp + (long)q * ld;
-        crow[p] = HAS_CENTROID ? centroids + (long)probe_list[(long)q * ldp + pi] * ld : nullptr;
+        crow[p] = HAS_CENTROID ? centroids + (long)__builtin_amdgcn_readfirstlane((int)probe_list[(long)q * ldp + pi]) * ld : nullptr;
         lbs[p] = 0.0f;
         if (have) alive |= 1u << p;
     }
@@ -811,6 +814,7 @@ __device__ __forceinline__ void pq_bound3_body(const float* __restrict__ Qp, int
         };
         f32x4q cwA[DSUB + 1], cwB[DSUB + 1];
         load_cw(0, cwA);
+#pragma unroll 1
         for (int k4 = 0; k4 < 16; k4 += 2) {
             load_cw(k4 + 1, cwB);
             quad(cwA);
@@ -841,7 +845,7 @@ __device__ __forceinline__ void pq_bound3_body(const float* __restrict__ Qp, int
     }
 }
 template <bool HAS_CENTROID, int DSUB, int P>
-__global__ __launch_bounds__(256) void pq_bound3_kernel(const float* __restrict__ Qp, int ld, const float* __restrict__ centroids, const float* __restrict__ btab3,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BND3_WPE, BND3_WPE))) void pq_bound3_kernel(const float* __restrict__ Qp, int ld, const float* __restrict__ centroids, const float* __restrict__ btab3,
                                                        const float* __restrict__ cmax2, int M, const unsigned* __restrict__ probe_list, int ldp, int np,
                                                        const unsigned* __restrict__ tq, unsigned char* __restrict__ dead, int* __restrict__ stats,
                                                        const unsigned* __restrict__ plist, const int* __restrict__ pcount) {
