@@ -232,7 +232,7 @@ def pmc_traffic(kernel, rows_local):
             pm = json.loads(f.read_text())
             for kname, kv in pm.get("kernels", {}).items():
                 names = {"flat_scan_f16": ("flat_scan_q8_kernelILi0ELi128ELb0E", "flat_scan_q8_kernel<0, 128, false>", "flat_scan_f16_kernel"),
-                         "flat_scan_i8": ("flat_scan_qr_kernelILi0ELi128ELi6E", "flat_scan_qr_kernel<0, 128, 6>", "flat_scan_q8_kernelILi0ELi128ELb1E", "flat_scan_q8_kernel<0, 128, true>"),
+                         "flat_scan_i8": ("flat_scan_qr_kernelILi0ELi128ELi6E", "flat_scan_qr_kernel<0, 128, 6", "flat_scan_q8_kernelILi0ELi128ELb1E", "flat_scan_q8_kernel<0, 128, true>"),
                          "flat_scan_f16_n64": ("flat_scan_f16_n64_kernelILi1ELb0E", "flat_scan_f16_n64_kernel<1, false>"),
                          "flat_scan_i8_n64": ("flat_scan_qn_kernelILi1ELi6E", "flat_scan_qn_kernel<1, 6>", "flat_scan_f16_n64_kernelILi1ELb1E", "flat_scan_f16_n64_kernel<1, true>"),
                          "ivf_scan_f16": ("ivf_scan_f16_kernelILi0ELb0E", "ivf_scan_f16_kernel<0, false>"),

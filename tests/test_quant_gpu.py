@@ -469,8 +469,8 @@ def test_ivfpq_two_stage_lower_bound_pruning(ctx, metric):
 
 @pytest.mark.parametrize("d,M", [(32, 8), (128, 8), (96, 8), (48, 24)])      # dsub 4, 16: the one-kernel lower bound; 12, 2: the two-kernel form
 def test_ivfpq_two_stage_subspace_widths(ctx, d, M):
-    """The lower-bound kernels of the two-stage search are instantiated per subspace width (pq_bound_kernel for dsub 4 / 8 / 16 with 8-bit
-    codebooks, pq_rowmin_kernel + pq_lb_kernel otherwise): every width returns the oracle's rows, and the pruned search the every-candidate one's."""
+    """The lower-bound kernels of the two-stage search are instantiated per subspace width (pq_bound_prep_kernel + pq_bound3_kernel for dsub 4 / 8 / 16
+    with 8-bit codebooks, pq_rowmin_kernel + pq_lb_kernel otherwise): every width returns the oracle's rows, and the pruned search the every-candidate one's."""
     nlist, nbits = 16, 8
     X = clustered(81 + d, 9000, d, 16, 0.05)
     ids = np.arange(1, len(X) + 1, dtype=np.uint32)
@@ -485,3 +485,25 @@ def test_ivfpq_two_stage_subspace_widths(ctx, d, M):
         m0 = g.search_batch(Q, k, nprobes=npb); m1 = g.search_batch(Q, k, nprobes=npb, mode=1)
         assert np.array_equal(m0[2], m1[2]) and np.array_equal(m0[0], m1[0]) and np.array_equal(bits(m0[1]), bits(m1[1]))
     assert g.stat("adc_pairs_behind_nearest") > b0 and g.stat("adc_pairs_alive") - a0 < g.stat("adc_pairs_behind_nearest") - b0
+
+
+@pytest.mark.parametrize("d,M", [(288, 72), (1040, 65)])      # dsub 4 / 16; more than 64 subspaces: a second round of pq_bound3_kernel with 8 / 1 live lanes
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (1.0e-3, 0.0), (1.0e3, 0.0), (1.0, 40.0)])
+def test_ivfpq_lower_bound_rounds_and_margins(ctx, d, M, scale, offset):
+    """pq_bound3_kernel's bound is NOT the table's arithmetic (fused multiply-adds on |c|^2 - 2 r.c + |r|^2, a tree sum, explicit margins): it must never
+    remove a pair that holds one of the K best. Tiny and large magnitudes, rows far from the origin (large codeword and residual norms against small
+    distances), subspace counts that need a second round: the pruned search returns the oracle's rows and the every-candidate search's."""
+    nlist, nbits = 12, 8
+    X = (clustered(91 + d, 5000, d, 12, 0.05) * np.float32(scale) + np.float32(offset)).astype(np.float32)
+    ids = np.arange(1, len(X) + 1, dtype=np.uint32)
+    g = IVFPQIndex(ctx, d, L2_SQUARED, nlist, M, nbits); o = orc.IVFPQ(d, L2_SQUARED, nlist, M, nbits)
+    g.train(X[:2000]); assert o.train(X[:2000]) == 0
+    g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
+    Q = np.vstack([X[3:11] + np.float32(0.002 * scale), (clustered(92 + d, 4, d, 12, 0.3) * np.float32(scale) + np.float32(offset)).astype(np.float32)])
+    g.stat("adc_stats_on")
+    b0 = g.stat("adc_pairs_behind_nearest")
+    for k, npb in ((1, 12), (10, 6), (64, 12)):
+        check_search(g, o, Q, k, npb)
+        m0 = g.search_batch(Q, k, nprobes=npb); m1 = g.search_batch(Q, k, nprobes=npb, mode=1)
+        assert np.array_equal(m0[2], m1[2]) and np.array_equal(m0[0], m1[0]) and np.array_equal(bits(m0[1]), bits(m1[1]))
+    assert g.stat("adc_pairs_behind_nearest") > b0
