@@ -128,6 +128,26 @@ def test_anchored_threshold_keeps_ties(ctx):
         same(g.search_batch(Q, 30, mode=2), g.search_batch(Q, 30, mode=1))
 
 
+@pytest.mark.parametrize("metric", METRICS)
+def test_final_order_cut_with_thresholds(ctx, metric):
+    """The post stage's final order only takes the candidates at or under phase 0's measured bound U (round 4). A score threshold below U leaves fewer
+    than K results, one between the K-th score and U must not lose any, one above changes nothing; K beyond the anchored phase's rows, K = 1: every
+    combination returns the strict path's rows."""
+    n, d, B = 120000, 128, 70
+    X, Q = synth(61, n, d), synth(62, B, d)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    g = make(ctx, d, metric, 1)
+    g.add_batch(ids, X)
+    for k in (1, 40, 100):
+        strict = g.search_batch(Q, k, mode=1)
+        fast = g.search_batch(Q, k, mode=2)
+        assert g.stat("i8_slices") == 1 and g.stat("fast_queries") + g.stat("fast_overflows") == B and g.stat("fast_candidates") >= B * k
+        same(fast, strict)
+        sc = strict[1]
+        for thr in (float(sc[0, k // 2]), float(sc[0, k - 1]), float(np.nextafter(sc[0, k - 1], np.float32(np.inf))), float(sc[:, k - 1].max()) * 1.01, float(sc[:, 0].min()) * 0.999):
+            same(g.search_batch(Q, k, mode=2, threshold=thr), g.search_batch(Q, k, mode=1, threshold=thr))
+
+
 # ---------------------------------------------------------------------------------------------- the IVF list scan's int8 shadow
 def make_ivf(ctx, d, nlist, metric, policy):
     from comet_amd import IVFIndex
