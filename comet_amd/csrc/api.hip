@@ -5,16 +5,21 @@ using namespace comet;
 
 namespace {
 
+void check_live_indexes(Ctx* c, const char* where) {
+    for (void* p : c->live_indexes) { const comet_index* ix = static_cast<const comet_index*>(p); if (!ix->guards_ok()) { ix->guards_dump(where); std::abort(); } }
+}
+comet_index* adopt(Ctx* c, comet_index* ix) { c->check_live = check_live_indexes; c->live_indexes.push_back(ix); return ix; }
 void check_metric(int m) { if (m < COMET_L2 || m > COMET_COSINE) COMET_FAIL(COMET_ERR_UNKNOWN_METRIC, "unknown distance kind"); }  // distance.go:9
 struct CallGuard {   // serialise calls on a context, bind the device, reset the per-call scratch arena
     Ctx* c; std::unique_lock<std::recursive_mutex> lk;
     // every call but an asynchronous search: lane 0, and lane 1 idle first (the call may change what a search in flight there reads)
     bool search = false;
-    explicit CallGuard(Ctx* c_) : c(c_), lk(c_->mu) { c->bind(); c->switch_lane(0); c->quiesce_alt(); c->scratch_reset(); }
+    explicit CallGuard(Ctx* c_) : c(c_), lk(c_->mu) { c->check_indexes("entry of a call"); c->bind(); c->switch_lane(0); c->quiesce_alt(); c->scratch_reset(); }
     // an asynchronous search enqueued on `lane` (its stream, its scratch arena); lane 0 is current again when the guard goes. A lane
     // other than 0 starts behind whatever non-search work lane 0 was last given (Ctx::lane0_fence): the queries may still be being written there
-    CallGuard(Ctx* c_, int lane) : c(c_), lk(c_->mu), search(true) { c->bind(); c->switch_lane(lane); c->scratch_reset(); c->follow_lane0(); }
+    CallGuard(Ctx* c_, int lane) : c(c_), lk(c_->mu), search(true) { c->check_indexes("entry of an asynchronous search"); c->bind(); c->switch_lane(lane); c->scratch_reset(); c->follow_lane0(); }
     ~CallGuard() {
+        c->check_indexes("exit of a call");
         if (c->cur_lane != 0) { c->mark_dirty(); try { c->switch_lane(0); } catch (...) {} }
         if (!search) { try { c->fence_lane0(); } catch (...) {} }     // what this call left queued on lane 0 is what later searches on lanes 1.. start behind
     }
@@ -196,13 +201,13 @@ int comet_preprocess(comet_ctx* c, int metric, const float* x, int d, float* out
 static void check_dim(int dim) { if (dim <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "dimension must be positive"); }  // flat_index.go:129
 
 int comet_flat_create(comet_ctx* c, int dim, int metric, comet_index** out) {
-    return guarded([&] { *out = nullptr; check_dim(dim); check_metric(metric); c->bind(); *out = make_flat(c, dim, metric); return (int)COMET_OK; });
+    return guarded([&] { *out = nullptr; check_dim(dim); check_metric(metric); c->bind(); *out = adopt(c, make_flat(c, dim, metric)); return (int)COMET_OK; });
 }
 int comet_ivf_create(comet_ctx* c, int dim, int metric, int nlist, comet_index** out) {
     return guarded([&] {
         *out = nullptr; check_dim(dim);
         if (nlist <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "nlist must be positive");   // ivf_index.go:147
-        check_metric(metric); c->bind(); *out = make_ivf(c, dim, metric, nlist); return (int)COMET_OK;
+        check_metric(metric); c->bind(); *out = adopt(c, make_ivf(c, dim, metric, nlist)); return (int)COMET_OK;
     });
 }
 static void check_pq(int dim, int M, int nbits) {
@@ -211,17 +216,19 @@ static void check_pq(int dim, int M, int nbits) {
     if (nbits <= 0 || nbits > 16) COMET_FAIL(COMET_ERR_INVALID_ARG, "parameter Nbits must be in [1,16]");       // pq_index.go:151
 }
 int comet_pq_create(comet_ctx* c, int dim, int metric, int M, int nbits, comet_index** out) {
-    return guarded([&] { *out = nullptr; check_dim(dim); check_pq(dim, M, nbits); check_metric(metric); c->bind(); *out = make_pq(c, dim, metric, M, nbits); return (int)COMET_OK; });
+    return guarded([&] { *out = nullptr; check_dim(dim); check_pq(dim, M, nbits); check_metric(metric); c->bind(); *out = adopt(c, make_pq(c, dim, metric, M, nbits)); return (int)COMET_OK; });
 }
 int comet_ivfpq_create(comet_ctx* c, int dim, int metric, int nlist, int M, int nbits, comet_index** out) {
     return guarded([&] {
         *out = nullptr; check_dim(dim);
         if (nlist <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "nlist must be positive");   // ivfpq_index.go:120
-        check_pq(dim, M, nbits); check_metric(metric); c->bind(); *out = make_ivfpq(c, dim, metric, nlist, M, nbits); return (int)COMET_OK;
+        check_pq(dim, M, nbits); check_metric(metric); c->bind(); *out = adopt(c, make_ivfpq(c, dim, metric, nlist, M, nbits)); return (int)COMET_OK;
     });
 }
 int comet_index_destroy(comet_index* idx) {
-    return guarded([&] { if (!idx) return (int)COMET_OK; Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->quiesce_all(); delete idx; return (int)COMET_OK; });
+    return guarded([&] { if (!idx) return (int)COMET_OK; Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->check_indexes("entry of comet_index_destroy"); c->bind(); c->quiesce_all();
+        (void)hipDeviceSynchronize();      // destroy is rare: every queue of the device idle (the index's private copy stream, runtime-internal copies) before its buffers, events and pinned slots are released
+        delete idx; return (int)COMET_OK; });
 }
 int comet_index_kind(const comet_index* idx) { return idx->kind; }
 int comet_index_dim(const comet_index* idx) { return idx->dim; }
@@ -539,7 +546,7 @@ int comet_index_export(const comet_index* idx, uint32_t* out_ids, int32_t* out_l
     return guarded([&] { CallGuard g(idx->c); idx->export_all(out_ids, out_lists, out_codes); return (int)COMET_OK; });
 }
 int comet_index_get_stat(const comet_index* idx, const char* name, double* out) {
-    return guarded([&] {
+    return guarded([&] { idx->c->check_indexes("comet_index_get_stat");
         std::lock_guard<std::recursive_mutex> lk(idx->c->mu); idx->c->bind();      // some statistics are read back from the device
         if (idx->shard_stat(name, out)) return (int)COMET_OK;
         if (!idx->get_stat(name, out)) COMET_FAIL(COMET_ERR_INVALID_ARG, "unknown stat '%s'", name);

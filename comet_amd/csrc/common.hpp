@@ -134,6 +134,10 @@ struct Ctx {
         for (int l = 0; l < kMaxLanes; l++) if (l != cur_lane && parked[l].stream) HIP_CHECK(hipStreamSynchronize(parked[l].stream));
         dirty_mask = 0;
     }
+    // the live indexes of this context and their integrity check (index.hpp: comet_index::guards_ok); set by api.hip
+    std::vector<void*> live_indexes;
+    void (*check_live)(Ctx*, const char*) = nullptr;
+    void check_indexes(const char* where) { if (check_live) check_live(this, where); }
     // pinned host staging for small readbacks
     void* pinned = nullptr; size_t pinned_cap = 0;
     // profiling

@@ -9,6 +9,7 @@
 #include <unordered_set>
 
 #include "kernels.hpp"
+#include <cstdio>
 #include "io.hpp"
 
 struct comet_ctx : comet::Ctx {};
@@ -17,6 +18,22 @@ struct comet_index {
     comet::Ctx* c = nullptr;
     int kind = 0, dim = 0, ld = 0, metric = 0;
     bool trained = false;
+    // Integrity guards around the host-side containers of the base object (a soak run of 7 000+ index lifetimes once ended in free(-1) inside this
+    // destructor: something had written 0xFF bytes over a vector's pointers). Checked on entry to and exit from every call on the index's context
+    // (CallGuard / comet_index_destroy): a mismatch aborts with the name of the call that first saw it.
+    static constexpr uint64_t kGuard = 0xC0FEE1D5A5A5F00Dull;
+    uint64_t guard0 = kGuard;
+    bool guards_ok() const {
+        auto sane = [](const std::vector<int32_t>& v) { return v.data() == nullptr ? (v.size() == 0 && v.capacity() == 0) : (v.size() <= v.capacity() && v.capacity() < ((size_t)1 << 40)); };
+        return guard0 == kGuard && guard1 == kGuard && guard2 == kGuard && sane(train_counts) && sane(list_owner) && deleted.bucket_count() < ((size_t)1 << 40);
+    }
+    void guards_dump(const char* where) const {
+        const uint64_t* w = reinterpret_cast<const uint64_t*>(this);
+        std::fprintf(stderr, "comet: index object %p (kind %d) corrupted, first seen at %s; guards %llx %llx %llx; words:", (const void*)this, kind, where,
+                     (unsigned long long)guard0, (unsigned long long)guard1, (unsigned long long)guard2);
+        for (int i = 0; i < 48; i++) std::fprintf(stderr, " %llx", (unsigned long long)w[i]);
+        std::fprintf(stderr, "\n");
+    }
     // soft deletes (deletedNodes roaring bitmap in the reference, flat_index.go:88)
     std::unordered_set<uint32_t> deleted;
     comet::DevBuf deleted_dev; int n_deleted_dev = 0; bool deleted_dirty = false;
@@ -30,6 +47,7 @@ struct comet_index {
     // least estimated rows (LPT; ties: fewer lists, then the lower rank) — a corpus with a few giant lists (the bench's clustered corpus: longest
     // list 23 x the mean) no longer piles them on the ranks their indices happen to name. Empty until trained: l % world then.
     std::vector<int32_t> train_counts, list_owner;
+    uint64_t guard1 = kGuard;
     int owner_of(int32_t l) const { return list_owner.empty() ? l % shard_world : list_owner[(size_t)l]; }
     void assign_list_owners() {
         list_owner.clear();
@@ -67,7 +85,10 @@ struct comet_index {
     // ranks of the communicator (the stage-1 bound exchange of the sharded two-stage IVFPQ search); null outside a sharded search
     void (*bound_exchange)(void* user, uint32_t* tq, int n) = nullptr; void* bound_exchange_user = nullptr;
 
-    virtual ~comet_index() { for (auto& r : done_ring) if (r.ev) (void)hipEventDestroy(r.ev); }
+    virtual ~comet_index() {
+        for (auto& r : done_ring) if (r.ev) (void)hipEventDestroy(r.ev);
+        if (c) { auto& L = c->live_indexes; for (size_t i = 0; i < L.size(); i++) if (L[i] == this) { L.erase(L.begin() + i); break; } }
+    }
     virtual int64_t size() const = 0;
     virtual int default_nprobes() const { return 0; }
     virtual void train_dev(const float* /*vecs_dev*/, int64_t /*n*/) {}   // VectorIndex.Train; no-op for Flat (flat_index.go:150)
@@ -98,6 +119,7 @@ struct comet_index {
     // completion tickets of the index kinds without deferred work: an event behind the search on the stream it was enqueued on
     struct DoneEv { uint64_t ticket = 0; hipEvent_t ev = nullptr; bool active = false; };
     DoneEv done_ring[8]; uint64_t done_next = 1;
+    uint64_t guard2 = kGuard;
     uint64_t record_done() {
         DoneEv* slot = nullptr;
         for (auto& r : done_ring) if (!r.active) { slot = &r; break; }

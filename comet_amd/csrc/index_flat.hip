@@ -91,6 +91,7 @@ struct FlatIndex : comet_index {
     Pending ring[kRing];
     uint64_t next_ticket = 1;
     ~FlatIndex() override {
+        if (copy_stream) (void)hipStreamSynchronize(copy_stream);      // nothing of this index is in flight on its private stream when its events and pinned slots go
         for (auto& r : ring) { if (r.ev) (void)hipEventDestroy(r.ev); if (r.ev_post) (void)hipEventDestroy(r.ev_post); if (r.flags) (void)hipHostFree(r.flags); if (r.dflags) (void)hipFree(r.dflags); }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
     }

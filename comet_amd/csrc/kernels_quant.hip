@@ -1238,6 +1238,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
         // phase cannot deliver a survivor: it skips the gathers of the item's remaining phases (the far lists of a query, mostly).
         // The bounds are read once per item, before the first phase (a stale bound is only looser).
         unsigned pTa = 0xFFFFFFFFu, pTb = 0xFFFFFFFFu;
+        unsigned Tpre[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
         bool dead = false;                                          // wave-uniform
         if (a.prune && na0 > 0) {                                   // (with the 4 ulp of slack of the epilogue's test; kept in SGPRs)
             auto slack = [](unsigned t) { return t >= 0x7F800000u ? 0xFFFFFFFFu : __float_as_uint(__uint_as_float(t) * 1.0000005f); };
@@ -1264,6 +1265,10 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
             }
             if (ph == 0) { nxt = decode(s_ticket[parity ^ 1][0], s_ticket[parity ^ 1][1]); if (nxt.live) rs_nxt = rsrc_of(nxt); }
             const bool last_ph = ph + 1 == P;
+            if (last_ph && a.cand != nullptr && na0 > 0) {           // the filter's bounds, requested a phase ahead of their use (a round trip of ~2 k clocks per query otherwise)
+                Tpre[0] = __builtin_nontemporal_load(&a.tq[cur.qA]);
+                Tpre[1] = cur.qB >= 0 ? __builtin_nontemporal_load(&a.tq[cur.qB]) : 0u;
+            }
             if (!last_ph) issue_table(cur, ph + 1, (stage + 1) & 1);
             else if (nxt.live) issue_table(nxt, 0, (stage + 1) & 1);
             const bool to_next = last_ph && nxt.live && chains_of(nxt, 0) > 0;   // the wave's next call belongs to the next item
@@ -1318,7 +1323,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
             for (int h = 0; h < 2; h++) {
                 const int q = h ? cur.qB : cur.qA, so = h ? cur.soB : cur.soA;
                 if (q < 0) continue;
-                const unsigned T = __builtin_nontemporal_load(&a.tq[q]);                  // float bits of a sum >= 0: unsigned order = value order
+                const unsigned T = Tpre[h];                                                // float bits of a sum >= 0: unsigned order = value order (read during the last phase: a stale bound is only looser)
                 const unsigned Ts = __float_as_uint(__uint_as_float(T) * 1.0000005f);     // sums within 4 ulp above the bound may round to the same distance
                 unsigned keys[ADC_SEG_PASSES][ADC_CHAINS];
                 unsigned lmin = 0xFFFFFFFFu;

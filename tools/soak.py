@@ -15,7 +15,7 @@ import comet_amd as ca  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 KINDS = sys.argv[3].split(",") if len(sys.argv) > 3 else ["flat", "ivf", "pq", "ivfpq"]
-ctx = ca.Context(0)
+ctx = ca.Context(0) if not __import__("os").environ.get("SOAK_FIND") else None
 METRICS = [ca.EUCLIDEAN, ca.L2_SQUARED, ca.COSINE]
 bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
 
@@ -35,22 +35,43 @@ def data(n, d, clusters):
     return x.astype(np.float32)
 
 
+TRACE = open(__import__("os").environ["SOAK_TRACE"], "w") if __import__("os").environ.get("SOAK_TRACE") else None      # last line = the configuration a crash happened in
+
+
+def probe(g, step):
+    """integrity probe between oracle / numpy work and the next library call: comet_index_get_stat checks the guards of every live index (a corrupted
+    index object aborts there, and the trace file names the step that came before)"""
+    if TRACE:
+        TRACE.seek(0); TRACE.truncate(); TRACE.write(f"probe after: {step}\n"); TRACE.flush()
+    out = __import__("ctypes").c_double()
+    g.lib.comet_index_get_stat(g.h, b"fast_queries", __import__("ctypes").byref(out))
+
+
 def compare(g, o, Q, k, tag, **kw):
+    if TRACE:
+        TRACE.seek(0); TRACE.truncate(); TRACE.write(f"{tag} k_call={k} kw={ {a: (b if a != 'filter_ids' else len(b)) for a, b in kw.items()} }\n"); TRACE.flush()
     opts = dict(threshold=kw.get("threshold", 0.0), document_ids=kw.get("filter_ids", ()))
     if "nprobes" in kw: opts["nprobes"] = kw["nprobes"]
     ids, sc, cnt = g.search_batch(Q, k, **opts)
+    probe(g, tag + " | gpu search")
     for b, q in enumerate(Q):
         if "nprobes" in kw:
             n, oi, os_ = o.search(q, k, kw["nprobes"], threshold=opts["threshold"], filter_ids=opts["document_ids"])
         else:
             n, oi, os_ = o.search(q, k, threshold=opts["threshold"], filter_ids=opts["document_ids"])
+        if b == len(Q) - 1:
+            probe(g, tag + " | oracle searches")
         m = min(n, ids.shape[1])
         if not (cnt[b] == n and np.array_equal(ids[b, :m], oi[:m]) and np.array_equal(bits(sc[b, :m]), bits(os_[:m]))):
             raise SystemExit(f"MISMATCH {tag} query {b}: gpu cnt {cnt[b]} ids {ids[b, :8]} vs oracle cnt {n} ids {oi[:8]}")
 
 
+import os
+SKIP = int(os.environ.get("SOAK_SKIP", "0"))          # replay: the first SKIP configurations only draw their random numbers (no GPU, no oracle)
+FIND = os.environ.get("SOAK_FIND")                    # print the number of the first configuration whose tag starts with this, and stop (no GPU)
 t_end, rounds, kinds = time.time() + budget, 0, {}
 while time.time() < t_end:
+    real = rounds >= SKIP and not FIND
     kind = rng.choice(KINDS)
     metric = METRICS[int(rng.integers(0, 3))]
     d = int(rng.choice([8, 16, 24, 32, 48, 64, 96, 130, 200]))
@@ -62,39 +83,57 @@ while time.time() < t_end:
     k = int(rng.choice([0, 1, 5, 10, 33, 64, 65, 200]))
     kw = {}
     tag = f"{kind} {metric} n={n} d={d} B={B} k={k}"
+    g = o = None
     if kind == "flat":
-        g = ca.FlatIndex(ctx, d, metric); o = orc.Flat(d, metric)
-        g.add_batch(ids, X); o.add_batch(ids, X)
+        if real:
+            g = ca.FlatIndex(ctx, d, metric); o = orc.Flat(d, metric)
+            g.add_batch(ids, X); probe(g, tag + " | gpu add"); o.add_batch(ids, X); probe(g, tag + " | oracle add")
     elif kind == "ivf":
         nlist = int(rng.choice([8, 64, 128, 256])); ntr = min(n, max(nlist * 20, 1000))
-        g = ca.IVFIndex(ctx, d, nlist, metric); o = orc.IVF(d, metric, nlist)
-        g.train(X[:ntr]); assert o.train(X[:ntr]) == 0
-        g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
+        if real:
+            g = ca.IVFIndex(ctx, d, nlist, metric); o = orc.IVF(d, metric, nlist)
+            g.train(X[:ntr]); probe(g, tag + " | gpu train"); assert o.train(X[:ntr]) == 0; probe(g, tag + " | oracle train")
+            g.add_batch(ids, X); probe(g, tag + " | gpu add"); assert o.add_batch(ids, X) == 0; probe(g, tag + " | oracle add")
         kw["nprobes"] = int(rng.choice([1, 2, max(1, nlist // 8), max(1, nlist // 4), nlist]))
         tag += f" nlist={nlist} nprobe={kw['nprobes']}"
     else:
         Ms = [m for m in (2, 4, 8, 16) if d % m == 0]; M = int(rng.choice(Ms)); nbits = int(rng.choice([3, 4, 6, 8]))
         ntr = min(n, max((1 << nbits) * 4, 1000))
         if kind == "pq":
-            g = ca.PQIndex(ctx, d, metric, M, nbits); o = orc.PQ(d, metric, M, nbits)
+            if real:
+                g = ca.PQIndex(ctx, d, metric, M, nbits); o = orc.PQ(d, metric, M, nbits)
         else:
             nlist = int(rng.choice([4, 64, 128])); ntr = min(n, max(ntr, nlist * 20))
-            g = ca.IVFPQIndex(ctx, d, metric, nlist, M, nbits); o = orc.IVFPQ(d, metric, nlist, M, nbits)
+            if real:
+                g = ca.IVFPQIndex(ctx, d, metric, nlist, M, nbits); o = orc.IVFPQ(d, metric, nlist, M, nbits)
             kw["nprobes"] = int(rng.choice([1, 2, max(1, nlist // 4), nlist])); tag += f" nlist={nlist} nprobe={kw['nprobes']}"
-        g.train(X[:ntr]); assert o.train(X[:ntr]) == 0
-        g.add_batch(ids, X); assert o.add_batch(ids, X) == 0
+        if real:
+            probe(g, tag + " | created (gpu + oracle)")
+            g.train(X[:ntr]); probe(g, tag + " | gpu train"); assert o.train(X[:ntr]) == 0; probe(g, tag + " | oracle train")
+            g.add_batch(ids, X); probe(g, tag + " | gpu add"); assert o.add_batch(ids, X) == 0; probe(g, tag + " | oracle add")
         tag += f" M={M} nbits={nbits}"
-    compare(g, o, Q, k, tag, **kw)
+    if FIND and tag.startswith(FIND):
+        print(f"configuration {rounds}: {tag}"); break
+    tag = f"#{rounds} " + tag
+    if real:
+        compare(g, o, Q, k, tag, **kw)
     if rng.random() < 0.5:
-        compare(g, o, Q, max(1, k), tag + " filter", filter_ids=[int(i) for i in rng.choice(ids, size=max(1, n // 3), replace=False)], **kw)
+        flt = [int(i) for i in rng.choice(ids, size=max(1, n // 3), replace=False)]
+        if real:
+            compare(g, o, Q, max(1, k), tag + " filter", filter_ids=flt, **kw)
     if rng.random() < 0.5:
         for i in rng.choice(ids, size=5, replace=False):
-            g.remove(int(i)); o.remove(int(i))
-        compare(g, o, Q, max(1, k), tag + " deletes", **kw)
+            if real:
+                g.remove(int(i)); o.remove(int(i))
+        if real:
+            compare(g, o, Q, max(1, k), tag + " deletes", **kw)
     if rng.random() < 0.4:
-        ref = (o.search(Q[0], 50, kw["nprobes"]) if "nprobes" in kw else o.search(Q[0], 50))[2]
-        if len(ref) > 6:
-            compare(g, o, Q, max(1, k), tag + " threshold", threshold=float(ref[5]), **kw)
-    g.close()
+        if real:
+            ref = (o.search(Q[0], 50, kw["nprobes"]) if "nprobes" in kw else o.search(Q[0], 50))[2]
+            if len(ref) > 6:
+                compare(g, o, Q, max(1, k), tag + " threshold", threshold=float(ref[5]), **kw)
+    if real:
+        probe(g, tag + " | before close")
+        g.close()
     rounds += 1; kinds[kind] = kinds.get(kind, 0) + 1
 print(f"soak OK: {rounds} random configurations in {budget:.0f} s, all bit-identical to the oracle: {kinds}")
