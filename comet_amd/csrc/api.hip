@@ -8,7 +8,7 @@ namespace {
 void check_live_indexes(Ctx* c, const char* where) {
     for (void* p : c->live_indexes) { const comet_index* ix = static_cast<const comet_index*>(p); if (!ix->guards_ok()) { ix->guards_dump(where); std::abort(); } }
 }
-comet_index* adopt(Ctx* c, comet_index* ix) { c->check_live = check_live_indexes; c->live_indexes.push_back(ix); return ix; }
+comet_index* adopt(Ctx* c, comet_index* ix) { std::lock_guard<std::recursive_mutex> lk(c->mu); c->check_live = check_live_indexes; c->live_indexes.push_back(ix); return ix; }
 void check_metric(int m) { if (m < COMET_L2 || m > COMET_COSINE) COMET_FAIL(COMET_ERR_UNKNOWN_METRIC, "unknown distance kind"); }  // distance.go:9
 struct CallGuard {   // serialise calls on a context, bind the device, reset the per-call scratch arena
     Ctx* c; std::unique_lock<std::recursive_mutex> lk;
@@ -546,8 +546,9 @@ int comet_index_export(const comet_index* idx, uint32_t* out_ids, int32_t* out_l
     return guarded([&] { CallGuard g(idx->c); idx->export_all(out_ids, out_lists, out_codes); return (int)COMET_OK; });
 }
 int comet_index_get_stat(const comet_index* idx, const char* name, double* out) {
-    return guarded([&] { idx->c->check_indexes("comet_index_get_stat");
+    return guarded([&] {
         std::lock_guard<std::recursive_mutex> lk(idx->c->mu); idx->c->bind();      // some statistics are read back from the device
+        idx->c->check_indexes("comet_index_get_stat");
         if (idx->shard_stat(name, out)) return (int)COMET_OK;
         if (!idx->get_stat(name, out)) COMET_FAIL(COMET_ERR_INVALID_ARG, "unknown stat '%s'", name);
         return (int)COMET_OK;
