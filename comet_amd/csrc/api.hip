@@ -17,11 +17,15 @@ struct CallGuard {   // serialise calls on a context, bind the device, reset the
     explicit CallGuard(Ctx* c_) : c(c_), lk(c_->mu) { c->check_indexes("entry of a call"); c->bind(); c->switch_lane(0); c->quiesce_alt(); c->scratch_reset(); }
     // an asynchronous search enqueued on `lane` (its stream, its scratch arena); lane 0 is current again when the guard goes. A lane
     // other than 0 starts behind whatever non-search work lane 0 was last given (Ctx::lane0_fence): the queries may still be being written there
-    CallGuard(Ctx* c_, int lane) : c(c_), lk(c_->mu), search(true) { c->check_indexes("entry of an asynchronous search"); c->bind(); c->switch_lane(lane); c->scratch_reset(); c->follow_lane0(); }
+    CallGuard(Ctx* c_, int lane) : c(c_), lk(c_->mu), search(true) {
+        c->check_indexes("entry of an asynchronous search"); c->bind();
+        if (!c->async_seen) { c->switch_lane(0); c->fence_lane0(); c->async_seen = true; }      // the first one: everything lane 0 holds so far is what it must start behind
+        c->switch_lane(lane); c->scratch_reset(); c->follow_lane0();
+    }
     ~CallGuard() {
         c->check_indexes("exit of a call");
         if (c->cur_lane != 0) { c->mark_dirty(); try { c->switch_lane(0); } catch (...) {} }
-        if (!search) { try { c->fence_lane0(); } catch (...) {} }     // what this call left queued on lane 0 is what later searches on lanes 1.. start behind
+        if (!search && c->async_seen) { try { c->fence_lane0(); } catch (...) {} }     // what this call left queued on lane 0 is what later searches on lanes 1.. start behind
     }
 };
 }  // namespace

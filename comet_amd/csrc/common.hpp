@@ -116,6 +116,8 @@ struct Ctx {
     // another lane waits for the newest record. Searches on lane 0 do NOT move the fence: a search on lane 1 must not queue up behind the
     // search that lane 0 is running (that would serialise the lanes).
     hipEvent_t lane0_fence = nullptr; bool lane0_fence_set = false;
+    bool async_seen = false;        // an asynchronous search has been issued on this context: only then do non-search calls record the fence (a context that is only
+                                    // ever used through the blocking calls re-recorded the event after every call for nobody — thousands of records on one event)
     hipEvent_t fork_ev = nullptr;   // segments_search: the other lanes start behind what lane 0 holds at the call (owned by the context: an event belongs to a device)
     void fence_lane0() {            // lane 0 current
         if (!lane0_fence) HIP_CHECK(hipEventCreateWithFlags(&lane0_fence, hipEventDisableTiming));
