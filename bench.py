@@ -820,9 +820,13 @@ def leg_hybrid(ctx, ca, args, timer, q_ptrs, Q0):
     from comet_amd.hybrid import reciprocal_rank_fusion_batch
     e2e = {}
     for tag, vec in (("nprobe1", vec_last), (f"nprobe{args.nprobe}", vec32)):
-        t0 = time.perf_counter()
-        f_ids, f_sc, f_cn = reciprocal_rank_fusion_batch(vec[0], vec[2], tr[0], tr[3], K)
-        fuse_ms = (time.perf_counter() - t0) * 1e3
+        reciprocal_rank_fusion_batch(vec[0], vec[2], tr[0], tr[3], K)            # (the first call pays numpy's one-time set-up: 0.5 ms against 0.18)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            f_ids, f_sc, f_cn = reciprocal_rank_fusion_batch(vec[0], vec[2], tr[0], tr[3], K)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        fuse_ms = sorted(ts)[2]                                                    # median of five warm calls: what a serving loop pays per batch
         vleg = out["ivf_nprobe1" if tag == "nprobe1" else f"ivf_nprobe{args.nprobe}"]
         e2e_ms = vleg["ms_per_step"] + trec["ms_per_step"] + fuse_ms
         e2e[tag] = {"qps": B / (e2e_ms * 1e-3), "ms_per_batch": e2e_ms, "fusion_host_ms_per_batch": fuse_ms}
