@@ -96,3 +96,28 @@ def test_rrf_batch_equals_per_query_form():
         assert cnt[b] == len(want)
         assert [int(x) for x in ids[b, :cnt[b]]] == [d for d, _ in want]
         assert np.array_equal(sc[b, :cnt[b]].view(np.uint64), np.array([s for _, s in want], np.float64).view(np.uint64))
+
+
+def test_bench_compact_line_is_driver_sized():
+    """The driver parses bench.py's LAST stdout line from a bounded tail: the compact record built from a full record of every leg (the committed
+    profiles/r04_bench_legs_k.json: all default legs present) stays under 6 KB and keeps the contract's keys, `roofline` and `cpu_baseline`."""
+    import importlib.util
+    import json
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec = importlib.util.spec_from_file_location("bench_for_test", root / "bench.py")
+        bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    full = json.loads((root / "profiles" / "r04_bench_legs_k.json").read_text())
+    line = json.dumps(bench.compact_line(full))
+    assert len(line) < 6 * 1024, len(line)
+    rec = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in rec, k
+    assert rec["config"]["workload"] and rec["roofline"]["kernel"] and rec["roofline"]["frac"] > 0 and rec["cpu_baseline"]["value"] > 0
+    for leg in ("c1", "flat_l2", "ivfpq", "ivfpq_uniform", "ivfpq10m", "hnsw", "hnsw_navigable", "hybrid"):
+        assert leg in rec["legs"], leg
