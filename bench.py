@@ -88,6 +88,11 @@ def parse():
     ap.add_argument("--docs", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--shard-mode", default="auto", choices=("auto", "rows", "replica", "grid"),
+                    help="N > 1: rows = one index split over all ranks (strong scaling, RCCL all-gather per batch); replica = every rank holds the whole index and "
+                         "serves its own query stream (throughput; no exchange); grid = --shard-group ranks share one index, world / group replicas of that; "
+                         "auto = `value` from replica (the 1M index is 0.8-3 GB of a 288 GB part) AND the rows form measured beside it (`sharded_rows`)")
+    ap.add_argument("--shard-group", type=int, default=2, help="ranks per index copy in --shard-mode grid (must divide the world size)")
     ap.add_argument("--full-line", action="store_true", help="print the full record (tens of KB) instead of the compact line; the full record is always written to bench_legs.json")
     return ap.parse_args()
 
@@ -506,10 +511,12 @@ def adc_lookups_ceiling():
         return {"error": f"tools/lds_gather_probe did not run: {e}"}
 
 
-def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, comm=None, rank=0, world=1, every_candidate=True, nsub=MIX_SUB, fill=None, corpus="clustered corpus"):
+def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, comm=None, rank=0, world=1, every_candidate=True, nsub=MIX_SUB, fill=None, corpus="clustered corpus",
+              replicas=1, solo=True):
     """world > 1: every rank trains on the same vectors (deterministic GPU k-means: replicated quantisers), owns the inverted lists
     dealt to it (comet_index_set_shard: by list length, identically on every rank) and adds every row (foreign members are dropped); searches go through the in-library
-    RCCL exchange, so every rank ends up with the merged global top-K."""
+    RCCL exchange, so every rank ends up with the merged global top-K. `replicas`: groups of `world` ranks, each with its own copy of the index and its
+    own query stream (qps counts all of them); `solo`: a one-GPU job (the every-candidate pass and the CPU baseline run only there)."""
     B, K, d, n = args.batch, args.ivfpq_k, args.dim, rows
     idx = ca.IVFPQIndex(ctx, d, ca.L2_SQUARED, nlist, args.M, args.nbits)
     ntrain = min(n, nlist * 100)
@@ -536,10 +543,11 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
     stat0, stat1 = (0.0, 0.0), (idx.stat("adc_pairs_alive"), idx.stat("adc_pairs_behind_nearest"))
     norm_kills = idx.stat("adc_norm_bound_kills")
     idx.stat("adc_stats_off")
-    rec, prof, med, times = measure(ctx, timer, args, pipe.step, "adc_scan", B)
+    rec, prof, med, times = measure(ctx, timer, args, pipe.step, "adc_scan", B * replicas)
     g = pipe.results_of(0)
     out = {"workload": f"IVFPQ l2_squared {n}x{d} ({corpus}), nlist={nlist} nprobe={args.nprobe} M={args.M} nbits={args.nbits}, batch={B}, K={K}"
-                       + (f"; inverted lists sharded over {world} ranks" if world > 1 else ""), **rec,
+                       + (f"; inverted lists sharded over {world} ranks" if world > 1 else "") + (f"; {replicas} index copies, one query stream each" if replicas > 1 else ""), **rec,
+           "layout": {"ranks_per_index_copy": world, "index_copies": replicas, "queries_per_step_all_ranks": B * replicas},
            "train_vectors": ntrain, "train_s": round(train_s, 2), "add_s": round(add_s, 2)}
     alive, behind = stat1[0] - stat0[0], stat1[1] - stat0[1]
     out["two_stage"] = {"what": "stage 1 scans every query's nearest list and seeds the per-query K-th-best bounds; an exact lower bound per remaining (query, list) pair — "
@@ -554,7 +562,7 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
         out["recall_at_10_vs_exact_flat"] = recall_of(f_ids, g[0], g[2], K)
     else:
         f_ids = None
-    if world == 1:
+    if solo:
         # what the ADC kernel itself sustains: the same search with every candidate scored (mode 1: no lower-bound pruning)
         e_ids, e_lists, _ = idx.export()
         list_len = np.bincount(e_lists, minlength=nlist)
@@ -623,6 +631,7 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
             out["cpu_baseline"] = cb
             out["recall_at_10_vs_oracle_ivfpq"] = 1.0 - cb["parity_mismatches"] / max(1, cb["parity_checked_queries"])   # identical lists on every sampled query -> 1.0
     pipe.free()
+    out["_g0"] = g                 # results of query batch 0 (numpy; main() compares layouts with it and drops it before the record is written)
     return out
 
 
@@ -850,76 +859,161 @@ def leg_hybrid(ctx, ca, args, timer, q_ptrs, Q0):
     return out
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks here, one process per GPU, exactly as
+    `torch.distributed.run --nproc-per-node N` would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT); rank 0 inherits stdout and
+    prints the one line. Returns the exit status (the first failing rank's; the others are stopped by PID)."""
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), COMET_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p_ in list(live):
+            c = p_.poll()
+            if c is None:
+                continue
+            live.remove(p_)
+            if c != 0 and rc == 0:
+                rc = c
+                for q_ in live:          # a rank died: its peers would wait in a collective for ever
+                    q_.terminate()
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     legs = set(args.legs.split(","))
     use_dist = world > 1 or os.environ.get("COMET_BENCH_FORCE_DIST") == "1"   # the env knob exercises the RCCL path at world size 1
+    # the layout of the job: `R` ranks share one copy of an index (row / list shards + the in-library exchange), `world / R` such groups serve
+    # their own query streams. rows: R = world; replica: R = 1; grid: R = --shard-group. auto: replica for `value`, rows measured beside it.
+    mode = args.shard_mode if world > 1 else "replica"
+    R_head = {"rows": world, "replica": 1, "grid": args.shard_group, "auto": 1}[mode]
+    if world % R_head:
+        raise SystemExit(f"--shard-group {R_head} does not divide the world size {world}")
+    also_rows = world > 1 and mode == "auto"
     import comet_amd as ca
     # COMET_BENCH_DEVICE: every rank on one device — only for exercising the multi-rank code path on a one-GPU box (with COMET_RCCL_LIB)
     ctx = ca.Context(int(os.environ.get("COMET_BENCH_DEVICE", local_rank)))
-    comm = None
+    wcomm = None
+    comms = {}
     if use_dist:
         # RCCL lives inside libcomet_hip.so (comet_comm_*): the host only carries the 128-byte id from rank 0 to the others
         from comet_amd.dist import Comm
-        comm = Comm.from_env(ctx)
+        wcomm = Comm.from_env(ctx)
+
+    def group_comm(R):
+        """the communicator of this rank's group of R ranks (None: no exchange; the world communicator when the group is the world)"""
+        if R <= 1 or wcomm is None:
+            return wcomm if (R == 1 and world == 1 and wcomm is not None) else None      # COMET_BENCH_FORCE_DIST: a world-1 communicator
+        if R == world:
+            return wcomm
+        if R not in comms:
+            from comet_amd.dist import Comm
+            base = int(os.environ.get("COMET_RDZV_PORT", int(os.environ.get("MASTER_PORT", "29540")) + 101))
+            comms[R] = Comm(ctx, rank % R, R, os.environ.get("MASTER_ADDR", "127.0.0.1"), base + 1 + rank // R)
+        return comms[R]
 
     def barrier():
         ctx.sync()
-        if comm is not None:
-            comm.barrier()
+        if wcomm is not None:
+            wcomm.barrier()
 
     def reduce_max(x):
-        return comm.allreduce_max(x) if comm is not None else x
+        return wcomm.allreduce_max(x) if wcomm is not None else x
     timer = Timer(barrier, reduce_max)
     t_start = time.time()
+    B, K = args.batch, args.k
 
     # ---------------------------------------------------------------- headline: Flat (configs[1])
-    idx = ca.FlatIndex(ctx, args.dim, args.metric)
-    lo = args.rows * rank // world
-    hi = args.rows * (rank + 1) // world
-    t0 = time.time()
-    add_rows(ctx, idx, lo, hi, args.dim, lambda buf, r0, m: ctx.synth_fill(buf, CORPUS_SEED, r0 * args.dim, m * args.dim))
-    ctx.sync()
-    build_s = time.time() - t0
-    B, K = args.batch, args.k
-    # query batch 0 is the stream the CPU baseline regenerates (QUERY_SEED from offset 0); batches 1.. continue it
-    q_ptrs = query_batches(ctx, B, args.dim, lambda p, i: ctx.synth_fill(p, QUERY_SEED, i * B * args.dim, B * args.dim))
-    pipe = Pipe(ctx, idx, q_ptrs, B, K, comm, mode=args.mode)
-    pipe.step(1)
-    rec, prof, med, times = measure(ctx, timer, args, pipe.step, FLAT_SCAN_SCOPES, B)
-    g0 = pipe.results_of(0)
+    def flat_pass(R):
+        """one Flat measurement with R ranks per index copy: (record, profile, times, results of query batch 0, fast-path counters, build s, local rows)"""
+        Qn, g, r = world // R, rank // R, rank % R
+        gc = group_comm(R)
+        idx = ca.FlatIndex(ctx, args.dim, args.metric)
+        lo, hi = args.rows * r // R, args.rows * (r + 1) // R
+        t0 = time.time()
+        add_rows(ctx, idx, lo, hi, args.dim, lambda buf, r0, m: ctx.synth_fill(buf, CORPUS_SEED, r0 * args.dim, m * args.dim))
+        ctx.sync()
+        build_s = time.time() - t0
+        # group 0's query batch 0 is the stream the CPU baseline regenerates (QUERY_SEED from offset 0); the other batches and groups continue it
+        q_ptrs = query_batches(ctx, B, args.dim, lambda p, i: ctx.synth_fill(p, QUERY_SEED, (g * NQB + i) * B * args.dim, B * args.dim))
+        pipe = Pipe(ctx, idx, q_ptrs, B, K, gc, mode=args.mode)
+        pipe.step(1)
+        rec, prof, _med, times = measure(ctx, timer, args, pipe.step, FLAT_SCAN_SCOPES, B * Qn)
+        g0 = pipe.results_of(0)
+        stats = {k: idx.stat(k) for k in ("fast_queries", "strict_queries", "fast_candidates", "fast_expansions", "fast_overflows", "i8_slices", "i8_backoffs", "i8_max_residual")}
+        hb = None
+        if world == 1:
+            Qh = ctx.download(q_ptrs[0], (B, args.dim), np.float32)
+            hb = host_buffers_qps(lambda: idx.search_batch(Qh, K, mode=args.mode), B)
+        pipe.free(); idx.close(); ctx.free(q_ptrs[0])
+        return {"rec": rec, "prof": prof, "times": times, "g0": g0, "stats": stats, "build_s": build_s, "rows_local": hi - lo, "host_buffers": hb,
+                "layout": {"ranks_per_index_copy": R, "index_copies": Qn, "queries_per_step_all_ranks": B * Qn,
+                           "exchange": None if R == 1 else "one RCCL all-gather of the packed per-shard top-K blocks per batch + merge_topk_kernel (comm.hip)"}}
 
+    hp = flat_pass(R_head)
+    rec, prof, times, g0 = hp["rec"], hp["prof"], hp["times"], hp["g0"]
+    sharding = (f"rows/{world}" if R_head == world and world > 1 else "none (1 GPU)" if world == 1 else
+                f"{world} replicas of the whole index, one query stream each (no exchange)" if R_head == 1 else f"rows/{R_head} x {world // R_head} replicas")
     line = None
     if rank == 0:
         line = {
             "metric": "queries/sec + recall@10, 1M x 768 Flat & IVFPQ (value = the Flat leg: exact search, recall@K = 1.0 by construction, ids bit-identical "
                       "to the CPU reference path; the IVFPQ leg with its recall@10 is in `ivfpq`; the other BASELINE configs are in `ivfpq10m`, `hnsw`, `hybrid`)",
             "value": rec["qps"], "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "strong" if (R_head == world and world > 1) else "weak", "vs_baseline": None,
             "dtype": DTYPE, "data": "synthetic",
             "timing": {"regions": len(times), "reported": "median region", "region_ms": rec["region_ms"], "query_batches_rotated": NQB},
             "sustained": rec["sustained"], "single_stream": rec.get("single_stream"),
             "execution_lanes": rec["execution_lanes"], "batches_in_flight": rec["batches_in_flight"], "batch_latency_ms_about": rec["batch_latency_ms_about"],
             "config": {"workload": f"Flat {args.metric} {args.rows}x{args.dim}, batch={B} queries, K={K} (BASELINE configs[1])",
                        "rows": args.rows, "dim": args.dim, "batch": B, "k": K, "metric": args.metric,
-                       "mode": {0: "auto", 1: "strict", 2: "fast"}[args.mode], "sharding": f"rows/{world}", "build_s": round(build_s, 2)},
-            "roofline": flat_roofline(prof, hi - lo, args.dim, B),
+                       "mode": {0: "auto", 1: "strict", 2: "fast"}[args.mode], "sharding": sharding, "shard_mode": mode, "layout": hp["layout"], "build_s": round(hp["build_s"], 2)},
+            "roofline": flat_roofline(prof, hp["rows_local"], args.dim, B),
             "kernels_ms_per_step": rec["kernels_ms_per_step"],
-            "fast_path": {k: idx.stat(k) for k in ("fast_queries", "strict_queries", "fast_candidates", "fast_expansions", "fast_overflows", "i8_slices", "i8_backoffs", "i8_max_residual")},
+            "fast_path": hp["stats"],
             "recall_at_10": {"flat": 1.0},
-            "scaling_note": None if world == 1 else "strong scaling of the named config: the 1M-row corpus is split over the ranks and every rank searches its shard for the "
-                            "same 256 queries; per batch a rank keeps a fixed cost that does not shrink with its shard (post stage per shard, query preparation, "
-                            "exchange + merge, launch gaps), see DESIGN.md 3.9; no multi-GPU box was available to the builder: the exchange ran at world size > 1 only "
-                            "as processes sharing one GPU (tests/test_comm_gpu.py)",
+            "scaling_note": None if world == 1 else
+                            ("a step = every rank's batch of 256 queries; `value` = all ranks' queries / the slowest rank's time (barrier + max over ranks). "
+                             + ("Every GPU holds the whole 1M x 768 index (int8 shadow 0.77 GB + f32 rows 3.1 GB of 288 GB) and searches its own query stream: no data-path "
+                                "collective (throughput mode; DESIGN.md 3.9). The row-sharded form of the same config with the RCCL all-gather is in `sharded_rows`."
+                                if R_head == 1 else
+                                "The 1M-row corpus is split over the ranks of a group and every rank searches its shard for the group's 256 queries; per batch a rank keeps "
+                                "a fixed cost that does not shrink with its shard (post stage per shard, query preparation, exchange + merge, launch gaps), DESIGN.md 3.9.")),
         }
-        if world == 1:
-            Qh = ctx.download(q_ptrs[0], (B, args.dim), np.float32)
-            line["host_buffers"] = host_buffers_qps(lambda: idx.search_batch(Qh, K, mode=args.mode), B)
-        line["cpu_baseline"] = cpu_baseline_flat(args, *g0) if (world == 1 and not args.no_cpu_baseline) else None
-    pipe.free()
+        if hp["host_buffers"]:
+            line["host_buffers"] = hp["host_buffers"]
+        if not args.no_cpu_baseline:
+            cb = cpu_baseline_flat(args, *g0)
+            if world == 1:
+                line["cpu_baseline"] = cb
+            else:       # N > 1: the CPU leg is a parity check only (the contract times it at N = 1)
+                line["cpu_baseline"] = None
+                line["parity"] = {"parity_checked_queries": cb["parity_checked_queries"], "parity_mismatches": cb["parity_mismatches"], "what": "rank 0's results for query batch 0 against the CPU oracle, bit for bit"}
+        else:
+            line["cpu_baseline"] = None
+    if also_rows:
+        # the partitioned form north_star names: ONE index split over all ranks by contiguous row blocks, every rank searches its shard for the same
+        # 256 queries, per-shard top-K all-gathered inside the library and merged — strong scaling of the 1M config
+        sp = flat_pass(world)
+        if rank == 0:
+            same = bool(np.array_equal(sp["g0"][2], g0[2]) and np.array_equal(sp["g0"][0], g0[0]) and np.array_equal(sp["g0"][1].view(np.uint32), g0[1].view(np.uint32)))
+            r2 = sp["rec"]
+            line["sharded_rows"] = {"qps": r2["qps"], "ms_per_step": r2["ms_per_step"], "scaling": "strong", "sharding": f"rows/{world}", "layout": sp["layout"],
+                                    "sustained": r2["sustained"], "single_stream": r2.get("single_stream"), "region_ms": r2["region_ms"],
+                                    "kernels_ms_per_step": r2["kernels_ms_per_step"], "roofline": flat_roofline(sp["prof"], sp["rows_local"], args.dim, B),
+                                    "identical_to_the_replica_results_for_batch_0": same}
 
     def guarded(name, fn):
         """a leg that fails leaves its error in the line instead of taking the headline with it"""
@@ -932,6 +1026,10 @@ def main():
     if "c1" in legs and world == 1:
         line["c1"] = guarded("c1", lambda: leg_c1(ctx, ca, args))
 
+    def mix_queries(g, rows, nsub=MIX_SUB):
+        """fresh draws from the corpus's mixture (rows past the corpus); replica group g continues group 0's stream"""
+        return query_batches(ctx, B, args.dim, lambda p, i: ctx.synth_mixture(p, MIX_SEED, MIX_CENTERS, MIX_SIGMA, nsub, MIX_NOISE, rows + 7 + (g * NQB + i) * B, B, args.dim))
+
     # ---------------------------------------------------------------- clustered 1M corpus: Flat L2^2 (N = 1), IVFPQ (any N), hybrid (N = 1)
     need_mix = legs & ({"flat_l2", "ivfpq", "ivfpq_uniform", "hybrid"} if world == 1 else {"ivfpq"})
     if need_mix:
@@ -939,20 +1037,34 @@ def main():
         if rank == 0 or world == 1:
             flat2 = ca.FlatIndex(ctx, args.dim, ca.L2_SQUARED)
             add_rows(ctx, flat2, 0, args.rows, args.dim, mix_fill(ctx, args.dim))
-        # queries: fresh draws from the same mixture (rows past the corpus)
-        q2 = query_batches(ctx, B, args.dim, lambda p, i: ctx.synth_mixture(p, MIX_SEED, MIX_CENTERS, MIX_SIGMA, MIX_SUB, MIX_NOISE, args.rows + 7 + i * B, B, args.dim))
+        q2 = mix_queries(rank // R_head, args.rows)
         Q2 = ctx.download(q2[0], (B, args.dim), np.float32)
         if "flat_l2" in legs and world == 1:
             r = guarded("flat_l2", lambda: leg_flat_l2(ctx, ca, args, timer, flat2, q2))
             line["flat_l2"] = r
         if "ivfpq" in legs:
-            iv = guarded("ivfpq", lambda: leg_ivfpq(ctx, ca, args, timer, flat2, q2, Q2, args.rows, args.nlist, "ivfpq", comm, rank, world))
+            iv = guarded("ivfpq", lambda: leg_ivfpq(ctx, ca, args, timer, flat2, q2, Q2, args.rows, args.nlist, "ivfpq", group_comm(R_head), rank % R_head, R_head,
+                                                    replicas=world // R_head, solo=world == 1))
+            g_rep = iv.pop("_g0", None)
             if rank == 0:
                 line["ivfpq"] = iv
                 if "recall_at_10_vs_exact_flat" in iv:
                     line["recall_at_10"]["ivfpq_vs_exact_flat"] = iv["recall_at_10_vs_exact_flat"]
                 if "recall_at_10_vs_oracle_ivfpq" in iv:
                     line["recall_at_10"]["ivfpq_vs_oracle_ivfpq"] = iv["recall_at_10_vs_oracle_ivfpq"]
+            if also_rows:
+                # the same index with its inverted lists dealt over ALL ranks, every rank searching for the same queries (group 0's stream)
+                q2s = q2 if rank // R_head == 0 else mix_queries(0, args.rows)
+                Q2s = ctx.download(q2s[0], (B, args.dim), np.float32)
+                iv = guarded("ivfpq_sharded", lambda: leg_ivfpq(ctx, ca, args, timer, flat2, q2s, Q2s, args.rows, args.nlist, "ivfpq_sharded", wcomm, rank, world, replicas=1, solo=False))
+                if q2s is not q2:
+                    ctx.free(q2s[0])
+                g_sh = iv.pop("_g0", None)
+                if rank == 0:
+                    if g_rep is not None and g_sh is not None:
+                        iv["identical_to_the_replica_results_for_batch_0"] = bool(np.array_equal(g_sh[2], g_rep[2]) and all(
+                            np.array_equal(g_sh[0][b, :g_rep[2][b]], g_rep[0][b, :g_rep[2][b]]) and np.array_equal(g_sh[1][b, :g_rep[2][b]].view(np.uint32), g_rep[1][b, :g_rep[2][b]].view(np.uint32)) for b in range(B)))
+                    line["ivfpq_sharded"] = iv
         if "ivfpq_uniform" in legs and world == 1:
             # SURVEY 8(d)'s primary input: i.i.d. SplitMix64 rows — no cluster structure, the two-stage lower bound has nothing to remove: the honest worst case
             def uni():
@@ -963,6 +1075,7 @@ def main():
                 qu = query_batches(ctx, B, args.dim, lambda p, i: ctx.synth_fill(p, qseed, i * B * args.dim, B * args.dim))
                 Qu = ctx.download(qu[0], (B, args.dim), np.float32)
                 r = leg_ivfpq(ctx, ca, args, timer, fu, qu, Qu, args.rows, args.nlist, "ivfpq_uniform", None, 0, 1, fill=ufill, corpus="UNIFORM SplitMix64 rows, SURVEY 8d")
+                r.pop("_g0", None)
                 fu.close(); ctx.free(qu[0])
                 return r
             line["ivfpq_uniform"] = guarded("ivfpq_uniform", uni)
@@ -973,36 +1086,46 @@ def main():
         if flat2 is not None:
             flat2.close()
         ctx.free(q2[0])
-    # ---------------------------------------------------------------- configs[3]: IVFPQ 10M (single GPU: the whole index; N > 1: list shards)
+    # ---------------------------------------------------------------- configs[3]: IVFPQ 10M (single GPU: the whole index; N > 1: list shards over ALL ranks,
+    # the sharded form the config names — whatever --shard-mode says; `auto` / `replica` / `grid` add the throughput layout beside it)
     if "ivfpq10m" in legs:
-        def big():
-            nb = args.big_rows
-            nsub = max(MIX_SUB, nb * MIX_SUB // N_ROWS)         # the same ~15 rows per sub-centre as the 1M corpus (with 65536 sub-centres a 10M corpus has 150 near-duplicates per query)
-            qb = query_batches(ctx, B, args.dim, lambda p, i: ctx.synth_mixture(p, MIX_SEED, MIX_CENTERS, MIX_SIGMA, nsub, MIX_NOISE, nb + 7 + i * B, B, args.dim))
+        nb = args.big_rows
+        nsub = max(MIX_SUB, nb * MIX_SUB // N_ROWS)         # the same ~15 rows per sub-centre as the 1M corpus (with 65536 sub-centres a 10M corpus has 150 near-duplicates per query)
+
+        def big(R, tag):
+            qb = mix_queries(rank // R, nb, nsub)
             Qb = ctx.download(qb[0], (B, args.dim), np.float32)
             fx = None
             if rank == 0:         # exact ground truth at 10M rows: a Flat index of the same rows (30 GB + 15 GB of fp16 shadow: nothing on a 288 GB part)
                 fx = ca.FlatIndex(ctx, args.dim, ca.L2_SQUARED)
                 add_rows(ctx, fx, 0, nb, args.dim, mix_fill(ctx, args.dim, nsub))
-            r = leg_ivfpq(ctx, ca, args, timer, fx, qb, Qb, nb, args.big_nlist, "ivfpq10m", comm, rank, world, every_candidate=True, nsub=nsub)
+            r = leg_ivfpq(ctx, ca, args, timer, fx, qb, Qb, nb, args.big_nlist, tag, group_comm(R), rank % R, R, every_candidate=True, nsub=nsub,
+                          replicas=world // R, solo=world == 1)
+            r.pop("_g0", None)
             r["corpus"] = f"{MIX_CENTERS} centres, {nsub} sub-centres at {MIX_SIGMA}, noise {MIX_NOISE}"
             if fx is not None:
                 fx.close()
             ctx.free(qb[0])
             return r
-        r = guarded("ivfpq10m", big)
+        r = guarded("ivfpq10m", lambda: big(world, "ivfpq10m"))
         if rank == 0:
             line["ivfpq10m"] = r
             if "recall_at_10_vs_exact_flat" in r:
                 line["recall_at_10"]["ivfpq10m_vs_exact_flat"] = r["recall_at_10_vs_exact_flat"]
+        if world > 1 and R_head != world:
+            r = guarded("ivfpq10m_throughput", lambda: big(R_head, "ivfpq10m_throughput"))
+            if rank == 0:
+                line["ivfpq10m_throughput"] = r
     if "hnsw" in legs and world == 1:
         line["hnsw"] = guarded("hnsw", lambda: leg_hnsw(ctx, ca, args, timer))
         if "recall_at_10_vs_exact_flat" in line["hnsw"]:
             line["recall_at_10"]["hnsw_vs_exact_flat"] = line["hnsw"]["recall_at_10_vs_exact_flat"]
 
-    if comm is not None:
-        comm.barrier()
-        comm.close()
+    if wcomm is not None:
+        wcomm.barrier()
+        for cm in comms.values():
+            cm.close()
+        wcomm.close()
     if rank == 0:
         line["wall_s"] = round(time.time() - t_start, 1)
         # the full record (every leg's regions, rooflines, notes: tens of KB) goes to a file; stdout's LAST line is a compact record the
@@ -1067,7 +1190,7 @@ def _leg(rec):
     if isinstance(c, dict):
         out["cpu_qps"] = _rnd(c.get("value")); out["parity_mismatches"] = c.get("parity_mismatches")
         out["parity_checked"] = c.get("parity_checked_queries")
-    for k in ("recall_at_10_vs_exact_flat", "recall_at_10_vs_oracle_ivfpq", "rows", "identical_to_exact_kernels", "expansions_per_query"):
+    for k in ("recall_at_10_vs_exact_flat", "recall_at_10_vs_oracle_ivfpq", "rows", "identical_to_exact_kernels", "expansions_per_query", "identical_to_the_replica_results_for_batch_0"):
         if k in rec:
             out[k] = _rnd(rec[k])
     return out
@@ -1081,10 +1204,31 @@ def compact_line(full):
     out["dtype"] = "int8 MFMA screening (i32 accumulate) + exact f32 rescoring: returned scores are f32, bit-identical to the CPU path"
     out["data"] = full.get("data")
     cfg = full.get("config") or {}
-    out["config"] = {k: cfg.get(k) for k in ("workload", "rows", "dim", "batch", "k", "metric", "sharding") if k in cfg}
+    out["config"] = {k: cfg.get(k) for k in ("workload", "rows", "dim", "batch", "k", "metric", "sharding", "shard_mode", "layout") if k in cfg}
     out["timing"] = {"regions": (full.get("timing") or {}).get("regions"), "reported": "median region", "region_ms": (full.get("timing") or {}).get("region_ms")}
     out["roofline"] = _roof(full.get("roofline"))
+    if isinstance(out["roofline"], dict):
+        # the other legs' dominant-kernel fractions ride inside `roofline` (the part of the line every consumer keeps): HBM fraction unless named otherwise
+        lf = {}
+        for b in ("batch1", "batch64", "batch256"):
+            r_ = ((full.get("flat_l2") or {}).get(b) or {}).get("roofline") if isinstance(full.get("flat_l2"), dict) else None
+            if isinstance(r_, dict):
+                lf[f"flat_l2_{b}"] = _rnd(r_.get("frac"))
+        for nm in ("ivfpq", "ivfpq_uniform", "ivfpq10m"):
+            r_ = (full.get(nm) or {}).get("roofline") if isinstance(full.get(nm), dict) else None
+            if isinstance(r_, dict):
+                lf[f"{nm}_adc"] = _rnd(r_.get("frac")); lf[f"{nm}_adc_lds"] = _rnd(r_.get("lds_frac_of_measured_ceiling"))
+        if lf:
+            out["roofline"]["other_legs_frac"] = lf
     out["cpu_baseline"] = _cpu(full.get("cpu_baseline"))
+    if isinstance(full.get("parity"), dict):
+        out["parity"] = {k: full["parity"].get(k) for k in ("parity_checked_queries", "parity_mismatches")}
+    if isinstance(full.get("sharded_rows"), dict):
+        sr = full["sharded_rows"]
+        out["sharded_rows"] = {"qps": _rnd(sr.get("qps")), "ms_per_step": _rnd(sr.get("ms_per_step")), "scaling": "strong", "sharding": sr.get("sharding"),
+                               "sustained_qps": _rnd((sr.get("sustained") or {}).get("qps")), "single_stream_qps": _rnd((sr.get("single_stream") or {}).get("qps")),
+                               "identical_to_the_replica_results_for_batch_0": sr.get("identical_to_the_replica_results_for_batch_0"),
+                               "scan_frac": _rnd((sr.get("roofline") or {}).get("frac"))}
     out["lanes"] = full.get("execution_lanes"); out["batches_in_flight"] = full.get("batches_in_flight")
     out["note_overlap"] = "value: `batches_in_flight` batches on `lanes` streams (kernels of different batches overlap); single_stream_qps: 1 lane, 1 batch in flight"
     if isinstance(full.get("single_stream"), dict):
@@ -1098,7 +1242,7 @@ def compact_line(full):
     full = dict(full)
     if isinstance(full.get("hnsw"), dict) and isinstance(full["hnsw"].get("navigable"), dict):
         full["hnsw_navigable"] = full["hnsw"]["navigable"]
-    for name in ("c1", "flat_l2", "ivfpq", "ivfpq_uniform", "ivfpq10m", "hnsw", "hnsw_navigable", "hybrid"):
+    for name in ("c1", "flat_l2", "ivfpq", "ivfpq_sharded", "ivfpq_uniform", "ivfpq10m", "ivfpq10m_throughput", "hnsw", "hnsw_navigable", "hybrid"):
         rec = full.get(name)
         if not isinstance(rec, dict):
             continue

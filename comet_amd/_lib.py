@@ -149,6 +149,8 @@ def load() -> C.CDLL:
         "comet_comm_sync": (i32, [p]),
         "comet_index_fetch_vectors": (i32, [p, p, i32, p]),
         "comet_index_set_shard": (i32, [p, i32, i32]),
+        "comet_index_get_list_owners": (i32, [p, p, i32]),
+        "comet_index_set_list_owners": (i32, [p, p, i32]),
         "comet_index_search_sharded_async": (i32, [p, p, p, i32, C.POINTER(SearchParams), p, p, p, i32, C.POINTER(u64)]),
         "comet_index_search_sharded_wait": (i32, [p, p, u64, i32]),
         "comet_index_write_to": (i32, [p, WRITE_CB, p, C.POINTER(i64)]),

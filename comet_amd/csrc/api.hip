@@ -99,12 +99,13 @@ int comet_memcpy_d2h(comet_ctx* c, void* d, const void* s, size_t bytes) {
     return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->d2h(d, s, bytes); HIP_CHECK(hipStreamSynchronize(c->stream)); return COMET_OK; });
 }
 int comet_synth_fill_dev(comet_ctx* c, uint64_t seed, uint64_t offset, uint64_t n, float* out_dev) {
-    return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); launch_synth_fill(c, seed, offset, n, out_dev); return COMET_OK; });
+    // enqueue-only on lane 0 (no quiesce: generators run beside searches in flight); the fence makes a later asynchronous search on lanes 1.. start behind it
+    return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->switch_lane(0); launch_synth_fill(c, seed, offset, n, out_dev); if (c->async_seen) c->fence_lane0(); return COMET_OK; });
 }
 
 int comet_synth_mixture_dev(comet_ctx* c, uint64_t seed, int32_t n_centers, float sigma, int32_t n_sub, float sigma_noise, uint64_t row_base,
                             uint64_t n_rows, int32_t dim, float* out_dev) {
-    return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); launch_synth_mixture(c, seed, n_centers, sigma, n_sub, sigma_noise, row_base, n_rows, dim, out_dev); return COMET_OK; });
+    return guarded([&] { std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->switch_lane(0); launch_synth_mixture(c, seed, n_centers, sigma, n_sub, sigma_noise, row_base, n_rows, dim, out_dev); if (c->async_seen) c->fence_lane0(); return COMET_OK; });
 }
 
 int comet_ctx_set_lanes(comet_ctx* c, int32_t lanes) {
@@ -485,8 +486,30 @@ int comet_index_set_shard(comet_index* idx, int32_t rank, int32_t world) {
         if (idx->kind != COMET_KIND_IVF && idx->kind != COMET_KIND_IVFPQ) COMET_FAIL(COMET_ERR_UNSUPPORTED, "list sharding applies to IVF / IVFPQ indexes (shard Flat / PQ rows on the caller's side)");
         if (idx->size() != 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "set the shard before adding vectors");
         std::lock_guard<std::recursive_mutex> lk(idx->c->mu);
-        idx->shard_rank = rank; idx->shard_world = world;
+        idx->shard_rank = rank; idx->shard_world = world; idx->owners_checked_on = nullptr;
         idx->assign_list_owners();          // trained already: lists dealt by their training-set lengths (before training: at the end of Train)
+        return (int)COMET_OK;
+    });
+}
+// The placement (which rank owns which list) is host-side state derived from training; it is not part of the reference's on-disk layouts. A host that
+// checkpoints a sharded index saves it next to the shard files (get) and hands it to every rank that loads one (set, before the first Add after the load).
+int comet_index_get_list_owners(const comet_index* idx, int32_t* out_owners, int32_t n_lists) {
+    return guarded([&] {
+        if (idx->kind != COMET_KIND_IVF && idx->kind != COMET_KIND_IVFPQ) COMET_FAIL(COMET_ERR_UNSUPPORTED, "list sharding applies to IVF / IVFPQ indexes");
+        if (n_lists < 0 || (n_lists > 0 && !out_owners)) COMET_FAIL(COMET_ERR_INVALID_ARG, "bad owner array");
+        std::lock_guard<std::recursive_mutex> lk(idx->c->mu);
+        for (int32_t l = 0; l < n_lists; l++) out_owners[l] = idx->shard_world > 1 ? idx->owner_of(l) : 0;
+        return (int)COMET_OK;
+    });
+}
+int comet_index_set_list_owners(comet_index* idx, const int32_t* owners, int32_t n_lists) {
+    return guarded([&] {
+        if (idx->kind != COMET_KIND_IVF && idx->kind != COMET_KIND_IVFPQ) COMET_FAIL(COMET_ERR_UNSUPPORTED, "list sharding applies to IVF / IVFPQ indexes");
+        if (idx->shard_world <= 1) COMET_FAIL(COMET_ERR_INVALID_ARG, "set the shard (comet_index_set_shard) before the placement");
+        if (idx->n_lists() != n_lists || !owners) COMET_FAIL(COMET_ERR_INVALID_ARG, "the placement must name an owner for each of the index's %d lists", idx->n_lists());
+        for (int32_t l = 0; l < n_lists; l++) if (owners[l] < 0 || owners[l] >= idx->shard_world) COMET_FAIL(COMET_ERR_INVALID_ARG, "list %d: owner %d is not a rank of %d", l, owners[l], idx->shard_world);
+        std::lock_guard<std::recursive_mutex> lk(idx->c->mu);
+        idx->train_counts.clear(); idx->list_owner.assign(owners, owners + n_lists); idx->owners_checked_on = nullptr;
         return (int)COMET_OK;
     });
 }

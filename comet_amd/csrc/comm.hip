@@ -70,6 +70,9 @@ struct comet_comm {
     void* comm = nullptr;
     hipStream_t xstream = nullptr;       // exchange + merge (+ the bound all-reduce of sharded IVFPQ searches): every collective is issued here
     hipEvent_t bound_a = nullptr, bound_b = nullptr;
+    int exch_done = 0;                   // bound exchanges issued so far by the search being enqueued (a failing search owes its peers the rest)
+    DevBuf idle_tq;                      // +inf bounds a failed search contributes
+    uint64_t owners_checked = 0;         // fingerprint of the last list placement the ranks compared (0: none yet)
     DevBuf scalar;                       // small device scratch for barrier / all-reduce
     struct Slot {
         bool active = false; uint64_t ticket = 0, search_ticket = 0;
@@ -79,6 +82,8 @@ struct comet_comm {
                                          // exchange stream while the context's stream is already recycling the scratch arena for the next search
         uint32_t* out_ids = nullptr; float* out_scores = nullptr; int32_t* out_counts = nullptr;
         hipEvent_t searched = nullptr, merged = nullptr;
+        int failed = 0; std::string why; // the local search threw after the slot was taken: this rank still joins every collective of the batch (its block carries
+                                         // counts = -code, which the merge hands to every rank), _wait reports the error here
     };
     static constexpr int kSlots = 4;
     Slot slots[kSlots];
@@ -135,16 +140,21 @@ int comet_comm_destroy(comet_comm* cm) {
 int comet_comm_rank(const comet_comm* cm) { return cm->rank; }
 int comet_comm_world(const comet_comm* cm) { return cm->world; }
 
+// host-value all-reduce on the exchange stream (context mutex held): op NCCL_MAX / NCCL_MIN / NCCL_SUM; returns when every rank's value is in
+static double allreduce_host(comet_comm* cm, double v, int op) {
+    double* d = cm->scalar.as<double>();
+    HIP_CHECK(hipMemcpyAsync(d, &v, 8, hipMemcpyHostToDevice, cm->xstream));
+    RCCL_CHECK(rccl().AllReduce(d, d + 1, 1, NCCL_FLOAT64, op, cm->comm, cm->xstream));
+    HIP_CHECK(hipMemcpyAsync(&v, d + 1, 8, hipMemcpyDeviceToHost, cm->xstream));
+    HIP_CHECK(hipStreamSynchronize(cm->xstream));
+    return v;
+}
 // all ranks: *inout = max over ranks (op 0) or sum over ranks (op 1) of a host double; blocks until complete (a barrier).
 int comet_comm_allreduce_f64(comet_comm* cm, double* inout, int32_t op) {
     return guarded([&] {
         Ctx* c = cm->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind();
         c->quiesce_all();                                                 // everything enqueued so far on the search streams is part of "before the barrier"
-        double* d = cm->scalar.as<double>();
-        HIP_CHECK(hipMemcpyAsync(d, inout, 8, hipMemcpyHostToDevice, cm->xstream));
-        RCCL_CHECK(rccl().AllReduce(d, d + 1, 1, NCCL_FLOAT64, op == 0 ? NCCL_MAX : NCCL_SUM, cm->comm, cm->xstream));
-        HIP_CHECK(hipMemcpyAsync(inout, d + 1, 8, hipMemcpyDeviceToHost, cm->xstream));
-        HIP_CHECK(hipStreamSynchronize(cm->xstream));
+        *inout = allreduce_host(cm, *inout, op == 0 ? NCCL_MAX : NCCL_SUM);
         return (int)COMET_OK;
     });
 }
@@ -157,9 +167,24 @@ int comet_index_search_sharded_async(comet_index* idx, comet_comm* cm, const flo
         if (!p || B <= 0 || k_cap <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "bad batch size / k_cap");
         if (idx->c != cm->c) COMET_FAIL(COMET_ERR_INVALID_ARG, "index and communicator live on different contexts");
         Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind();
+        // A list-sharded index: every rank must deal the lists to the ranks the same way (the placement comes from host-side training state, which a rank that
+        // LOADED its quantisers does not have — comet_index_set_list_owners). The first sharded search of an index on a communicator compares a fingerprint of
+        // the placement over the ranks (two blocking all-reduces, once): ranks that disagree would own some lists twice and others not at all, silently.
+        if (cm->world > 1 && idx->shard_world > 1 && idx->owners_checked_on != cm) {
+            if (idx->shard_world != cm->world || idx->shard_rank != cm->rank)
+                COMET_FAIL(COMET_ERR_INVALID_ARG, "index is shard %d of %d, the communicator is rank %d of %d", idx->shard_rank, idx->shard_world, cm->rank, cm->world);
+            const double fp = (double)(idx->owners_fingerprint() & ((1ull << 52) - 1));
+            const double hi = allreduce_host(cm, fp, NCCL_MAX), lo = allreduce_host(cm, fp, NCCL_MIN);
+            if (hi != lo) COMET_FAIL(COMET_ERR_INVALID_ARG, "the ranks of this communicator disagree on which rank owns which inverted list (placement fingerprints %.0f .. %.0f): "
+                                                            "train every rank on the same vectors or hand every rank the same placement (comet_index_set_list_owners)", lo, hi);
+            idx->owners_checked_on = cm;
+        }
         // every other sharded search of an index on the context's second lane, like comet_index_search_dev_async: a rank's
         // short kernels (query preparation, post stage, coarse ranking) are the part of its step that does not shrink with the shard
         struct LaneBack { Ctx* c; ~LaneBack() { if (c->cur_lane != 0) { c->mark_dirty(); c->switch_lane(0); } } } lane_back{c};
+        // the first asynchronous search of the context (same sequence as api.hip's CallGuard(c, lane)): everything lane 0 holds so far — the queries'
+        // upload or generation — is what a search on lanes 1.. must start behind; from here on non-search calls keep the fence current
+        if (!c->async_seen) { c->switch_lane(0); c->fence_lane0(); c->async_seen = true; }
         { const int m = std::min(c->lanes, idx->max_lanes()); c->switch_lane(m > 1 ? (idx->lane_toggle = (idx->lane_toggle + 1) % m) : 0); }
         c->scratch_reset();
         c->follow_lane0();          // lanes 1..: behind the non-search work lane 0 was last given (the queries' upload / generation)
@@ -188,9 +213,33 @@ int comet_index_search_sharded_async(comet_index* idx, comet_comm* cm, const flo
                 RCCL_CHECK(rccl().AllReduce(tq, tq, (size_t)n, NCCL_FLOAT32, NCCL_MIN, m->comm, m->xstream));
                 HIP_CHECK(hipEventRecord(m->bound_b, m->xstream));
                 HIP_CHECK(hipStreamWaitEvent(m->c->stream, m->bound_b, 0));
+                m->exch_done++;
             };
         }
-        s->search_ticket = idx->search_begin(queries_dev, B, *p, pids, psc, pcn, k_cap);
+        // From here on the peers are (or will be) inside this batch's collectives: a failure of THIS rank's search (out of memory, a shape its kernels refuse)
+        // must not leave them waiting. The rank issues the bound exchanges it still owes (+inf: "no bound from me"), hands its peers a block whose counts are
+        // -code (the merge passes a negative count through to every rank), and reports the error from _wait.
+        int per = 0; const int owed = cm->world > 1 ? idx->sharded_exchanges(B, *p, k_cap, &per) : 0;
+        cm->exch_done = 0; s->failed = 0; s->why.clear(); s->search_ticket = 0;
+        auto failed_search = [&](int code, const std::string& msg) {
+            s->failed = code ? code : (int)COMET_ERR_HIP; s->why = msg;
+            if (cm->exch_done < owed && idx->bound_exchange) {
+                cm->idle_tq.reserve((size_t)std::max(B, 1) * 4, c->stream, 0);
+                HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)cm->idle_tq.p, 0x7F800000, (size_t)B, c->stream));
+                for (int e = cm->exch_done; e < owed; e++) { const int b0 = e * per; idx->bound_exchange(cm, cm->idle_tq.as<uint32_t>() + b0, std::min(per, B - b0)); }
+            }
+            HIP_CHECK(hipMemsetAsync(pids, 0, (size_t)2 * B * k_cap * 4, c->stream));
+            HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)pcn, (int)(-s->failed), (size_t)B, c->stream));
+        };
+        // test hook (read once): COMET_TEST_FAIL_SEARCH="rank:ticket" makes that rank's search with that ticket throw before it enqueues anything
+        static const std::pair<int, long> inject = [] { const char* e = getenv("COMET_TEST_FAIL_SEARCH"); int r = -1; long t = -1; if (e) sscanf(e, "%d:%ld", &r, &t); return std::make_pair(r, t); }();
+        try {
+            if (inject.first == cm->rank && inject.second == (long)cm->next_ticket) COMET_FAIL(COMET_ERR_UNSUPPORTED, "injected failure (COMET_TEST_FAIL_SEARCH)");
+            s->search_ticket = idx->search_begin(queries_dev, B, *p, pids, psc, pcn, k_cap);
+        }
+        catch (const StatusError& e) { failed_search(e.code, last_error()); }
+        catch (const HipError& h) { char m[384]; snprintf(m, sizeof(m), "HIP error %d (%s) in %s at %s:%d", (int)h.e, hipGetErrorString(h.e), h.what, h.file, h.line); failed_search(COMET_ERR_HIP, m); }
+        catch (const std::bad_alloc&) { failed_search(COMET_ERR_HIP, "host allocation failed"); }
         s->idx = idx; s->B = B; s->k_cap = k_cap; s->k = p->k; s->out_ids = out_ids_dev; s->out_scores = out_scores_dev; s->out_counts = out_counts_dev;
         HIP_CHECK(hipEventRecord(s->searched, c->stream));          // the exchange of this batch depends on THIS search only, not on later ones
         s->ticket = cm->next_ticket++; s->active = true;
@@ -210,7 +259,7 @@ int comet_index_search_sharded_wait(comet_index* idx, comet_comm* cm, uint64_t t
         if (!s) { if (block) HIP_CHECK(hipStreamSynchronize(cm->xstream)); return (int)COMET_OK; }
         // waits for THIS search only (its event), not for later ones; a rare strict re-run of overflowed queries lands behind the
         // later searches on the stream, so the dependency is re-recorded in that case
-        if (idx->search_finish(s->search_ticket)) HIP_CHECK(hipEventRecord(s->searched, c->stream));
+        if (!s->failed && idx->search_finish(s->search_ticket)) HIP_CHECK(hipEventRecord(s->searched, c->stream));
         HIP_CHECK(hipStreamWaitEvent(cm->xstream, s->searched, 0));
         const size_t words = (size_t)2 * s->B * s->k_cap + s->B;
         {
@@ -224,6 +273,7 @@ int comet_index_search_sharded_wait(comet_index* idx, comet_comm* cm, uint64_t t
         HIP_CHECK(hipEventRecord(s->merged, cm->xstream));
         s->active = false;
         if (block) HIP_CHECK(hipEventSynchronize(s->merged));
+        if (s->failed) { const int code = s->failed; s->failed = 0; COMET_FAIL(code, "sharded search failed on rank %d (every rank's counts for the batch are %d): %s", cm->rank, -code, s->why.c_str()); }
         return (int)COMET_OK;
     });
 }

@@ -49,6 +49,18 @@ struct comet_index {
     std::vector<int32_t> train_counts, list_owner;
     uint64_t guard1 = kGuard;
     int owner_of(int32_t l) const { return list_owner.empty() ? l % shard_world : list_owner[(size_t)l]; }
+    // what the ranks of a communicator compare before the first sharded search (comm.hip): FNV-1a over (world, the placement; "l % world" when there is none)
+    const void* owners_checked_on = nullptr;
+    uint64_t owners_fingerprint() const {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](uint32_t v) { for (int b = 0; b < 4; b++) { h ^= (v >> (8 * b)) & 0xFF; h *= 1099511628211ull; } };
+        mix((uint32_t)shard_world); mix((uint32_t)list_owner.size());
+        for (int32_t o : list_owner) mix((uint32_t)o);
+        return h;
+    }
+    // the placement is not part of the reference's on-disk layouts: an index that loads its quantisers (read_from) starts without one (l % world on every
+    // rank that loaded) until the host hands it the placement it saved (comet_index_get_list_owners / _set_list_owners)
+    void forget_placement() { train_counts.clear(); list_owner.clear(); owners_checked_on = nullptr; }
     void assign_list_owners() {
         list_owner.clear();
         if (shard_world <= 1 || train_counts.empty()) return;
@@ -84,6 +96,9 @@ struct comet_index {
     // set by comet_index_search_sharded_async for the duration of the call: all-reduce(min) of n floats on the context's stream across the
     // ranks of the communicator (the stage-1 bound exchange of the sharded two-stage IVFPQ search); null outside a sharded search
     void (*bound_exchange)(void* user, uint32_t* tq, int n) = nullptr; void* bound_exchange_user = nullptr;
+    // how many bound exchanges a sharded search of B queries issues on EVERY rank (whatever the rank's own lists look like), *per = queries per exchange:
+    // a rank whose search fails half way still owes its peers the rest of them (comm.hip)
+    virtual int sharded_exchanges(int /*B*/, const comet_search_params& /*p*/, int /*k_cap*/, int* per) const { if (per) *per = 0; return 0; }
 
     virtual ~comet_index() {
         for (auto& r : done_ring) if (r.ev) (void)hipEventDestroy(r.ev);
@@ -91,6 +106,7 @@ struct comet_index {
     }
     virtual int64_t size() const = 0;
     virtual int default_nprobes() const { return 0; }
+    virtual int n_lists() const { return 0; }
     virtual void train_dev(const float* /*vecs_dev*/, int64_t /*n*/) {}   // VectorIndex.Train; no-op for Flat (flat_index.go:150)
     // add n rows already on device (dense n x dim); returns rows added; sets *zero_at = index of first
     // zero-norm vector (or -1). normalized_dev (nullable): receives the preprocessed rows (dense).

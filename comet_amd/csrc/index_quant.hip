@@ -209,6 +209,7 @@ static void note_training(comet_index* ix, Ctx* c, const int32_t* assign_dev, in
 // ------------------------------------------------------------------------------------------------
 struct IVFIndex : comet_index {
     int nlist = 0;
+    int n_lists() const override { return nlist; }
     DevBuf centroids;   // nlist x ld
     DevBuf V;           // arrival-order rows, n x ld
     ListLayout lay;
@@ -363,6 +364,7 @@ struct IVFIndex : comet_index {
         const std::vector<uint32_t> del = read_bitmap(s);
         // commit
         trained = tr;
+        forget_placement();       // host-side training state, not in the stream: stale counts of an earlier Train must not outlive it (every loader falls back to l % world)
         std::swap(centroids.p, ncent.p); std::swap(centroids.cap, ncent.cap);
         std::swap(V.p, nV.p); std::swap(V.cap, nV.cap);
         lay.ids.swap(nlay.ids); lay.list_of.swap(nlay.list_of); lay.id_count.swap(nlay.id_count); lay.n = nlay.n; lay.dirty = true;
@@ -701,6 +703,7 @@ comet_index* make_ivf(Ctx* c, int dim, int metric, int nlist) {
 struct PQFamilyIndex : comet_index {
     bool ivf = false;
     int nlist = 1, M = 0, nbits = 0, Ksub = 0, dsub = 0, M4 = 0;
+    int n_lists() const override { return nlist; }
     DevBuf centroids;   // nlist x ld (IVFPQ only)
     DevBuf codebooks;   // M x Ksub x dsub dense fp32 (pq_index.go:99-101 layout)
     DevBuf codes_arr;   // arrival-order codes, n x M4 words (byte m of a row = code[m])
@@ -832,6 +835,12 @@ struct PQFamilyIndex : comet_index {
                                 lay.list_len.as<int32_t>(), nlist, list_rmax.as<float>());
         }
         HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    int sharded_exchanges(int B, const comet_search_params& p, int k_cap, int* per) const override {
+        if (per) *per = 0;
+        static const bool fuse_off = getenv("COMET_ADC_NO_FUSE") != nullptr;
+        if (!ivf || shard_world <= 1 || fuse_off || p.mode == 1 || !(p.k >= 1 && p.k <= ADC_FILTER_MAX_K && p.k <= k_cap)) return 0;
+        return adc_exchange_plan(M, Ksub, sanitize_nprobes(p.nprobes, nlist), B, nlist, per);
     }
     // pqIndexSearch.searchSingleQuery pq_index_search.go:218-325 / ivfpqIndexSearch.searchSingleQuery ivfpq_index_search.go:231-341
     void search_dev(const float* queries_dev, int B, const comet_search_params& p, uint32_t* out_ids, float* out_scores,
@@ -1028,6 +1037,7 @@ struct PQFamilyIndex : comet_index {
         }
         // commit
         trained = tr;
+        forget_placement();       // host-side training state, not in the stream: stale counts of an earlier Train must not outlive it (every loader falls back to l % world)
         std::swap(centroids.p, ncent.p); std::swap(centroids.cap, ncent.cap);
         std::swap(codebooks.p, ncb.p); std::swap(codebooks.cap, ncb.cap);
         std::swap(codes_arr.p, ncodes.p); std::swap(codes_arr.cap, ncodes.cap);

@@ -112,6 +112,9 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
                      int np, const int32_t* seg_off, const uint8_t* elig, int B, int nlist, int max_list_len, float* D, int64_t ldD, const AdcFilter* flt = nullptr);
 // the exchanges launch_adc_scan would issue for B queries, with +inf bounds: for a rank of a sharded search whose shard has no candidate (flt->tq: B words)
 void adc_exchange_idle(Ctx* c, const AdcFilter* flt, int M, int Ksub, int np, int B, int nlist);
+// the bound exchanges a two-stage search with an exchange callback issues for a batch of B queries: their number, *per = queries per exchange (the last one
+// carries the rest). Depends only on (M, Ksub, np, B, nlist): the same on every rank of a sharded search. 0: the search is single-stage for this shape.
+int adc_exchange_plan(int M, int Ksub, int np, int B, int nlist, int* per);
 
 // ---- kernels_fast.hip (MFMA fast path of the Flat scan) ------------------------------------------
 int flat_fast_tile_rows();

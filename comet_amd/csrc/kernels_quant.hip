@@ -1427,6 +1427,13 @@ void adc_exchange_idle(Ctx* c, const AdcFilter* flt, int M, int Ksub, int np, in
     const int qc = (int)adc_sub_batch(M, Ksub, np, B);
     for (int b0 = 0; b0 < B; b0 += qc) flt->exchange(flt->exchange_user, flt->tq + b0, std::min(qc, B - b0));
 }
+int adc_exchange_plan(int M, int Ksub, int np, int B, int nlist, int* per) {
+    AdcFilter two{}; two.one_stage = 0;
+    if (B <= 0 || np <= 0 || !adc_two_stage(&two, np, nlist)) { if (per) *per = 0; return 0; }
+    const int qc = (int)adc_sub_batch(M, Ksub, np, B);
+    if (per) *per = qc;
+    return (B + qc - 1) / qc;
+}
 void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* centroids, const float* codebooks, int M, int Ksub, int dsub,
                      const uint32_t* codes, int M4, const int64_t* list_base, const int32_t* list_len, const uint32_t* probe_list, int ldp,
                      int np, const int32_t* seg_off, const uint8_t* elig, int B, int nlist, int max_list_len, float* D, int64_t ldD, const AdcFilter* flt) {

@@ -649,8 +649,19 @@ class _TrainedIndex(VectorIndex):
             raise RuntimeError(self.not_trained_msg)
 
     def set_shard(self, rank: int, world: int) -> None:
-        """Multi-GPU list sharding (IVF / IVFPQ): keep only the members of lists l with l % world == rank (before the first add)."""
+        """Multi-GPU list sharding (IVF / IVFPQ): keep only the members of the lists this rank owns (before the first add). Lists are dealt by their
+        training-set lengths (the same on every rank that trained); a rank that loaded its quantisers instead needs `set_list_owners`."""
         check(self.lib.comet_index_set_shard(self.h, int(rank), int(world)))
+
+    def list_owners(self, nlist: int) -> np.ndarray:
+        """owner rank of every inverted list: host-side state a sharded checkpoint has to carry beside the shard files"""
+        out = np.zeros(nlist, dtype=np.int32)
+        check(self.lib.comet_index_get_list_owners(self.h, out.ctypes.data_as(C.c_void_p), int(nlist)))
+        return out
+
+    def set_list_owners(self, owners) -> None:
+        o = np.ascontiguousarray(owners, dtype=np.int32)
+        check(self.lib.comet_index_set_list_owners(self.h, o.ctypes.data_as(C.c_void_p), int(len(o))))
 
     def centroids(self, nlist: int) -> np.ndarray:
         out = np.empty((nlist, self.dim), dtype=np.float32)

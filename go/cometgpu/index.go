@@ -214,6 +214,27 @@ func (ix *vectorIndex) SetShard(rank, world int) error {
 	return lastError(C.comet_index_set_shard(ix.h, C.int32_t(rank), C.int32_t(world)))
 }
 
+// ListOwners returns the rank owning each inverted list (comet_index_get_list_owners): host-side state that is not part of the
+// reference's on-disk layouts — a sharded checkpoint saves it beside the shard files.
+func (ix *vectorIndex) ListOwners(nlist int) ([]int32, error) {
+	out := make([]int32, nlist)
+	if nlist == 0 {
+		return out, nil
+	}
+	if err := lastError(C.comet_index_get_list_owners(ix.h, (*C.int32_t)(unsafe.Pointer(&out[0])), C.int32_t(nlist))); err != nil {
+		return nil, err
+	}
+	return out, nil
+}
+
+// SetListOwners hands a rank that LOADED its quantisers (ReadFrom) the placement the ranks that trained derived (comet_index_set_list_owners).
+func (ix *vectorIndex) SetListOwners(owners []int32) error {
+	if len(owners) == 0 {
+		return nil
+	}
+	return lastError(C.comet_index_set_list_owners(ix.h, (*C.int32_t)(unsafe.Pointer(&owners[0])), C.int32_t(len(owners))))
+}
+
 // nodeVectors = lookupNodeVectors (flat_index_search.go:171-196): the stored vectors behind WithNode(ids...).
 func (ix *vectorIndex) nodeVectors(ids []uint32) ([][]float32, error) {
 	if len(ids) == 0 {

@@ -294,13 +294,25 @@ COMET_API int comet_comm_sync(comet_comm* comm);          /* wait for the contex
 /* Sharded search. `_async` enqueues this rank's shard search and returns a ticket (up to 4 in flight); `_wait` makes the
  * local results final, enqueues all-gather + merge on the exchange stream and — if block != 0 — returns when the MERGED
  * rows (same layout and meaning as comet_index_search_dev's outputs) are in the output buffers; with block == 0 they are
- * final after the next blocking wait / comet_comm_sync. Every rank must issue the same sequence of calls. */
+ * final after the next blocking wait / comet_comm_sync. Every rank must issue the same sequence of calls.
+ * A rank whose own shard search fails after the batch was entered (out of memory, a shape its kernels refuse) still takes
+ * part in every collective of the batch: `_async` returns COMET_OK there, the rank's block carries out_counts = -code for
+ * every query — which the merge hands to EVERY rank — and its `_wait` returns the error. No rank is left waiting. */
 /* List sharding for IVF / IVFPQ (call before the first Add, after or before Train; every rank trains on the same vectors —
  * the GPU k-means is deterministic, so centroids and codebooks are replicated bit for bit — and is handed EVERY vector):
- * this rank keeps only the members of lists l with l % world == rank. All ranks rank all centroids and pick the same
- * nprobe lists; lists a rank does not own are empty there, so its table build, scan and selection cover 1/world of the
- * work. Remove / filters act on the local members (a Remove of an id stored on another rank reports NOT_FOUND here). */
+ * this rank keeps only the members of the lists it owns. Lists are dealt to the ranks BY LENGTH: longest first to the rank
+ * with the fewest estimated rows (LPT over the members per list seen in training — identical on every rank because training
+ * is; before training, and on a rank that loaded its quantisers with ReadFrom instead of training, list l belongs to rank
+ * l % world). All ranks rank all centroids and pick the same nprobe lists; lists a rank does not own are empty there, so
+ * its table build, scan and selection cover 1/world of the work. Remove / filters act on the local members (a Remove of an
+ * id stored on another rank reports NOT_FOUND here).
+ * The placement is host-side state, NOT part of the reference's on-disk layouts: a host that checkpoints a sharded index
+ * saves comet_index_get_list_owners() next to the shard files and calls comet_index_set_list_owners() on every rank that
+ * loads one. The first sharded search of an index on a communicator compares a fingerprint of the placement across the
+ * ranks and fails on every rank (COMET_ERR_INVALID_ARG) if they disagree. */
 COMET_API int comet_index_set_shard(comet_index* idx, int32_t rank, int32_t world);
+COMET_API int comet_index_get_list_owners(const comet_index* idx, int32_t* out_owners, int32_t n_lists);   /* out_owners[l] = rank owning list l */
+COMET_API int comet_index_set_list_owners(comet_index* idx, const int32_t* owners, int32_t n_lists);       /* after set_shard, before the first Add */
 COMET_API int comet_index_search_sharded_async(comet_index* idx, comet_comm* comm, const float* queries_dev, int32_t B,
                                                const comet_search_params* p, uint32_t* out_ids_dev, float* out_scores_dev,
                                                int32_t* out_counts_dev, int32_t k_cap, uint64_t* out_ticket);

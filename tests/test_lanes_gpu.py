@@ -109,3 +109,32 @@ def test_set_lanes_bounds_and_single_lane(ctx):
         ctx.set_lanes(4)
     for p in [qd] + [x for o in outs for x in o]:
         ctx.free(p)
+
+
+def test_async_search_starts_behind_synth_fill_on_lane0(ctx):
+    """The header's own example (include/comet_gpu.h, comet_ctx_fence): a generator call that only ENQUEUES on lane 0 (comet_synth_fill_dev holds no CallGuard)
+    followed at once by asynchronous searches that land on lanes 1..3 — the searches must read the finished queries. The buffer is refilled many times with a
+    large fill in front (the race needs the generator still running when the search is enqueued); every result is compared with a blocking search of the
+    same queries generated on the host."""
+    n, d, B, k = 20000, 64, 64, 5
+    X = synth(191, n, d)
+    g = make(ctx, "ivfpq", d, X)
+    big = ctx.alloc(64 << 20)
+    qd = ctx.alloc(B * d * 4)
+    outs = [(ctx.alloc(B * k * 4), ctx.alloc(B * k * 4), ctx.alloc(B * 4)) for _ in range(4)]
+    ctx.set_lanes(4)
+    try:
+        g.search_wait(g.search_batch_dev_async(qd, B, k, *outs[0], k, nprobes=4))        # the context has seen an asynchronous search: lanes exist
+        for rnd in range(12):
+            seed = 500 + rnd
+            want = g.search_batch(synth(seed, B, d), k, nprobes=4)
+            ctx.synth_fill(big, 7, 0, (64 << 20) // 4)          # ~10 us .. 100 us of generator work queued on lane 0
+            ctx.synth_fill(qd, seed, 0, B * d)                  # then the queries, still only enqueued
+            ts = [g.search_batch_dev_async(qd, B, k, *o, k, nprobes=4) for o in outs]    # lanes 1, 2, 3, 0
+            for t, o in zip(ts, outs):
+                g.search_wait(t)
+                same((ctx.download(o[0], (B, k), np.uint32), ctx.download(o[1], (B, k), np.float32), ctx.download(o[2], (B,), np.int32)), want)
+    finally:
+        ctx.set_lanes(4)
+    for p in [qd, big] + [x for o in outs for x in o]:
+        ctx.free(p)
