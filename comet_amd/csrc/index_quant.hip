@@ -178,6 +178,7 @@ static bool coarse_probe(Ctx* c, int metric, const float* centroids, int nlist, 
     float* psc = c->salloc<float>((size_t)B * np);
     int32_t* pcnt = c->salloc<int32_t>(B);
     launch_select_topk(c, Dc, ldDc, B, nlist, nullptr, 0.0f, np, probe_list, psc, pcnt, np);
+    launch_probe_complete(c, probe_list, np, pcnt, B);
     return false;
 }
 static int sanitize_nprobes(int nprobes, int nlist) { return (nprobes <= 0 || nprobes > nlist) ? nlist : nprobes; }  // ivf_index_search.go:233-236

@@ -83,6 +83,7 @@ void launch_pq_bound_tab3(Ctx* c, const float* codebooks, int M, int dsub, float
 void launch_pq_list_rmax(Ctx* c, const float* codebooks, int M, int Ksub, int dsub, const uint32_t* codes_arr, int M4, const uint32_t* row_of_slot,
                          const int64_t* list_base, const int32_t* list_len, int nlist, float* rmax);
 void launch_interleave_codes(Ctx* c, const uint32_t* src_words, int M4, const uint32_t* row_of_slot, int64_t nslots, uint32_t* dst);
+void launch_probe_complete(Ctx* c, uint32_t* probe_list, int np, const int32_t* pcnt, int B);   // queries the exact coarse ranking gave fewer than np lists: lists 0 .. np-1
 void launch_probe_segments(Ctx* c, const uint32_t* probe_list, int ldp, const int32_t* probe_cnt, const int32_t* list_len, int B, int np,
                            int32_t* seg_off, int32_t* cnts);
 bool launch_order_pairs(Ctx* c, const uint32_t* probe_list, int ldp, int np, const int32_t* seg_off, int n_pairs, int nlist, uint32_t* order,

@@ -526,9 +526,12 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(const float* __restric
     }
     const float kappa = __uint_as_float(cq_key2f(kth));
     const float tau = kappa + 2.0f * E + 2.0e-6f * fabsf(kappa);
+    // a query with non-finite components has non-finite approximate distances: kappa / tau are NaN or +inf, `a <= tau` would admit nothing (or not the np
+    // the list needs) and the probe list would stay unwritten — every centroid is re-scored then (keys of NaN sort last, ties by index: deterministic)
+    const bool all_lists = !(fabsf(tau) < INFINITY);
     for (int l = t; l < nlist; l += 256) {
         const float a = __uint_as_float(cq_key2f(keys[l]));
-        if (a <= tau) list[atomicAdd(&s_n, 1)] = (unsigned)l;
+        if (all_lists || a <= tau) list[atomicAdd(&s_n, 1)] = (unsigned)l;
     }
     __syncthreads();
     const int ncand = s_n;

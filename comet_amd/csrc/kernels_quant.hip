@@ -319,6 +319,19 @@ __global__ __launch_bounds__(64) void probe_segments_kernel(const unsigned* __re
     }
     if (lane == 0) { seg_off[(long)q * (np + 1) + np] = run; cnts[q] = run; }
 }
+// The exact coarse ranking selects np of nlist distances; a distance whose bits equal the selection's EXCLUDED sentinel (0xFFFFFFFF: a NaN with that payload,
+// which only a query or centroid component with that very bit pattern produces) is dropped there, and the probe list would keep stale scratch beyond the
+// count. A query that got fewer than np lists probes lists 0 .. np-1 instead: valid, unique, deterministic (its distances are NaN whatever it probes).
+__global__ __launch_bounds__(64) void probe_complete_kernel(unsigned* __restrict__ probe_list, int np, const int* __restrict__ pcnt) {
+    const int q = blockIdx.x;
+    if (pcnt[q] >= np) return;
+    for (int p = threadIdx.x; p < np; p += 64) probe_list[(long)q * np + p] = (unsigned)p;
+}
+void launch_probe_complete(Ctx* c, uint32_t* probe_list, int np, const int32_t* pcnt, int B) {
+    if (B <= 0 || np <= 0) return;
+    probe_complete_kernel<<<dim3((unsigned)B), dim3(64), 0, c->stream>>>(probe_list, np, pcnt);
+    LAUNCH_CHECK();
+}
 void launch_probe_segments(Ctx* c, const uint32_t* probe_list, int ldp, const int32_t* probe_cnt, const int32_t* list_len, int B, int np,
                            int32_t* seg_off, int32_t* cnts) {
     if (B <= 0) return;
