@@ -289,6 +289,7 @@ __device__ __forceinline__ void hn_drain(HC* res, int nres, const HnswLds& L, Em
     bool tie = false;
     for (int i = lane; i < nres && !tie; i += 64) {
         const float di = res[i].d;
+        if (!(di == di)) { tie = true; break; }     // a NaN distance (non-finite query): ranks by counting would all be 0 — the serial pops are what the reference does
         for (int j = 0; j < nres; j++) if (j != i && res[j].d == di) { tie = true; break; }
     }
     if (__ballot(tie) == 0ull) {

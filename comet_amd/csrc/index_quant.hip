@@ -711,6 +711,17 @@ struct PQFamilyIndex : comet_index {
     DevBuf codes_il;    // compiled, block-interleaved
     DevBuf adc_stats;   // two-stage search counters (AdcFilter::stats), read by get_stat
     mutable bool stats_on = false;   // adc_* counters are collected (get_stat "adc_stats_on" / "adc_stats_off")
+    // Adaptive staging of the fused search (IVFPQ, one GPU). The two-stage search pays a lower-bound kernel and a second set of launches to remove the (query, list)
+    // pairs that cannot matter — 97 % of them on clustered data, NONE on data without cluster structure (SURVEY 8d's uniform rows: pairs_left_alive 1.0), where it
+    // is pure cost. Every kAutoEvery-th search runs two-stage with the counters on (a buffer of its own); their read-back is asynchronous (pinned slot + event,
+    // polled by later searches, never waited for); when more than half of the pairs behind the nearest lists survived, the searches in between run single-stage.
+    // Results are bit-identical in every mode (tests/test_quant_gpu.py), so the switch is invisible. Never on a list shard: the ranks' collectives must pair up.
+    static constexpr int64_t kAutoEvery = 32;
+    DevBuf auto_stats; int32_t* auto_host = nullptr; hipEvent_t auto_ev = nullptr; bool auto_pending = false, auto_one = false; int64_t auto_n = 0;
+    ~PQFamilyIndex() override {
+        if (auto_ev) { (void)hipEventSynchronize(auto_ev); (void)hipEventDestroy(auto_ev); }
+        if (auto_host) (void)hipHostFree(auto_host);
+    }
     DevBuf bound_tab3, bound_cmax2;   // the lower bound's transposed codebook (IVFPQ, Ksub == 256; rebuilt with the interleaved codes)
     DevBuf list_rmax;   // per list: upper bound on the norm of its members' decoded residuals (IVFPQ; rebuilt with the interleaved codes)
     bool il_dirty = true;
@@ -885,6 +896,7 @@ struct PQFamilyIndex : comet_index {
             const int qb = exchanging ? B : (int)std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(budget / ((size_t)ldD * (fuse ? 8 : 4)))));
             float* D = fuse ? nullptr : c->salloc<float>((size_t)qb * ldD);
             AdcFilter afl{};
+            bool auto_sample = false;
             if (fuse) {
                 afl.cand = c->salloc<unsigned long long>((size_t)qb * ldD); afl.cursor = c->salloc<int32_t>(qb); afl.tq = c->salloc<uint32_t>(qb); afl.K = p.k; afl.thr = p.threshold;
                 if (!adc_stats.p) { adc_stats.reserve(32, c->stream, 0); HIP_CHECK(hipMemsetAsync(adc_stats.p, 0, 32, c->stream)); }
@@ -903,6 +915,21 @@ struct PQFamilyIndex : comet_index {
                 afl.list_rmax = (ivf && !norm_bound_off && list_rmax.p) ? list_rmax.as<float>() : nullptr;
                 afl.bound_tab3 = (ivf && Ksub == 256 && bound_tab3.p) ? bound_tab3.as<float>() : nullptr; afl.bound_cmax2 = afl.bound_tab3 ? bound_cmax2.as<float>() : nullptr;
                 afl.one_stage = (p.mode == 1 || (shard_world > 2 && !afl.exchange)) ? 1 : 0;
+                static const bool auto_off = getenv("COMET_ADC_NO_AUTO_STAGE") != nullptr;
+                if (!auto_off && ivf && shard_world == 1 && p.mode == 0 && !stats_on && np >= 2) {
+                    if (auto_pending) {
+                        const hipError_t e = hipEventQuery(auto_ev);
+                        if (e == hipSuccess) { auto_pending = false; if (auto_host[1] > 0) auto_one = (int64_t)auto_host[0] * 2 > (int64_t)auto_host[1]; }
+                        else (void)hipGetLastError();
+                    }
+                    auto_sample = !auto_pending && (auto_n % kAutoEvery) == 0;
+                    auto_n++;
+                    if (auto_sample) {
+                        auto_stats.reserve(32, c->stream, 0);
+                        HIP_CHECK(hipMemsetAsync(auto_stats.p, 0, 32, c->stream));
+                        afl.stats = auto_stats.as<int32_t>();
+                    } else if (auto_one) afl.one_stage = 1;
+                }
             }
             for (int b0 = 0; b0 < B; b0 += qb) {
                 const int bn = std::min(qb, B - b0);
@@ -912,6 +939,12 @@ struct PQFamilyIndex : comet_index {
                 if (fuse) launch_select_composites(c, afl.cand, ldD, afl.cursor, bn, p.k, pos + (size_t)b0 * k_cap, out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);
                 else launch_select_topk(c, D, ldD, bn, Cmax, cnts + b0, p.threshold, p.k, pos + (size_t)b0 * k_cap,
                                         out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);
+            }
+            if (auto_sample) {      // the sampled search's counters travel to a pinned slot behind it; a later search polls the event
+                if (!auto_host) { HIP_CHECK(hipHostMalloc((void**)&auto_host, 32, hipHostMallocDefault)); HIP_CHECK(hipEventCreateWithFlags(&auto_ev, hipEventDisableTiming)); }
+                HIP_CHECK(hipMemcpyAsync(auto_host, auto_stats.p, 32, hipMemcpyDeviceToHost, c->stream));
+                HIP_CHECK(hipEventRecord(auto_ev, c->stream));
+                auto_pending = true;
             }
         } else {
             // nothing to scan on this rank (an empty shard): its peers still exchange their stage-1 bounds — take part with +inf

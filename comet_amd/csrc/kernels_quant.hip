@@ -409,6 +409,9 @@ void launch_finalize_probe(Ctx* c, const uint32_t* pos, int B, int k_cap, const 
 #ifndef ADC_LOADERS_N
 #define ADC_LOADERS_N 2
 #endif
+#ifndef ADC_WPE
+#define ADC_WPE 4            // waves per SIMD the scan kernel is compiled for (4: 128 registers per lane)
+#endif
 constexpr int ADC_THREADS = ADC_THREADS_N;
 constexpr int ADC_LOADERS = ADC_LOADERS_N;
 constexpr int ADC_WAVES = ADC_THREADS / 64 - ADC_LOADERS;       // the gathering waves (chains, code blocks and the epilogue are laid out over these)
@@ -423,6 +426,7 @@ constexpr int ADC_XCD_CHUNK = 4;                               // adjacent duos 
 constexpr int ADC_G = ADC_G_N;                                       // code words (4 subspaces each) per software-pipelined group
 constexpr int ADC_BUF_BYTES = ADC_BUF_KB * 1024;                       // one phase buffer; two of them in LDS
 constexpr unsigned ADC_HOLE = 0xFFFFFFFFu;
+constexpr int ADC_REFINE_MAX = 512;                                 // entries of a query's survivor row the bound refinement looks at
 constexpr int LUT_PAIRS_PER_WG = 32;
 constexpr int ORDER_MAX_LISTS = 36 * 1024;                     // counting-sort bins that fit in LDS
 typedef float f32x4q __attribute__((ext_vector_type(4)));
@@ -918,7 +922,17 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
                                                          unsigned* __restrict__ order, unsigned* __restrict__ slist, AdcRec* __restrict__ qitems, int qcap,
                                                          int* __restrict__ qcount, int* __restrict__ queues, unsigned* __restrict__ tq, int* __restrict__ cursor, int n_q, int lead,
                                                          const long* __restrict__ list_base, int stage, const unsigned char* __restrict__ dead, int* __restrict__ used,
-                                                         int* __restrict__ gstats /*nullable: [2] += 64-code blocks the items cover, [3] += items, [4] += (query, block) pairs, [5] += searches*/, int strict) {
+                                                         int* __restrict__ gstats /*nullable: [2] += 64-code blocks the items cover, [3] += items, [4] += (query, block) pairs, [5] += searches*/, int strict,
+                                                         unsigned long long* __restrict__ cand_init /*nullable*/, long ldD) {
+    // workgroups 1.. (launched only where a search begins: stage <= 1 of a fused-filter search) fill the first ADC_REFINE_MAX entries of every query's survivor
+    // row with all-ones: the scan's bound refinement reads a row while it is being appended to, and a slot not yet written must read as +inf
+    if (blockIdx.x > 0) {
+        if (!cand_init) return;
+        const int per_row = (int)min(ldD, (long)ADC_REFINE_MAX);
+        for (int qq = (int)blockIdx.x - 1; qq < n_q; qq += (int)gridDim.x - 1)
+            for (int e = threadIdx.x; e < per_row; e += 1024) cand_init[(long)qq * ldD + e] = ~0ull;
+        return;
+    }
     // stage (two-stage fused search, see launch_adc_scan): 0 = every pair; 1 = only every query's nearest non-empty list, which seeds the
     // bounds; 2 = the other pairs that the lower-bound test (pq_lb_kernel) left alive. Pairs outside the stage take no slot at all.
     // lead (fused filter, np >= 2): every query's NEAREST list (probe 0) gets a duo of its own in the first 2 * n_q slots, so that
@@ -1135,6 +1149,9 @@ struct AdcArgs {
     // cand[q * ldD + cursor[q]++] as (order-preserving key << 32 | position in the query's candidate row)
     unsigned long long* cand; int* cursor; unsigned* tq; int K; float thr;
     int prune;                  // fused filter: waves skip the remaining phases of an item once all their partial sums exceed the bounds
+    int refine;                 // fused filter: the bound is refined from the survivors' row (the caller filled the first ADC_REFINE_MAX entries of every row with ~0)
+    // tables built in LDS by the scanning workgroup (adc_scan_kernel<DSUB>): the queries, the coarse centroids (null: PQ, residual = query) and the codebooks
+    const float* Qp; const float* centroids /*PQ: a row of zeros*/; const float* codebooks; int ldq, Ksub, slist_is_list /*0: PQ, one list, the centroid row is row 0*/;
 };
 // The table slabs' LDS-DMA pieces are issued from inline asm (16 bytes per lane from sbase + voff to LDS byte address lds_addr + lane * 16,
 // non-temporal): with the builtin, hipcc's wait-count pass sees a pending access that may complete on either counter and turns EVERY wait of the
@@ -1154,11 +1171,64 @@ __device__ __forceinline__ unsigned adc_f2key(unsigned u) { return (u & 0x800000
 // s_memtime stamps of workgroup 8's thread 0 (build with -DADC_TRACE; tools/adc_trace.py reads them): per item [start, then per phase: after the barrier,
 // after the gathers ..., epilogue done]
 __device__ unsigned long long adc_trace_buf[32 * 16];
-#define ADC_STAMP(ITEM, SLOT) do { if (blockIdx.x == 8 && threadIdx.x == 0 && (ITEM) < 32) adc_trace_buf[(ITEM) * 16 + (SLOT)] = __builtin_amdgcn_s_memtime(); } while (0)
+// (thread 0 = wave 0, which builds its share of the next slab AFTER its gathers, fills rows 0..15; thread 64 = wave 1, which builds BEFORE them, rows 16..31)
+#define ADC_STAMP(ITEM, SLOT) do { if (blockIdx.x == 8 && (threadIdx.x == 0 || threadIdx.x == 64) && (ITEM) < 16) adc_trace_buf[((ITEM) + (threadIdx.x ? 16 : 0)) * 16 + (SLOT)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define ADC_STAMP(ITEM, SLOT) do { } while (0)
 #endif
-__global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) {
+// One phase of a duo's table built straight into its LDS buffer by the workgroup that will gather from it (KL = 256): entry (m, k) = {LUT_A[m][k], LUT_B[m][k]},
+// LUT[m][k] = sum_i ((q[m*DSUB+i] - centroid[m*DSUB+i]) - cb[m][k][i])^2 — the expression, the order and the rounding of pq_lut_kernel (and of
+// ivfpq_index_search.go:350-375), the two queries of the duo in the two halves of packed float32 operations. The streamed form writes every table to HBM
+// (pq_lut_kernel: 0.8 GB per batch at M = 96) and reads it back through LDS-DMA; on lists of a few thousand codes an item is then a chain of slab waits
+// (DESIGN.md 3.5). Here a slab never leaves the CU: every wave forms 1/16 of the next phase's entries (4 units of 128 codewords: 3 packed VALU
+// operations per dimension and codeword for the two queries together) before it gathers from the current one; what it reads is the codebook slice of
+// the phase (from L2) and 2 x DSUB floats of queries / centroid per subspace.
+template <int DSUB>
+__device__ __forceinline__ void adc_build_slab(const AdcArgs& a, int live, long duo, int qA, int qB, int ph, f32x2q* __restrict__ slab, int wid, unsigned lane) {
+    if (!live) return;
+    const int m0 = ph * a.mp, nm = min(a.M, m0 + a.mp) - m0;          // the subspaces of this phase
+    const float* __restrict__ qa = a.Qp + (long)qA * a.ldq;
+    const float* __restrict__ qb = a.Qp + (long)(qB >= 0 ? qB : qA) * a.ldq;   // a duo with a hole: the second half repeats the first (never read back)
+    // the list's centroid (PQ: a row of zeros — x - 0 is x, bit for bit): the address is formed without waiting for the list id where it can be
+    const float* __restrict__ cen = a.centroids + (long)(a.slist_is_list ? RFL((int)a.slist[2 * duo]) : 0) * a.ldq;
+    constexpr int NW = ADC_THREADS / 64;
+    const int per = (nm + NW - 1) / NW;                               // whole subspaces per wave (32 per phase: 2)
+    const int ml_hi = min(nm, (wid + 1) * per);
+    for (int ml = wid * per; ml < ml_hi; ml++) {
+        const int m = m0 + ml;
+        // every load of the subspace in flight at once: 3 x DSUB uniform floats (queries, centroid) and the lane's four codewords
+        f32x4q va[DSUB / 4], vb[DSUB / 4], vc[DSUB / 4], cw[4][DSUB / 4];
+#pragma unroll
+        for (int i = 0; i < DSUB / 4; i++) {
+            va[i] = *reinterpret_cast<const f32x4q*>(qa + m * DSUB + i * 4); vb[i] = *reinterpret_cast<const f32x4q*>(qb + m * DSUB + i * 4);
+            vc[i] = *reinterpret_cast<const f32x4q*>(cen + m * DSUB + i * 4);
+        }
+        const float* __restrict__ cp = a.codebooks + ((long)m * a.Ksub + (int)lane) * DSUB;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < DSUB / 4; i++) cw[j][i] = *reinterpret_cast<const f32x4q*>(cp + (long)j * 64 * DSUB + i * 4);
+        f32x2q r2[DSUB];
+#pragma unroll
+        for (int i = 0; i < DSUB; i++) { r2[i][0] = va[i >> 2][i & 3] - vc[i >> 2][i & 3]; r2[i][1] = vb[i >> 2][i & 3] - vc[i >> 2][i & 3]; }   // queryResidual[d] = q[d] - centroid[d]
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f32x2q acc; acc[0] = 0.0f; acc[1] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < DSUB; i++) {
+                f32x2q c2; c2[0] = cw[j][i >> 2][i & 3]; c2[1] = c2[0];
+                const f32x2q diff = r2[i] - c2;
+                const f32x2q sq = diff * diff;
+                acc = acc + sq;
+            }
+            slab[ml * 256 + j * 64 + (int)lane] = acc;
+        }
+    }
+}
+
+// BUILD = 0: the duo tables are streamed from HBM (built by pq_lut_kernel); BUILD = DSUB (4 / 8 / 16; KL = 256): built in LDS by this workgroup
+template <int BUILD>
+__global__ __launch_bounds__(ADC_THREADS) __attribute__((amdgpu_waves_per_eu(ADC_WPE, ADC_WPE))) void adc_scan_kernel(const AdcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // two phase buffers of ADC_BUF_BYTES
     __shared__ int s_ticket[2][2];                                  // [item parity][0] queue, [1] ticket (-1: all queues drained)
     const unsigned lane = threadIdx.x & 63u, voff = lane * 4u;
@@ -1209,6 +1279,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
     };
     auto off_of = [&](int ps) -> int { return (ps * (ADC_PASS_CODES >> 6) + wid) * M4 * 256; };    // the wave's first block of pass ps, bytes
     auto issue_table = [&](const AdcItem& it, int ph, int buf) {
+        if constexpr (BUILD > 0) { adc_build_slab<BUILD>(a, it.live, it.duo, it.qA, it.qB, ph, reinterpret_cast<f32x2q*>(lds + (long)buf * (ADC_BUF_BYTES / 4)), wid, lane); return; }
         const float* __restrict__ src = a.lutg + (it.duo * n_ent + (long)ph * mp * KL) * 2;
         const int cnt = (min(M, (ph + 1) * mp) - ph * mp) * KL * 2;  // floats; a multiple of 4
         const unsigned dst = lds0 + (unsigned)buf * ADC_BUF_BYTES;
@@ -1259,7 +1330,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
             pTb = cur.qB >= 0 ? (unsigned)RFL((int)slack(__builtin_nontemporal_load(&a.tq[cur.qB]))) : 0u;
         }
         for (int ph = 0; ph < P; ph++, stage++) {
-            ADC_TABLE_WAIT();       // this wave's pieces of table (cur, ph) have landed ...
+            if constexpr (BUILD == 0) ADC_TABLE_WAIT();       // this wave's pieces of table (cur, ph) have landed ... (BUILD: its entries are written — the barrier waits for the LDS stores)
             __syncthreads();        // ... everybody's have; nobody still reads the other buffer; ticket visible
             ADC_STAMP(trace_item, 1 + 2 * ph);
             if (a.prune && ph > 0 && !dead && na0 > 0) {
@@ -1282,8 +1353,13 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
                 Tpre[0] = __builtin_nontemporal_load(&a.tq[cur.qA]);
                 Tpre[1] = cur.qB >= 0 ? __builtin_nontemporal_load(&a.tq[cur.qB]) : 0u;
             }
-            if (!last_ph) issue_table(cur, ph + 1, (stage + 1) & 1);
-            else if (nxt.live) issue_table(nxt, 0, (stage + 1) & 1);
+            const bool build_late = BUILD > 0 && (wid & 1) == 0;            // BUILD: half of the waves form their share of the next slab AFTER their gathers — a build is a
+                                                                            // chain of load round trips (residual slices, codewords), which then runs under the other half's gathers
+            if (!build_late) {
+                if (!last_ph) issue_table(cur, ph + 1, (stage + 1) & 1);
+                else if (nxt.live) issue_table(nxt, 0, (stage + 1) & 1);
+                ADC_STAMP(trace_item, 7 + ph);
+            }
             const bool to_next = last_ph && nxt.live && chains_of(nxt, 0) > 0;   // the wave's next call belongs to the next item
             if (to_next && na0 == 0) {                               // idle in this item: fetch the next item's first code words now
 #pragma unroll
@@ -1310,6 +1386,11 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
                 }
             }
             ADC_STAMP(trace_item, 2 + 2 * ph);
+            if (build_late) {
+                if (!last_ph) issue_table(cur, ph + 1, (stage + 1) & 1);
+                else if (nxt.live) issue_table(nxt, 0, (stage + 1) & 1);
+                ADC_STAMP(trace_item, 7 + ph);
+            }
         }
         if (a.cand == nullptr) {
 #pragma unroll
@@ -1338,6 +1419,10 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
                 if (q < 0) continue;
                 const unsigned T = Tpre[h];                                                // float bits of a sum >= 0: unsigned order = value order (read during the last phase: a stale bound is only looser)
                 const unsigned Ts = __float_as_uint(__uint_as_float(T) * 1.0000005f);     // sums within 4 ulp above the bound may round to the same distance
+#ifdef ADC_TRACE
+                if (Ts == 12345u) asm volatile("s_nop 0");       // force the wait for the bound before the stamp
+                ADC_STAMP(trace_item, 10 + 2 * h);
+#endif
                 unsigned keys[ADC_SEG_PASSES][ADC_CHAINS];
                 unsigned lmin = 0xFFFFFFFFu;
 #pragma unroll
@@ -1353,6 +1438,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
                         if (ok) { keys[ps][c] = __float_as_uint(acc[ps][c][h]); lmin = min(lmin, keys[ps][c]); }
                     }
                 }
+                ADC_STAMP(trace_item, 11 + 2 * h);
                 if (__ballot(lmin <= Ts) == 0ull) continue;                  // nothing of this wave can matter (and its K-th minimum is above the bound)
                 // K-th smallest lane minimum, bit by bit from the top (ballots only: the LDS pipe is the kernel's bottleneck)
                 unsigned kth = 0xFFFFFFFFu;
@@ -1368,6 +1454,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
                 const unsigned bnd = min(T, kth);
                 const unsigned bs = bnd >= 0x7F800000u ? 0x7F800000u : __float_as_uint(__uint_as_float(bnd) * 1.0000005f);
                 const float Td = go_sqrt32q(__uint_as_float(bnd));           // the bound as a distance
+                int app_lo = 0x7FFFFFFF, app_hi = 0;                         // the slots this wave's survivors took in the query's row (wave-uniform)
 #pragma unroll
                 for (int ps = 0; ps < ADC_SEG_PASSES; ps++) {
                     const int na = ps == 0 ? na0 : na1;
@@ -1382,12 +1469,47 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const AdcArgs a) 
                         if (m) {
                             const int j = ((cur.start >> 6) + ps * (ADC_PASS_CODES >> 6) + c * ADC_WAVES + wid) * 64 + (int)lane;
                             const int leader = __builtin_ctzll(m);
+                            const int cnt = (int)__builtin_popcountll(m);
                             int base = 0;
-                            if ((int)lane == leader) base = atomicAdd(&a.cursor[q], (int)__builtin_popcountll(m));
-                            base = __shfl(base, leader, 64);
-                            if (keep) a.cand[(long)q * a.ldD + base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] =
-                                ((unsigned long long)adc_f2key(__float_as_uint(d)) << 32) | (unsigned)(so + j);
+                            if ((int)lane == leader) base = atomicAdd(&a.cursor[q], cnt);
+                            base = RFL(__shfl(base, leader, 64));
+                            app_lo = min(app_lo, base); app_hi = max(app_hi, base + cnt);
+                            // (agent-scope store: written through the XCD's L2, so that a refining wave on another XCD can see it — see below)
+                            if (keep) __hip_atomic_store(&a.cand[(long)q * a.ldD + base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))],
+                                                         ((unsigned long long)adc_f2key(__float_as_uint(d)) << 32) | (unsigned)(so + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
+                    }
+                }
+                // Bound refinement from the survivors. A wave can only offer the K-th smallest of ITS lanes' minima — of 64 .. 512 candidates; on data without cluster
+                // structure (SURVEY 8d's uniform rows) that is the ~K / 100-quantile of a query's distances, every wave of every later item still has candidates under
+                // it, and every item runs this slow path (5 - 14 k clocks per half: adc_trace). The query's survivor row, though, holds every candidate that passed so
+                // far: the K-th smallest DISTANCE among any of them is the K-th best of a subset of the query's candidates, hence an upper bound on the K-th best of all.
+                // The wave whose append crosses a power of two (16, 32, ... ADC_REFINE_MAX) reads the row's first entries (unwritten slots read as the row's initial
+                // all-ones = +inf: looser, never wrong), finds their K-th smallest key bit by bit and lowers tq to the smallest sum bound that cannot cut a candidate at
+                // that distance: the correctly rounded root of S is D  =>  S <= D^2 (1 + 2^-23), and the test against tq carries its own 4 ulp.
+                if (a.refine && app_hi > app_lo && app_hi >= 16 && (31 - __builtin_clz((unsigned)app_hi)) != (31 - __builtin_clz((unsigned)max(app_lo, 1))) ) {
+                    const int n = min(min(app_hi, ADC_REFINE_MAX), (int)min(a.ldD, (long)ADC_REFINE_MAX));
+                    unsigned rk[ADC_REFINE_MAX / 64];
+#pragma unroll
+                    for (int i = 0; i < ADC_REFINE_MAX / 64; i++) {
+                        const int e = i * 64 + (int)lane;
+                        rk[i] = e < n ? (unsigned)(__hip_atomic_load(&a.cand[(long)q * a.ldD + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) : 0xFFFFFFFFu;
+                    }
+                    int have = 0;
+#pragma unroll
+                    for (int i = 0; i < ADC_REFINE_MAX / 64; i++) have += (int)__builtin_popcountll(__ballot(rk[i] != 0xFFFFFFFFu));
+                    if (have >= a.K) {
+                        unsigned kk = 0u;
+                        for (int bit = 31; bit >= 0; bit--) {
+                            const unsigned tv = kk | ((1u << bit) - 1u);
+                            int cntb = 0;
+#pragma unroll
+                            for (int i = 0; i < ADC_REFINE_MAX / 64; i++) cntb += (int)__builtin_popcountll(__ballot(rk[i] <= tv));
+                            if (cntb < a.K) kk |= 1u << bit;
+                        }
+                        const float Dk = __uint_as_float((kk & 0x80000000u) ? (kk & 0x7FFFFFFFu) : ~kk);      // the key back to the distance (adc_f2key's inverse)
+                        const float Sb = (Dk * Dk) * 1.000001f;
+                        if (lane == 0 && Sb == Sb && __float_as_uint(Sb) < 0x7F800000u) atomicMin(&a.tq[q], __float_as_uint(Sb));
                     }
                 }
             }
@@ -1455,7 +1577,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
     const int KL = Ksub < 256 ? Ksub : 256;
     const int kl_shift = 31 - __builtin_clz((unsigned)KL);
     const size_t lds = adc_lds_bytes(M, Ksub, dim);
-    const int mp = std::max(16, (int)(ADC_BUF_BYTES / ((size_t)KL * 8)) / 16 * 16);        // subspaces per phase buffer (KL <= 256: >= 32)
+    const int mp = std::max(8, (int)(ADC_BUF_BYTES / ((size_t)KL * 8)) / 8 * 8);           // subspaces per phase buffer: whole groups of ADC_G = 2 code words (KL <= 256 and 64 KiB buffers: >= 32)
     const bool identity = nlist > ORDER_MAX_LISTS;
     // queries per sub-batch: tables of a sub-batch live in HBM between the two kernels
     const int64_t qc = adc_sub_batch(M, Ksub, np, B);
@@ -1467,7 +1589,13 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
     const int64_t qcap = ceil_div(max_chunks, 8) * ADC_XCD_CHUNK * segs;
     if (qcap > (int64_t)1 << 28) COMET_FAIL(COMET_ERR_UNSUPPORTED, "ADC work queue too large (%lld items)", (long long)qcap);
     ScratchMark mark(c);
-    float* lut = c->salloc<float>((size_t)max_slots * M * KL);
+    // 8-bit codebooks with 4 / 8 / 16 dimensions per subspace: the scanning workgroups build the tables themselves, in LDS (adc_scan_kernel<DSUB>): no table kernel,
+    // no table bytes in HBM. COMET_ADC_STREAM_TABLES=1 keeps the streamed form (pq_lut_kernel -> HBM -> LDS-DMA), which every other shape uses.
+    static const bool stream_tables = getenv("COMET_ADC_STREAM_TABLES") != nullptr;
+    const int build = (!stream_tables && KL == 256 && (dsub == 4 || dsub == 8) && (size_t)M * dsub <= (size_t)ld && mp * KL * 8 <= ADC_BUF_BYTES) ? dsub : 0;
+    float* lut = build ? nullptr : c->salloc<float>((size_t)max_slots * M * KL);
+    float* zero_row = nullptr;                                       // PQ has no coarse centroid: its "residual" is the query minus a row of zeros
+    if (build && !centroids) { zero_row = c->salloc<float>((size_t)ld); c->zero(zero_row, (size_t)ld * 4); }
     uint32_t* order = c->salloc<uint32_t>((size_t)max_slots);
     uint32_t* slist = c->salloc<uint32_t>((size_t)max_slots);
     AdcRec* qitems = c->salloc<AdcRec>((size_t)8 * qcap);
@@ -1480,7 +1608,10 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
     if (lut_lds > 150 * 1024) COMET_FAIL(COMET_ERR_UNSUPPORTED, "PQ subspace slice too wide for the table-build kernel (%zu bytes of LDS)", lut_lds);
     static bool attr_done = false;
     if (!attr_done) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_CHECK(hipFuncSetAttribute((const void*)adc_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (ORDER_MAX_LISTS + 1) * 4));
         attr_done = true;
     }
@@ -1505,13 +1636,15 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
             const int n_slots = (int)(stage == 0 ? slots_for(n_pairs) : round_up((stage == 1 ? bn : (strict ? n_pairs : n_pairs - bn)) + std::min<int64_t>(nlist, n_pairs), 2));
             {
                 ProfScope ps(c, "adc_order");
-                adc_order_kernel<<<dim3(1), dim3(1024), identity ? 0 : (size_t)(nlist + 1) * 4, c->stream>>>(pl, ldp, np, so, n_pairs, nlist, identity ? 1 : 0, list_len,
+                const bool init_rows = flt && flt->cand && stage <= 1;
+                adc_order_kernel<<<dim3(init_rows ? 1 + (unsigned)std::min(bn, 64) : 1), dim3(1024), identity ? 0 : (size_t)(nlist + 1) * 4, c->stream>>>(pl, ldp, np, so, n_pairs, nlist, identity ? 1 : 0, list_len,
                                                                                                            n_slots, order, slist, qitems, (int)qcap, qcount, queues,
                                                                                                            flt ? flt->tq + b0 : nullptr, flt ? flt->cursor + b0 : nullptr, bn, (lead && stage == 0) ? 1 : 0, (const long*)list_base,
-                                                                                                           stage, dead, used, flt ? flt->stats : nullptr, strict);
+                                                                                                           stage, dead, used, flt ? flt->stats : nullptr, strict,
+                                                                                                           init_rows ? flt->cand + (size_t)b0 * ldD : nullptr, (long)ldD);
                 LAUNCH_CHECK();
             }
-            {
+            if (!build) {
                 ProfScope ps(c, "pq_lut");
                 dim3 grid((unsigned)ceil_div(M, mw), (unsigned)ceil_div(n_slots, ppw)), blk(256);
 #define LUT_LAUNCH(HC, DS) do { if (lut_lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)pq_lut_kernel<HC, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lut_lds)); \
@@ -1525,12 +1658,19 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
             }
             {   // (timed through Ctx::launch_timed: no event-record packets around the kernel when a bench times this scope)
                 const long n_items = (long)(n_slots / 2) * segs;
-                long g = std::min<long>(n_items, (long)c->prop.multiProcessorCount * (160 / (2 * ADC_BUF_KB + 2)));    // as many workgroups per CU as their LDS allows
+                long g = std::min<long>(n_items, (long)c->prop.multiProcessorCount * std::min(160 / (2 * ADC_BUF_KB + 2), ADC_WPE * 256 / ADC_THREADS));    // as many workgroups per CU as their LDS and registers allow
                 g = std::max<long>(8, (g + 7) / 8 * 8);          // a multiple of the XCD count so that blockIdx % 8 is the XCD of every slot
                 static const bool prune_on = getenv("COMET_ADC_NO_PRUNE") == nullptr;
+                static const bool refine_on = getenv("COMET_ADC_NO_REFINE") == nullptr;
                 AdcArgs a{lut, codes, (const long*)list_base, list_len, so, elig, order, slist, qitems, qcount, queues, D ? D + (size_t)b0 * ldD : nullptr, (long)ldD, M, KL, mp, M4, np, (int)qcap,
-                          flt ? flt->cand + (size_t)b0 * ldD : nullptr, flt ? flt->cursor + b0 : nullptr, flt ? flt->tq + b0 : nullptr, flt ? flt->K : 0, flt ? flt->thr : 0.0f, (flt && prune_on) ? 1 : 0};
-                c->launch_timed("adc_scan", adc_scan_kernel, dim3((unsigned)g), dim3(ADC_THREADS), lds, a);
+                          flt ? flt->cand + (size_t)b0 * ldD : nullptr, flt ? flt->cursor + b0 : nullptr, flt ? flt->tq + b0 : nullptr, flt ? flt->K : 0, flt ? flt->thr : 0.0f, (flt && prune_on) ? 1 : 0, (flt && refine_on) ? 1 : 0,
+                          Qb, centroids ? centroids : zero_row, codebooks, ld, Ksub, centroids ? 1 : 0};
+                switch (build) {
+                    case 4: c->launch_timed("adc_scan", adc_scan_kernel<4>, dim3((unsigned)g), dim3(ADC_THREADS), lds, a); break;
+                    case 8: c->launch_timed("adc_scan", adc_scan_kernel<8>, dim3((unsigned)g), dim3(ADC_THREADS), lds, a); break;
+                    case 16: c->launch_timed("adc_scan", adc_scan_kernel<16>, dim3((unsigned)g), dim3(ADC_THREADS), lds, a); break;
+                    default: c->launch_timed("adc_scan", adc_scan_kernel<0>, dim3((unsigned)g), dim3(ADC_THREADS), lds, a); break;
+                }
                 LAUNCH_CHECK();
             }
         };
