@@ -406,8 +406,10 @@ void launch_finalize_probe(Ctx* c, const uint32_t* pos, int B, int k_cap, const 
 // ADC_LOADERS_N of the workgroup's waves only stream table slabs (LDS-DMA); the others only gather. Vector-memory operations return in order per wave:
 // with every wave issuing its share of a 64 KB slab, a wave's next 256-byte group of code words queued up behind the slab (~1 800 clocks per group,
 // four groups per phase, s_memtime trace) — on short lists, where an item is a chain of such waits, that was most of an item's 30 us.
+// Round 5: 8-bit codebooks build their tables in LDS (adc_scan_kernel<DSUB>), where a loader wave has nothing to stream — the default is 0 (every wave
+// gathers and builds); the streamed form, left to the other codebook shapes, gained 15 % from -DADC_LOADERS_N=2 on clustered data (round 4).
 #ifndef ADC_LOADERS_N
-#define ADC_LOADERS_N 2
+#define ADC_LOADERS_N 0
 #endif
 #ifndef ADC_WPE
 #define ADC_WPE 4            // waves per SIMD the scan kernel is compiled for (4: 128 registers per lane)

@@ -57,6 +57,13 @@ def reciprocal_rank_fusion_batch(v_ids, v_counts, t_ids, t_counts, k_out: int, k
     v_counts = np.asarray(v_counts, np.int64); t_counts = np.asarray(t_counts, np.int64)
     B, kv = v_ids.shape
     kt = t_ids.shape[1]
+    if kv == 0 or kt == 0:       # a leg without columns (k = 0 on that side): the other leg alone, by the same rule (argmax over an empty axis raises)
+        one_ids, one_cnt, kk = (t_ids, t_counts, kt) if kv == 0 else (v_ids, v_counts, kv)
+        r1 = 1.0 / (k + np.arange(kk, dtype=np.float64))
+        ok = np.arange(kk)[None, :] < one_cnt[:, None]
+        sc = np.where(ok, r1[None, :], -np.inf) if kk else np.zeros((B, 0))
+        order = np.argsort(-sc, axis=1, kind="stable")[:, :k_out]
+        return (np.take_along_axis(one_ids, order, 1).astype(np.uint32), np.take_along_axis(sc, order, 1), np.minimum(k_out, ok.sum(1)).astype(np.int32))
     rv = 1.0 / (k + np.arange(kv, dtype=np.float64))
     rt = 1.0 / (k + np.arange(kt, dtype=np.float64))
     v_ok = np.arange(kv)[None, :] < v_counts[:, None]

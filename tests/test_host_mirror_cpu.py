@@ -121,3 +121,17 @@ def test_bench_compact_line_is_driver_sized():
     assert rec["config"]["workload"] and rec["roofline"]["kernel"] and rec["roofline"]["frac"] > 0 and rec["cpu_baseline"]["value"] > 0
     for leg in ("c1", "flat_l2", "ivfpq", "ivfpq_uniform", "ivfpq10m", "hnsw", "hnsw_navigable", "hybrid"):
         assert leg in rec["legs"], leg
+
+
+def test_rrf_batch_with_an_empty_leg():
+    """round-4 advisor: a leg with zero columns (k = 0 on that side) used to raise in argmax over an empty axis"""
+    import numpy as np
+    from comet_amd.hybrid import reciprocal_rank_fusion_batch
+    v_ids = np.array([[5, 9, 2], [7, 1, 0]], np.uint32); v_cnt = np.array([3, 2])
+    none = np.zeros((2, 0), np.uint32); zero = np.zeros(2, np.int64)
+    ids, sc, cnt = reciprocal_rank_fusion_batch(v_ids, v_cnt, none, zero, 2)
+    assert cnt.tolist() == [2, 2] and ids[0].tolist() == [5, 9] and ids[1].tolist() == [7, 1] and np.allclose(sc[0], [1 / 60, 1 / 61])
+    ids, sc, cnt = reciprocal_rank_fusion_batch(none, zero, v_ids, v_cnt, 3)
+    assert cnt.tolist() == [3, 2] and ids[0].tolist() == [5, 9, 2]
+    ids, sc, cnt = reciprocal_rank_fusion_batch(none, zero, none, zero, 3)
+    assert cnt.tolist() == [0, 0] and ids.shape == (2, 0)

@@ -2,6 +2,7 @@
 // For every COMET_SCAN_VARIANT it runs the scan on random data and compares the emitted unit keys (two smallest approximate
 // distances + the bound of every (query, 128-row unit)) with a float64 host computation on the same fp16-rounded operands.
 // usage: scan_check [rows] [dim] [queries] [iters]        build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DQR_TRACE] tools/scan_check.hip -o tools/scan_check
+#define COMET_SCAN_QR_RUNTIME_SWITCH 1
 #include "../comet_amd/csrc/kernels_fast.hip"
 #include "../comet_amd/csrc/kernels_scanq.hip"
 #include "../comet_amd/csrc/kernels_scanq_l2.hip"

@@ -147,3 +147,16 @@ for tag, rows, nlist in (("ivfpq1m", 1_000_000, 1024), ("ivfpq10m", 10_000_000, 
     results[tag] = [model(tag, N, pq_rank, q_ptrs, 10, nprobes=32) for N in (1, 2, 4, 8)]
     ctx.free(tbuf); ctx.free(q_ptrs[0])
 print(json.dumps(results))
+# What a node of W GPUs delivers under the layouts bench.py --shard-mode offers (rows = R ranks share one index copy and exchange; replica = R 1; grid = R x W / R):
+# W / R groups serve their own query streams, a group's step is the modelled step of an R-rank job. Throughput relative to one GPU = (W / R) * t(1) / t(R).
+# (The exchange's own transfer time over xGMI is not in t(R): one all-gather of R x B x K x 8 bytes per batch — 0.2 MB per rank at B 256, K 100 — a few microseconds.)
+print("\n# layouts of a W-GPU node from the per-rank steps above: queries/s relative to ONE GPU (slowest rank's step; B = %d per group)" % B)
+for tag, res in results.items():
+    t = {r["world"]: r["slowest_rank_ms_per_step"] for r in res}
+    print("# %s: t(R) ms = %s" % (tag, {k: round(v, 4) for k, v in t.items()}))
+    for W in (2, 4, 8):
+        cells = []
+        for R in (1, 2, 4, 8):
+            if R <= W and R in t:
+                cells.append("R=%d x %d copies: %.2fx (%.0f q/s)" % (R, W // R, (W / R) * t[1] / t[R], (W / R) * B / (t[R] * 1e-3)))
+        print("#   W=%d  " % W + "   ".join(cells))
