@@ -850,8 +850,30 @@ def leg_hybrid(ctx, ca, args, timer, q_ptrs, Q0):
             bad_f += 1
     out["rrf"] = {"host_ms_per_batch": e2e["nprobe1"]["fusion_host_ms_per_batch"], "batch_form_mismatches_vs_per_query_form": bad_f,
                   "what": "reciprocalRankFusion.Combine + sort + cut (fusion.go:174-243) on the host for the whole batch in one vectorised call (O(k^2) per query)"}
-    out["end_to_end"] = dict(e2e["nprobe1"], what="vector leg (nprobe 1, the hybrid default) + text leg + fusion, run one after the other")
-    out["end_to_end_nprobe32"] = dict(e2e[f"nprobe{args.nprobe}"], what=f"the same with the vector leg at nprobe {args.nprobe}")
+    out["legs_added"] = dict(e2e["nprobe1"], what="round 4's figure: vector leg (nprobe 1) + text leg + host fusion, their times ADDED (run one after the other)")
+    out["legs_added_nprobe32"] = dict(e2e[f"nprobe{args.nprobe}"], what=f"the same with the vector leg at nprobe {args.nprobe}")
+    # ---- the whole hybrid search as ONE call (comet_hybrid_rrf_search): host queries + token lists in, fused lists out; the vector leg on a second lane beside
+    # the text leg, the fusion on the device (rrf_fuse_kernel). Timed as a caller sees it: blocking calls, rotating query batches. ----
+    from comet_amd.hybrid import hybrid_rrf_search_batch
+    Qh = [ctx.download(q_ptrs[i], (B, d), np.float32) for i in range(NQB)]
+    # token ids as the C ABI takes them (flat uint32 + offsets): what the Go shim hands over after tokenising; the Python list form costs 0.1 ms of flattening per batch
+    flat = [(np.ascontiguousarray([t for qt in qs for t in qt], np.uint32), np.concatenate([[0], np.cumsum([len(qt) for qt in qs])]).astype(np.int32)) for qs in qsets]
+    for tag, npb in (("end_to_end", 1), ("end_to_end_nprobe32", args.nprobe)):
+        hybrid_rrf_search_batch(ivf, gt, Qh[0], flat[0], k=K, n_probes=npb)
+        reps = max(10, args.steps)
+        ctx.sync(); t0 = time.perf_counter()
+        for i in range(reps):
+            hybrid_rrf_search_batch(ivf, gt, Qh[i % NQB], flat[i % NQB], k=K, n_probes=npb)
+        el = (time.perf_counter() - t0) / reps
+        di, ds, dc = hybrid_rrf_search_batch(ivf, gt, Qh[0], flat[0], k=K, n_probes=npb)
+        vec = vec_last if npb == 1 else vec32
+        hi_, hs_, hc_ = reciprocal_rank_fusion_batch(vec[0], vec[2], tr[0], tr[3], K)
+        both = (np.asarray(vec[2]) > 0) & (np.asarray(tr[3]) > 0)         # (a query with an empty leg keeps the other leg's own scores in the reference: compared in tests/test_hybrid.py)
+        bad = int(sum(1 for b in range(B) if both[b] and not (dc[b] == hc_[b] and np.array_equal(ds[b, :dc[b]], hs_[b, :dc[b]]) and
+                                                             set(di[b, :dc[b]][ds[b, :dc[b]] > ds[b, dc[b] - 1]].tolist()) == set(hi_[b, :dc[b]][hs_[b, :dc[b]] > hs_[b, dc[b] - 1]].tolist()))))
+        out[tag] = {"qps": B / el, "ms_per_batch": el * 1e3, "fusion": "on the device (rrf_fuse_kernel, one wave per query)", "mismatches_vs_host_fusion_of_the_two_legs": bad,
+                    "queries_compared": int(both.sum()),
+                    "what": f"ONE blocking call per batch: {B} host queries + token lists in, fused top-{K} out; vector leg (nprobe {npb}) on a second execution lane beside the text leg"}
     if orc:
         blob = ivf.to_bytes()
         out["cpu_baseline"] = cpu_baseline_from_bytes(lambda: orc.IVF(d, "cosine", nlist), blob, lambda o, q: o.search(q, K, args.nprobe, cap=K), Q0, K, vec32, "IVFX", None)
@@ -1254,7 +1276,7 @@ def compact_line(full):
         elif name == "hybrid":
             legs[name] = {b: {k: v for k, v in _leg(rec[b]).items() if k in ("qps", "single_stream_qps", "cpu_qps", "parity_mismatches", "parity_checked")}
                           for b in rec if b.startswith("ivf_nprobe") or b == "bm25"}
-            for b in ("rrf", "end_to_end", "end_to_end_nprobe32"):
+            for b in ("rrf", "end_to_end", "end_to_end_nprobe32", "legs_added"):
                 if isinstance(rec.get(b), dict):
                     legs[name][b] = {k: _rnd(v) for k, v in rec[b].items() if isinstance(v, (int, float))}
             if isinstance(rec.get("cpu_baseline"), dict):

@@ -138,6 +138,7 @@ def load() -> C.CDLL:
         "comet_bm25_num_docs": (i64, [p]),
         "comet_bm25_avg_doc_len": (C.c_double, [p]),
         "comet_bm25_search": (i32, [p, p, p, i32, i32, p, i32, p, p, p, p, i32]),
+        "comet_hybrid_rrf_search": (i32, [p, p, p, p, p, i32, i32, i32, i32, C.c_double, p, p, p]),
         "comet_index_export": (i32, [p, p, p, p]),
         "comet_comm_unique_id": (i32, [p]),
         "comet_comm_create": (i32, [p, p, i32, i32, pp]),

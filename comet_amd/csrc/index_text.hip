@@ -14,9 +14,7 @@
 #include <algorithm>
 #include <cmath>
 
-#include "kernels.hpp"
-
-struct comet_ctx : comet::Ctx {};
+#include "index.hpp"
 
 namespace comet {
 
@@ -354,26 +352,18 @@ int comet_bm25_flush(comet_text_index* ix) {
 int64_t comet_bm25_num_docs(const comet_text_index* ix) { return ix->num_docs; }
 double comet_bm25_avg_doc_len(const comet_text_index* ix) { return ix->avg_doc_len; }
 
-// bm25TextSearch.searchSingleQuery bm25_index_search.go:278-397 for B tokenised queries
-int comet_bm25_search(comet_text_index* ix, const uint32_t* q_tokens, const int32_t* q_offsets, int32_t B, int32_t k,
-                      const uint32_t* filter_ids, int32_t n_filter, uint32_t* out_ids, float* out_scores, double* out_scores64,
-                      int32_t* out_counts, int32_t k_cap) {
-    return guarded([&] {
-        if (B <= 0) return (int)COMET_OK;
-        if (k_cap <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "k_cap must be positive");
+}  // extern "C"
+
+// bm25TextSearch.searchSingleQuery bm25_index_search.go:278-397 for B tokenised queries: everything ENQUEUED on the context's current stream, results in
+// device memory (B x k_cap ids / float32 scores / float64 scores, B counts). The caller holds the context mutex and has reset the scratch arena.
+// Returns false when the index is empty (`if N == 0 { return nil, nil }`, :290): nothing was enqueued, every count is zero.
+static bool bm25_search_enqueue(comet_text_index* ix, const uint32_t* q_tokens, const int32_t* q_offsets, int32_t B, int32_t k, const uint32_t* filter_ids, int32_t n_filter,
+                                uint32_t* d_ids, float* d_sc, double* d_sc64, int32_t* d_cn, int32_t k_cap) {
         Ctx* c = ix->c;
-        std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->scratch_reset();
         ix->compile();
         const int64_t nd = ix->nd;
-        uint32_t* d_ids = c->salloc<uint32_t>((size_t)B * k_cap);
-        float* d_sc = c->salloc<float>((size_t)B * k_cap);
-        double* d_sc64 = c->salloc<double>((size_t)B * k_cap);
-        int32_t* d_cn = c->salloc<int32_t>(B);
         const double N = (double)ix->num_docs;
-        if (nd == 0 || N == 0) {   // `if N == 0 { return nil, nil }` (:290)
-            std::fill(out_counts, out_counts + B, 0);
-            return (int)COMET_OK;
-        }
+        if (nd == 0 || N == 0) return false;
         // eligibility: soft deletes + document filter (by id)
         const uint8_t* elig = nullptr;
         std::vector<uint32_t> del(ix->deleted.begin(), ix->deleted.end()); std::sort(del.begin(), del.end());
@@ -446,10 +436,127 @@ int comet_bm25_search(comet_text_index* ix, const uint32_t* q_tokens, const int3
                 LAUNCH_CHECK();
             }
         }
+        return true;
+}
+
+extern "C" {
+
+int comet_bm25_search(comet_text_index* ix, const uint32_t* q_tokens, const int32_t* q_offsets, int32_t B, int32_t k,
+                      const uint32_t* filter_ids, int32_t n_filter, uint32_t* out_ids, float* out_scores, double* out_scores64,
+                      int32_t* out_counts, int32_t k_cap) {
+    return guarded([&] {
+        if (B <= 0) return (int)COMET_OK;
+        if (k_cap <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "k_cap must be positive");
+        Ctx* c = ix->c;
+        std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->switch_lane(0); c->quiesce_alt(); c->scratch_reset();
+        uint32_t* d_ids = c->salloc<uint32_t>((size_t)B * k_cap);
+        float* d_sc = c->salloc<float>((size_t)B * k_cap);
+        double* d_sc64 = c->salloc<double>((size_t)B * k_cap);
+        int32_t* d_cn = c->salloc<int32_t>(B);
+        if (!bm25_search_enqueue(ix, q_tokens, q_offsets, B, k, filter_ids, n_filter, d_ids, d_sc, d_sc64, d_cn, k_cap)) {
+            std::fill(out_counts, out_counts + B, 0);
+            return (int)COMET_OK;
+        }
         c->d2h(out_ids, d_ids, (size_t)B * k_cap * 4);
         c->d2h(out_scores, d_sc, (size_t)B * k_cap * 4);
         if (out_scores64) c->d2h(out_scores64, d_sc64, (size_t)B * k_cap * 8);
         c->d2h(out_counts, d_cn, (size_t)B * 4);
+        c->sync();
+        return (int)COMET_OK;
+    });
+}
+
+// ---- hybrid search on the device: vector leg + text leg + Reciprocal Rank Fusion (hybridSearch.Execute hybrid_search_index.go:477-615 with
+// WithFusionKind(ReciprocalRankFusion); reciprocalRankFusion.Combine + scoreMapToRanks fusion.go:174-243) ----------------------------------------------
+// The reference runs the two sub-searches one after the other, cuts both to k (:518, :555), turns each result list into 0-based ranks, sums 1 / (K + rank)
+// per document in float64 (vector term first), sorts descending and cuts to k. Here the vector leg is enqueued on another execution lane of the context
+// and runs BESIDE the text leg (whose host part — term lookup, idf — happens while the vector leg's kernels are already queued), the fusion is one wave
+// per query on the device, and the host receives one block of results: no per-leg download, no host-side rank arithmetic.
+}  // extern "C"
+
+namespace comet {
+// one wave per query. Candidates in insertion order: the vector hits (position = rank), then the text hits that are not vector hits; a vector hit that is
+// also a text hit adds the text term (existing + rrfScore). Order: score descending, ties in insertion order (the stable sort of the host mirror).
+__global__ __launch_bounds__(64) void rrf_fuse_kernel(const unsigned* __restrict__ v_ids, const float* __restrict__ v_sc, const int* __restrict__ v_cnt, int kv,
+                                                     const unsigned* __restrict__ t_ids, const float* __restrict__ t_sc, const int* __restrict__ t_cnt, int kt, double rrf_k, int k_out,
+                                                     unsigned* __restrict__ out_ids, double* __restrict__ out_sc, int* __restrict__ out_cnt, int out_ld) {
+    __shared__ unsigned s_id[128]; __shared__ double s_sc[128]; __shared__ unsigned char s_ok[128];
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int vc = min(max(v_cnt[q], 0), kv), tc = min(max(t_cnt[q], 0), kt);
+    const int verr = v_cnt[q] < 0 ? v_cnt[q] : 0;                              // a search-time error of the vector leg (a zero query under cosine) is passed through
+    const unsigned vid = lane < vc ? v_ids[(long)q * kv + lane] : 0u, tid = lane < tc ? t_ids[(long)q * kt + lane] : 0u;
+    s_id[lane] = vid; s_id[64 + lane] = tid;
+    __syncthreads();
+    int hit = -1;                                                               // position of this lane's vector hit in the text list
+    if (lane < vc) for (int j = 0; j < tc; j++) if (s_id[64 + j] == vid) { hit = j; break; }
+    bool t_only = lane < tc;
+    if (t_only) for (int i = 0; i < vc; i++) if (s_id[i] == tid) { t_only = false; break; }
+    // `if len(vectorResults) > 0 && len(textResults) > 0` (hybrid_search_index.go:577): both legs have hits -> fused ranks; otherwise the leg that has hits
+    // keeps its OWN scores (vector: distances; text: float32 BM25 scores) and only the descending sort + the cut apply (:603-611)
+    const bool fuse = vc > 0 && tc > 0;
+    const double r_own = 1.0 / (rrf_k + (double)lane);                         // 1 / (K + rank): a hit's rank is its position in its list
+    double sv, st;
+    if (fuse) { sv = hit >= 0 ? r_own + 1.0 / (rrf_k + (double)hit) : r_own; st = r_own; }      // existing + rrfScore: the vector term first (fusion.go:196-199)
+    else { sv = lane < vc ? (double)v_sc[(long)q * kv + lane] : 0.0; st = lane < tc ? (double)t_sc[(long)q * kt + lane] : 0.0; }
+    // concatenated candidates in insertion order: slot lane = vector hit, slot 64 + lane = text hit that is not a vector hit
+    s_sc[lane] = sv; s_ok[lane] = lane < vc ? 1 : 0;
+    s_sc[64 + lane] = st; s_ok[64 + lane] = (lane < tc && t_only) ? 1 : 0;
+    __syncthreads();
+    const int total = vc + (int)__builtin_popcountll(__ballot(lane < tc && t_only));
+    const int kq = verr ? 0 : ((k_out <= 0 || k_out > total) ? total : k_out);
+    for (int h = 0; h < 2; h++) {
+        const int me = h * 64 + lane;
+        if (!s_ok[me]) continue;
+        const double sc = s_sc[me];
+        int rank = 0;
+        for (int j = 0; j < 128; j++) { const double o = s_sc[j]; rank += (s_ok[j] && (o > sc || (o == sc && j < me))) ? 1 : 0; }
+        if (rank < kq && rank < out_ld) { out_ids[(long)q * out_ld + rank] = s_id[me]; out_sc[(long)q * out_ld + rank] = sc; }
+    }
+    for (int i = kq + lane; i < out_ld; i += 64) { out_ids[(long)q * out_ld + i] = 0u; out_sc[(long)q * out_ld + i] = 0.0; }
+    if (lane == 0) out_cnt[q] = verr ? verr : min(kq, out_ld);
+}
+}  // namespace comet
+
+extern "C" {
+
+int comet_hybrid_rrf_search(comet_index* vec, comet_text_index* txt, const float* queries, const uint32_t* q_tokens, const int32_t* q_offsets, int32_t B,
+                            int32_t k, int32_t nprobes, int32_t ef_search, double rrf_k, uint32_t* out_ids, double* out_scores, int32_t* out_counts) {
+    return guarded([&] {
+        if (B <= 0) return (int)COMET_OK;
+        if (k <= 0 || k > 64) COMET_FAIL(COMET_ERR_UNSUPPORTED, "the device fusion ranks up to 64 hits per leg (k = %d): fuse larger lists on the host", k);
+        if (vec->c != txt->c) COMET_FAIL(COMET_ERR_INVALID_ARG, "the vector index and the text index live on different contexts");
+        Ctx* c = vec->c;
+        std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->switch_lane(0); c->quiesce_alt(); c->scratch_reset();
+        const size_t nk = (size_t)B * k;
+        // results of the legs and of the fusion: lane 0's scratch (alive until the next call resets it; this call ends with a sync)
+        uint32_t* v_ids = c->salloc<uint32_t>(nk); float* v_sc = c->salloc<float>(nk); int32_t* v_cn = c->salloc<int32_t>(B);
+        uint32_t* t_ids = c->salloc<uint32_t>(nk); float* t_sc = c->salloc<float>(nk); double* t_sc64 = c->salloc<double>(nk); int32_t* t_cn = c->salloc<int32_t>(B);
+        uint32_t* f_ids = c->salloc<uint32_t>(nk); double* f_sc = c->salloc<double>(nk); int32_t* f_cn = c->salloc<int32_t>(B);
+        float* qd = c->salloc<float>((size_t)B * vec->dim);
+        c->h2d(qd, queries, (size_t)B * vec->dim * sizeof(float));
+        c->fence_lane0();
+        // vector leg: on lane 1 (its own stream and scratch arena) when the context has more than one lane, behind the upload
+        comet_search_params p{}; p.k = k; p.nprobes = nprobes; p.ef_search = ef_search; p.mode = 0;
+        const int vlane = c->lanes > 1 ? 1 : 0;
+        uint64_t ticket = 0;
+        {
+            struct LaneBack { Ctx* c; ~LaneBack() { if (c->cur_lane != 0) { c->mark_dirty(); c->switch_lane(0); } } } lane_back{c};
+            c->switch_lane(vlane);
+            if (vlane) { c->scratch_reset(); c->follow_lane0(); }
+            ticket = vec->search_begin(qd, B, p, v_ids, v_sc, v_cn, k);
+        }
+        // text leg on lane 0 (host part first: the vector leg's kernels are already queued)
+        if (!bm25_search_enqueue(txt, q_tokens, q_offsets, B, k, nullptr, 0, t_ids, t_sc, t_sc64, t_cn, k)) HIP_CHECK(hipMemsetAsync(t_cn, 0, (size_t)B * 4, c->stream));
+        // the vector leg's results are final (the Flat / IVF fast path may re-run a query exactly), then the fusion behind both legs
+        {
+            struct LaneBack { Ctx* c; ~LaneBack() { if (c->cur_lane != 0) { c->mark_dirty(); c->switch_lane(0); } } } lane_back{c};
+            c->switch_lane(vlane);
+            vec->search_finish(ticket);
+            if (vlane) HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
+        { ProfScope ps(c, "rrf_fuse");
+          rrf_fuse_kernel<<<dim3((unsigned)B), dim3(64), 0, c->stream>>>(v_ids, v_sc, v_cn, k, t_ids, t_sc, t_cn, k, rrf_k, k, f_ids, f_sc, f_cn, k); LAUNCH_CHECK(); }
+        c->d2h(out_ids, f_ids, nk * 4); c->d2h(out_scores, f_sc, nk * 8); c->d2h(out_counts, f_cn, (size_t)B * 4);
         c->sync();
         return (int)COMET_OK;
     });

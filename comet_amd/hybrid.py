@@ -156,6 +156,34 @@ class HybridSearch:
         return res[:self.k] if len(res) > self.k else res
 
 
+def hybrid_rrf_search_batch(vector_index, text_index, queries, token_lists, k: int = 10, n_probes: int = 1, ef_search: int = 0, rrf_k: float = 60.0):
+    """B hybrid searches with Reciprocal Rank Fusion in ONE call on the device (comet_hybrid_rrf_search): the vector leg on a second execution lane beside
+    the text leg, the fusion one wave per query, one block of results back — what B times HybridSearch(...).with_fusion_kind(RECIPROCAL_RANK_FUSION).execute()
+    returns (hybrid_search_index.go:477-615). queries: B x dim float32; token_lists: B lists of token ids. Returns (ids uint32 [B, k], scores float64 [B, k], counts)."""
+    import ctypes as C
+    import numpy as np
+    from ._lib import check
+    Q = np.ascontiguousarray(queries, dtype=np.float32)
+    B = len(Q)
+    if isinstance(token_lists, tuple) and len(token_lists) == 2 and isinstance(token_lists[0], np.ndarray):
+        toks, offs = token_lists               # already flat: (uint32 tokens, int32 offsets[B + 1]) — what a Go caller hands the C ABI
+        toks = np.ascontiguousarray(toks, dtype=np.uint32); offs = np.ascontiguousarray(offs, dtype=np.int32)
+        if len(offs) != B + 1:
+            raise ValueError("one token list per vector query")
+    else:
+        if B != len(token_lists):
+            raise ValueError("one token list per vector query")
+        offs = np.zeros(B + 1, dtype=np.int32)
+        for i, qt in enumerate(token_lists):
+            offs[i + 1] = offs[i] + len(qt)
+        toks = np.ascontiguousarray([t for qt in token_lists for t in qt], dtype=np.uint32)
+    ids = np.zeros((B, k), np.uint32); sc = np.zeros((B, k), np.float64); cnt = np.zeros(B, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(vector_index.lib.comet_hybrid_rrf_search(vector_index.h, text_index.h, p(Q), p(toks), p(offs), B, int(k), int(n_probes), int(ef_search), C.c_double(rrf_k),
+                                                   p(ids), p(sc), p(cnt)))
+    return ids, sc, cnt
+
+
 # ---- segment layer (storage.go:489-626): one hybrid index per memtable / segment, results merged on the host -------------
 def merge_results(results: list[HybridSearchResult]) -> list[HybridSearchResult] | None:
     """mergeResults storage_merge.go:13-46: deduplicate by document id, keep the HIGHEST score; nil for no input.

@@ -346,6 +346,20 @@ COMET_API int comet_bm25_search(comet_text_index* idx, const uint32_t* q_tokens,
                                 const uint32_t* filter_ids, int32_t n_filter, uint32_t* out_ids, float* out_scores,
                                 double* out_scores64, int32_t* out_counts, int32_t k_cap);
 
+/* Hybrid search with Reciprocal Rank Fusion on the device — hybridSearch.Execute (hybrid_search_index.go:477-615) with
+ * WithFusionKind(ReciprocalRankFusion) for B (vector, text) query pairs: both sub-searches cut to k (:518, :555), a hit's
+ * 0-based rank is its position in its list (scoreMapToRanks fusion.go:205-243 on lists that arrive sorted), a document's
+ * score is the float64 sum of 1 / (rrf_k + rank) over the lists it appears in (vector term first: fusion.go:174-203), the
+ * fused list is sorted by score descending (ties: vector hits in their order, then text-only hits in theirs) and cut to k.
+ * The vector leg runs on a second execution lane beside the text leg, the fusion is one wave per query, the host receives
+ * one block: out_ids / out_scores (float64) are B x k, out_counts B (a vector-leg search error, e.g. a zero query under
+ * cosine, arrives as a negative count). queries: B x dim HOST floats; tokens as for comet_bm25_search. 1 <= k <= 64;
+ * nprobes / ef_search as in comet_search_params (0 = the index default). Metadata filters (WithDocumentIDs) stay with the
+ * two-call form (comet_index_search + comet_bm25_search + a host-side fusion). */
+COMET_API int comet_hybrid_rrf_search(comet_index* vec, comet_text_index* txt, const float* queries, const uint32_t* q_tokens,
+                                      const int32_t* q_offsets, int32_t B, int32_t k, int32_t nprobes, int32_t ef_search, double rrf_k,
+                                      uint32_t* out_ids, double* out_scores, int32_t* out_counts);
+
 /* WithNode(nodeIDs...): the stored (preprocessed) vectors of the given node ids, n x dim, in order — lookupNodeVectors
  * flat_index_search.go:171-196, ivf_index_search.go:176-206, hnsw_index_search.go:212-226 (first match in the reference's
  * scan order; "node ID %d not found in index" / "... (deleted)"). PQ / IVFPQ keep codes only: UNSUPPORTED. */

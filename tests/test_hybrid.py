@@ -241,3 +241,53 @@ def test_segments_search_device_buffers(ctx):
     assert np.array_equal(di, hi) and np.array_equal(ds.view(np.uint32), hs.view(np.uint32))
     for p in (q_dev, o_ids, o_sc, o_cn):
         ctx.free(p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["ivf", "flat_cos", "ivfpq"])
+def test_hybrid_rrf_on_the_device_equals_the_per_query_form(ctx, kind):
+    """comet_hybrid_rrf_search (vector leg on a second lane beside the text leg, rrf_fuse_kernel, one block back) against B calls of the per-query host mirror
+    HybridSearch(...).with_fusion_kind(RECIPROCAL_RANK_FUSION).execute() — hybridSearch.Execute hybrid_search_index.go:477-615 — and, for the fused scores,
+    against the oracle's RRF (fusion.go:174-243). Includes queries whose text matches nothing (the vector leg's own scores come back, sorted descending)."""
+    import ctypes as C
+    import oracle_lib as orc
+    from comet_amd import COSINE, L2_SQUARED, BM25SearchIndex, FlatIndex, IVFIndex, IVFPQIndex
+    from comet_amd.hybrid import hybrid_rrf_search_batch
+    n, d, k, B = 6000, 32, 10, 48
+    X = orc.synth(13, 0, n * d).reshape(n, d)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    if kind == "ivf":
+        g = IVFIndex(ctx, d, 16, L2_SQUARED); g.train(X[:1500]); npb = 4
+    elif kind == "flat_cos":
+        g = FlatIndex(ctx, d, COSINE); npb = 0
+    else:
+        g = IVFPQIndex(ctx, d, L2_SQUARED, 16, 8, 6); g.train(X[:1500]); npb = 4
+    g.add_batch(ids, X)
+    rng = np.random.default_rng(14)
+    tg = BM25SearchIndex(ctx)
+    for i in range(1, n + 1):
+        tg.add(i, np.minimum((rng.pareto(1.1, int(rng.integers(8, 40))) * 3).astype(np.int64), 199).astype(np.uint32))
+    Q = (X[(np.arange(B) * 53) % n] + orc.synth(15, 0, B * d).reshape(B, d) * np.float32(0.05)).astype(np.float32)
+    toks = [[int(t) for t in rng.integers(0, 20, 3)] for _ in range(B)]
+    toks[3] = [100000, 100001]                 # unknown terms: no text hits -> the vector hits with their own scores
+    toks[7] = []                               # no text at all
+    gi, gs, gc = hybrid_rrf_search_batch(g, tg, Q, toks, k=k, n_probes=npb)
+    for b in range(B):
+        s = HybridSearch(g, tg).with_vector(Q[b]).with_k(k).with_fusion_kind(RECIPROCAL_RANK_FUSION)
+        if npb:
+            s = s.with_n_probes(npb)
+        if toks[b]:
+            s = s.with_text(toks[b])
+        want = s.execute()
+        assert gc[b] == len(want), (b, gc[b], len(want))
+        assert np.array_equal(np.sort(gs[b, :gc[b]])[::-1], gs[b, :gc[b]])                                  # descending
+        assert sorted(r.score for r in want) == sorted(gs[b, :gc[b]].tolist()), (b, [r.score for r in want], gs[b, :gc[b]])
+        cut = min(r.score for r in want) if want else 0.0
+        assert {r.id for r in want if r.score > cut} == {int(i) for i, sc in zip(gi[b, :gc[b]], gs[b, :gc[b]]) if sc > cut}, b
+    # same call with the context on ONE lane (both legs on lane 0)
+    ctx.set_lanes(1)
+    try:
+        hi, hs, hc = hybrid_rrf_search_batch(g, tg, Q, toks, k=k, n_probes=npb)
+    finally:
+        ctx.set_lanes(4)
+    assert np.array_equal(hi, gi) and np.array_equal(hs.view(np.uint64), gs.view(np.uint64)) and np.array_equal(hc, gc)

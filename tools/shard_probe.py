@@ -98,6 +98,15 @@ def model(name, N, make_rank, q_ptrs, K, **kw):
         seq = C.CDLL(str(SEQ))            # the handle comm.hip's dlopen made: same library, same logs
     seq.seq_rccl_reset()
     ranks = [(make_rank(r, N), VComm(ident, r, N)) for r in range(N)]
+    # priming pass: the first sharded search of an index on a communicator compares the list placement across the ranks (two host all-reduces, once) — it must
+    # not be part of the recorded sequence, which the replay pass repeats WITHOUT it
+    seq.seq_rccl_set_mode(0)
+    for idx, cm in ranks:
+        o = (ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4))
+        cm.wait(idx, cm.search_async(idx, q_ptrs[0], B, K, *o, **kw), True); cm.sync()
+        for p_ in o:
+            ctx.free(p_)
+    seq.seq_rccl_reset()
     seq.seq_rccl_set_mode(0)
     for idx, cm in ranks:
         loop(cm, idx, q_ptrs, K, False, **kw)
