@@ -26,8 +26,8 @@ constexpr int BM_TCOUNT_STRIDE = 32;      // ints between two queries' touched c
 struct TermRef { int off; int df; double idf; };   // per (query, position); df == 0 -> no such term / padding
 
 __global__ __launch_bounds__(256) void bm25_score_kernel(const TermRef* __restrict__ refs /*[B]*/, const int* __restrict__ post_doc,
-                                                         const int* __restrict__ post_tf, const int* __restrict__ doc_len,
-                                                         const unsigned char* __restrict__ elig, double avg_doc_len,
+                                                         const int* __restrict__ post_tf, const double* __restrict__ kin,
+                                                         const unsigned char* __restrict__ elig,
                                                          double* __restrict__ acc, long nd, int* __restrict__ touched, long tcap, int* __restrict__ tcount) {
     const int q = blockIdx.y;
     const TermRef r = refs[q];
@@ -37,12 +37,10 @@ __global__ __launch_bounds__(256) void bm25_score_kernel(const TermRef* __restri
     const int doc = live ? post_doc[r.off + i] : 0;
     const bool ok = live && !(elig && !elig[doc]);        // deleted / filtered documents are skipped (:312-319)
     const double tfv = ok ? (double)post_tf[r.off + i] : 1.0;
-    const double dl = (double)doc_len[doc];
     // score := idf * (tfVal * (K1 + 1)) / (tfVal + K1*(1-B+B*(docLen/avgDocLen)))  (:321-324), K1=1.2, B=0.75;
-    // the untyped constants K1+1 and 1-B fold exactly to 2.2 and 0.25. Compiled with -ffp-contract=off.
-    const double ratio = dl / avg_doc_len;
-    const double inner = 0.25 + 0.75 * ratio;
-    const double den = tfv + 1.2 * inner;
+    // the untyped constants K1+1 and 1-B fold exactly to 2.2 and 0.25. Compiled with -ffp-contract=off. The document's part of the denominator,
+    // kin[doc] = 1.2 * (0.25 + 0.75 * (docLen / avgDocLen)), is formed once per document (compile()) with these very operations.
+    const double den = tfv + kin[doc];
     const double num = r.idf * (tfv * 2.2);
     const double score = num / den;
     const double old = ok ? acc[(long)q * nd + doc] : 1.0;     // one thread per (query, document) in a launch: no race
@@ -63,6 +61,56 @@ __global__ __launch_bounds__(256) void bm25_score_kernel(const TermRef* __restri
         if (s < tcap) touched[(long)q * tcap + s] = doc;
     }
     if (ok) acc[(long)q * nd + doc] = old + score;
+}
+
+// ---- document-major scoring for queries whose terms are all HOT (round 5) -------------------------------
+// The term-at-a-time launches above are a read-modify-write stream over the accumulator: a frequent term touches most documents of every query that holds
+// it (Zipf-like vocabularies: a three-term query touches ~50 % of 100 k documents, 38 M float64 updates per batch of 256 = 0.38 ms). For the terms with
+// df >= n_docs / 64 the index keeps a DENSE tf column (uint16 per document; compile()), and a query all of whose known terms are hot is scored by one thread
+// per document: its terms in token order (the reference's order of additions: scores[docID] += score, bm25_index_search.go:325, term by term), each
+// `idf * (tf * 2.2) / (tf + kin[doc])` exactly as above (kin[doc] = 1.2 * (0.25 + 0.75 * (docLen / avgDocLen)), formed once per document with the same
+// operations), one write per touched document, no read, no zeroed row. Unknown terms contribute nothing, as in the reference (:301-304).
+struct DenseRef { int h; int pad; double idf; };     // h: hot-column index, -1: the term has no postings
+__global__ __launch_bounds__(256) void bm25_dense_kernel(const int* __restrict__ qrow /*[n]: local query (row) index*/, const DenseRef* __restrict__ refs /*[n][maxlen]*/, int maxlen,
+                                                         const unsigned short* __restrict__ tfcol, const double* __restrict__ kin, const unsigned char* __restrict__ elig,
+                                                         double* __restrict__ acc, long nd, int* __restrict__ touched, long tcap, int* __restrict__ tcount) {
+    const int q = qrow[blockIdx.y];
+    const long doc = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = doc < nd && !(elig && !elig[doc]);
+    const DenseRef* r = refs + (long)blockIdx.y * maxlen;
+    double score = 0.0;
+    if (ok) {
+        const double kd = kin[doc];
+        for (int j = 0; j < maxlen; j++) {
+            const int h = r[j].h;
+            if (h < 0) continue;
+            const unsigned tf = tfcol[(long)h * nd + doc];
+            if (!tf) continue;
+            const double tfv = (double)tf;
+            const double den = tfv + kd;
+            const double num = r[j].idf * (tfv * 2.2);
+            score = score + num / den;
+        }
+    }
+    __shared__ int s_wcnt[4], s_base;
+    const bool first = ok && score != 0.0;               // (scores are > 0: idf = ln(1 + ...) > 0, tf > 0)
+    const unsigned long long m = __ballot(first);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_wcnt[w] = (int)__builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]; s_base = tot ? atomicAdd(&tcount[q * BM_TCOUNT_STRIDE], tot) : 0; }
+    __syncthreads();
+    if (first) {
+        int sl = s_base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        for (int j = 0; j < w; j++) sl += s_wcnt[j];
+        if (sl < tcap) touched[(long)q * tcap + sl] = (int)doc;
+    }
+    if (doc < nd) acc[(long)q * nd + doc] = score;     // every entry of the row, zeros included: the top-K walks the ROW, not the touched list, when most documents were touched
+}
+// the accumulator rows of the queries that take the term-at-a-time path (the document-major kernel writes every entry of its rows itself)
+__global__ __launch_bounds__(256) void bm25_zero_rows_kernel(const int* __restrict__ qrow, double* __restrict__ acc, long nd) {
+    double* row = acc + (long)qrow[blockIdx.y] * nd;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nd; i += (long)gridDim.x * 256) row[i] = 0.0;
 }
 
 // ---- top-k by (score desc, doc index asc) on float64 ------------------------------------------------
@@ -267,6 +315,8 @@ struct comet_text_index {
     bool dirty = true;
     std::vector<uint32_t> doc_ids_h; std::unordered_map<uint32_t, int> term_index; std::vector<int> term_off_h;
     DevBuf doc_ids, doc_len_dev, post_doc, post_tf, deleted_dev;
+    DevBuf kin_dev;                                   // per document: 1.2 * (0.25 + 0.75 * (docLen / avgDocLen)) — the document's part of the score's denominator
+    DevBuf tfcol; std::vector<int> hot_of_term;       // dense tf columns (uint16 per document) of the hot terms; hot_of_term[term index] = column or -1
     DevBuf acc; int64_t acc_rows = 0, acc_nd = -1;   // dense float64 accumulator rows (<= 224 MB: see comet_bm25_search)
     int64_t nd = 0;
 
@@ -303,6 +353,31 @@ struct comet_text_index {
         }
         doc_ids.reserve(std::max<size_t>(4, nd * 4), c->stream, 0); doc_len_dev.reserve(std::max<size_t>(4, nd * 4), c->stream, 0);
         post_doc.reserve(std::max<size_t>(4, pd.size() * 4), c->stream, 0); post_tf.reserve(std::max<size_t>(4, pt.size() * 4), c->stream, 0);
+        // the document's part of the denominator, once per document (the scoring kernels' own operations, in their order)
+        std::vector<double> kin(nd);
+        for (int64_t i = 0; i < nd; i++) { const double ratio = (double)dl[i] / avg_doc_len; const double inner = 0.25 + 0.75 * ratio; kin[i] = 1.2 * inner; }
+        kin_dev.reserve(std::max<size_t>(8, nd * 8), c->stream, 0);
+        c->h2d(kin_dev.p, kin.data(), nd * 8);
+        // dense tf columns for the hot terms (df >= n_docs / 64, at most 256 of them, every tf <= 65535): bm25_dense_kernel
+        hot_of_term.assign(term_off_h.size() - 1, -1);
+        std::vector<unsigned short> cols;
+        if (nd >= 4096) {
+            std::vector<std::pair<int, int>> hot;             // (df, term index)
+            for (size_t t = 0; t + 1 < term_off_h.size(); t++) { const int df = term_off_h[t + 1] - term_off_h[t]; if ((int64_t)df * 64 >= nd) hot.push_back({df, (int)t}); }
+            std::sort(hot.begin(), hot.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+            if (hot.size() > 256) hot.resize(256);
+            int nh = 0;
+            for (auto& hp : hot) {
+                const int t = hp.second; bool fits = true;
+                for (int i = term_off_h[t]; i < term_off_h[t + 1]; i++) if (pt[i] > 65535) { fits = false; break; }
+                if (!fits) continue;
+                cols.resize((size_t)(nh + 1) * nd, 0);
+                for (int i = term_off_h[t]; i < term_off_h[t + 1]; i++) cols[(size_t)nh * nd + pd[i]] = (unsigned short)pt[i];
+                hot_of_term[t] = nh++;
+            }
+        }
+        tfcol.reserve(std::max<size_t>(4, cols.size() * 2), c->stream, 0);
+        c->h2d(tfcol.p, cols.data(), cols.size() * 2);
         c->h2d(doc_ids.p, doc_ids_h.data(), nd * 4); c->h2d(doc_len_dev.p, dl.data(), nd * 4);
         c->h2d(post_doc.p, pd.data(), pd.size() * 4); c->h2d(post_tf.p, pt.data(), pt.size() * 4);
         HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -379,12 +454,19 @@ static bool bm25_search_enqueue(comet_text_index* ix, const uint32_t* q_tokens, 
         int maxlen = 0;
         for (int b = 0; b < B; b++) maxlen = std::max(maxlen, q_offsets[b + 1] - q_offsets[b]);
         std::vector<TermRef> refs((size_t)std::max(1, maxlen) * B);
+        // queries all of whose known terms have a dense tf column are scored document-major (bm25_dense_kernel); the others term-at-a-time
+        static const bool dense_off = getenv("COMET_BM25_NO_DENSE") != nullptr;
+        std::vector<DenseRef> dense_refs; std::vector<int> dense_q, sparse_q;
+        std::vector<DenseRef> one((size_t)std::max(1, maxlen));
         int maxdf = 0; int64_t tcap = 1;
         for (int b = 0; b < B; b++) {
             int64_t touched_max = 0;
             const int len = q_offsets[b + 1] - q_offsets[b];
+            bool dense = !dense_off && ix->tfcol.p != nullptr && len > 0;
+            int q_maxdf = 0;
             for (int j = 0; j < maxlen; j++) {
                 TermRef r{0, 0, 0.0};
+                one[j] = DenseRef{-1, 0, 0.0};
                 if (j < len) {
                     auto it = ix->term_index.find(q_tokens[q_offsets[b] + j]);
                     if (it != ix->term_index.end()) {
@@ -392,12 +474,19 @@ static bool bm25_search_enqueue(comet_text_index* ix, const uint32_t* q_tokens, 
                         r.df = ix->term_off_h[it->second + 1] - r.off;
                         const double df = (double)r.df;
                         r.idf = go_log((N - df + 0.5) / (df + 0.5) + 1.0);     // :306
-                        maxdf = std::max(maxdf, r.df);
+                        q_maxdf = std::max(q_maxdf, r.df);
                         touched_max += r.df;
+                        const int h = ix->hot_of_term[it->second];
+                        if (h < 0) dense = false; else one[j] = DenseRef{h, 0, r.idf};
                     }
                 }
                 refs[(size_t)j * B + b] = r;
             }
+            // (document-major costs one thread per DOCUMENT whatever the terms' frequencies: it pays when the query's postings cover a good part of the collection)
+            if (dense && touched_max * 8 >= nd) {
+                for (int j = 0; j < maxlen; j++) refs[(size_t)j * B + b] = TermRef{0, 0, 0.0};       // nothing for the term-at-a-time launches
+                dense_q.push_back(b); dense_refs.insert(dense_refs.end(), one.begin(), one.end());
+            } else { sparse_q.push_back(b); maxdf = std::max(maxdf, q_maxdf); }
             tcap = std::max(tcap, std::min<int64_t>(touched_max, nd));
         }
         // The dense accumulator lives in the index and is zeroed per sub-batch of queries — deliberately: sized to stay inside the
@@ -417,18 +506,38 @@ static bool bm25_search_enqueue(comet_text_index* ix, const uint32_t* q_tokens, 
         int32_t* tcount = c->salloc<int32_t>((size_t)rows * BM_TCOUNT_STRIDE);
         int64_t slab_ld = 1; while (slab_ld < std::min<int64_t>(k_cap, tcap)) slab_ld <<= 1;
         KP* slab = (std::min<int64_t>(k_cap, tcap) > BM_KMAX) ? c->salloc<KP>((size_t)rows * slab_ld) : nullptr;
+        DenseRef* d_dense = dense_refs.empty() ? nullptr : c->salloc<DenseRef>(dense_refs.size());
+        int* d_dq = c->salloc<int>((size_t)B + 1); int* d_sq = c->salloc<int>((size_t)B + 1);
+        std::vector<int> loc_d(dense_q.size()), loc_s(sparse_q.size());
+        for (size_t i = 0; i < dense_q.size(); i++) loc_d[i] = dense_q[i] % (int)rows;          // local row inside the query's sub-batch
+        for (size_t i = 0; i < sparse_q.size(); i++) loc_s[i] = sparse_q[i] % (int)rows;
+        if (d_dense) c->h2d(d_dense, dense_refs.data(), dense_refs.size() * sizeof(DenseRef));
+        c->h2d(d_dq, loc_d.data(), loc_d.size() * 4); c->h2d(d_sq, loc_s.data(), loc_s.size() * 4);
+        size_t di = 0, si = 0;                        // dense_q / sparse_q are ascending: a sub-batch owns a contiguous run of each
         for (int b0 = 0; b0 < B; b0 += (int)rows) {
             const int bn = std::min<int>((int)rows, B - b0);
             c->zero(tcount, sizeof(int32_t) * bn * BM_TCOUNT_STRIDE);
-            c->zero(acc, (size_t)bn * nd * 8);
-            if (maxdf > 0) {
+            size_t d1 = di, s1 = si;
+            while (d1 < dense_q.size() && dense_q[d1] < b0 + bn) d1++;
+            while (s1 < sparse_q.size() && sparse_q[s1] < b0 + bn) s1++;
+            const int n_dense = (int)(d1 - di), n_sparse = (int)(s1 - si);
+            if (n_sparse > 0 && maxdf > 0) {
+                { ProfScope ps(c, "bm25_zero");
+                  bm25_zero_rows_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(nd, 256 * 8), 64), n_sparse), dim3(256), 0, c->stream>>>(d_sq + si, acc, nd); LAUNCH_CHECK(); }
                 for (int j = 0; j < maxlen; j++) {
                     ProfScope ps(c, "bm25_score");
                     bm25_score_kernel<<<dim3((unsigned)ceil_div(maxdf, 256), bn), dim3(256), 0, c->stream>>>(drefs + (size_t)j * B + b0, ix->post_doc.as<int>(), ix->post_tf.as<int>(),
-                                                                                                        ix->doc_len_dev.as<int>(), elig, ix->avg_doc_len, acc, nd, touched, tcap, tcount);
+                                                                                                        ix->kin_dev.as<double>(), elig, acc, nd, touched, tcap, tcount);
                     LAUNCH_CHECK();
                 }
             }
+            if (n_dense > 0) {
+                ProfScope ps(c, "bm25_dense");
+                bm25_dense_kernel<<<dim3((unsigned)ceil_div(nd, 256), n_dense), dim3(256), 0, c->stream>>>(d_dq + di, d_dense + di * (size_t)std::max(1, maxlen), std::max(1, maxlen),
+                                                                                                          ix->tfcol.as<unsigned short>(), ix->kin_dev.as<double>(), elig, acc, nd, touched, tcap, tcount);
+                LAUNCH_CHECK();
+            }
+            di = d1; si = s1;
             {
                 ProfScope ps(c, "bm25_topk");
                 bm25_topk_kernel<<<dim3(bn), dim3(BM_THREADS), 0, c->stream>>>(acc, nd, touched, tcap, tcount, tkeys, k, ix->doc_ids.as<uint32_t>(), slab, slab_ld,
