@@ -59,7 +59,16 @@ int comet_ctx_create(int device_id, comet_ctx** out) {
             std::string arch = c->prop.gcnArchName; delete c;
             COMET_FAIL(COMET_ERR_NO_DEVICE, "device %d is %s; this library contains gfx950 (MI355X) code only", device_id, arch.c_str());
         }
-        HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        // All of the context's streams are made NOW. The runtime multiplexes streams onto a few hardware queues per priority level (four), and a stream made
+        // when every queue of its level is taken shares the least-used one — which two lanes created lazily, with indexes' private copy streams made and
+        // destroyed in between, did whenever the order of a program's calls was unlucky: their searches then take turns instead of overlapping (bench: the
+        // HNSW leg at four batches in flight 1.65 M -> 1.08 M q/s and IVFPQ 1.8 -> 1.4 M after the legs flat_l2 + ivfpq had run, kernel times unchanged).
+        // The four lanes therefore get a priority level of their OWN (the highest): the first four streams of a level each open a queue, so the lanes never
+        // share one with each other or with anything else of the process.
+        int pr_least = 0, pr_greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr_greatest));
+        for (int l = 1; l < Ctx::kMaxLanes; l++) HIP_CHECK(hipStreamCreateWithPriority(&c->parked[l].stream, hipStreamNonBlocking, pr_greatest));
         *out = c;
         return COMET_OK;
     });
@@ -232,7 +241,10 @@ int comet_ivfpq_create(comet_ctx* c, int dim, int metric, int nlist, int M, int 
 }
 int comet_index_destroy(comet_index* idx) {
     return guarded([&] { if (!idx) return (int)COMET_OK; Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->check_indexes("entry of comet_index_destroy"); c->bind(); c->quiesce_all();
-        (void)hipDeviceSynchronize();      // destroy is rare: every queue of the device idle (the index's private copy stream, runtime-internal copies) before its buffers, events and pinned slots are released
+        // destroy is rare: every queue of the device idle (runtime-internal copies included) before the index's buffers, events and pinned slots are released
+        // (COMET_DESTROY_NO_DEVICE_SYNC=1 leaves it to the context's own streams — tools/soak.py runs with it to test whether the drain is still needed)
+        static const bool no_dev_sync = getenv("COMET_DESTROY_NO_DEVICE_SYNC") != nullptr;
+        if (!no_dev_sync) (void)hipDeviceSynchronize();
         delete idx; return (int)COMET_OK; });
 }
 int comet_index_kind(const comet_index* idx) { return idx->kind; }

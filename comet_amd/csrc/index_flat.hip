@@ -93,7 +93,7 @@ struct FlatIndex : comet_index {
     ~FlatIndex() override {
         if (copy_stream) (void)hipStreamSynchronize(copy_stream);      // nothing of this index is in flight on its private stream when its events and pinned slots go
         for (auto& r : ring) { if (r.ev) (void)hipEventDestroy(r.ev); if (r.ev_post) (void)hipEventDestroy(r.ev_post); if (r.flags) (void)hipHostFree(r.flags); if (r.dflags) (void)hipFree(r.dflags); }
-        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        // (the stream belongs to the context since round 5: comet_ctx_create)
     }
 
     int64_t size() const override { return n; }
@@ -336,7 +336,7 @@ struct FlatIndex : comet_index {
         if (!slot->flags) HIP_CHECK(hipHostMalloc((void**)&slot->flags, sizeof(int32_t) * kSliceInts * kMaxSlices, hipHostMallocDefault));
         if (!slot->dflags) HIP_CHECK(hipMalloc((void**)&slot->dflags, sizeof(int32_t) * kSliceInts * kMaxSlices));
         if (!slot->ev_post) HIP_CHECK(hipEventCreateWithFlags(&slot->ev_post, hipEventDisableTiming));
-        if (!copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        copy_stream = c->stream;      // the flag copy follows the search on its own lane (round 5; a private stream until then: see below)
         slot->ticket = next_ticket++; slot->B = B; slot->k_cap = k_cap; slot->nfast_slices = 0; slot->i8_mask = 0; slot->queries = queries_dev;
         n_searches++;
         slot->p = p; slot->flt.clear();
@@ -345,8 +345,10 @@ struct FlatIndex : comet_index {
         st_candidates = st_overflows = st_expansions = st_fast_queries = st_strict_queries = st_i8_slices = 0;
         search_core(queries_dev, B, p, out_ids, out_scores, out_counts, k_cap, slot);
         if (slot->nfast_slices > 0) {
-            // overflow flags + statistics go to pinned host memory on the copy stream: the copy (a kernel of its own plus two launch
-            // gaps) leaves the chain of the next batch; search_finish() waits for it and therefore for everything before it
+            // overflow flags + statistics go to pinned host memory behind the search, on its lane's stream; search_finish() waits for the copy and therefore
+            // for everything before it. (Rounds 2-4 sent the copy to a private stream so that it left the chain of the next batch; with the searches alternating
+            // between lanes the next batch's chain is on another stream anyway, and a fifth stream beside the four lanes shares a hardware queue with one of them:
+            // Flat single stream 855 -> 875 k q/s, IVF 1.09 -> 1.13 M with the copy inline, comet_ctx_create.)
             HIP_CHECK(hipEventRecord(slot->ev_post, c->stream));
             HIP_CHECK(hipStreamWaitEvent(copy_stream, slot->ev_post, 0));
             HIP_CHECK(hipMemcpyAsync(slot->flags, slot->dflags, sizeof(int32_t) * kSliceInts * slot->nfast_slices, hipMemcpyDeviceToHost, copy_stream));

@@ -253,7 +253,7 @@ struct IVFIndex : comet_index {
     ~IVFIndex() override {
         if (copy_stream) (void)hipStreamSynchronize(copy_stream);      // nothing of this index is in flight on its private stream when its events and pinned slots go
         for (auto& r : ring) { if (r.ev) (void)hipEventDestroy(r.ev); if (r.ev_post) (void)hipEventDestroy(r.ev_post); if (r.flags) (void)hipHostFree(r.flags); if (r.dflags) (void)hipFree(r.dflags); }
-        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        // (the stream belongs to the context since round 5: comet_ctx_create)
     }
 
     int64_t size() const override { return lay.n; }
@@ -550,7 +550,7 @@ struct IVFIndex : comet_index {
         if (!slot->ev_post) HIP_CHECK(hipEventCreateWithFlags(&slot->ev_post, hipEventDisableTiming));
         if (!slot->flags) HIP_CHECK(hipHostMalloc((void**)&slot->flags, sizeof(int32_t) * kSliceInts * kMaxSlices, hipHostMallocDefault));
         if (!slot->dflags) HIP_CHECK(hipMalloc((void**)&slot->dflags, sizeof(int32_t) * kSliceInts * kMaxSlices));
-        if (!copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        copy_stream = c->stream;      // the flag copy follows the search on its own lane (round 5; a private stream until then: see below)
         slot->ticket = next_ticket++; slot->B = B; slot->k_cap = k_cap; slot->nfast_slices = 0; slot->i8_mask = 0; slot->queries = queries_dev;
         n_searches++;
         slot->p = p; slot->flt.clear();
