@@ -1165,6 +1165,8 @@ def main():
 
 def _rnd(x, nd=4):
     if isinstance(x, float):
+        if abs(x) >= 1000:
+            return int(round(x))                 # rates and byte counts: whole numbers (the compact line is read from a bounded tail)
         return float(f"{x:.{nd + 2}g}") if abs(x) < 1 else round(x, nd)
     return x
 
@@ -1252,7 +1254,7 @@ def compact_line(full):
                                "identical_to_the_replica_results_for_batch_0": sr.get("identical_to_the_replica_results_for_batch_0"),
                                "scan_frac": _rnd((sr.get("roofline") or {}).get("frac"))}
     out["lanes"] = full.get("execution_lanes"); out["batches_in_flight"] = full.get("batches_in_flight")
-    out["note_overlap"] = "value: `batches_in_flight` batches on `lanes` streams (kernels of different batches overlap); single_stream_qps: 1 lane, 1 batch in flight"
+    out["note_overlap"] = "value: `batches_in_flight` batches on `lanes` streams; single_stream_qps: 1 lane, 1 batch in flight"
     if isinstance(full.get("single_stream"), dict):
         out["single_stream_qps"] = _rnd(full["single_stream"].get("qps"))
     if isinstance(full.get("sustained"), dict):
@@ -1276,9 +1278,11 @@ def compact_line(full):
         elif name == "hybrid":
             legs[name] = {b: {k: v for k, v in _leg(rec[b]).items() if k in ("qps", "single_stream_qps", "cpu_qps", "parity_mismatches", "parity_checked")}
                           for b in rec if b.startswith("ivf_nprobe") or b == "bm25"}
-            for b in ("rrf", "end_to_end", "end_to_end_nprobe32", "legs_added"):
+            for b in ("rrf", "end_to_end", "end_to_end_nprobe32"):
                 if isinstance(rec.get(b), dict):
-                    legs[name][b] = {k: _rnd(v) for k, v in rec[b].items() if isinstance(v, (int, float))}
+                    legs[name][b] = {k: _rnd(v) for k, v in rec[b].items() if isinstance(v, (int, float)) and k != "queries_compared"}
+            if isinstance(rec.get("legs_added"), dict):
+                legs[name]["legs_added_qps"] = _rnd(rec["legs_added"].get("qps"))
             if isinstance(rec.get("cpu_baseline"), dict):
                 legs[name]["cpu_qps"] = _rnd(rec["cpu_baseline"].get("value")); legs[name]["parity_mismatches"] = rec["cpu_baseline"].get("parity_mismatches")
         elif name == "c1":
