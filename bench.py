@@ -585,7 +585,7 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
             p1.free()
             ctx.set_lanes(LANES)
             adc_ms = ex_prof.get("adc_scan", (0.0, 0))[0] / ex_steps
-            phys = code_bytes + table_bytes
+            phys = code_bytes + (0.0 if args.nbits == 8 and (d // args.M) in (4, 8) and not os.environ.get("COMET_ADC_STREAM_TABLES") else table_bytes)
             same = bool(np.array_equal(x[2], g[2]) and all(np.array_equal(x[0][b, :g[2][b]], g[0][b, :g[2][b]]) and
                                                          np.array_equal(x[1][b, :g[2][b]].view(np.uint32), g[1][b, :g[2][b]].view(np.uint32)) for b in range(B)))
             ceil_ = adc_lookups_ceiling()
@@ -597,6 +597,10 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
             probed = np.unique(np.argsort(d2, axis=1, kind="stable")[:, :args.nprobe])
             uniq_code_bytes = float(list_len[probed].sum()) * ((args.M + 3) // 4 * 4)
             pair_tables = float((list_len[np.argsort(d2, axis=1, kind="stable")[:, :args.nprobe]] > 0).sum()) * args.M * min(1 << args.nbits, 256) * 4
+            # round 5: 8-bit codebooks with 4 / 8 dimensions per subspace build their tables in LDS (adc_scan_kernel<DSUB>): no table byte touches HBM
+            tables_in_lds = args.nbits == 8 and (d // args.M) in (4, 8) and not os.environ.get("COMET_ADC_STREAM_TABLES")
+            if tables_in_lds:
+                pair_tables = 0.0
             must = uniq_code_bytes + pair_tables
             ach = must / (adc_ms * 1e-3) / 1e9 if adc_ms > 0 else 0.0
             traffic, src = pmc_traffic("adc_scan", n)
@@ -606,12 +610,14 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                                "avg_kernel_ms": adc_ms,
                                "algorithmic_bytes_per_launch": must,
-                               "algorithmic_bytes_are": "what must come from HBM: the code words of every distinct probed list once + one lookup table per scanned (query, list) pair "
-                                                        "(the tables are built into HBM by pq_lut and streamed back once)",
+                               "algorithmic_bytes_are": "what must come from HBM: the code words of every distinct probed list once" + (" — the lookup tables are built in LDS by the scanning "
+                                                        "workgroups and never touch HBM (what `traffic` holds beyond the code words: duos of one list on different XCDs re-reading its codes, and the part of "
+                                                        "the codebook slices, re-read per item, that misses L2)" if tables_in_lds else " + one lookup table per scanned (query, list) pair (built into HBM by pq_lut, streamed back once)"),
+                               "tables": "built in LDS (adc_scan_kernel<DSUB>)" if tables_in_lds else "streamed through HBM (pq_lut_kernel)",
                                "unique_code_bytes": uniq_code_bytes, "pair_table_bytes": pair_tables,
                                "requested_bytes_per_launch": phys,
                                "requested_bytes_are": "what the launch's work items ask the memory system for: every item's code words (a list's codes once per PAIR of queries sharing it) "
-                                                      "+ its duo's table per 8192-code item — counted by the kernel that lays out the work (get_stat adc_code_bytes / adc_table_bytes); "
+                                                      "+ (streamed tables only) its duo's table per item — counted by the kernel that lays out the work (get_stat adc_code_bytes / adc_table_bytes); "
                                                       "the difference to the HBM bytes is served by L2 and the 256 MB Infinity Cache (the 1M index's codes are 96 MB)",
                                "requested_code_bytes": code_bytes, "requested_table_bytes": table_bytes,
                                "requested_GBps": phys / (adc_ms * 1e-3) / 1e9 if adc_ms > 0 else 0.0,
