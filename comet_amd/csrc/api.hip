@@ -241,10 +241,12 @@ int comet_ivfpq_create(comet_ctx* c, int dim, int metric, int nlist, int M, int 
 }
 int comet_index_destroy(comet_index* idx) {
     return guarded([&] { if (!idx) return (int)COMET_OK; Ctx* c = idx->c; std::lock_guard<std::recursive_mutex> lk(c->mu); c->check_indexes("entry of comet_index_destroy"); c->bind(); c->quiesce_all();
-        // destroy is rare: every queue of the device idle (runtime-internal copies included) before the index's buffers, events and pinned slots are released
-        // (COMET_DESTROY_NO_DEVICE_SYNC=1 leaves it to the context's own streams — tools/soak.py runs with it to test whether the drain is still needed)
-        static const bool no_dev_sync = getenv("COMET_DESTROY_NO_DEVICE_SYNC") != nullptr;
-        if (!no_dev_sync) (void)hipDeviceSynchronize();
+        // quiesce_all() above: every lane of the context is idle — and since round 5 an index owns no stream of its own (the Flat / IVF flag copies follow their
+        // search on its lane), so nothing of the index can be in flight. Round 4 drained the whole DEVICE here (hipDeviceSynchronize) as a mitigation for the
+        // wild write its soak had found; that stalls every other context of the process and can block behind a peer's collective. Three 900 s
+        // soaks of the round-4 seed ran clean without it on round 5's code (profiles/r05_soak.txt): it is now opt-in, COMET_DESTROY_DEVICE_SYNC=1.
+        static const bool dev_sync = getenv("COMET_DESTROY_DEVICE_SYNC") != nullptr;
+        if (dev_sync) (void)hipDeviceSynchronize();
         delete idx; return (int)COMET_OK; });
 }
 int comet_index_kind(const comet_index* idx) { return idx->kind; }

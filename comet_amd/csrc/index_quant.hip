@@ -1082,6 +1082,8 @@ struct PQFamilyIndex : comet_index {
     bool get_stat(const char* name, double* out) const override {
         std::string k(name);
         if (k == "max_list_len") { const_cast<ListLayout&>(lay).compile(c); *out = (double)lay.max_len; return true; }
+        if (k == "adc_auto_one_stage") { *out = auto_one ? 1.0 : 0.0; return true; }        // adaptive staging: the searches between two samples run single-stage
+        if (k == "adc_auto_searches") { *out = (double)auto_n; return true; }
         if (k.rfind("adc_", 0) == 0) {
             // cumulative counters of the fused ADC search. Two-stage search: (query, list) pairs the lower bound left / all pairs behind the nearest
             // lists. What the scan launches were given to move and score: code bytes (every item's blocks, once per duo), table bytes (every item

@@ -121,7 +121,8 @@ def test_ranks_that_disagree_on_the_list_placement_fail_together(tmp_path):
 
 
 @pytest.mark.skipif(not SHIM.exists(), reason="tests/libshm_rccl.so not built (__graft_entry__.build())")
-def test_bench_gpus2_launches_two_ranks_itself(tmp_path):
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_gpus2_launches_two_ranks_itself(tmp_path, launcher):
     """`python bench.py --gpus 2` with no launcher around it starts two ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), rank 0 prints ONE line with n_gpus = 2:
     `value` from the throughput layout (a replica per rank, own query streams, no exchange), the row-sharded form with the in-library all-gather + merge beside
     it, both bit-identical to each other and rank 0's batch bit-identical to the CPU oracle. Both ranks share this box's one GPU (COMET_BENCH_DEVICE, the
@@ -129,10 +130,13 @@ def test_bench_gpus2_launches_two_ranks_itself(tmp_path):
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(COMET_RCCL_LIB=str(SHIM), COMET_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--legs", "flat,ivfpq", "--rows", "200000", "--steps", "4", "--warmup", "2", "--regions", "2",
-                        "--sustain-s", "0.2", "--cpu-seconds", "2"], env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    bench = [str(ROOT / "bench.py"), "--gpus", "2", "--legs", "flat,ivfpq", "--rows", "200000", "--steps", "4", "--warmup", "2", "--regions", "2", "--sustain-s", "0.2", "--cpu-seconds", "2"]
+    # "torchrun": the driver's own launch line for N > 1 (one rank per process, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher)
+    cmd = [sys.executable] + bench if launcher == "self" else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                                               "--master-port", "29871"] + bench
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["cpu_baseline"] is None
     assert line["config"]["layout"] == {"ranks_per_index_copy": 1, "index_copies": 2, "queries_per_step_all_ranks": 512, "exchange": None}
     assert line["parity"]["parity_mismatches"] == 0 and line["parity"]["parity_checked_queries"] >= 64

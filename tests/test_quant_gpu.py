@@ -507,3 +507,35 @@ def test_ivfpq_lower_bound_rounds_and_margins(ctx, d, M, scale, offset):
         m0 = g.search_batch(Q, k, nprobes=npb); m1 = g.search_batch(Q, k, nprobes=npb, mode=1)
         assert np.array_equal(m0[2], m1[2]) and np.array_equal(m0[0], m1[0]) and np.array_equal(bits(m0[1]), bits(m1[1]))
     assert g.stat("adc_pairs_behind_nearest") > b0
+
+
+def test_ivfpq_adaptive_staging_and_bound_refinement_keep_results(ctx):
+    """Round 5: (i) on rows without cluster structure the lower bound of the two-stage search removes nothing, and after the first sampled search (every 32nd
+    runs two-stage with counters on) the searches in between run single-stage; on clustered rows they stay two-stage. (ii) The fused filter's bound is
+    refined from the survivors' row. Whatever the policy decides, every search returns what the every-candidate search (mode 1) and the oracle return."""
+    import oracle_lib as orc
+    from comet_amd import L2_SQUARED, IVFPQIndex
+    n, d, nlist, M, B, k = 40_000, 64, 64, 8, 48, 10
+    for kind in ("uniform", "clustered"):
+        if kind == "uniform":
+            X = orc.synth(41, 0, n * d).reshape(n, d)
+            Qs = [orc.synth(42 + i, 0, B * d).reshape(B, d) for i in range(3)]
+        else:
+            cen = orc.synth(51, 0, 200 * d).reshape(200, d)
+            X = (cen[np.arange(n) % 200] + orc.synth(52, 0, n * d).reshape(n, d) * np.float32(0.05)).astype(np.float32)
+            Qs = [(cen[(np.arange(B) * 3 + i) % 200] + orc.synth(53 + i, 0, B * d).reshape(B, d) * np.float32(0.05)).astype(np.float32) for i in range(3)]
+        g = IVFPQIndex(ctx, d, L2_SQUARED, nlist, M, 8)
+        g.train(X[:8000]); g.add_batch(np.arange(1, n + 1, dtype=np.uint32), X)
+        o = orc.IVFPQ(d, "l2_squared", nlist, M, 8)
+        blob = g.to_bytes(); assert o.from_bytes(blob) == len(blob)
+        want = [g.search_batch(Q, k, nprobes=16, mode=1) for Q in Qs]
+        for b in range(0, B, 7):
+            cnt, oi, os_ = o.search(Qs[0][b], k, 16)
+            assert want[0][2][b] == cnt and np.array_equal(want[0][0][b, :cnt], oi) and np.array_equal(want[0][1][b, :cnt].view(np.uint32), np.asarray(os_, np.float32).view(np.uint32))
+        for it in range(70):                                     # samples at searches 0, 32, 64 of the default mode
+            got = g.search_batch(Qs[it % 3], k, nprobes=16)
+            w = want[it % 3]
+            assert np.array_equal(got[2], w[2]) and np.array_equal(got[0], w[0]) and np.array_equal(got[1].view(np.uint32), w[1].view(np.uint32)), (kind, it)
+        ctx.sync()
+        assert g.stat("adc_auto_searches") >= 70
+        assert g.stat("adc_auto_one_stage") == (1.0 if kind == "uniform" else 0.0), kind
