@@ -500,7 +500,7 @@ int comet_index_set_shard(comet_index* idx, int32_t rank, int32_t world) {
         if (idx->kind != COMET_KIND_IVF && idx->kind != COMET_KIND_IVFPQ) COMET_FAIL(COMET_ERR_UNSUPPORTED, "list sharding applies to IVF / IVFPQ indexes (shard Flat / PQ rows on the caller's side)");
         if (idx->size() != 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "set the shard before adding vectors");
         std::lock_guard<std::recursive_mutex> lk(idx->c->mu);
-        idx->shard_rank = rank; idx->shard_world = world; idx->owners_checked_on = nullptr;
+        idx->shard_rank = rank; idx->shard_world = world; idx->owners_checked_on = 0;
         idx->assign_list_owners();          // trained already: lists dealt by their training-set lengths (before training: at the end of Train)
         return (int)COMET_OK;
     });
@@ -523,7 +523,7 @@ int comet_index_set_list_owners(comet_index* idx, const int32_t* owners, int32_t
         if (idx->n_lists() != n_lists || !owners) COMET_FAIL(COMET_ERR_INVALID_ARG, "the placement must name an owner for each of the index's %d lists", idx->n_lists());
         for (int32_t l = 0; l < n_lists; l++) if (owners[l] < 0 || owners[l] >= idx->shard_world) COMET_FAIL(COMET_ERR_INVALID_ARG, "list %d: owner %d is not a rank of %d", l, owners[l], idx->shard_world);
         std::lock_guard<std::recursive_mutex> lk(idx->c->mu);
-        idx->train_counts.clear(); idx->list_owner.assign(owners, owners + n_lists); idx->owners_checked_on = nullptr;
+        idx->train_counts.clear(); idx->list_owner.assign(owners, owners + n_lists); idx->owners_checked_on = 0;
         return (int)COMET_OK;
     });
 }

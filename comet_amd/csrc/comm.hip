@@ -13,6 +13,8 @@
 // library never load it.
 #include <dlfcn.h>
 
+#include <atomic>
+
 #include "index.hpp"
 
 namespace comet {
@@ -72,7 +74,7 @@ struct comet_comm {
     hipEvent_t bound_a = nullptr, bound_b = nullptr;
     int exch_done = 0;                   // bound exchanges issued so far by the search being enqueued (a failing search owes its peers the rest)
     DevBuf idle_tq;                      // +inf bounds a failed search contributes
-    uint64_t owners_checked = 0;         // fingerprint of the last list placement the ranks compared (0: none yet)
+    uint64_t uid = 0;                    // never reused (a later communicator may be allocated at this one's address): what an index remembers its placement check by
     DevBuf scalar;                       // small device scratch for barrier / all-reduce
     struct Slot {
         bool active = false; uint64_t ticket = 0, search_ticket = 0;
@@ -114,7 +116,8 @@ int comet_comm_create(comet_ctx* c, const uint8_t* id128, int32_t rank, int32_t 
         if (!init) COMET_FAIL(COMET_ERR_UNSUPPORTED, "ncclCommInitRank not found in librccl");
         UniqueId id; std::memcpy(&id, id128, sizeof(id));
         auto* cm = new comet_comm();
-        cm->c = c; cm->rank = rank; cm->world = world;
+        static std::atomic<uint64_t> next_uid{1};
+        cm->c = c; cm->rank = rank; cm->world = world; cm->uid = next_uid++;
         int rc = init(&cm->comm, world, id, rank);
         if (rc != 0) { delete cm; COMET_FAIL(COMET_ERR_HIP, "ncclCommInitRank failed: %d (%s)", rc, r.GetErrorString ? r.GetErrorString(rc) : "?"); }
         HIP_CHECK(hipStreamCreateWithFlags(&cm->xstream, hipStreamNonBlocking));
@@ -170,14 +173,14 @@ int comet_index_search_sharded_async(comet_index* idx, comet_comm* cm, const flo
         // A list-sharded index: every rank must deal the lists to the ranks the same way (the placement comes from host-side training state, which a rank that
         // LOADED its quantisers does not have — comet_index_set_list_owners). The first sharded search of an index on a communicator compares a fingerprint of
         // the placement over the ranks (two blocking all-reduces, once): ranks that disagree would own some lists twice and others not at all, silently.
-        if (cm->world > 1 && idx->shard_world > 1 && idx->owners_checked_on != cm) {
+        if (cm->world > 1 && idx->shard_world > 1 && idx->owners_checked_on != cm->uid) {
             if (idx->shard_world != cm->world || idx->shard_rank != cm->rank)
                 COMET_FAIL(COMET_ERR_INVALID_ARG, "index is shard %d of %d, the communicator is rank %d of %d", idx->shard_rank, idx->shard_world, cm->rank, cm->world);
             const double fp = (double)(idx->owners_fingerprint() & ((1ull << 52) - 1));
             const double hi = allreduce_host(cm, fp, NCCL_MAX), lo = allreduce_host(cm, fp, NCCL_MIN);
             if (hi != lo) COMET_FAIL(COMET_ERR_INVALID_ARG, "the ranks of this communicator disagree on which rank owns which inverted list (placement fingerprints %.0f .. %.0f): "
                                                             "train every rank on the same vectors or hand every rank the same placement (comet_index_set_list_owners)", lo, hi);
-            idx->owners_checked_on = cm;
+            idx->owners_checked_on = cm->uid;
         }
         // every other sharded search of an index on the context's second lane, like comet_index_search_dev_async: a rank's
         // short kernels (query preparation, post stage, coarse ranking) are the part of its step that does not shrink with the shard

@@ -50,7 +50,7 @@ struct comet_index {
     uint64_t guard1 = kGuard;
     int owner_of(int32_t l) const { return list_owner.empty() ? l % shard_world : list_owner[(size_t)l]; }
     // what the ranks of a communicator compare before the first sharded search (comm.hip): FNV-1a over (world, the placement; "l % world" when there is none)
-    const void* owners_checked_on = nullptr;
+    uint64_t owners_checked_on = 0;      // comet_comm::uid of the communicator the placement was last compared on (0: none)
     uint64_t owners_fingerprint() const {
         uint64_t h = 1469598103934665603ull;
         auto mix = [&](uint32_t v) { for (int b = 0; b < 4; b++) { h ^= (v >> (8 * b)) & 0xFF; h *= 1099511628211ull; } };
@@ -60,7 +60,7 @@ struct comet_index {
     }
     // the placement is not part of the reference's on-disk layouts: an index that loads its quantisers (read_from) starts without one (l % world on every
     // rank that loaded) until the host hands it the placement it saved (comet_index_get_list_owners / _set_list_owners)
-    void forget_placement() { train_counts.clear(); list_owner.clear(); owners_checked_on = nullptr; }
+    void forget_placement() { train_counts.clear(); list_owner.clear(); owners_checked_on = 0; }
     void assign_list_owners() {
         list_owner.clear();
         if (shard_world <= 1 || train_counts.empty()) return;

@@ -646,7 +646,7 @@ int comet_hybrid_rrf_search(comet_index* vec, comet_text_index* txt, const float
         c->fence_lane0();
         // vector leg: on lane 1 (its own stream and scratch arena) when the context has more than one lane, behind the upload
         comet_search_params p{}; p.k = k; p.nprobes = nprobes; p.ef_search = ef_search; p.mode = 0;
-        const int vlane = c->lanes > 1 ? 1 : 0;
+        const int vlane = (c->lanes > 1 && vec->max_lanes() > 1) ? 1 : 0;
         uint64_t ticket = 0;
         {
             struct LaneBack { Ctx* c; ~LaneBack() { if (c->cur_lane != 0) { c->mark_dirty(); c->switch_lane(0); } } } lane_back{c};
