@@ -428,6 +428,7 @@ constexpr int ADC_XCD_CHUNK = 4;                               // adjacent duos 
 constexpr int ADC_G = ADC_G_N;                                       // code words (4 subspaces each) per software-pipelined group
 constexpr int ADC_BUF_BYTES = ADC_BUF_KB * 1024;                       // one phase buffer; two of them in LDS
 constexpr unsigned ADC_HOLE = 0xFFFFFFFFu;
+constexpr int ADC_STAGE_CAP = 512;                                  // survivors of one (item, query half) staged in LDS before they are appended (more: appended directly)
 constexpr int ADC_REFINE_MAX = 512;                                 // entries of a query's survivor row the bound refinement looks at
 constexpr int LUT_PAIRS_PER_WG = 32;
 constexpr int ORDER_MAX_LISTS = 36 * 1024;                     // counting-sort bins that fit in LDS
@@ -1233,6 +1234,14 @@ template <int BUILD>
 __global__ __launch_bounds__(ADC_THREADS) __attribute__((amdgpu_waves_per_eu(ADC_WPE, ADC_WPE))) void adc_scan_kernel(const AdcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // two phase buffers of ADC_BUF_BYTES
     __shared__ int s_ticket[2][2];                                  // [item parity][0] queue, [1] ticket (-1: all queues drained)
+    // Fused filter: an item's survivors are STAGED here per query half and flushed by the last wave of the item to arrive — one returning global atomic per
+    // (item, half) on the query's cursor instead of one per wave and chain. With few queries in a batch (or loose bounds: the first items of every launch) all
+    // workgroups append to the same few rows and the same-address returning atomics serialise in the L2: the epilogue was 0.52 of a 0.61 ms launch at B = 32 and
+    // 0.10 of 0.52 ms at B = 256 on uniform rows (profiles/r05_adc_ablation.txt).
+    __shared__ unsigned long long s_stage[2][ADC_STAGE_CAP];
+    __shared__ int s_scnt[2], s_sdone[2], s_svalid[2];
+    __shared__ unsigned s_kmin[2];                                  // the smallest bound the item's waves offer for the half: ONE global atomicMin per (item, half), by the flushing wave
+    if (threadIdx.x < 2) { s_scnt[threadIdx.x] = 0; s_sdone[threadIdx.x] = 0; s_svalid[threadIdx.x] = 0x7FFFFFFF; s_kmin[threadIdx.x] = 0xFFFFFFFFu; }
     const unsigned lane = threadIdx.x & 63u, voff = lane * 4u;
     const int wid = RFL((int)(threadIdx.x >> 6));
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
@@ -1441,7 +1450,10 @@ __global__ __launch_bounds__(ADC_THREADS) __attribute__((amdgpu_waves_per_eu(ADC
                     }
                 }
                 ADC_STAMP(trace_item, 11 + 2 * h);
-                if (__ballot(lmin <= Ts) == 0ull) continue;                  // nothing of this wave can matter (and its K-th minimum is above the bound)
+                // waves of the item that hold chains: every one of them "arrives" once per half, the last one flushes the staged survivors
+                const int nblk0 = (min(cur.seg_end, cur.start + ADC_PASS_CODES) - cur.start + 63) >> 6;
+                const int nw = min(ADC_WAVES, nblk0);
+                if (__ballot(lmin <= Ts) != 0ull) {                          // else: nothing of this wave can matter (and its K-th minimum is above the bound)
                 // K-th smallest lane minimum, bit by bit from the top (ballots only: the LDS pipe is the kernel's bottleneck)
                 unsigned kth = 0xFFFFFFFFu;
                 if ((int)__builtin_popcountll(__ballot(lmin != 0xFFFFFFFFu)) >= a.K) {
@@ -1452,11 +1464,12 @@ __global__ __launch_bounds__(ADC_THREADS) __attribute__((amdgpu_waves_per_eu(ADC
                         if ((int)__builtin_popcountll(__ballot(lmin <= tv)) < a.K) kth |= 1u << bit;
                     }
                 }
-                if (lane == 0 && kth < T) atomicMin(&a.tq[q], kth);
+                // (the bound goes to the query's word through the item's flushing wave: tq[] is a dense array — 32 queries share a 128-byte line — and a global
+                // atomic per wave from every workgroup of a launch serialised on a handful of lines: the first item of a B = 32 launch took 0.4 of its 0.54 ms)
+                if (lane == 0 && kth < T) atomicMin(&s_kmin[h], kth);
                 const unsigned bnd = min(T, kth);
                 const unsigned bs = bnd >= 0x7F800000u ? 0x7F800000u : __float_as_uint(__uint_as_float(bnd) * 1.0000005f);
                 const float Td = go_sqrt32q(__uint_as_float(bnd));           // the bound as a distance
-                int app_lo = 0x7FFFFFFF, app_hi = 0;                         // the slots this wave's survivors took in the query's row (wave-uniform)
 #pragma unroll
                 for (int ps = 0; ps < ADC_SEG_PASSES; ps++) {
                     const int na = ps == 0 ? na0 : na1;
@@ -1472,46 +1485,74 @@ __global__ __launch_bounds__(ADC_THREADS) __attribute__((amdgpu_waves_per_eu(ADC
                             const int j = ((cur.start >> 6) + ps * (ADC_PASS_CODES >> 6) + c * ADC_WAVES + wid) * 64 + (int)lane;
                             const int leader = __builtin_ctzll(m);
                             const int cnt = (int)__builtin_popcountll(m);
-                            int base = 0;
-                            if ((int)lane == leader) base = atomicAdd(&a.cursor[q], cnt);
-                            base = RFL(__shfl(base, leader, 64));
-                            app_lo = min(app_lo, base); app_hi = max(app_hi, base + cnt);
-                            // (agent-scope store: written through the XCD's L2, so that a refining wave on another XCD can see it — see below)
-                            if (keep) __hip_atomic_store(&a.cand[(long)q * a.ldD + base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))],
-                                                         ((unsigned long long)adc_f2key(__float_as_uint(d)) << 32) | (unsigned)(so + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const unsigned long long comp = ((unsigned long long)adc_f2key(__float_as_uint(d)) << 32) | (unsigned)(so + j);
+                            const int rank = (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                            int slot = 0;
+                            if ((int)lane == leader) slot = atomicAdd(&s_scnt[h], cnt);                    // LDS: a slot range of the item's staging area
+                            slot = RFL(__shfl(slot, leader, 64));
+                            if (slot + cnt <= ADC_STAGE_CAP) { if (keep) s_stage[h][slot + rank] = comp; }
+                            else {                                                                        // the staging area is full: append directly (rare)
+                                if ((int)lane == leader) atomicMin(&s_svalid[h], slot);
+                                int base = 0;
+                                if ((int)lane == leader) base = atomicAdd(&a.cursor[q], cnt);
+                                base = RFL(__shfl(base, leader, 64));
+                                if (keep) __hip_atomic_store(&a.cand[(long)q * a.ldD + base + rank], comp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                         }
                     }
                 }
-                // Bound refinement from the survivors. A wave can only offer the K-th smallest of ITS lanes' minima — of 64 .. 512 candidates; on data without cluster
-                // structure (SURVEY 8d's uniform rows) that is the ~K / 100-quantile of a query's distances, every wave of every later item still has candidates under
-                // it, and every item runs this slow path (5 - 14 k clocks per half: adc_trace). The query's survivor row, though, holds every candidate that passed so
-                // far: the K-th smallest DISTANCE among any of them is the K-th best of a subset of the query's candidates, hence an upper bound on the K-th best of all.
-                // The wave whose append crosses a power of two (16, 32, ... ADC_REFINE_MAX) reads the row's first entries (unwritten slots read as the row's initial
-                // all-ones = +inf: looser, never wrong), finds their K-th smallest key bit by bit and lowers tq to the smallest sum bound that cannot cut a candidate at
-                // that distance: the correctly rounded root of S is D  =>  S <= D^2 (1 + 2^-23), and the test against tq carries its own 4 ulp.
-                if (a.refine && app_hi > app_lo && app_hi >= 16 && (31 - __builtin_clz((unsigned)app_hi)) != (31 - __builtin_clz((unsigned)max(app_lo, 1))) ) {
-                    const int n = min(min(app_hi, ADC_REFINE_MAX), (int)min(a.ldD, (long)ADC_REFINE_MAX));
-                    unsigned rk[ADC_REFINE_MAX / 64];
-#pragma unroll
-                    for (int i = 0; i < ADC_REFINE_MAX / 64; i++) {
-                        const int e = i * 64 + (int)lane;
-                        rk[i] = e < n ? (unsigned)(__hip_atomic_load(&a.cand[(long)q * a.ldD + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) : 0xFFFFFFFFu;
+                }
+                // arrival: the last wave of the item to get here appends what was staged for this half — ONE returning atomic on the query's cursor
+                __threadfence_block();
+                int arrived = 0;
+                if (lane == 0) arrived = atomicAdd(&s_sdone[h], 1);
+                arrived = RFL(__shfl(arrived, 0, 64));
+                if (arrived == nw - 1) {
+                    __threadfence_block();
+                    const int n = min(min(s_scnt[h], s_svalid[h]), ADC_STAGE_CAP);
+                    int app_lo = 0, app_hi = 0;
+                    if (n > 0) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&a.cursor[q], n);
+                        base = RFL(__shfl(base, 0, 64));
+                        // (agent-scope stores: written through the XCD's L2, so that a refining wave on another XCD can see them)
+                        for (int i = (int)lane; i < n; i += 64) __hip_atomic_store(&a.cand[(long)q * a.ldD + base + i], s_stage[h][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        app_lo = base; app_hi = base + n;
                     }
-                    int have = 0;
+                    const unsigned kmin = s_kmin[h];
+                    if (lane == 0 && kmin != 0xFFFFFFFFu) atomicMin(&a.tq[q], kmin);
+                    if (lane == 0) { s_scnt[h] = 0; s_sdone[h] = 0; s_svalid[h] = 0x7FFFFFFF; s_kmin[h] = 0xFFFFFFFFu; }           // for the next item (three phase barriers away)
+                    // Bound refinement from the survivors. A wave can only offer the K-th smallest of ITS lanes' minima — of 64 .. 512 candidates; on data without cluster
+                    // structure (SURVEY 8d's uniform rows) that is the ~K / 100-quantile of a query's distances, every wave of every later item still has candidates under
+                    // it, and every item runs the slow path above. The query's survivor row, though, holds every candidate that passed so far: the K-th smallest DISTANCE
+                    // among any of them is the K-th best of a subset of the query's candidates, hence an upper bound on the K-th best of all. The flushing wave whose append
+                    // crosses a power of two (16, 32, ... ADC_REFINE_MAX) reads the row's first entries (unwritten slots read as the row's initial all-ones = +inf: looser,
+                    // never wrong), finds their K-th smallest key bit by bit and lowers tq to the smallest sum bound that cannot cut a candidate at that distance: the
+                    // correctly rounded root of S is D  =>  S <= D^2 (1 + 2^-23), and the test against tq carries its own 4 ulp.
+                    if (a.refine && app_hi > app_lo && app_hi >= 16 && (31 - __builtin_clz((unsigned)app_hi)) != (31 - __builtin_clz((unsigned)max(app_lo, 1)))) {
+                        const int nr = min(min(app_hi, ADC_REFINE_MAX), (int)min(a.ldD, (long)ADC_REFINE_MAX));
+                        unsigned rk[ADC_REFINE_MAX / 64];
 #pragma unroll
-                    for (int i = 0; i < ADC_REFINE_MAX / 64; i++) have += (int)__builtin_popcountll(__ballot(rk[i] != 0xFFFFFFFFu));
-                    if (have >= a.K) {
-                        unsigned kk = 0u;
-                        for (int bit = 31; bit >= 0; bit--) {
-                            const unsigned tv = kk | ((1u << bit) - 1u);
-                            int cntb = 0;
-#pragma unroll
-                            for (int i = 0; i < ADC_REFINE_MAX / 64; i++) cntb += (int)__builtin_popcountll(__ballot(rk[i] <= tv));
-                            if (cntb < a.K) kk |= 1u << bit;
+                        for (int i = 0; i < ADC_REFINE_MAX / 64; i++) {
+                            const int e = i * 64 + (int)lane;
+                            rk[i] = e < nr ? (unsigned)(__hip_atomic_load(&a.cand[(long)q * a.ldD + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) : 0xFFFFFFFFu;
                         }
-                        const float Dk = __uint_as_float((kk & 0x80000000u) ? (kk & 0x7FFFFFFFu) : ~kk);      // the key back to the distance (adc_f2key's inverse)
-                        const float Sb = (Dk * Dk) * 1.000001f;
-                        if (lane == 0 && Sb == Sb && __float_as_uint(Sb) < 0x7F800000u) atomicMin(&a.tq[q], __float_as_uint(Sb));
+                        int have = 0;
+#pragma unroll
+                        for (int i = 0; i < ADC_REFINE_MAX / 64; i++) have += (int)__builtin_popcountll(__ballot(rk[i] != 0xFFFFFFFFu));
+                        if (have >= a.K) {
+                            unsigned kk = 0u;
+                            for (int bit = 31; bit >= 0; bit--) {
+                                const unsigned tv = kk | ((1u << bit) - 1u);
+                                int cntb = 0;
+#pragma unroll
+                                for (int i = 0; i < ADC_REFINE_MAX / 64; i++) cntb += (int)__builtin_popcountll(__ballot(rk[i] <= tv));
+                                if (cntb < a.K) kk |= 1u << bit;
+                            }
+                            const float Dk = __uint_as_float((kk & 0x80000000u) ? (kk & 0x7FFFFFFFu) : ~kk);      // the key back to the distance (adc_f2key's inverse)
+                            const float Sb = (Dk * Dk) * 1.000001f;
+                            if (lane == 0 && Sb == Sb && __float_as_uint(Sb) < 0x7F800000u) atomicMin(&a.tq[q], __float_as_uint(Sb));
+                        }
                     }
                 }
             }
