@@ -12,9 +12,11 @@
 //
 // Graph construction (insertNode, hnsw_index.go:493-552) is not on the GPU yet: a graph built by the
 // reference (or the oracle) is loaded with comet_hnsw_load_graph.
+#include <type_traits>
 #include "index.hpp"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace comet {
 
@@ -34,6 +36,9 @@ constexpr int HN_LD = HN_TD + 4;     // LDS row stride
 constexpr int HN_CAND_CAP = 4096;    // candidates min-heap capacity (LDS)
 constexpr int HN_EF_MAX = 1024;
 constexpr unsigned HN_NONE = 0xFFFFFFFFu;
+#ifdef HN_TRACE
+__device__ unsigned long long* g_hn_trace = nullptr;      // phase sums (s_memtime ticks) over all queries: pop | record+edges | distances | replay | - | loop | row fetch | slices
+#endif
 
 struct HC { unsigned id; float d; };
 
@@ -85,7 +90,38 @@ template <bool MAXHEAP> __device__ __forceinline__ void heap_push_wave(HC* h, in
     n = n + 1;
     __builtin_amdgcn_wave_barrier();
 }
+// Pop of a heap of at most 129 entries (m = n - 1 <= 128 live slots after the swap: at most 64 internal nodes, ONE PER LANE; the result heap at
+// efSearch <= 128). down() follows, from the root, the child that wins among each node's two children — which child that is does not depend on the
+// element being sifted, and a swap only ever moves y and the followed child: the children of the nodes further down are the array's values from
+// before the pop. So every lane decides "left or right" for its own node in one round of LDS reads, a ballot carries the 64 decisions to every lane,
+// lane l walks l steps of the path in registers (the path has at most 7 levels), reads the path's node of its level, and one more ballot finds
+// where y stops; the path's nodes above that move up one level each and y lands. The same array heap.go's down() leaves, in ~60 instructions
+// instead of ~20 per level (a wave of this kernel pays ~8 clocks per instruction of any kind).
+template <bool MAXHEAP> __device__ __forceinline__ HC heap_pop_wave_small(HC* h, int& n) {
+    const int lane = threadIdx.x & 63;
+    const int m = n - 1;
+    const HC root = hc_load(h), y = hc_load(h + m);         // h.Swap(0, m)
+    const int j1 = 2 * lane + 1;
+    const HC c1 = hc_load(h + (j1 < m ? j1 : 0)), c2 = hc_load(h + (j1 + 1 < m ? j1 + 1 : 0));
+    const bool right = (j1 + 1 < m) && hless<MAXHEAP>(c2, c1);          // `j2 < n && h.Less(j2, j1)`
+    const unsigned long long rmask = __ballot(right);
+    int node = 0, par = 0;                                              // the path's node at level `lane`, and the one above it
+#pragma unroll
+    for (int k = 0; k < 7; k++) if (k < lane) { par = node; node = 2 * node + 1 + (int)((rmask >> (node & 63)) & 1ull); }
+    const bool valid = lane >= 1 && lane <= 7 && node < m;              // `j1 >= n -> break`
+    const HC c = hc_load(h + (valid ? node : 0));
+    const bool cont = valid && hless<MAXHEAP>(c, y);                    // `!h.Less(j, i) -> break`
+    const int t = __builtin_ctzll(__ballot(!cont && lane >= 1));        // first level down() does not reach: y lands on the path's node of level t - 1
+    if (cont && lane < t) hc_store(h + par, c);
+    if (lane == t - 1) hc_store(h + node, y);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) hc_store(h + m, root);
+    __builtin_amdgcn_wave_barrier();
+    n = m;
+    return root;
+}
 template <bool MAXHEAP> __device__ __forceinline__ HC heap_pop_wave(HC* h, int& n) {
+    if (n <= 129) return heap_pop_wave_small<MAXHEAP>(h, n);
     const int m = n - 1;
     const HC root = hc_load(h), y = hc_load(h + m);         // h.Swap(0, m): y sifts down among the first m slots, the old root leaves
     int i = 0;
@@ -107,14 +143,16 @@ template <bool MAXHEAP> __device__ __forceinline__ HC heap_pop_wave(HC* h, int& 
 }
 
 // exact distances from the query to up to 64 rows (rows[j] == HN_NONE -> skipped); lane j gets row j's distance.
-// The 256-byte row pieces of slice k+1 are requested (into registers) before slice k is summed: the traversal is a chain of
-// dependent random reads, so every exposed load latency is paid once per expansion.
-template <int METRIC>
-__device__ __forceinline__ float wave_dists(const float* __restrict__ V, int ld, const float* __restrict__ qv, const unsigned* rows, int cnt, float* tile) {
+// The traversal is a chain of dependent random reads, so every exposed load latency is paid once per expansion — and a row is ld / 64
+// slices of 256 bytes. Round 5: the slices are requested in BLOCKS of DEPTH (all 256-byte pieces of DEPTH slices of every row in flight at
+// once, 192 registers: a wave of this kernel has the SIMD to itself) and consumed in order — at d = 384 and <= 32 neighbours the whole
+// row set is ONE block, one latency per expansion instead of one per slice (the one-slice-ahead prefetch of rounds 2-4 exposed most of
+// a ~1 us random-read latency six times per expansion). NI = load instructions per slice (4 rows each): 8 for <= 32 rows, else 16.
+template <int METRIC, int NI, int DEPTH>
+__device__ __forceinline__ float wave_dists_n(const float* __restrict__ V, int ld, const float* __restrict__ qv, const unsigned* rows, int cnt, float* tile) {
     const int lane = threadIdx.x;
     float acc = 0.0f;
-    const int lrow = lane >> 4, lc = (lane & 15) * 4;      // loader: 4 rows x 16 float4 per instruction, up to 16 instructions per slice
-    constexpr int NI = 16;
+    const int lrow = lane >> 4, lc = (lane & 15) * 4;      // loader: 4 rows x 16 float4 per instruction
     const float* src[NI];
 #pragma unroll
     for (int j = 0; j < NI; j++) {
@@ -122,34 +160,75 @@ __device__ __forceinline__ float wave_dists(const float* __restrict__ V, int ld,
         unsigned row = r < cnt ? rows[r] : HN_NONE; if (row == HN_NONE) row = 0;
         src[j] = V + (long)row * ld + lc;
     }
-    const int ni = (cnt + 3) >> 2;                          // instructions actually needed (wave-uniform)
-    f32x4 pre[NI];
+    const int nsl = (ld + HN_TD - 1) / HN_TD;
+    for (int sb = 0; sb < nsl; sb += DEPTH) {
+        f32x4 xb[DEPTH][NI];
 #pragma unroll
-    for (int j = 0; j < NI; j++) if (j < ni) pre[j] = (lc < min(HN_TD, ld)) ? *reinterpret_cast<const f32x4*>(src[j]) : f32x4{0, 0, 0, 0};
-    for (int k0 = 0; k0 < ld; k0 += HN_TD) {
-        const int kn = min(HN_TD, ld - k0);                // multiple of 32
+        for (int dd = 0; dd < DEPTH; dd++) {
+            if (sb + dd >= nsl) break;                      // wave-uniform
+            const int k0 = (sb + dd) * HN_TD;
+            const int kn = min(HN_TD, ld - k0);             // multiple of 32
+            // every one of the NI instructions is issued (rows past cnt re-read row 0: cache hits) — a wave of this kernel pays ~8 clocks per instruction of
+            // ANY kind, and a uniform branch + exec juggling per piece was as much of a slice as its sums
+            if (kn == HN_TD) {
 #pragma unroll
-        for (int j = 0; j < NI; j++) if (j < ni && lc < kn) *reinterpret_cast<f32x4*>(&tile[(j * 4 + lrow) * HN_LD + lc]) = pre[j];
-        const int k1 = k0 + HN_TD;
-        if (k1 < ld) {
-            const int kn1 = min(HN_TD, ld - k1);
+                for (int j = 0; j < NI; j++) xb[dd][j] = *reinterpret_cast<const f32x4*>(src[j] + k0);
+            } else {
 #pragma unroll
-            for (int j = 0; j < NI; j++) if (j < ni && lc < kn1) pre[j] = *reinterpret_cast<const f32x4*>(src[j] + k1);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < cnt) {
-#pragma unroll 4
-            for (int i = 0; i < kn; i += 4) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(&tile[lane * HN_LD + i]);
-                acc = hn_step<METRIC>(acc, qv[k0 + i + 0], x[0]);
-                acc = hn_step<METRIC>(acc, qv[k0 + i + 1], x[1]);
-                acc = hn_step<METRIC>(acc, qv[k0 + i + 2], x[2]);
-                acc = hn_step<METRIC>(acc, qv[k0 + i + 3], x[3]);
+                for (int j = 0; j < NI; j++) xb[dd][j] = (lc < kn) ? *reinterpret_cast<const f32x4*>(src[j] + k0) : f32x4{0, 0, 0, 0};
             }
         }
-        __builtin_amdgcn_wave_barrier();
+#ifdef HN_TRACE
+        const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tw1 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+        for (int dd = 0; dd < DEPTH; dd++) {
+            if (sb + dd < nsl) {                            // wave-uniform
+                const int k0 = (sb + dd) * HN_TD;
+                const int kn = min(HN_TD, ld - k0);
+#pragma unroll
+                for (int j = 0; j < NI; j++) *reinterpret_cast<f32x4*>(&tile[(j * 4 + lrow) * HN_LD + lc]) = xb[dd][j];      // (a short last slice: zeros past the row's end)
+                __builtin_amdgcn_wave_barrier();
+                if (lane < cnt) {
+                    // The slice's row piece is read into registers in one go (16 LDS reads in flight together), the query piece arrives in SGPRs (uniform
+                    // address: scalar loads, operands of the packed instructions — a copy of the query in LDS was tried: 16 more ds_read_b128 per slice, 2 %
+                    // slower), then the sum runs out of registers: differences and squares two at a time (v_pk_add_f32 / v_pk_mul_f32: the same IEEE
+                    // operations), the additions in the reference's order.
+                    const float* tp = &tile[lane * HN_LD];
+                    const float* qp = qv + k0;
+                    auto sum = [&](auto NQ_c) __attribute__((always_inline)) {
+                        constexpr int NQ = decltype(NQ_c)::value;
+                        f32x4 xv[NQ], qq[NQ];
+#pragma unroll
+                        for (int i = 0; i < NQ; i++) xv[i] = *reinterpret_cast<const f32x4*>(tp + 4 * i);
+#pragma unroll
+                        for (int i = 0; i < NQ; i++) qq[i] = *reinterpret_cast<const f32x4*>(qp + 4 * i);
+#pragma unroll
+                        for (int i = 0; i < NQ; i++) {
+                            const f32x2 qa = {qq[i][0], qq[i][1]}, qb = {qq[i][2], qq[i][3]}, xa = {xv[i][0], xv[i][1]}, xc = {xv[i][2], xv[i][3]};
+                            f32x2 ta, tb;
+                            if constexpr (METRIC == COMET_COSINE) { ta = qa * xa; tb = qb * xc; }
+                            else { const f32x2 da = qa - xa, db = qb - xc; ta = da * da; tb = db * db; }
+                            acc = acc + ta[0]; acc = acc + ta[1]; acc = acc + tb[0]; acc = acc + tb[1];
+                        }
+                    };
+                    if (kn == HN_TD) sum(std::integral_constant<int, HN_TD / 4>{}); else sum(std::integral_constant<int, HN_TD / 8>{});
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+#ifdef HN_TRACE
+        if (lane == 0 && g_hn_trace && cnt > 1) { atomicAdd(&g_hn_trace[6], tw1 - tw0); atomicAdd(&g_hn_trace[7], __builtin_amdgcn_s_memtime() - tw1); }
+#endif
     }
     return hn_finish<METRIC>(acc);
+}
+template <int METRIC>
+__device__ __forceinline__ float wave_dists(const float* __restrict__ V, int ld, const float* __restrict__ qv, const unsigned* rows, int cnt, float* tile) {
+    if (cnt <= 32) return wave_dists_n<METRIC, 8, 6>(V, ld, qv, rows, cnt, tile);
+    return wave_dists_n<METRIC, 16, 3>(V, ld, qv, rows, cnt, tile);
 }
 
 // Graph in HBM: per (node, layer <= level) one edge SLOT. edge_off[s] is the slot's first entry in `edges` (dense node indices),
@@ -161,7 +240,15 @@ struct HnswGraph {
     const int* level; const long* slot_base; const long* edge_off; const int* deg; unsigned* edges;
     unsigned entry; int max_level;
     const unsigned* deleted;   // bitmap over dense node indices (nullable)
+    const long* rec0 = nullptr;   // per node {edge_off[slot_base[node]], slot_base[node]}: the layer-0 slot in ONE dependent load (hnsw_rec0_kernel)
+    long n_edges = 0;             // entries of `edges` in use (the speculative first edge batch is clamped to it)
 };
+__global__ __launch_bounds__(256) void hnsw_rec0_kernel(const long* __restrict__ slot_base, const long* __restrict__ edge_off, long first, long count, long* __restrict__ rec0) {
+    const long i = first + (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= first + count) return;
+    const long s = slot_base[i];
+    rec0[2 * i] = edge_off[s]; rec0[2 * i + 1] = s;
+}
 __device__ __forceinline__ bool bit_get(const unsigned* bm, unsigned i) { return bm && ((bm[i >> 5] >> (i & 31)) & 1u); }
 
 // LDS work area of one wave (search and insert kernels)
@@ -221,15 +308,32 @@ __device__ __forceinline__ int hn_search_layer(const HnswGraph& g, const float* 
         if (lane == 0) atomicOr(&vis[entry >> 5], 1u << (entry & 31));
         n_eval += 1;
     }
+#ifdef HN_TRACE
+    unsigned long long tr_acc[6] = {0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
+#define HN_T(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tr_acc[i] += now_ - tr_last; tr_last = now_; } while (0)
+#else
+#define HN_T(i) do { } while (0)
+#endif
     for (;;) {
         if (ncand == 0) break;
+        HN_T(5);
         const HC cur = heap_pop_wave<false>(cand, ncand);
+        HN_T(0);
         if (nres >= ef && cur.d > hc_load(res).d) break;    // early termination hnsw_index.go:592-594
         const unsigned cid = cur.id;
         n_exp += 1;
-        if (layer > g.level[cid]) continue;                                            // `if layer < len(node.Edges)`
-        const long s = g.slot_base[cid] + layer;
-        const long off = g.edge_off[s]; const int deg = g.deg[s];
+        // layer 0 (every node has it): the slot comes from ONE 16-byte record per node, and the first 64 entries of the list are requested beside
+        // the degree (entries past the degree are dropped, past the array clamped) — three dependent round trips per expansion instead of four
+        long s, off; unsigned e0 = HN_NONE; bool have_e0 = false;
+        if (layer == 0 && g.rec0) {
+            off = g.rec0[2 * (long)cid]; s = g.rec0[2 * (long)cid + 1];
+            const long e_at = off + lane < g.n_edges ? off + lane : g.n_edges - 1;
+            e0 = g.edges[e_at]; have_e0 = true;
+        } else {
+            if (layer > g.level[cid]) continue;                                        // `if layer < len(node.Edges)`
+            s = g.slot_base[cid] + layer; off = g.edge_off[s];
+        }
+        const int deg = g.deg[s];
         for (int b0 = 0; b0 < deg; b0 += 64) {
             const int cnt = min(64, deg - b0);
             // The traversal is a chain of dependent memory round trips, so the visited test-and-set and the soft-delete lookup are
@@ -237,16 +341,25 @@ __device__ __forceinline__ int hn_search_layer(const HnswGraph& g, const float* 
             // turns out visited or deleted is dropped afterwards (a lane per neighbour: the wasted evaluations cost no time).
             unsigned nb = HN_NONE, vold = 0u; bool dead = false;
             if (lane < cnt) {
-                nb = g.edges[off + b0 + lane];
+                nb = (have_e0 && b0 == 0) ? e0 : g.edges[off + b0 + lane];
                 dead = bit_get(g.deleted, nb);                                             // SOFT DELETE CHECK
                 if (!dead) vold = atomicOr(&vis[nb >> 5], 1u << (nb & 31));                // !visited.Contains -> visited.Add
             }
             L.rows[lane] = nb;
             __builtin_amdgcn_wave_barrier();
+#ifdef HN_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            HN_T(1);
             const float d = wave_dists<METRIC>(g.V, g.ld, qv, L.rows, cnt, L.tile);
+            HN_T(2);
             if (lane < cnt && (dead || ((vold >> (nb & 31)) & 1u))) nb = HN_NONE;
             // the batch in edge-list order (hnsw_index.go:600-619), every lane following along: lane j's pair is broadcast
-            unsigned long long todo = __ballot(lane < cnt && nb != HN_NONE);
+            // the top of a FULL result heap only ever moves down while the batch is replayed, so a neighbour at or above the top as it is now cannot be
+            // admitted later in the batch either: such lanes leave the replay up front (a NaN distance stays in: `dj < top` is false for it in the
+            // reference too, but the comparison below must be the one that says so)
+            const bool full0 = nres >= ef; const float top0 = full0 ? hc_load(res).d : 0.0f;
+            unsigned long long todo = __ballot(lane < cnt && nb != HN_NONE && !(full0 && d >= top0));
             while (todo) {
                 const int j = __builtin_ctzll(todo); todo &= todo - 1ull;
                 const float dj = __shfl(d, j, 64); const unsigned idj = (unsigned)__shfl((int)nb, j, 64);
@@ -259,8 +372,12 @@ __device__ __forceinline__ int hn_search_layer(const HnswGraph& g, const float* 
                 }
             }
             n_eval += cnt;
+            HN_T(3);
         }
     }
+#ifdef HN_TRACE
+    if (lane == 0 && g_hn_trace) for (int i = 0; i < 6; i++) atomicAdd(&g_hn_trace[i], tr_acc[i]);
+#endif
     nres_out = nres;
     return overflow;
 }
@@ -304,6 +421,7 @@ __device__ __forceinline__ void hn_drain(HC* res, int nres, const HnswLds& L, Em
     }
     __builtin_amdgcn_wave_barrier();
 }
+
 
 constexpr size_t HN_LDS_BYTES = sizeof(HC) * (HN_CAND_CAP + HN_EF_MAX + 1) + sizeof(float) * 64 * HN_LD + 64 * 4 + 64 * 4 + 64;
 
@@ -458,6 +576,7 @@ struct HNSWIndex : comet_index {
     int M = 16, efC = 200, efS = 200;
     int64_t n = 0; int max_level = -1; uint32_t entry = 0;   // entry: dense node index
     DevBuf V, ids_dev, level, slot_base, edge_off, deg_dev, edges, del_bm, state_dev, ins_vis;
+    DevBuf rec0;                // per node {edge offset of the layer-0 slot, its slot index} (hnsw_rec0_kernel): the first thing a layer-0 expansion reads
     DevBuf sorted_dev;          // per edge slot: 1 once a full list has been re-sorted by pruneConnections (a further prune is then a no-op)
     int64_t n_slots = 0, edge_cap = 0;       // slots (sum of level+1) and total edge capacity in use
     bool mirror_dirty = false;               // the device graph changed (GPU insert): host mirror is rebuilt before Flush / WriteTo
@@ -546,6 +665,9 @@ struct HNSWIndex : comet_index {
         c->h2d(ids_dev.as<uint32_t>() + n, nid.data(), added * 4);
         c->h2d(slot_base.as<int64_t>() + n, sb.data(), (added + 1) * 8);
         c->h2d(edge_off.as<int64_t>() + n_slots, eo.data(), eo.size() * 8);
+        rec0.reserve((size_t)(n + added) * 16, c->stream, (size_t)n * 16);
+        hnsw_rec0_kernel<<<dim3((unsigned)ceil_div(added, 256)), dim3(256), 0, c->stream>>>((const long*)slot_base.p, (const long*)edge_off.p, (long)n, (long)added, (long*)rec0.p);
+        LAUNCH_CHECK();
         c->zero(deg_dev.as<int32_t>() + n_slots, (size_t)(slots - n_slots) * 4);
         sorted_dev.reserve((size_t)std::max<int64_t>(slots, 1), c->stream, (size_t)n_slots);
         c->zero(sorted_dev.as<uint8_t>() + n_slots, (size_t)(slots - n_slots));
@@ -700,6 +822,8 @@ struct HNSWIndex : comet_index {
         n_slots = slots; edge_cap = deoff[slots]; mirror_dirty = false;
         c->h2d(ids_dev.p, ids.data(), nn * 4); c->h2d(level.p, levels, nn * 4);
         c->h2d(slot_base.p, sb.data(), (nn + 1) * 8); c->h2d(edge_off.p, deoff.data(), (slots + 1) * 8); c->h2d(edges.p, eidx.data(), eidx.size() * 4);
+        rec0.reserve(std::max<size_t>(16, nn * 16), c->stream, 0);
+        if (nn > 0) { hnsw_rec0_kernel<<<dim3((unsigned)ceil_div((int64_t)nn, 256)), dim3(256), 0, c->stream>>>((const long*)slot_base.p, (const long*)edge_off.p, 0l, (long)nn, (long*)rec0.p); LAUNCH_CHECK(); }
         HIP_CHECK(hipStreamSynchronize(c->stream));
         trained = true; del_dirty = true;
     }
@@ -832,6 +956,7 @@ struct HNSWIndex : comet_index {
         unsigned long long* st = c->salloc<unsigned long long>(2);
         c->zero(st, 16);
         HnswGraph g{V.as<float>(), ld, n, level.as<int>(), (const long*)slot_base.p, (const long*)edge_off.p, deg_dev.as<int>(), edges.as<uint32_t>(), entry, max_level, deleted_bitmap()};
+        g.rec0 = (const long*)rec0.p; g.n_edges = (long)std::max<int64_t>(edge_cap, 1);
         // heaps in LDS (ef <= 1024, <= 4096 live candidates) or, beyond that, in HBM: one slab per query, queries in sub-batches of <= 2 GiB.
         // The LDS heaps are sized for this search: result heap ef + 1, candidate heap 16 ef (>= 1024) first — 35 KiB per wave at ef 128,
         // four waves per CU instead of two — and the full 4096 only if a query's live candidates outgrow that (the batch is re-run).
@@ -888,6 +1013,18 @@ struct HNSWIndex : comet_index {
         unsigned long long hst[2];
         c->d2h(hst, st, 16);
         HIP_CHECK(hipStreamSynchronize(c->stream));
+#ifdef HN_TRACE
+        {
+            static unsigned long long* tb = nullptr;
+            if (!tb) { HIP_CHECK(hipMalloc(&tb, 64)); HIP_CHECK(hipMemset(tb, 0, 64)); HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_hn_trace), &tb, sizeof(tb))); }
+            else {
+                unsigned long long h[8]; HIP_CHECK(hipMemcpy(h, tb, 64, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemset(tb, 0, 64));
+                const double ex = (double)hst[1];
+                fprintf(stderr, "[hnsw trace] ticks per expansion: pop %.0f  record+edges+visited-issue %.0f  distances %.0f  replay %.0f  loop %.0f | inside distances: row fetch wait %.0f  slices %.0f   (%.0f expansions, %.0f evals)\n",
+                        h[0] / ex, h[1] / ex, h[2] / ex, h[3] / ex, h[5] / ex, h[6] / ex, h[7] / ex, ex, (double)hst[0]);
+            }
+        }
+#endif
         st_evals = hst[0]; st_exp = hst[1];
     }
     bool get_stat(const char* name, double* out) const override {

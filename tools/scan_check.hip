@@ -83,6 +83,7 @@ int main(int argc, char** argv) {
     // variant 9: the register-stationary int8 tile (flat_scan_qr_kernel; wide batches, ld8 in {256, 512, 768}); variant 8: the query-stationary one
     for (int variant : {0, 1, 8, 9}) {
         if (variant == 1 && unit == 64 && B > 64) continue;
+        if (getenv("SCAN_ONLY") && atoi(getenv("SCAN_ONLY")) != variant) continue;
         if (variant == 9 && flat_scan_qr_steps(ld8) == 0) continue;
         setenv("COMET_SCAN_VARIANT_RT", variant == 1 ? "1" : "0", 1);
         setenv("COMET_SCAN_QR_RT", variant == 9 ? "1" : "0", 1);
