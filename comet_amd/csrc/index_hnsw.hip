@@ -148,6 +148,9 @@ template <bool MAXHEAP> __device__ __forceinline__ HC heap_pop_wave(HC* h, int& 
 // once, 192 registers: a wave of this kernel has the SIMD to itself) and consumed in order — at d = 384 and <= 32 neighbours the whole
 // row set is ONE block, one latency per expansion instead of one per slice (the one-slice-ahead prefetch of rounds 2-4 exposed most of
 // a ~1 us random-read latency six times per expansion). NI = load instructions per slice (4 rows each): 8 for <= 32 rows, else 16.
+// a - b on two floats at once. hipcc turns `a - b` (and `a + (-b)`) on float2 into two v_sub_f32; the packed add with both halves of the second operand
+// negated is the same IEEE subtraction, one instruction
+__device__ __forceinline__ f32x2 hn_pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <int METRIC, int NI, int DEPTH>
 __device__ __forceinline__ float wave_dists_n(const float* __restrict__ V, int ld, const float* __restrict__ qv, const unsigned* rows, int cnt, float* tile) {
     const int lane = threadIdx.x;
@@ -162,12 +165,13 @@ __device__ __forceinline__ float wave_dists_n(const float* __restrict__ V, int l
     }
     const int nsl = (ld + HN_TD - 1) / HN_TD;
     for (int sb = 0; sb < nsl; sb += DEPTH) {
-        f32x4 xb[DEPTH][NI];
+        f32x4 xb[DEPTH][NI], qb[DEPTH];                    // qb: the query's four floats of this lane's column group, per slice
 #pragma unroll
         for (int dd = 0; dd < DEPTH; dd++) {
             if (sb + dd >= nsl) break;                      // wave-uniform
             const int k0 = (sb + dd) * HN_TD;
             const int kn = min(HN_TD, ld - k0);             // multiple of 32
+            qb[dd] = (lc < kn) ? *reinterpret_cast<const f32x4*>(qv + k0 + lc) : f32x4{0, 0, 0, 0};
             // every one of the NI instructions is issued (rows past cnt re-read row 0: cache hits) — a wave of this kernel pays ~8 clocks per instruction of
             // ANY kind, and a uniform branch + exec juggling per piece was as much of a slice as its sums
             if (kn == HN_TD) {
@@ -188,31 +192,29 @@ __device__ __forceinline__ float wave_dists_n(const float* __restrict__ V, int l
             if (sb + dd < nsl) {                            // wave-uniform
                 const int k0 = (sb + dd) * HN_TD;
                 const int kn = min(HN_TD, ld - k0);
+                // The PRODUCTS are formed in the loader's layout — all 64 lanes busy, the lane's query floats in registers, differences and squares two at a
+                // time (v_pk_add_f32 with a negated operand / v_pk_mul_f32: the same IEEE operations as the scalar ones) — and the tile carries them to the
+                // lane that owns the row, which only adds, in the reference's order. (Rounds 2-4 formed them in the summing lane: half the lanes idle,
+                // the query piece in SGPRs — which the packed instructions do not take — three instructions per element instead of 1.5.)
+                const f32x2 qlo = {qb[dd][0], qb[dd][1]}, qhi = {qb[dd][2], qb[dd][3]};
 #pragma unroll
-                for (int j = 0; j < NI; j++) *reinterpret_cast<f32x4*>(&tile[(j * 4 + lrow) * HN_LD + lc]) = xb[dd][j];      // (a short last slice: zeros past the row's end)
+                for (int j = 0; j < NI; j++) {
+                    const f32x2 xlo = {xb[dd][j][0], xb[dd][j][1]}, xhi = {xb[dd][j][2], xb[dd][j][3]};
+                    f32x2 tlo, thi;
+                    if constexpr (METRIC == COMET_COSINE) { tlo = qlo * xlo; thi = qhi * xhi; }
+                    else { const f32x2 dlo = hn_pk_sub(qlo, xlo), dhi = hn_pk_sub(qhi, xhi); tlo = dlo * dlo; thi = dhi * dhi; }
+                    *reinterpret_cast<f32x4*>(&tile[(j * 4 + lrow) * HN_LD + lc]) = f32x4{tlo[0], tlo[1], thi[0], thi[1]};      // (a short last slice: zeros past the row's end)
+                }
                 __builtin_amdgcn_wave_barrier();
                 if (lane < cnt) {
-                    // The slice's row piece is read into registers in one go (16 LDS reads in flight together), the query piece arrives in SGPRs (uniform
-                    // address: scalar loads, operands of the packed instructions — a copy of the query in LDS was tried: 16 more ds_read_b128 per slice, 2 %
-                    // slower), then the sum runs out of registers: differences and squares two at a time (v_pk_add_f32 / v_pk_mul_f32: the same IEEE
-                    // operations), the additions in the reference's order.
                     const float* tp = &tile[lane * HN_LD];
-                    const float* qp = qv + k0;
                     auto sum = [&](auto NQ_c) __attribute__((always_inline)) {
                         constexpr int NQ = decltype(NQ_c)::value;
-                        f32x4 xv[NQ], qq[NQ];
+                        f32x4 tv[NQ];
 #pragma unroll
-                        for (int i = 0; i < NQ; i++) xv[i] = *reinterpret_cast<const f32x4*>(tp + 4 * i);
+                        for (int i = 0; i < NQ; i++) tv[i] = *reinterpret_cast<const f32x4*>(tp + 4 * i);
 #pragma unroll
-                        for (int i = 0; i < NQ; i++) qq[i] = *reinterpret_cast<const f32x4*>(qp + 4 * i);
-#pragma unroll
-                        for (int i = 0; i < NQ; i++) {
-                            const f32x2 qa = {qq[i][0], qq[i][1]}, qb = {qq[i][2], qq[i][3]}, xa = {xv[i][0], xv[i][1]}, xc = {xv[i][2], xv[i][3]};
-                            f32x2 ta, tb;
-                            if constexpr (METRIC == COMET_COSINE) { ta = qa * xa; tb = qb * xc; }
-                            else { const f32x2 da = qa - xa, db = qb - xc; ta = da * da; tb = db * db; }
-                            acc = acc + ta[0]; acc = acc + ta[1]; acc = acc + tb[0]; acc = acc + tb[1];
-                        }
+                        for (int i = 0; i < NQ; i++) { acc = acc + tv[i][0]; acc = acc + tv[i][1]; acc = acc + tv[i][2]; acc = acc + tv[i][3]; }
                     };
                     if (kn == HN_TD) sum(std::integral_constant<int, HN_TD / 4>{}); else sum(std::integral_constant<int, HN_TD / 8>{});
                 }
@@ -385,17 +387,17 @@ __device__ __forceinline__ int hn_search_layer(const HnswGraph& g, const float* 
 // LDS of one wave: candidate heap [cand_cap] | result heap [res_cap] | staging tile | rows | distances. The search kernel sizes the heaps
 // for its efSearch (the 59 KiB of the full-size layout admit two waves per CU: a search at efSearch 128 needs 1 KiB of results and
 // rarely more than a few hundred live candidates); the insert kernel keeps the full-size layout.
-__device__ __forceinline__ HnswLds hn_carve(unsigned char* smem, unsigned* s_cur, int* s_flag, float* s_dist, int cand_cap = HN_CAND_CAP, int res_cap = HN_EF_MAX + 1) {
+__device__ __forceinline__ HnswLds hn_carve(unsigned char* smem, unsigned* s_cur, int* s_flag, float* s_dist, int cand_cap = HN_CAND_CAP, int res_cap = HN_EF_MAX + 1, int tile_rows = 64) {
     HnswLds L;
     L.cand = reinterpret_cast<HC*>(smem);                                    // cand_cap
     L.res = L.cand + cand_cap;                                               // ef + 1 <= res_cap
-    L.tile = reinterpret_cast<float*>(L.res + res_cap);                      // 64 x HN_LD
-    L.rows = reinterpret_cast<unsigned*>(L.tile + 64 * HN_LD);               // 64
+    L.tile = reinterpret_cast<float*>(L.res + res_cap);                      // tile_rows x HN_LD (32 rows when no edge list of the graph is longer)
+    L.rows = reinterpret_cast<unsigned*>(L.tile + tile_rows * HN_LD);        // 64
     L.dd = reinterpret_cast<float*>(L.rows + 64);                            // 64
     L.s_cur = s_cur; L.s_flag = s_flag; L.s_dist = s_dist; L.cand_cap = cand_cap;
     return L;
 }
-static size_t hn_lds_bytes(int cand_cap, int res_cap) { return sizeof(HC) * ((size_t)cand_cap + res_cap) + sizeof(float) * 64 * HN_LD + 64 * 4 + 64 * 4 + 64; }
+static size_t hn_lds_bytes(int cand_cap, int res_cap, int tile_rows = 64) { return sizeof(HC) * ((size_t)cand_cap + res_cap) + sizeof(float) * tile_rows * HN_LD + 64 * 4 + 64 * 4 + 64; }
 // The result max-heap drained into ascending order (hnsw_index.go:623-626: pop everything, fill from the back). Popping is a
 // chain of dependent LDS round trips on one lane (~800 cycles per pop); when all distances are distinct the popped order is
 // simply the sorted order, which the whole wave finds by counting ranks. Equal distances (duplicated vectors) keep the serial
@@ -430,10 +432,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswGraph g, const floa
                                                          long vwords, unsigned* __restrict__ res_idx, float* __restrict__ res_dist,
                                                          int* __restrict__ res_cnt, int* __restrict__ status, unsigned long long* __restrict__ stats,
                                                          HC* __restrict__ spill /*nullable: heaps in HBM*/, long spill_cand, long spill_res, int ef_ld,
-                                                         int cand_cap, int res_cap) {
+                                                         int cand_cap, int res_cap, int tile_rows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned s_cur; __shared__ int s_flag; __shared__ float s_dist;
-    HnswLds L = hn_carve(smem, &s_cur, &s_flag, &s_dist, cand_cap, res_cap);
+    HnswLds L = hn_carve(smem, &s_cur, &s_flag, &s_dist, cand_cap, res_cap, tile_rows);
     const int q = blockIdx.x, lane = threadIdx.x;
     if (spill) {        // ef beyond the LDS heaps (or a candidate heap that outgrew them): same code, heaps in HBM, one slab per query
         L.cand = spill + (long)q * (spill_cand + spill_res); L.res = L.cand + spill_cand;
@@ -587,6 +589,8 @@ struct HNSWIndex : comet_index {
     uint32_t entry_id = 0;
     bool del_dirty = true;
     uint64_t st_evals = 0, st_exp = 0;
+    int64_t max_list = 0;       // longest edge list / slot capacity of the graph (<= 32: the search stages 32-row tiles)
+    int cand_hint = 0;          // candidate-heap capacity the last overflowing search needed (LDS sizing of the next searches)
     // Asynchronous searches (round 3): search_begin enqueues the search with the LDS heaps sized for its efSearch and copies the overflow
     // flag and the counters to pinned memory behind it; search_finish waits for the search's event and, if a query's live candidates
     // outgrew the heap (rare), runs the whole search again synchronously with the escalation of search_dev. Nothing persistent is
@@ -655,6 +659,7 @@ struct HNSWIndex : comet_index {
             slots += lv[i] + 1;
         }
         sb[added] = slots; eo.push_back(ecap);
+        max_list = std::max<int64_t>(max_list, 2 * (int64_t)M);
         level.reserve((size_t)(n + added) * 4, c->stream, (size_t)n * 4);
         ids_dev.reserve((size_t)(n + added) * 4, c->stream, (size_t)n * 4);
         slot_base.reserve((size_t)(n + added + 1) * 8, c->stream, (size_t)(n + 1) * 8);
@@ -783,7 +788,7 @@ struct HNSWIndex : comet_index {
         // every slot gets the capacity insertNode needs (2M on layer 0, M above; more if the loaded list is longer)
         std::vector<uint32_t> eidx; eidx.reserve(std::max<int64_t>(ne, 1));
         std::vector<int64_t> deoff(slots + 1, 0); std::vector<int32_t> ddeg(std::max<int64_t>(slots, 1), 0);
-        uint32_t new_entry = 0;
+        uint32_t new_entry = 0; int64_t new_max_list = 0;
         {
             int64_t sl = 0;
             for (int64_t i = 0; i < nn; i++)
@@ -799,12 +804,13 @@ struct HNSWIndex : comet_index {
                     ddeg[sl] = (int32_t)(eidx.size() - s0);
                     const size_t cap = std::max<size_t>(eidx.size() - s0, (size_t)(l == 0 ? 2 * M : M));
                     eidx.resize(s0 + cap, 0u);
+                    new_max_list = std::max<int64_t>(new_max_list, (int64_t)cap);
                     deoff[sl + 1] = (int64_t)eidx.size();
                 }
         }
         if (eidx.empty()) eidx.push_back(0);
         if (nn > 0 && maxl >= 0) { auto it = nmap.find(entry_id_in); if (it == nmap.end()) COMET_FAIL(COMET_ERR_INVALID_ARG, "entry point %u is not a node", entry_id_in); new_entry = it->second; }
-        n = nn; max_level = nn > 0 ? maxl : -1; entry = new_entry; entry_id = entry_id_in;
+        n = nn; max_level = nn > 0 ? maxl : -1; entry = new_entry; entry_id = entry_id_in; max_list = new_max_list; cand_hint = 0;
         ids.swap(nid); id2idx.swap(nmap);
         h_levels.assign(levels, levels + nn); h_eoff.assign(eoff, eoff + slots + 1); h_edges.assign(edge_ids, edge_ids + ne);
         V.reserve(std::max<size_t>(4, (size_t)nn * ld * 4), c->stream, 0);
@@ -961,9 +967,14 @@ struct HNSWIndex : comet_index {
         // The LDS heaps are sized for this search: result heap ef + 1, candidate heap 16 ef (>= 1024) first — 35 KiB per wave at ef 128,
         // four waves per CU instead of two — and the full 4096 only if a query's live candidates outgrow that (the batch is re-run).
         const int res_cap = (int)std::min<int64_t>(HN_EF_MAX, ef_ld) + 1;
-        int cand_cap = (int)std::min<int64_t>(HN_CAND_CAP, std::max<int64_t>(1024, 16 * (int64_t)ef));
+        // LDS per wave decides how many searches a CU holds (a lone wave issues one instruction per ~8 clocks: two waves per SIMD nearly double a large
+        // batch's rate). Candidate heap: 8 ef (>= 1024) entries to start with, doubled — and remembered by the index — when a search outgrows it (a graph
+        // whose searches run ~efSearch expansions keeps ~12 ef live candidates); staging tile: 32 rows when no edge list of the graph is longer.
+        // 18 KiB per wave at efSearch 128 on a graph built here (M 16): 8 waves per CU; 26 KiB after one doubling: 6.
+        int cand_cap = (int)std::min<int64_t>(HN_CAND_CAP, std::max<int64_t>(std::max<int64_t>(1024, 8 * (int64_t)ef), cand_hint));
+        const int tile_rows = max_list <= 32 ? 32 : 64;
         auto run = [&](bool spill) {
-            const size_t lds = spill ? hn_lds_bytes(64, 64) : hn_lds_bytes(cand_cap, res_cap);
+            const size_t lds = spill ? hn_lds_bytes(64, 64, tile_rows) : hn_lds_bytes(cand_cap, res_cap, tile_rows);
             c->zero(vis, (size_t)B * vwords * 4); c->zero(status, 4);
             ScratchMark mark(c);
             const int64_t s_cand = n, s_res = (int64_t)ef_ld + 1;
@@ -976,7 +987,7 @@ struct HNSWIndex : comet_index {
                 // "set" and "launch"); only the launch parameter varies
 #define HS(MT) do { HIP_CHECK(hipFuncSetAttribute((const void*)hnsw_search_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HN_LDS_BYTES)); \
                     hnsw_search_kernel<MT><<<dim3(bn), dim3(64), lds, c->stream>>>(g, Qp + (size_t)b0 * ld, ef, vis + (size_t)b0 * vwords, vwords, res_idx + (size_t)b0 * ef_ld, \
-                        res_dist + (size_t)b0 * ef_ld, res_cnt + b0, status, st, slab, s_cand, s_res, ef_ld, spill ? 64 : cand_cap, spill ? 64 : res_cap); } while (0)
+                        res_dist + (size_t)b0 * ef_ld, res_cnt + b0, status, st, slab, s_cand, s_res, ef_ld, spill ? 64 : cand_cap, spill ? 64 : res_cap, tile_rows); } while (0)
                 switch (metric) { case COMET_L2: HS(COMET_L2); break; case COMET_L2SQ: HS(COMET_L2SQ); break; default: HS(COMET_COSINE); break; }
 #undef HS
                 LAUNCH_CHECK();
@@ -990,7 +1001,7 @@ struct HNSWIndex : comet_index {
             HIP_CHECK(hipStreamSynchronize(c->stream));
             if (!hs) break;
             c->zero(st, 16);
-            if (cand_cap < HN_CAND_CAP) cand_cap = HN_CAND_CAP; else spill = true;
+            if (cand_cap < HN_CAND_CAP) { cand_cap = std::min(HN_CAND_CAP, 2 * cand_cap); cand_hint = cand_cap; } else spill = true;
             run(spill);
         }
         // phase 3: document filter + threshold applied AFTER the search (can return < k), sort, top-k (:321-351)
