@@ -120,8 +120,52 @@ template <bool MAXHEAP> __device__ __forceinline__ HC heap_pop_wave_small(HC* h,
     n = m;
     return root;
 }
+// The same for a heap of up to 4 095 entries (the candidate heap: <= 12 levels) in TWO rounds: the decisions of the 63 nodes of levels 0-5 give the
+// path's node of level 6; the 31 nodes of the five levels under THAT node (a sub-tree with the same index arithmetic relative to its root) give the
+// rest. Four dependent LDS round trips instead of one per level.
+template <bool MAXHEAP> __device__ __forceinline__ HC heap_pop_wave_mid(HC* h, int& n) {
+    const int lane = threadIdx.x & 63;
+    const int m = n - 1;
+    const HC root = hc_load(h), y = hc_load(h + m);         // h.Swap(0, m)
+    auto decide = [&](int node) __attribute__((always_inline)) {      // would down() go right at `node`?
+        const int j1 = 2 * node + 1;
+        const HC c1 = hc_load(h + (j1 < m ? j1 : 0)), c2 = hc_load(h + (j1 + 1 < m ? j1 + 1 : 0));
+        return (j1 + 1 < m) && hless<MAXHEAP>(c2, c1);
+    };
+    // a sub-tree's node t (0 = its root, children 2t+1 / 2t+2) as an index of the heap whose node `r` is that root
+    auto glob = [&](int r, int t) __attribute__((always_inline)) { const int d = 31 - __builtin_clz(t + 1); return ((r + 1) << d) - 1 + (t + 1 - (1 << d)); };
+    const unsigned long long mA = __ballot(lane < 63 && decide(lane));
+    int p6 = 0;                                                         // the path's node of level 6 (uniform; may lie beyond m)
+#pragma unroll
+    for (int k = 0; k < 6; k++) p6 = 2 * p6 + 1 + (int)((mA >> p6) & 1ull);
+    const unsigned long long mB = __ballot(lane < 31 && decide(glob(p6, lane)));
+    // lane l: the path's node of level l and of level l - 1
+    int node = 0, par = 0;
+    {
+        int t = 0, tp = 0;                                               // walk inside tree A (levels <= 6) or tree B (levels 7 ..)
+        const bool inB = lane > 6;
+        const unsigned long long mk = inB ? mB : mA;
+        const int steps = inB ? lane - 6 : lane;
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k < steps) { tp = t; t = 2 * t + 1 + (int)((mk >> (t & 63)) & 1ull); }
+        node = inB ? glob(p6, t) : t;
+        par = inB ? glob(p6, tp) : tp;                                    // (lane 7: tp = 0 -> p6)
+    }
+    const bool valid = lane >= 1 && lane <= 11 && node < m && (lane <= 6 || p6 < m);
+    const HC c = hc_load(h + (valid ? node : 0));
+    const bool cont = valid && hless<MAXHEAP>(c, y);
+    const int t_stop = __builtin_ctzll(__ballot(!cont && lane >= 1));
+    if (cont && lane < t_stop) hc_store(h + par, c);
+    if (lane == t_stop - 1) hc_store(h + node, y);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) hc_store(h + m, root);
+    __builtin_amdgcn_wave_barrier();
+    n = m;
+    return root;
+}
 template <bool MAXHEAP> __device__ __forceinline__ HC heap_pop_wave(HC* h, int& n) {
     if (n <= 129) return heap_pop_wave_small<MAXHEAP>(h, n);
+    if (n <= 4095) return heap_pop_wave_mid<MAXHEAP>(h, n);
     const int m = n - 1;
     const HC root = hc_load(h), y = hc_load(h + m);         // h.Swap(0, m): y sifts down among the first m slots, the old root leaves
     int i = 0;

@@ -167,3 +167,29 @@ def test_hnsw_own_levels_are_seeded_and_searchable(ctx):
         assert o.add(int(ids[i]), X[i], int(lv[i])) == 0
     assert a.to_bytes() == o.to_bytes()
     check(a, o, synth(42, 16, d), 10, ef=128)
+
+
+def test_hnsw_navigable_graph_large_heaps_and_ties(ctx):
+    """A graph whose searches run ~efSearch expansions (layer 0 only: 16 exact neighbours + 16 random edges per node, loaded as is): the candidate
+    heap grows to many hundreds of entries (the multi-round Pop, an LDS heap that is doubled on overflow) and, with a tenth of the rows duplicated,
+    equal distances meet every order decision of the two heaps — ids, scores and order must still be the oracle's (container/heap's)."""
+    n, d = 4000, 32
+    X = synth(31, n, d).copy()
+    X[2000:2400] = X[0:400]
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    f = FlatIndex(ctx, d, L2_SQUARED); f.add_batch(ids, X)
+    knn = f.search_batch(X, 17)[0]
+    f.close()
+    rng = np.random.default_rng(3)
+    edges = np.concatenate([knn[:, 1:17], rng.integers(1, n + 1, (n, 16), dtype=np.uint32)], axis=1)
+    for metric in (L2_SQUARED, EUCLIDEAN):
+        g = HNSWIndex(ctx, d, metric, 16, 200, 128)
+        g.load_graph(ids, np.zeros(n, np.int32), X, np.arange(0, (n + 1) * 32, 32, dtype=np.int64), edges.reshape(-1), 1, 0)
+        blob = g.to_bytes()
+        o = orc.HNSW(d, metric, 16, 200, 128)
+        assert o.from_bytes(blob) == len(blob)
+        Q = np.concatenate([synth(32, 24, d), X[5:13]])          # stored (duplicated) vectors as queries too
+        check(g, o, Q, 10, ef=128)
+        check(g, o, Q, 0, ef=200)                                # results beyond the one-round Pop's 129 entries
+        assert g.stat("hnsw_expansions") / len(Q) > 60
+        g.close()
