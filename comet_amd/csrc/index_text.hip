@@ -160,8 +160,24 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(const double* __r
     bool done = false;
     if (kq > 0 && kq <= 64 && (long)total * 16 >= nd && nd >= BM_THREADS) {
         KP mine; mine.key = ~0ull; mine.pos = 0xFFFFFFFFu; mine.pad = 0;
-        for (long i = t; i < nd; i += BM_THREADS) { const double v = row[i]; if (v != 0.0) { const unsigned long long k = d2key_desc(v); if (k < mine.key) { mine.key = k; mine.pos = (unsigned)i; } } }
-        sel_lds[t] = mine;                                           // (ascending i: of equal keys the lowest document index stays)
+        // both walks read the row as 16-byte pairs, four pairs per thread in flight (one 8-byte load per trip of a branchy loop left a workgroup with a
+        // single load per thread outstanding: 2.9 TB/s over the two walks); of equal keys the lowest document index stays
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const long npair = nd >> 1;
+        auto walk = [&](auto&& f) {
+            for (long p0 = 0; p0 < npair; p0 += 4 * BM_THREADS) {
+                f64x2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const long pr = p0 + (long)u * BM_THREADS + t; v[u] = pr < npair ? *reinterpret_cast<const f64x2*>(row + 2 * pr) : f64x2{0.0, 0.0}; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const long pr = p0 + (long)u * BM_THREADS + t; f(v[u][0], 2 * pr); f(v[u][1], 2 * pr + 1); }
+            }
+            if ((nd & 1) && t == 0) f(row[nd - 1], nd - 1);
+        };
+        walk([&](double v, long i) {
+            if (v != 0.0) { const unsigned long long k = d2key_desc(v); if (k < mine.key || (k == mine.key && (unsigned)i < mine.pos)) { mine.key = k; mine.pos = (unsigned)i; } }
+        });
+        sel_lds[t] = mine;
         if (t == 0) s_n = 0;
         __syncthreads();
         auto sort_lds = [&](KP* a, int n2) {                        // bitonic, ascending by (key, pos)
@@ -182,13 +198,12 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(const double* __r
         const KP bnd = sel_lds[kq - 1];                              // (an unused thread's ~0 minimum here: everything passes, the count below decides)
         __syncthreads();
         KP* col = sel_lds + BM_THREADS;                              // BM_KMAX - BM_THREADS = BM_SMALL slots
-        for (long i = t; i < nd; i += BM_THREADS) {
-            const double v = row[i];
+        walk([&](double v, long i) {
             if (v != 0.0) {
                 const unsigned long long k = d2key_desc(v);
                 if (k < bnd.key || (k == bnd.key && (unsigned)i <= bnd.pos)) { const int sl = atomicAdd(&s_n, 1); if (sl < BM_SMALL) { col[sl].key = k; col[sl].pos = (unsigned)i; col[sl].pad = 0; } }
             }
-        }
+        });
         __syncthreads();
         const int members = s_n;
         if (members <= BM_SMALL) {                                   // (>= kq: the kq smallest minima are among them)
