@@ -52,11 +52,14 @@ def compare(g, o, Q, k, tag, **kw):
         TRACE.seek(0); TRACE.truncate(); TRACE.write(f"{tag} k_call={k} kw={ {a: (b if a != 'filter_ids' else len(b)) for a, b in kw.items()} }\n"); TRACE.flush()
     opts = dict(threshold=kw.get("threshold", 0.0), document_ids=kw.get("filter_ids", ()))
     if "nprobes" in kw: opts["nprobes"] = kw["nprobes"]
+    if "ef" in kw: opts["ef_search"] = kw["ef"]
     ids, sc, cnt = g.search_batch(Q, k, **opts)
     probe(g, tag + " | gpu search")
     for b, q in enumerate(Q):
         if "nprobes" in kw:
             n, oi, os_ = o.search(q, k, kw["nprobes"], threshold=opts["threshold"], filter_ids=opts["document_ids"])
+        elif "ef" in kw:
+            n, oi, os_ = o.search(q, k, kw["ef"], threshold=opts["threshold"], filter_ids=opts["document_ids"])
         else:
             n, oi, os_ = o.search(q, k, threshold=opts["threshold"], filter_ids=opts["document_ids"])
         if b == len(Q) - 1:
@@ -76,6 +79,7 @@ while time.time() < t_end:
     metric = METRICS[int(rng.integers(0, 3))]
     d = int(rng.choice([8, 16, 24, 32, 48, 64, 96, 130, 200]))
     n = int(rng.integers(1500, 9000)) if kind != "flat" else int(rng.integers(6000, 30000))
+    if kind == "hnsw": n = int(rng.integers(300, 4000)); d = min(d, 96)
     X = data(n, d, int(rng.integers(5, 60)))
     ids = np.arange(1, n + 1, dtype=np.uint32)
     B = int(rng.choice([1, 3, 8, 17, 40, 70, 130, 256], p=[0.2, 0.15, 0.15, 0.15, 0.15, 0.08, 0.07, 0.05]))
@@ -88,6 +92,27 @@ while time.time() < t_end:
         if real:
             g = ca.FlatIndex(ctx, d, metric); o = orc.Flat(d, metric)
             g.add_batch(ids, X); probe(g, tag + " | gpu add"); o.add_batch(ids, X); probe(g, tag + " | oracle add")
+    elif kind == "hnsw":
+        # the oracle's own graph (insertNode restated; searches stop after a few dozen expansions) or a navigable layer-0 graph (random degree, kNN + random
+        # edges: searches run ~efSearch expansions, heaps of many hundreds of entries); duplicated rows (data()) put equal distances into the heaps
+        M = int(rng.choice([4, 8, 16, 24, 40])); efc = int(rng.choice([20, 60, 100])); navig = bool(rng.random() < 0.5)
+        deg = int(rng.choice([6, 16, 32, 48, 70]))
+        eseed = int(rng.integers(1, 1 << 30))
+        kw["ef"] = int(rng.choice([0, 1, 7, 40, 128, 129, 130, 200, 300]))
+        tag += f" M={M} efc={efc} ef={kw['ef']} " + (f"navigable deg={deg}" if navig else "reference graph")
+        if real:
+            g = ca.HNSWIndex(ctx, d, metric, M, efc, 64); o = orc.HNSW(d, metric, M, efc, 64, seed=eseed)
+            if navig:
+                er = np.random.default_rng(eseed)
+                near = np.argsort(((X[:, None, :8] - X[None, :64, :8]) ** 2).sum(-1), axis=1)[:, :2] + 1      # two cheap "near" edges into the first 64 nodes
+                edges = np.concatenate([near.astype(np.uint32), er.integers(1, n + 1, (n, deg - 2), dtype=np.uint32)], axis=1)
+                g.load_graph(ids, np.zeros(n, np.int32), X, np.arange(0, (n + 1) * deg, deg, dtype=np.int64), edges.reshape(-1), 1, 0)
+                blob = g.to_bytes(); assert o.from_bytes(blob) == len(blob)
+            else:
+                assert o.add_batch(ids, X) == 0
+                oi_, lv_, vv_, eo_, ed_ = o.export()
+                g.load_graph(oi_, lv_, vv_, eo_, ed_, o.entry(), o.max_level())
+            probe(g, tag + " | graph loaded")
     elif kind == "ivf":
         nlist = int(rng.choice([8, 64, 128, 256])); ntr = min(n, max(nlist * 20, 1000))
         if real:
@@ -129,7 +154,7 @@ while time.time() < t_end:
             compare(g, o, Q, max(1, k), tag + " deletes", **kw)
     if rng.random() < 0.4:
         if real:
-            ref = (o.search(Q[0], 50, kw["nprobes"]) if "nprobes" in kw else o.search(Q[0], 50))[2]
+            ref = (o.search(Q[0], 50, kw["nprobes"]) if "nprobes" in kw else o.search(Q[0], 50, kw["ef"]) if "ef" in kw else o.search(Q[0], 50))[2]
             if len(ref) > 6:
                 compare(g, o, Q, max(1, k), tag + " threshold", threshold=float(ref[5]), **kw)
     if real:
