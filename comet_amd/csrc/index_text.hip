@@ -514,20 +514,29 @@ static bool bm25_search_enqueue(comet_text_index* ix, const uint32_t* q_tokens, 
             ix->acc_rows = rows; ix->acc_nd = nd;
         }
         double* acc = ix->acc.as<double>();
-        TermRef* drefs = c->salloc<TermRef>(refs.size());
-        c->h2d(drefs, refs.data(), refs.size() * sizeof(TermRef));
+        // the search's host-made tables go up in ONE copy (term references | dense references | the two query lists): a copy from pageable memory costs
+        // ~10 us of host time whatever its size, and there were four of them in a 0.5 ms call
+        std::vector<int> loc_d(dense_q.size()), loc_s(sparse_q.size());
+        const int64_t rows_pre = std::max<int64_t>(1, std::min<int64_t>(B, ((int64_t)224 << 20) / (nd * 8)));
+        for (size_t i = 0; i < dense_q.size(); i++) loc_d[i] = dense_q[i] % (int)rows_pre;          // local row inside the query's sub-batch
+        for (size_t i = 0; i < sparse_q.size(); i++) loc_s[i] = sparse_q[i] % (int)rows_pre;
+        const size_t o_refs = 0, o_dense = round_up(o_refs + refs.size() * sizeof(TermRef), 16), o_dq = round_up(o_dense + dense_refs.size() * sizeof(DenseRef), 16),
+                     o_sq = round_up(o_dq + ((size_t)B + 1) * 4, 16), up_bytes = round_up(o_sq + ((size_t)B + 1) * 4, 16);
+        std::vector<unsigned char> up(up_bytes, 0);
+        memcpy(up.data() + o_refs, refs.data(), refs.size() * sizeof(TermRef));
+        if (!dense_refs.empty()) memcpy(up.data() + o_dense, dense_refs.data(), dense_refs.size() * sizeof(DenseRef));
+        if (!loc_d.empty()) memcpy(up.data() + o_dq, loc_d.data(), loc_d.size() * 4);
+        if (!loc_s.empty()) memcpy(up.data() + o_sq, loc_s.data(), loc_s.size() * 4);
+        unsigned char* d_up = c->salloc<unsigned char>(up_bytes);
+        c->h2d(d_up, up.data(), up_bytes);
+        TermRef* drefs = reinterpret_cast<TermRef*>(d_up + o_refs);
         int32_t* touched = c->salloc<int32_t>((size_t)rows * tcap);
         unsigned long long* tkeys = c->salloc<unsigned long long>((size_t)rows * tcap);
         int32_t* tcount = c->salloc<int32_t>((size_t)rows * BM_TCOUNT_STRIDE);
         int64_t slab_ld = 1; while (slab_ld < std::min<int64_t>(k_cap, tcap)) slab_ld <<= 1;
         KP* slab = (std::min<int64_t>(k_cap, tcap) > BM_KMAX) ? c->salloc<KP>((size_t)rows * slab_ld) : nullptr;
-        DenseRef* d_dense = dense_refs.empty() ? nullptr : c->salloc<DenseRef>(dense_refs.size());
-        int* d_dq = c->salloc<int>((size_t)B + 1); int* d_sq = c->salloc<int>((size_t)B + 1);
-        std::vector<int> loc_d(dense_q.size()), loc_s(sparse_q.size());
-        for (size_t i = 0; i < dense_q.size(); i++) loc_d[i] = dense_q[i] % (int)rows;          // local row inside the query's sub-batch
-        for (size_t i = 0; i < sparse_q.size(); i++) loc_s[i] = sparse_q[i] % (int)rows;
-        if (d_dense) c->h2d(d_dense, dense_refs.data(), dense_refs.size() * sizeof(DenseRef));
-        c->h2d(d_dq, loc_d.data(), loc_d.size() * 4); c->h2d(d_sq, loc_s.data(), loc_s.size() * 4);
+        DenseRef* d_dense = dense_refs.empty() ? nullptr : reinterpret_cast<DenseRef*>(d_up + o_dense);
+        int* d_dq = reinterpret_cast<int*>(d_up + o_dq); int* d_sq = reinterpret_cast<int*>(d_up + o_sq);
         size_t di = 0, si = 0;                        // dense_q / sparse_q are ascending: a sub-batch owns a contiguous run of each
         for (int b0 = 0; b0 < B; b0 += (int)rows) {
             const int bn = std::min<int>((int)rows, B - b0);
@@ -573,19 +582,24 @@ int comet_bm25_search(comet_text_index* ix, const uint32_t* q_tokens, const int3
         if (k_cap <= 0) COMET_FAIL(COMET_ERR_INVALID_ARG, "k_cap must be positive");
         Ctx* c = ix->c;
         std::lock_guard<std::recursive_mutex> lk(c->mu); c->bind(); c->switch_lane(0); c->quiesce_alt(); c->scratch_reset();
-        uint32_t* d_ids = c->salloc<uint32_t>((size_t)B * k_cap);
-        float* d_sc = c->salloc<float>((size_t)B * k_cap);
-        double* d_sc64 = c->salloc<double>((size_t)B * k_cap);
-        int32_t* d_cn = c->salloc<int32_t>(B);
+        // one result block (float64 scores | ids | float32 scores | counts), one copy back into pinned memory
+        const size_t nk = (size_t)B * k_cap, o_sc64 = 0, o_ids = nk * 8, o_sc = o_ids + nk * 4, o_cn = o_sc + nk * 4, blk = o_cn + (size_t)B * 4;
+        unsigned char* d_blk = c->salloc<unsigned char>(blk);
+        uint32_t* d_ids = reinterpret_cast<uint32_t*>(d_blk + o_ids);
+        float* d_sc = reinterpret_cast<float*>(d_blk + o_sc);
+        double* d_sc64 = reinterpret_cast<double*>(d_blk + o_sc64);
+        int32_t* d_cn = reinterpret_cast<int32_t*>(d_blk + o_cn);
         if (!bm25_search_enqueue(ix, q_tokens, q_offsets, B, k, filter_ids, n_filter, d_ids, d_sc, d_sc64, d_cn, k_cap)) {
             std::fill(out_counts, out_counts + B, 0);
             return (int)COMET_OK;
         }
-        c->d2h(out_ids, d_ids, (size_t)B * k_cap * 4);
-        c->d2h(out_scores, d_sc, (size_t)B * k_cap * 4);
-        if (out_scores64) c->d2h(out_scores64, d_sc64, (size_t)B * k_cap * 8);
-        c->d2h(out_counts, d_cn, (size_t)B * 4);
+        unsigned char* hb = static_cast<unsigned char*>(c->pinned_buf(blk));
+        c->d2h(hb, d_blk, blk);
         c->sync();
+        memcpy(out_ids, hb + o_ids, nk * 4);
+        memcpy(out_scores, hb + o_sc, nk * 4);
+        if (out_scores64) memcpy(out_scores64, hb + o_sc64, nk * 8);
+        memcpy(out_counts, hb + o_cn, (size_t)B * 4);
         return (int)COMET_OK;
     });
 }
