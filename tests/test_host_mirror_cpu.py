@@ -100,7 +100,7 @@ def test_rrf_batch_equals_per_query_form():
 
 def test_bench_compact_line_is_driver_sized():
     """The driver parses bench.py's LAST stdout line from a bounded tail: the compact record built from a full record of every leg (the committed
-    profiles/r05_bench_legs_e.json: all default legs present) stays under 6 KB and keeps the contract's keys, `roofline` and `cpu_baseline`."""
+    profiles/r05_bench_legs_f.json: all default legs present) stays under 6 KB and keeps the contract's keys, `roofline` and `cpu_baseline`."""
     import importlib.util
     import json
     import sys
@@ -112,7 +112,7 @@ def test_bench_compact_line_is_driver_sized():
         bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
     finally:
         sys.argv = argv
-    full = json.loads((root / "profiles" / "r05_bench_legs_e.json").read_text())
+    full = json.loads((root / "profiles" / "r05_bench_legs_f.json").read_text())
     line = json.dumps(bench.compact_line(full))
     assert len(line) < 6 * 1024, len(line)
     rec = json.loads(line)
