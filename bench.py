@@ -679,7 +679,8 @@ def leg_hnsw(ctx, ca, args, timer):
                           "construction; parity means identical results on the identical graph",
            "roofline": {"bound": "hbm", "kernel": "hnsw_search", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                         "avg_kernel_ms": avg_ms, "launches": nl, "algorithmic_bytes_per_launch": alg,
-                        "algorithmic_bytes_are": "distance evaluations x d x 4 + expansions x 2M x 4, both counted by the kernel (random 1.5 KB row reads: latency-bound, one wave per query)"}}
+                        "algorithmic_bytes_are": "distance evaluations x d x 4 + expansions x 2M x 4, both counted by the kernel (random 1.5 KB row reads, one wave per query)",
+                        "note": "the kernel is instruction-issue-bound, not memory-bound (one wave per SIMD issues an instruction per ~8 clocks; DESIGN.md 3.8, profiles/r05_hnsw_trace.txt): the HBM fraction is informational"}}
     sweep = {}
     for Bs in (1024, 4096, 8192):
         p2 = Pipe(ctx, g, q_ptrs, Bs, K, None, depth=4, **params)
