@@ -935,7 +935,7 @@ struct PQFamilyIndex : comet_index {
                 const int bn = std::min(qb, B - b0);
                 launch_adc_scan(c, Qp + (size_t)b0 * ld, ld, dim, ivf ? centroids.as<float>() : nullptr, codebooks.as<float>(), M, Ksub, dsub,
                                 codes_il.as<uint32_t>(), M4, lay.list_base.as<int64_t>(), lay.list_len.as<int32_t>(),
-                                probe_list + (size_t)b0 * np, np, np, seg_off + (size_t)b0 * (np + 1), elig, bn, ivf ? nlist : 1, lay.max_len, D, ldD, fuse ? &afl : nullptr);
+                                probe_list + (size_t)b0 * np, np, np, seg_off + (size_t)b0 * (np + 1), elig, bn, ivf ? nlist : 1, lay.max_len, D, ldD, fuse ? &afl : nullptr, (int64_t)lay.nslots);
                 if (fuse) launch_select_composites(c, afl.cand, ldD, afl.cursor, bn, p.k, pos + (size_t)b0 * k_cap, out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);
                 else launch_select_topk(c, D, ldD, bn, Cmax, cnts + b0, p.threshold, p.k, pos + (size_t)b0 * k_cap,
                                         out_scores + (size_t)b0 * k_cap, out_counts + b0, k_cap);

@@ -110,7 +110,8 @@ struct AdcFilter { unsigned long long* cand; int32_t* cursor; uint32_t* tq; int 
 };
 void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* centroids, const float* codebooks, int M, int Ksub, int dsub,
                      const uint32_t* codes, int M4, const int64_t* list_base, const int32_t* list_len, const uint32_t* probe_list, int ldp,
-                     int np, const int32_t* seg_off, const uint8_t* elig, int B, int nlist, int max_list_len, float* D, int64_t ldD, const AdcFilter* flt = nullptr);
+                     int np, const int32_t* seg_off, const uint8_t* elig, int B, int nlist, int max_list_len, float* D, int64_t ldD, const AdcFilter* flt = nullptr,
+                     int64_t n_codes = 0 /*codes in the index: picks the scan kernel (adc_scan2_kernel on lists of a few thousand codes)*/);
 // the exchanges launch_adc_scan would issue for B queries, with +inf bounds: for a rank of a sharded search whose shard has no candidate (flt->tq: B words)
 void adc_exchange_idle(Ctx* c, const AdcFilter* flt, int M, int Ksub, int np, int B, int nlist);
 // the bound exchanges a two-stage search with an exchange callback issues for a batch of B queries: their number, *per = queries per exchange (the last one

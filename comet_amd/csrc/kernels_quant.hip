@@ -926,7 +926,7 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
                                                          int* __restrict__ qcount, int* __restrict__ queues, unsigned* __restrict__ tq, int* __restrict__ cursor, int n_q, int lead,
                                                          const long* __restrict__ list_base, int stage, const unsigned char* __restrict__ dead, int* __restrict__ used,
                                                          int* __restrict__ gstats /*nullable: [2] += 64-code blocks the items cover, [3] += items, [4] += (query, block) pairs, [5] += searches*/, int strict,
-                                                         unsigned long long* __restrict__ cand_init /*nullable*/, long ldD) {
+                                                         unsigned long long* __restrict__ cand_init /*nullable*/, long ldD, int seg_codes /*codes per item: ADC_SEG_CODES or A2_SEG_CODES*/) {
     // workgroups 1.. (launched only where a search begins: stage <= 1 of a fused-filter search) fill the first ADC_REFINE_MAX entries of every query's survivor
     // row with all-ones: the scan's bound refinement reads a row while it is being appended to, and a slot not yet written must read as +inf
     if (blockIdx.x > 0) {
@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
         duo = (x + 8 * (u / ADC_XCD_CHUNK)) * ADC_XCD_CHUNK + (u % ADC_XCD_CHUNK);
         if (u >= u1 || duo >= n_duos) return 0;
         const unsigned L = slist[2 * duo];
-        return L < (unsigned)nlist ? (list_len[L] + ADC_SEG_CODES - 1) / ADC_SEG_CODES : 0;
+        return L < (unsigned)nlist ? (list_len[L] + seg_codes - 1) / seg_codes : 0;
     };
     int tot = 0;
     for (int u = u0 + lane; u < u1; u += 64) { int duo; tot += segs_of(u, duo); }
@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
                 r[b].qA = (int)pa / np; r[b].soA = seg_off[(long)r[b].qA * (np + 1) + ((int)pa - r[b].qA * np)];
                 r[b].qB = -1; r[b].soB = 0;
                 if (pb != ADC_HOLE) { r[b].qB = (int)pb / np; r[b].soB = seg_off[(long)r[b].qB * (np + 1) + ((int)pb - r[b].qB * np)]; }
-                r[b].base_lo = (unsigned)(bb & 0xFFFFFFFFl); r[b].base_hi = (unsigned)(bb >> 32); r[b].pad0 = r[b].pad1 = r[b].pad2 = 0;
+                r[b].base_lo = (unsigned)(bb & 0xFFFFFFFFl); r[b].base_hi = (unsigned)(bb >> 32); r[b].pad0 = L /*adc_scan2: the list (its centroid row)*/; r[b].pad1 = r[b].pad2 = 0;
                 const int nblk = (len[b] + 63) >> 6;
                 st_blocks += nblk; st_items += ns[b]; st_qblocks += nblk * (r[b].qB >= 0 ? 2 : 1);
             }
@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
             for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
             const int off = base + inc - ns[b];
             for (int sgi = 0; sgi < ns[b]; sgi++) if (off + sgi < qcap) {
-                r[b].start = sgi * ADC_SEG_CODES; r[b].seg_end = min(len[b], r[b].start + ADC_SEG_CODES);
+                r[b].start = sgi * seg_codes; r[b].seg_end = min(len[b], r[b].start + seg_codes);
                 qitems[(long)x * qcap + off + sgi] = r[b];
             }
             base += __shfl(inc, 63);
@@ -1565,6 +1565,7 @@ __global__ __launch_bounds__(ADC_THREADS) __attribute__((amdgpu_waves_per_eu(ADC
 #endif
     }
 }
+#include "kernels_adc2.inc.hpp"
 // pairs of a (sub-)batch grouped by probed list; falls back to the identity order when the list count does not fit in LDS
 bool launch_order_pairs(Ctx* c, const uint32_t* probe_list, int ldp, int np, const int32_t* seg_off, int n_pairs, int nlist, uint32_t* order, uint32_t* olist) {
     if (n_pairs <= 0) return false;
@@ -1614,7 +1615,7 @@ int adc_exchange_plan(int M, int Ksub, int np, int B, int nlist, int* per) {
 }
 void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* centroids, const float* codebooks, int M, int Ksub, int dsub,
                      const uint32_t* codes, int M4, const int64_t* list_base, const int32_t* list_len, const uint32_t* probe_list, int ldp,
-                     int np, const int32_t* seg_off, const uint8_t* elig, int B, int nlist, int max_list_len, float* D, int64_t ldD, const AdcFilter* flt) {
+                     int np, const int32_t* seg_off, const uint8_t* elig, int B, int nlist, int max_list_len, float* D, int64_t ldD, const AdcFilter* flt, int64_t n_codes) {
     if (B <= 0 || np <= 0) return;
     if (max_list_len <= 0) { adc_exchange_idle(c, flt, M, Ksub, np, B, nlist); return; }
     const int KL = Ksub < 256 ? Ksub : 256;
@@ -1627,15 +1628,26 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
     const bool lead = flt != nullptr && np >= 2 && !identity;
     auto slots_for = [&](int64_t n_pairs) { return identity ? 2 * n_pairs : (lead ? 2 * (n_pairs / np) : 0) + round_up(n_pairs + std::min<int64_t>(nlist, n_pairs), 2); };
     const int64_t max_slots = slots_for(qc * np);
-    const int segs = (int)ceil_div(max_list_len, ADC_SEG_CODES);
-    const int64_t max_chunks = ceil_div(max_slots / 2, ADC_XCD_CHUNK);
-    const int64_t qcap = ceil_div(max_chunks, 8) * ADC_XCD_CHUNK * segs;
-    if (qcap > (int64_t)1 << 28) COMET_FAIL(COMET_ERR_UNSUPPORTED, "ADC work queue too large (%lld items)", (long long)qcap);
-    ScratchMark mark(c);
     // 8-bit codebooks with 4 / 8 / 16 dimensions per subspace: the scanning workgroups build the tables themselves, in LDS (adc_scan_kernel<DSUB>): no table kernel,
     // no table bytes in HBM. COMET_ADC_STREAM_TABLES=1 keeps the streamed form (pq_lut_kernel -> HBM -> LDS-DMA), which every other shape uses.
     static const bool stream_tables = getenv("COMET_ADC_STREAM_TABLES") != nullptr;
     const int build = (!stream_tables && KL == 256 && (dsub == 4 || dsub == 8) && (size_t)M * dsub <= (size_t)ld && mp * KL * 8 <= ADC_BUF_BYTES) ? dsub : 0;
+    // round 6: the batched, phase-major form (adc_scan2_kernel: codeword slices in registers, A2_G items per slice, batches software-pipelined) for the same
+    // shapes. It wins where a launch is many items of a few thousand codes (configs[3]'s shape: 0.506 -> 0.460 ms for the every-candidate scan) and loses on
+    // short or very uneven lists and on the small launches of the two-stage search (a batch of four items per workgroup is a longer critical path than four
+    // workgroups with one item each) — so: single-stage launches of indexes whose average list holds >= 1536 codes. COMET_ADC_KERNEL=1 / 2 forces a kernel
+    // (read per search: the tests run both forms in one process).
+    const char* kenv = getenv("COMET_ADC_KERNEL");
+    const int kforce = kenv ? atoi(kenv) : 0;
+    const bool scan2_ok = build != 0 && Ksub == 256 && M * dsub <= A2_RES_DIMS;
+    const bool scan2_auto = !adc_two_stage(flt, np, nlist) && n_codes / std::max(1, nlist) >= 1536;
+    const bool scan2 = scan2_ok && (kforce == 2 || (kforce != 1 && scan2_auto));
+    const int seg_codes = scan2 ? A2_SEG_CODES : ADC_SEG_CODES;
+    const int segs = (int)ceil_div(max_list_len, seg_codes);
+    const int64_t max_chunks = ceil_div(max_slots / 2, ADC_XCD_CHUNK);
+    const int64_t qcap = ceil_div(max_chunks, 8) * ADC_XCD_CHUNK * segs;
+    if (qcap > (int64_t)1 << 28) COMET_FAIL(COMET_ERR_UNSUPPORTED, "ADC work queue too large (%lld items)", (long long)qcap);
+    ScratchMark mark(c);
     float* lut = build ? nullptr : c->salloc<float>((size_t)max_slots * M * KL);
     float* zero_row = nullptr;                                       // PQ has no coarse centroid: its "residual" is the query minus a row of zeros
     if (build && !centroids) { zero_row = c->salloc<float>((size_t)ld); c->zero(zero_row, (size_t)ld * 4); }
@@ -1656,6 +1668,8 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
         HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_CHECK(hipFuncSetAttribute((const void*)adc_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (ORDER_MAX_LISTS + 1) * 4));
+        HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A2_LDS_BYTES));
+        HIP_CHECK(hipFuncSetAttribute((const void*)adc_scan2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A2_LDS_BYTES));
         attr_done = true;
     }
     // Two-stage fused search (K <= 64, np >= 2): stage 1 scans every query's NEAREST list only, which seeds the per-query bounds; a
@@ -1684,7 +1698,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
                                                                                                            n_slots, order, slist, qitems, (int)qcap, qcount, queues,
                                                                                                            flt ? flt->tq + b0 : nullptr, flt ? flt->cursor + b0 : nullptr, bn, (lead && stage == 0) ? 1 : 0, (const long*)list_base,
                                                                                                            stage, dead, used, flt ? flt->stats : nullptr, strict,
-                                                                                                           init_rows ? flt->cand + (size_t)b0 * ldD : nullptr, (long)ldD);
+                                                                                                           init_rows ? flt->cand + (size_t)b0 * ldD : nullptr, (long)ldD, seg_codes);
                 LAUNCH_CHECK();
             }
             if (!build) {
@@ -1708,6 +1722,12 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
                 AdcArgs a{lut, codes, (const long*)list_base, list_len, so, elig, order, slist, qitems, qcount, queues, D ? D + (size_t)b0 * ldD : nullptr, (long)ldD, M, KL, mp, M4, np, (int)qcap,
                           flt ? flt->cand + (size_t)b0 * ldD : nullptr, flt ? flt->cursor + b0 : nullptr, flt ? flt->tq + b0 : nullptr, flt ? flt->K : 0, flt ? flt->thr : 0.0f, (flt && prune_on) ? 1 : 0, (flt && refine_on) ? 1 : 0,
                           Qb, centroids ? centroids : zero_row, codebooks, ld, Ksub, centroids ? 1 : 0};
+                if (scan2) {
+                    long g2 = std::min<long>(n_items, (long)c->prop.multiProcessorCount);     // one 8-wave workgroup of 256 registers per CU
+                    g2 = std::max<long>(8, (g2 + 7) / 8 * 8);
+                    if (build == 4) c->launch_timed("adc_scan", adc_scan2_kernel<4>, dim3((unsigned)g2), dim3(A2_THREADS), (size_t)A2_LDS_BYTES, a);
+                    else c->launch_timed("adc_scan", adc_scan2_kernel<8>, dim3((unsigned)g2), dim3(A2_THREADS), (size_t)A2_LDS_BYTES, a);
+                } else
                 switch (build) {
                     case 4: c->launch_timed("adc_scan", adc_scan_kernel<4>, dim3((unsigned)g), dim3(ADC_THREADS), lds, a); break;
                     case 8: c->launch_timed("adc_scan", adc_scan_kernel<8>, dim3((unsigned)g), dim3(ADC_THREADS), lds, a); break;
@@ -1765,6 +1785,11 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
 
 }  // namespace comet
 
+#ifdef A2_TRACE
+extern "C" __attribute__((visibility("default"))) int comet_debug_a2_trace(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(comet::a2_trace_buf), (size_t)n * 8);
+}
+#endif
 #ifdef ADC_TRACE
 extern "C" __attribute__((visibility("default"))) int comet_debug_adc_trace(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(comet::adc_trace_buf), (size_t)n * 8);
