@@ -1102,6 +1102,25 @@ __device__ __forceinline__ void adc_chains2(const f32x2q* __restrict__ lut, int 
                 for (int i = 0; i < G; i++) nxt[c][i] = adc_ldw(nrs, voff, nxw[i] + c * stride16b);
         }
         const f32x2q* l0 = lut + (long)g * (G * 4) * KL;
+        if constexpr (C <= 2) {
+            // one or two chains (lists of a few hundred codes: the short-list regime): a whole group's gathers of a chain at once — 8 (C = 1: both words) or
+            // 2 x 4 (C = 2: word by word) in flight per wait instead of 2 C. With two in flight the LDS pipe ran at a third of its gather rate (round 5's ablation).
+            constexpr int WI = C == 1 ? G : 1;                                   // words per round
+#pragma unroll
+            for (int i0 = 0; i0 < G; i0 += WI) {
+                f32x2q v[C][WI * 4];
+#pragma unroll
+                for (int c = 0; c < C; c++)
+#pragma unroll
+                    for (int i = 0; i < WI; i++)
+#pragma unroll
+                        for (int b = 0; b < 4; b++) v[c][i * 4 + b] = l0[((i0 + i) * 4 + b) * KL + ((cur[c][i0 + i] >> (8 * b)) & 255u)];
+#pragma unroll
+                for (int e = 0; e < WI * 4; e++)
+#pragma unroll
+                    for (int c = 0; c < C; c++) { acc[c][0] = acc[c][0] + v[c][e][0]; acc[c][1] = acc[c][1] + v[c][e][1]; }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < G; i++) {
 #pragma unroll
@@ -1117,6 +1136,7 @@ __device__ __forceinline__ void adc_chains2(const f32x2q* __restrict__ lut, int 
 #pragma unroll
                     for (int c = 0; c < C; c++) { acc[c][0] = acc[c][0] + v[c][b][0]; acc[c][1] = acc[c][1] + v[c][b][1]; }
             }
+        }
         }
 #pragma unroll
         for (int c = 0; c < ADC_CHAINS; c++)
