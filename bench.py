@@ -227,7 +227,7 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel, rows_local):
+def pmc_traffic(kernel, rows_local, leg=None):
     """HBM bytes per launch from the committed rocprofv3 --pmc pass (newest profiles/r*_pmc*.json naming the kernel). The file carries
     the fingerprint of the kernel sources it was measured on (tools/pmc_collect.py); a file measured on other code is NOT quoted."""
     best, stale = None, None
@@ -241,8 +241,14 @@ def pmc_traffic(kernel, rows_local):
                          "flat_scan_f16_n64": ("flat_scan_f16_n64_kernelILi1ELb0E", "flat_scan_f16_n64_kernel<1, false>"),
                          "flat_scan_i8_n64": ("flat_scan_qn_kernelILi1ELi6E", "flat_scan_qn_kernel<1, 6>", "flat_scan_f16_n64_kernelILi1ELb1E", "flat_scan_f16_n64_kernel<1, true>"),
                          "ivf_scan_f16": ("ivf_scan_f16_kernelILi0ELb0E", "ivf_scan_f16_kernel<0, false>"),
-                         "ivf_scan_i8": ("ivf_scan_f16_kernelILi0ELb1E", "ivf_scan_f16_kernel<0, true>")}.get(kernel, (kernel + "_kernel",))
+                         "ivf_scan_i8": ("ivf_scan_f16_kernelILi0ELb1E", "ivf_scan_f16_kernel<0, true>"),
+                         "adc_scan": ("adc_scan_kernel", "adc_scan2_kernel")}.get(kernel, (kernel + "_kernel",))
                 if kname.split("<")[0].strip() == kernel or any(nm in kname for nm in names):
+                    # a counter value is the measurement of ONE leg: the adc_scan launches of a PMC file belong to the leg the pass ran (tools/pmc_bench.sh: PMC_ADC_LEG,
+                    # default the clustered 1M leg) — the uniform and 10M legs quote their own passes or nothing
+                    if leg is not None and pm.get("adc_leg", "ivfpq") != leg:
+                        stale = f"{f.name} (its adc_scan launches are the {pm.get('adc_leg', 'ivfpq')} leg's, not {leg}'s)"
+                        continue
                     if pm.get("source_sha") != sha:
                         stale = f.name
                         continue
@@ -603,7 +609,7 @@ def leg_ivfpq(ctx, ca, args, timer, flat_exact, q_ptrs, Q0, rows, nlist, tag, co
                 pair_tables = 0.0
             must = uniq_code_bytes + pair_tables
             ach = must / (adc_ms * 1e-3) / 1e9 if adc_ms > 0 else 0.0
-            traffic, src = pmc_traffic("adc_scan", n)
+            traffic, src = pmc_traffic("adc_scan", n, leg=tag)
             out["every_candidate_search"] = {"qps": B / ex_el, "ms_per_step": ex_el * 1e3, "steps": ex_steps, "adc_scan_ms": adc_ms, "identical_to_pruned_search": same,
                                              "candidates_per_query": cand}
             out["roofline"] = {"bound": "hbm", "kernel": "adc_scan", "measured_on": "the every-candidate search (mode 1) on one execution lane: the pruned search's launches see only what the lower bound left, and two lanes would overlap two scans",

@@ -11,6 +11,8 @@ import re
 import sys
 
 src, out = sys.argv[1], sys.argv[2]
+adc_leg = sys.argv[3] if len(sys.argv) > 3 else "ivfpq"                  # which bench leg the pass's adc_scan launches belong to
+rows_of_pass = int(sys.argv[4]) if len(sys.argv) > 4 else 1000000
 acc = collections.defaultdict(lambda: collections.defaultdict(list))     # kernel -> counter -> per-dispatch values
 for f in sorted(glob.glob(f"{src}/p*/**/*counter_collection.csv", recursive=True)):
     per_dispatch = collections.defaultdict(float)
@@ -21,6 +23,28 @@ for f in sorted(glob.glob(f"{src}/p*/**/*counter_collection.csv", recursive=True
         names[key[0]] = r["Kernel_Name"]
     for (did, cname), v in per_dispatch.items():
         acc[names[did]][cname].append(v)
+
+
+# effective shader clock per kernel: the pass that carries --kernel-trace next to GRBM_GUI_ACTIVE gives every dispatch's begin / end time; GRBM_GUI_ACTIVE is
+# summed over the chip's 8 XCDs, so clock = (GRBM_GUI_ACTIVE / 8) / (end - begin)
+clock = collections.defaultdict(list)
+for d in sorted(glob.glob(f"{src}/p*")):
+    ktr = glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True)
+    cc = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)
+    if not ktr or not cc:
+        continue
+    dur = {}
+    for f in ktr:
+        for r in csv.DictReader(open(f)):
+            k = r.get("Dispatch_Id") or r.get("Correlation_Id")
+            dur[k] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"])
+    for f in cc:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != "GRBM_GUI_ACTIVE":
+                continue
+            k = r.get("Dispatch_Id") or r.get("Correlation_Id")
+            if k in dur and dur[k][0] > 0:
+                clock[dur[k][1]].append((float(r["Counter_Value"]) / 8.0 / dur[k][0] * 1e3, dur[k][0]))     # MHz, ns
 
 
 def short(name):
@@ -41,6 +65,11 @@ for name, ctrs in acc.items():
         e["hbm_write_bytes_per_launch_uncalibrated"] = e["WRITE_SIZE_per_launch"] * 1024.0
     if "SQ_LDS_BANK_CONFLICT" in ctrs and e.get("SQ_LDS_IDX_ACTIVE_per_launch"):
         e["lds_conflict_fraction"] = e["SQ_LDS_BANK_CONFLICT_per_launch"] / e["SQ_LDS_IDX_ACTIVE_per_launch"]
+    if name in clock and len(clock[name]) >= 3:
+        c = sorted(x[0] for x in clock[name][len(clock[name]) // 4:])        # (the first quarter: warm-up launches)
+        e["effective_clock_mhz"] = {"median": round(c[len(c) // 2]), "p10": round(c[len(c) // 10]), "p90": round(c[(9 * len(c)) // 10]), "dispatches": len(c),
+                                    "kernel_us_in_this_pass": round(sorted(x[1] for x in clock[name])[len(clock[name]) // 2] / 1e3, 1),
+                                    "how": "GRBM_GUI_ACTIVE / 8 XCDs / (End - Start) per dispatch, rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE"}
     key = name if name not in kern else name + "#2"
     kern[key] = e
     e["short"] = short(name)
@@ -52,5 +81,5 @@ for _f in sorted((pathlib.Path(__file__).resolve().parent.parent / "comet_amd" /
 json.dump({"source_sha": _h.hexdigest()[:16],       # fingerprint of the kernel sources (bench.py quotes this file only while it matches)
            "what": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | LDS | TCC, one pass each) over `bench.py --no-cpu-baseline --regions 1 --steps 3 --warmup 1`",
            "correction": "gfx950: read bytes = 2 * FETCH_SIZE(KB) * 1024 (MI355X_MICROARCH.md §HBM); WRITE_SIZE uncalibrated",
-           "rows": 1000000, "kernels": kern}, open(out, "w"), indent=1)
+           "rows": rows_of_pass, "adc_leg": adc_leg, "kernels": kern}, open(out, "w"), indent=1)
 print(f"wrote {out}: {len(kern)} kernels")
