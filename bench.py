@@ -16,9 +16,10 @@ Legs (all inside the one line; `--legs` selects):
     Flat search and against the CPU oracle on the same index; N > 1: inverted lists sharded over the ranks;
   * `ivfpq10m` = configs[3]'s shape on the GPUs present: IVFPQ 10M x 768, nlist 4096, nprobe 32, M 96, nbits 8, K 10, built on the
     GPU inside the run (N > 1: list shards, the sharded form the config names);
-  * `hnsw` (N = 1) = configs[2]: HNSW L2 d 384, M 16, efConstruction 200, efSearch 128, K 10, graph built on the GPU inside the run
-    (`--hnsw-rows`, default 100k: the reference's insertion is sequential — a 1M-node build is minutes on any hardware; the 1M line is
-    in profiles/), recall@10 against exact Flat search, batch sweep;
+  * `hnsw` (N = 1) = configs[2]: HNSW L2 d 384, M 16, efSearch 128, K 10. TIMED on `hnsw_navigable`: a 1M-node (`--hnsw-nav-rows`) layer-0 graph built on the
+    GPU inside the run from exact Flat k-NN (16 nearest + 16 random edges per node), searched by the same kernel, 256-query parity against the CPU oracle on that
+    graph, recall@10 against exact Flat search. The reference-construction graph (`--hnsw-rows`, default 100k, built by the GPU insert kernel one insertion at a
+    time as the reference's semantics demand) is a PARITY line: the reference's insertNode leaves graphs whose searches stop after a few dozen expansions;
   * `hybrid` (N = 1) = configs[4]: IVF 1M x 768 (nlist 1024; nprobe 32 and the hybrid default 1) + BM25 over 100k documents +
     Reciprocal Rank Fusion.
 Every leg rotates 8 distinct query batches (no step replays the previous step's queries), reports the median of R timed regions of
@@ -54,7 +55,7 @@ CORPUS_SEED, QUERY_SEED = 0xC0FFEE + 2, 0xBEEF + 2
 # a query's true neighbours are the rows of its own sub-centre
 MIX_SEED, MIX_CENTERS, MIX_SIGMA, MIX_SUB, MIX_NOISE = 0xC0FFEE + 4, 2048, 0.15, 65536, 0.02
 HBM_PEAK_GBS = 8000.0
-LANES = max(1, min(4, int(os.environ.get("COMET_LANES", "4"))))    # execution lanes of the timed regions (the library's default: 4; Flat / IVF use two of them)
+LANES = max(1, min(8, int(os.environ.get("COMET_LANES", "8"))))    # execution lanes of the timed regions (the library's default: 8; Flat / IVF use two of them, PQ / IVFPQ four, HNSW eight)
 NQB = 8               # distinct query batches a leg rotates through
 DTYPE = ("f32 results: every returned score is the reference's serial float32 sum (bit-identical to the CPU path); candidates are "
          "screened on int8 MFMA (v_mfma_i32_32x32x32_i8, exact int32 accumulate; fp16 v_mfma_f32_32x32x16_f16 where int8 is too coarse for the "
@@ -83,7 +84,8 @@ def parse():
     ap.add_argument("--ivfpq-k", type=int, default=10)
     ap.add_argument("--big-rows", type=int, default=10_000_000, help="rows of the ivfpq10m leg (configs[3])")
     ap.add_argument("--big-nlist", type=int, default=4096)
-    ap.add_argument("--hnsw-rows", type=int, default=100_000)
+    ap.add_argument("--hnsw-rows", type=int, default=100_000)         # the reference-construction graph (sequential insertion: a parity line)
+    ap.add_argument("--hnsw-nav-rows", type=int, default=1_000_000)   # the navigable graph the search kernel is timed on: configs[2]'s stated size
     ap.add_argument("--hnsw-dim", type=int, default=384)
     ap.add_argument("--docs", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -314,7 +316,7 @@ class Pipe:
 
     def __init__(self, ctx, idx, q_ptrs, B, K, comm=None, depth=2, **params):
         self.ctx, self.idx, self.q, self.B, self.K, self.comm, self.params = ctx, idx, q_ptrs, B, K, comm, params
-        self.depth = max(1, min(int(depth), 4 if comm is None else 3))      # a communicator has four slots
+        self.depth = max(1, min(int(depth), 8 if comm is None else 3))      # a communicator has four slots; an HNSW index eight pending searches
         self.bufs = [(ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)) for _ in range(self.depth + 1)]
         self.i = 0
 
@@ -666,7 +668,7 @@ def leg_hnsw(ctx, ca, args, timer):
     q_ptrs = query_batches(ctx, 8192, d, lambda p, i: ctx.synth_mixture(p, MIX_SEED + 1, MIX_CENTERS, MIX_SIGMA, nsub, MIX_NOISE, n + 7 + i * 8192, 8192, d))   # 8 x 8192 fresh draws (the sweep's largest batch)
     Q0 = ctx.download(q_ptrs[0], (B, d), np.float32)
     params = dict(ef_search=efs)
-    pipe = Pipe(ctx, g, q_ptrs, B, K, None, depth=4, **params)                 # a 256-query search is 256 waves: four of them side by side
+    pipe = Pipe(ctx, g, q_ptrs, B, K, None, depth=min(8, LANES), **params)     # a 256-query search is 256 waves: eight of them side by side
     pipe.step(2)
     rec, prof, med, times = measure(ctx, timer, args, pipe.step, "hnsw_search", B)
     gr = pipe.results_of(0)
@@ -704,8 +706,10 @@ def leg_hnsw(ctx, ca, args, timer):
     # neighbours (Flat search on the GPU) + 16 random nodes, loaded through comet_hnsw_load_graph — the reference's own insertNode leaves a graph
     # whose searches stop after ~33 expansions; here a search runs its ~efSearch expansions, which is what the kernel is for ----
     def navigable():
-        nn = min(n, 100_000)
-        buf = ctx.alloc(nn * d * 4); fill(buf, 0, nn); Xh = ctx.download(buf, (nn, d), np.float32); ctx.free(buf)
+        nn = args.hnsw_nav_rows
+        nsub_n = max(64, nn // 15)
+        fill_n = lambda buf, lo, m: ctx.synth_mixture(buf, MIX_SEED + 1, MIX_CENTERS, MIX_SIGMA, nsub_n, MIX_NOISE, lo, m, d)
+        buf = ctx.alloc(nn * d * 4); fill_n(buf, 0, nn); Xh = ctx.download(buf, (nn, d), np.float32); ctx.free(buf)
         fl = ca.FlatIndex(ctx, d, ca.EUCLIDEAN)
         ids_n = np.arange(1, nn + 1, dtype=np.uint32)
         fl.add_batch(ids_n, Xh)
@@ -719,9 +723,9 @@ def leg_hnsw(ctx, ca, args, timer):
         gn = ca.HNSWIndex(ctx, d, ca.EUCLIDEAN, M, efc, efs)
         gn.load_graph(ids_n, np.zeros(nn, np.int32), Xh, np.arange(0, (nn + 1) * 32, 32, dtype=np.int64), edges.reshape(-1), 1, 0)
         build_nav_s = time.time() - t0
-        qn_ = query_batches(ctx, B, d, lambda p, i: ctx.synth_mixture(p, MIX_SEED + 1, MIX_CENTERS, MIX_SIGMA, nsub, MIX_NOISE, n + 7 + i * B, B, d))
+        qn_ = query_batches(ctx, B, d, lambda p, i: ctx.synth_mixture(p, MIX_SEED + 1, MIX_CENTERS, MIX_SIGMA, nsub_n, MIX_NOISE, nn + 7 + i * B, B, d))
         Qn = ctx.download(qn_[0], (B, d), np.float32)
-        pn = Pipe(ctx, gn, qn_, B, K, None, depth=4, **params)
+        pn = Pipe(ctx, gn, qn_, B, K, None, depth=min(8, LANES), **params)      # one wave per query: 8 x 256 queries in flight = two waves per SIMD
         pn.step(2)
         recn, profn, _m, _t = measure(ctx, timer, args, pn.step, "hnsw_search", B)
         grn = pn.results_of(0)
@@ -734,6 +738,7 @@ def leg_hnsw(ctx, ca, args, timer):
         f2 = fl2.search_batch(Qn, K)[0]; fl2.close()
         r = {"workload": f"HNSW l2 {nn}x{d} on a NAVIGABLE layer-0 graph (16 exact nearest neighbours + 16 random edges per node, built in {build_nav_s:.1f}s on the GPU, loaded through "
                          f"comet_hnsw_load_graph): NOT the reference's construction — shown to time the search kernel at ~efSearch expansions", **recn,
+             "rows": nn, "graph_build_s": round(build_nav_s, 1),
              "distance_evals_per_query": ev / B, "expansions_per_query": ex / B, "recall_at_10_vs_exact_flat": recall_of(f2, grn[0], grn[2], K),
              "roofline": {"bound": "hbm", "kernel": "hnsw_search", "achieved": achn, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achn / HBM_PEAK_GBS, "traffic": None,
                           "avg_kernel_ms": a_ms, "launches": a_n, "algorithmic_bytes_per_launch": algn}}
@@ -1300,6 +1305,12 @@ def compact_line(full):
                 legs[name]["cpu_qps"] = _rnd(rec["cpu_baseline"].get("value")); legs[name]["parity_mismatches"] = rec["cpu_baseline"].get("parity_mismatches")
         elif name == "c1":
             legs[name] = {k: _rnd(v) for k, v in rec.items() if isinstance(v, (int, float, bool))}
+        elif name == "hnsw":
+            # the reference-construction graph is a PARITY line: insertNode never promotes the entry point and prunes before the new node is linked, a search on it
+            # stops after a few dozen expansions (recall ~0) — its q/s says nothing about the kernel and is not quoted; configs[2] is timed on `hnsw_navigable`
+            lg = _leg(rec)
+            legs["hnsw_reference_graph_parity"] = {k: lg[k] for k in ("parity_mismatches", "parity_checked", "recall_at_10_vs_exact_flat", "expansions_per_query") if k in lg}
+            legs["hnsw_reference_graph_parity"]["rows"] = rec.get("rows"); legs["hnsw_reference_graph_parity"]["gpu_build_s"] = rec.get("build_s")
         else:
             legs[name] = _leg(rec)
             ec = rec.get("every_candidate_search")

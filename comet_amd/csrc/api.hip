@@ -65,10 +65,17 @@ int comet_ctx_create(int device_id, comet_ctx** out) {
         // HNSW leg at four batches in flight 1.65 M -> 1.08 M q/s and IVFPQ 1.8 -> 1.4 M after the legs flat_l2 + ivfpq had run, kernel times unchanged).
         // The four lanes therefore get a priority level of their OWN (the highest): the first four streams of a level each open a queue, so the lanes never
         // share one with each other or with anything else of the process.
+        // Lanes 4 .. 7 (round 6; only HNSW rotates through more than four) take the NEXT level, for the same reason. COMET_STREAM_PRIORITY=normal puts lanes
+        // 0 .. 3 on the default level instead (and 4 .. 7 on the lowest): for a process that embeds the library next to work of its own on default-priority
+        // streams and does not want the searches to take precedence over it (round-5 advisor); the lanes may then share hardware queues with that work.
         int pr_least = 0, pr_greatest = 0;
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
-        HIP_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr_greatest));
-        for (int l = 1; l < Ctx::kMaxLanes; l++) HIP_CHECK(hipStreamCreateWithPriority(&c->parked[l].stream, hipStreamNonBlocking, pr_greatest));
+        const char* pe = getenv("COMET_STREAM_PRIORITY");
+        const bool normal = pe && (pe[0] == 'n' || pe[0] == 'N' || pe[0] == '0');
+        const int pr_a = normal ? std::min(pr_least, pr_greatest + 1) : pr_greatest;          // numerically lower = more urgent
+        const int pr_b = std::min(pr_least, pr_a + 1);
+        HIP_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr_a));
+        for (int l = 1; l < Ctx::kMaxLanes; l++) HIP_CHECK(hipStreamCreateWithPriority(&c->parked[l].stream, hipStreamNonBlocking, l < 4 ? pr_a : pr_b));
         *out = c;
         return COMET_OK;
     });
@@ -410,7 +417,7 @@ static void segments_search(comet_index* const* segs, int S, const float* querie
     HIP_CHECK(hipEventRecord(ev, c->stream));
     // whatever happens below (a search_begin that throws half-way included), lanes that were given work are marked for quiesce_alt()
     struct LaneBack { Ctx* c; ~LaneBack() { try { c->switch_lane(0); } catch (...) {} } } lane_back{c};
-    bool used[Ctx::kMaxLanes] = {true, false, false, false};
+    bool used[Ctx::kMaxLanes] = {true};
     int rot = 0;
     // newest first, as the reference walks memtables and segments (the order has no effect on the merged result)
     for (int s = S - 1; s >= 0; s--) {

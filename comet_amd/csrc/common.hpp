@@ -93,7 +93,7 @@ struct Ctx {
     // 828 k / 1.30 M / 1.56 M / 1.69 M; IVF and Flat peak at two: 858 k / 1.16 M / 0.99 M, 800 k / 895 k / 861 k) — comet_index::max_lanes().
     // `stream` / `scratch*` / `retired` always describe the CURRENT lane; `parked` holds the others'. Lane 0 is current whenever no
     // asynchronous search is being enqueued; everything that is not such a search first waits for the other lanes (quiesce_alt).
-    static constexpr int kMaxLanes = 4;
+    static constexpr int kMaxLanes = 8;      // (round 6: eight — an HNSW search is one wave per query, 8 x 256 queries are two waves per SIMD; the other kinds stop at comet_index::max_lanes())
     struct LaneState { hipStream_t stream = nullptr; void* scratch = nullptr; size_t scratch_cap = 0, scratch_off = 0; std::vector<void*> retired; };
     LaneState parked[kMaxLanes]; // parked[l]: lane l's state while another lane is current (parked[cur_lane] is stale)
     int cur_lane = 0;

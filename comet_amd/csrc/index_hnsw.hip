@@ -649,7 +649,7 @@ struct HNSWIndex : comet_index {
     static constexpr int kRing = 8;
     Pending ring[kRing]; uint64_t next_ticket = 1;
     ~HNSWIndex() override { for (auto& r : ring) { if (r.ev) (void)hipEventDestroy(r.ev); if (r.host) (void)hipHostFree(r.host); } }
-    int max_lanes() const override { return 4; }
+    int max_lanes() const override { return 8; }      // 8 x 256 queries = two query-waves per SIMD (18 KiB of LDS per wave: eight per CU); kRing pending searches
 
     int64_t size() const override { return n; }
     bool contains_id(uint32_t id) const override { return id2idx.count(id) != 0; }

@@ -217,7 +217,7 @@ struct IVFIndex : comet_index {
     // fp16 shadow for the MFMA fast path (kernels_ivf.hip): slot-ordered rows, squared norms per slot, magnitude statistics;
     // rebuilt lazily when the slot layout was recompiled (shadow_version != lay.version)
     int ldh = 0;
-    DevBuf Vh, rn_slot, stats_dev, scan_counts[4];       // scan_counts: written by every search's item builder — one per execution lane
+    DevBuf Vh, rn_slot, stats_dev, scan_counts[Ctx::kMaxLanes];       // scan_counts: written by every search's item builder — one per execution lane
     int last_lane = 0;
     uint64_t shadow_version = 0;
     float xmax_abs = 0.0f, xmax_norm2 = 0.0f;

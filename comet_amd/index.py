@@ -105,7 +105,7 @@ class Context:
         check(self.lib.comet_profile_enable(self.h, 1 if on else 0))
 
     def set_lanes(self, lanes: int) -> None:
-        """1 .. 4 execution lanes (default 4): the asynchronous searches of an index rotate through up to that many streams"""
+        """1 .. 8 execution lanes (default 8; Flat / IVF use two of them, PQ / IVFPQ four, HNSW eight): the asynchronous searches of an index rotate through up to that many streams"""
         check(self.lib.comet_ctx_set_lanes(self.h, int(lanes)))
 
     def profile_only(self, name: str | None) -> None:

@@ -37,7 +37,7 @@ func (c *Context) Close() {
 	}
 }
 
-// SetLanes sets the number of execution lanes (1 .. 4, default 4): the streams the asynchronous searches of an index rotate through.
+// SetLanes sets the number of execution lanes (1 .. 8, default 8): the streams the asynchronous searches of an index rotate through.
 // The synchronous Execute() path of this package always runs on lane 0; the setting matters to callers of the asynchronous C entry points.
 func (c *Context) SetLanes(lanes int) error {
 	if rc := C.comet_ctx_set_lanes(c.h, C.int32_t(lanes)); rc != C.COMET_OK {

@@ -89,9 +89,10 @@ COMET_API int comet_synth_fill_dev(comet_ctx* ctx, uint64_t seed, uint64_t offse
 COMET_API int comet_synth_mixture_dev(comet_ctx* ctx, uint64_t seed, int32_t n_centers, float sigma, int32_t n_sub, float sigma_noise,
                                       uint64_t row_base, uint64_t n_rows, int32_t dim, float* out_dev);
 
-/* Execution lanes of a context (1 .. 4; default 4, or COMET_LANES): the asynchronous searches of an index (comet_index_search_dev_async,
+/* Execution lanes of a context (1 .. 8; default 8, or COMET_LANES): the asynchronous searches of an index (comet_index_search_dev_async,
  * comet_index_search_sharded_async) rotate through that many streams, each with a scratch arena of its own — as many as the index kind gains
- * from: two for Flat and IVF (one kernel of their step fills the GPU), four for PQ / IVFPQ and HNSW — so that the short latency-bound kernels
+ * from: two for Flat and IVF (one kernel of their step fills the GPU), four for PQ / IVFPQ, eight for HNSW (one wave per query: 8 x 256 queries are
+ * two waves per SIMD) — so that the short latency-bound kernels
  * of the batches in flight run beside each other. Results and the meaning of comet_index_search_wait are unchanged; every other call first
  * waits for the other lanes. Replaces nothing in the reference (a Go caller overlaps searches with goroutines); the call itself waits for all lanes. */
 COMET_API int comet_ctx_set_lanes(comet_ctx* ctx, int32_t lanes);

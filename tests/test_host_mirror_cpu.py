@@ -119,7 +119,7 @@ def test_bench_compact_line_is_driver_sized():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in rec, k
     assert rec["config"]["workload"] and rec["roofline"]["kernel"] and rec["roofline"]["frac"] > 0 and rec["cpu_baseline"]["value"] > 0
-    for leg in ("c1", "flat_l2", "ivfpq", "ivfpq_uniform", "ivfpq10m", "hnsw", "hnsw_navigable", "hybrid"):
+    for leg in ("c1", "flat_l2", "ivfpq", "ivfpq_uniform", "ivfpq10m", "hnsw_reference_graph_parity", "hnsw_navigable", "hybrid"):
         assert leg in rec["legs"], leg
 
 

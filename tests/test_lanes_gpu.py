@@ -89,7 +89,7 @@ def test_alternating_lanes_equal_sync(ctx, kind):
 
 def test_set_lanes_bounds_and_single_lane(ctx):
     from comet_amd import CometError
-    for bad in (0, 5, -1):
+    for bad in (0, 9, -1):
         with pytest.raises(CometError):
             ctx.set_lanes(bad)
     n, d, B, k = 20000, 48, 64, 5

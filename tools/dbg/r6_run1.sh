@@ -1,7 +1,10 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-COMET_ADC_KERNEL=1 timeout 900 python -m pytest tests/test_quant_gpu.py tests/test_configs_gpu.py -m gpu -x -q -k "pq or adc or config3" > gpurun_out/r6_t1.log 2>&1; echo "pytest rc $?" >> gpurun_out/r6_t1.log
-tail -3 gpurun_out/r6_t1.log
-AB_LEGS=ivfpq,ivfpq_uniform,ivfpq10m timeout 1500 bash tools/ab_adc.sh comet_amd/libcomet_hip.so > gpurun_out/r6_ab_auto.log 2>&1; cat gpurun_out/r6_ab_auto.log
-COMET_ADC_KERNEL=1 AB_LEGS=ivfpq10m timeout 1500 bash tools/ab_adc.sh comet_amd/libcomet_hip.so > gpurun_out/r6_ab_v1.log 2>&1; cat gpurun_out/r6_ab_v1.log
+timeout 900 python -m pytest tests/test_lanes_gpu.py tests/test_hnsw_gpu.py tests/test_concurrency_gpu.py tests/test_hybrid.py -m gpu -x -q > gpurun_out/r6_t1.log 2>&1; tail -3 gpurun_out/r6_t1.log
+( time timeout 1200 python bench.py --legs hnsw --regions 3 --sustain-s 0.5 --no-cpu-baseline > gpurun_out/r6_hnsw.log 2> gpurun_out/r6_hnsw.err ) 2>&1 | tail -3
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r6_hnsw.log').read().strip().splitlines()[-1])
+print(json.dumps(d['legs'], indent=0))
+PY
