@@ -518,6 +518,7 @@ int comet_index_get_list_owners(const comet_index* idx, int32_t* out_owners, int
     return guarded([&] {
         if (idx->kind != COMET_KIND_IVF && idx->kind != COMET_KIND_IVFPQ) COMET_FAIL(COMET_ERR_UNSUPPORTED, "list sharding applies to IVF / IVFPQ indexes");
         if (n_lists < 0 || (n_lists > 0 && !out_owners)) COMET_FAIL(COMET_ERR_INVALID_ARG, "bad owner array");
+        if (n_lists != idx->n_lists()) COMET_FAIL(COMET_ERR_INVALID_ARG, "the index has %d lists, the owner array %d (owner_of reads past the placement otherwise)", idx->n_lists(), n_lists);
         std::lock_guard<std::recursive_mutex> lk(idx->c->mu);
         for (int32_t l = 0; l < n_lists; l++) out_owners[l] = idx->shard_world > 1 ? idx->owner_of(l) : 0;
         return (int)COMET_OK;

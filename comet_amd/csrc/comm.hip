@@ -173,13 +173,21 @@ int comet_index_search_sharded_async(comet_index* idx, comet_comm* cm, const flo
         // A list-sharded index: every rank must deal the lists to the ranks the same way (the placement comes from host-side training state, which a rank that
         // LOADED its quantisers does not have — comet_index_set_list_owners). The first sharded search of an index on a communicator compares a fingerprint of
         // the placement over the ranks (two blocking all-reduces, once): ranks that disagree would own some lists twice and others not at all, silently.
-        if (cm->world > 1 && idx->shard_world > 1 && idx->owners_checked_on != cm->uid) {
-            if (idx->shard_world != cm->world || idx->shard_rank != cm->rank)
-                COMET_FAIL(COMET_ERR_INVALID_ARG, "index is shard %d of %d, the communicator is rank %d of %d", idx->shard_rank, idx->shard_world, cm->rank, cm->world);
-            const double fp = (double)(idx->owners_fingerprint() & ((1ull << 52) - 1));
+        // EVERY rank of the communicator joins the two all-reduces, whatever its own state (round-5 advisor: a rank that failed its local check before them, or
+        // skipped them because its own shard was unset, left its peers waiting in them for ever): a rank whose shard does not match the communicator contributes
+        // a sentinel instead of a fingerprint, and all ranks fail together AFTER the collectives.
+        if (cm->world > 1 && (idx->kind == COMET_KIND_IVF || idx->kind == COMET_KIND_IVFPQ) && idx->owners_checked_on != cm->uid) {
+            const bool unset = idx->shard_world <= 1;
+            const bool mismatch = !unset && (idx->shard_world != cm->world || idx->shard_rank != cm->rank);
+            const double fp = mismatch ? -2.0 : unset ? -1.0 : (double)(idx->owners_fingerprint() & ((1ull << 52) - 1));
             const double hi = allreduce_host(cm, fp, NCCL_MAX), lo = allreduce_host(cm, fp, NCCL_MIN);
-            if (hi != lo) COMET_FAIL(COMET_ERR_INVALID_ARG, "the ranks of this communicator disagree on which rank owns which inverted list (placement fingerprints %.0f .. %.0f): "
-                                                            "train every rank on the same vectors or hand every rank the same placement (comet_index_set_list_owners)", lo, hi);
+            if (mismatch) COMET_FAIL(COMET_ERR_INVALID_ARG, "index is shard %d of %d, the communicator is rank %d of %d", idx->shard_rank, idx->shard_world, cm->rank, cm->world);
+            if (lo == -2.0) COMET_FAIL(COMET_ERR_INVALID_ARG, "a rank of this communicator holds a shard that does not match its rank / the communicator's size (comet_index_set_shard)");
+            if (hi != lo) {
+                if (lo == -1.0) COMET_FAIL(COMET_ERR_INVALID_ARG, "some ranks of this communicator hold a list shard of the index and others the whole index (comet_index_set_shard on every rank, or on none)");
+                COMET_FAIL(COMET_ERR_INVALID_ARG, "the ranks of this communicator disagree on which rank owns which inverted list (placement fingerprints %.0f .. %.0f): "
+                                                  "train every rank on the same vectors or hand every rank the same placement (comet_index_set_list_owners)", lo, hi);
+            }
             idx->owners_checked_on = cm->uid;
         }
         // every other sharded search of an index on the context's second lane, like comet_index_search_dev_async: a rank's

@@ -646,8 +646,16 @@ __global__ __launch_bounds__(64) void rrf_fuse_kernel(const unsigned* __restrict
         const int me = h * 64 + lane;
         if (!s_ok[me]) continue;
         const double sc = s_sc[me];
+        // rank by counting on a TOTAL order (round-5 advisor: with `o > sc || (o == sc && j < me)` every NaN — a leg's own distances of a non-finite query —
+        // got the same rank, slots below kq stayed unwritten and came back as ids): the order-preserving image of the score, NaN last, ties by slot
+        auto key = [](double x) -> unsigned long long {
+            if (x != x) return 0ull;
+            const unsigned long long u = (unsigned long long)__double_as_longlong(x + 0.0);      // (-0 + 0 = +0: the two zeros tie, as under ==)
+            return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+        };
+        const unsigned long long ks = key(sc);
         int rank = 0;
-        for (int j = 0; j < 128; j++) { const double o = s_sc[j]; rank += (s_ok[j] && (o > sc || (o == sc && j < me))) ? 1 : 0; }
+        for (int j = 0; j < 128; j++) { const unsigned long long ko = key(s_sc[j]); rank += (s_ok[j] && (ko > ks || (ko == ks && j < me))) ? 1 : 0; }
         if (rank < kq && rank < out_ld) { out_ids[(long)q * out_ld + rank] = s_id[me]; out_sc[(long)q * out_ld + rank] = sc; }
     }
     for (int i = kq + lane; i < out_ld; i += 64) { out_ids[(long)q * out_ld + i] = 0u; out_sc[(long)q * out_ld + i] = 0.0; }

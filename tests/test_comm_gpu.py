@@ -41,3 +41,35 @@ def test_world1_sharded_search_equals_plain_search(ctx):
             gi = ctx.download(outs[i][0], (B, K), np.uint32); gs = ctx.download(outs[i][1], (B, K), np.float32); gc = ctx.download(outs[i][2], (B,), np.int32)
             assert np.array_equal(gc, wc) and np.array_equal(gi, wi) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32)), i
     comm.close()
+
+
+def test_world1_real_rccl_round_trip_at_the_headline_block_size(ctx):
+    """The packed block of the headline step (B = 256 queries x K = 100: 2 x 25 600 words + 256 counts) through the REAL ncclAllGather on the exchange stream, four
+    batches in flight (the communicator's slots), plus the host all-reduces (max, sum) the bench's timing uses — what the driver's first multi-GPU run issues,
+    at world size 1 (the only size this box can give real RCCL)."""
+    comm = Comm(ctx, 0, 1, port=29735)
+    assert comm.allreduce_max(-2.25) == -2.25
+    for _ in range(3):
+        comm.barrier()
+    n, d, B, K = 60_000, 128, 256, 100
+    X = orc.synth(91, 0, n * d).reshape(n, d)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    flat = FlatIndex(ctx, d, COSINE); flat.add_batch(ids, X)
+    Qs = [orc.synth(92 + i, 0, B * d).reshape(B, d) for i in range(6)]
+    q_dev = [ctx.alloc(B * d * 4) for _ in Qs]
+    for p, q in zip(q_dev, Qs):
+        ctx.upload(p, q)
+    outs = [(ctx.alloc(B * K * 4), ctx.alloc(B * K * 4), ctx.alloc(B * 4)) for _ in Qs]
+    want = [flat.search_batch(q, K) for q in Qs]
+    tickets = []
+    for i in range(len(Qs)):
+        tickets.append(comm.search_async(flat, q_dev[i], B, K, *outs[i], K))
+        if i >= 3:
+            comm.search_wait(flat, tickets[i - 3], block=False)
+    for t in tickets[-3:]:
+        comm.search_wait(flat, t, block=True)
+    comm.sync()
+    for i, (wi, ws, wc) in enumerate(want):
+        gi = ctx.download(outs[i][0], (B, K), np.uint32); gs = ctx.download(outs[i][1], (B, K), np.float32); gc = ctx.download(outs[i][2], (B,), np.int32)
+        assert np.array_equal(gc, wc) and np.array_equal(gi, wi) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32)), i
+    comm.close()

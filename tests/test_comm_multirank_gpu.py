@@ -144,3 +144,35 @@ def test_bench_gpus2_launches_two_ranks_itself(tmp_path, launcher):
     assert sr["scaling"] == "strong" and sr["sharding"] == "rows/2" and sr["qps"] > 0 and sr["identical_to_the_replica_results_for_batch_0"] is True
     assert line["legs"]["ivfpq"]["qps"] > 0 and line["legs"]["ivfpq_sharded"]["qps"] > 0
     assert line["legs"]["ivfpq_sharded"]["identical_to_the_replica_results_for_batch_0"] is True
+
+
+@pytest.mark.skipif(not SHIM.exists(), reason="tests/libshm_rccl.so not built (__graft_entry__.build())")
+def test_bench_gpus8_the_drivers_launch_line_on_one_gpu(tmp_path):
+    """The driver's 8-GPU line — `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` with the legs that shard (flat, ivfpq, ivfpq10m) — as eight ranks on this
+    box's one GPU over the shared-memory stand-in for RCCL, at reduced row counts: the first REAL 8-GPU run is the driver's, so everything but the xGMI timing is
+    exercised here: the layouts (`value` from eight replicas, row shards / list shards with the in-library all-gather + merge beside it), configs[3]'s shape as list
+    shards over all eight ranks, parity of rank 0's batch with the CPU oracle, sharded == replica results, ONE line from rank 0, done well inside ten minutes."""
+    import json
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(COMET_RCCL_LIB=str(SHIM), COMET_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    bench = [str(ROOT / "bench.py"), "--gpus", "8", "--legs", "flat,ivfpq,ivfpq10m", "--rows", "200000", "--big-rows", "400000", "--steps", "4", "--warmup", "2", "--regions", "2",
+             "--sustain-s", "0.2", "--cpu-seconds", "2"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29881"] + bench
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, len(lines)                                    # rank 0 alone prints
+    line = json.loads(lines[-1])
+    assert len(lines[-1]) < 6 * 1024
+    assert line["n_gpus"] == 8 and line["value"] > 0 and line["scaling"] == "weak" and line["cpu_baseline"] is None
+    assert line["config"]["layout"]["index_copies"] == 8 and line["config"]["layout"]["queries_per_step_all_ranks"] == 8 * 256
+    assert line["parity"]["parity_mismatches"] == 0 and line["parity"]["parity_checked_queries"] >= 64
+    sr = line["sharded_rows"]
+    assert sr["sharding"] == "rows/8" and sr["qps"] > 0 and sr["identical_to_the_replica_results_for_batch_0"] is True
+    legs = line["legs"]
+    assert legs["ivfpq"]["qps"] > 0 and legs["ivfpq_sharded"]["qps"] > 0 and legs["ivfpq_sharded"]["identical_to_the_replica_results_for_batch_0"] is True
+    assert "error" not in legs.get("ivfpq10m", {"error": "missing"}) and legs["ivfpq10m"]["qps"] > 0, legs.get("ivfpq10m")
+    assert wall < 600, wall
