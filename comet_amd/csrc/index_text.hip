@@ -380,13 +380,20 @@ struct comet_text_index {
             std::vector<std::pair<int, int>> hot;             // (df, term index)
             for (size_t t = 0; t + 1 < term_off_h.size(); t++) { const int df = term_off_h[t + 1] - term_off_h[t]; if ((int64_t)df * 64 >= nd) hot.push_back({df, (int)t}); }
             std::sort(hot.begin(), hot.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
-            if (hot.size() > 256) hot.resize(256);
-            int nh = 0;
+            // at most 256 columns, inside a byte budget (COMET_BM25_DENSE_MB, default 1024: 2 bytes per (column, document), on the host and on the device — 256 columns
+            // of a 10 M-document collection would be 5 GB each; the lowest-df columns go first, their terms keep the term-at-a-time path). `cols` is sized ONCE.
+            static const size_t budget = [] { const char* e = getenv("COMET_BM25_DENSE_MB"); long mb = e ? atol(e) : 1024; return (size_t)std::max(0l, mb) << 20; }();
+            const size_t fit = std::min<size_t>(256, budget / ((size_t)nd * 2));
+            std::vector<int> keep;
             for (auto& hp : hot) {
+                if (keep.size() >= fit) break;
                 const int t = hp.second; bool fits = true;
                 for (int i = term_off_h[t]; i < term_off_h[t + 1]; i++) if (pt[i] > 65535) { fits = false; break; }
-                if (!fits) continue;
-                cols.resize((size_t)(nh + 1) * nd, 0);
+                if (fits) keep.push_back(t);
+            }
+            cols.assign(keep.size() * (size_t)nd, 0);
+            int nh = 0;
+            for (int t : keep) {
                 for (int i = term_off_h[t]; i < term_off_h[t + 1]; i++) cols[(size_t)nh * nd + pd[i]] = (unsigned short)pt[i];
                 hot_of_term[t] = nh++;
             }
