@@ -35,15 +35,22 @@ buf = (C.c_ulonglong * 1024)()
 ctx.lib.comet_debug_a2_trace.restype = C.c_int
 assert ctx.lib.comet_debug_a2_trace(buf, 1024) == 0
 t = np.array(buf[:], dtype=np.int64).reshape(2, 64, 8)
+# stamps (kernels_adc2.inc.hpp, -DA2_TRACE, workgroup 8, batch A2_TRACE_BATCH): row 63 = [batch start (behind the previous batch's epilogue), first table built, loop done, sums parked,
+# next loop-top]; row 61 = [next batch's requests issued, epilogue staged, flushed, residuals + bounds formed, barrier passed] (61[0..2] belong to the NEXT iteration's top: they are written
+# while `trace_on` still holds the traced batch); rows 0..23: per step [start, barrier + code-word requests, build, late barrier, gathers]
 for w, name in ((0, "wave 0 (early: barrier, build next, gather)"), (1, "wave 4 (late: build, barrier, gather)")):
     r = t[w]
     print(name)
-    print(f"  batch: prologue {r[63][1]-r[63][0]}, loop {r[63][2]-r[63][1]}, park {r[63][3]-r[63][2]}, epilogues {r[63][4]-r[63][3]}, total {r[63][4]-r[63][0]} ticks (x clock/100MHz shader clocks)")
-    print(f"  prologue: top barrier {r[61][0]-r[63][0]}, records {r[61][1]-r[61][0]}, residuals {r[61][2]-r[61][1]}, bounds+codewords {r[61][3]-r[61][2]}, barrier {r[61][4]-r[61][3]}, first build {r[63][1]-r[61][4]}; epilogue: staging {r[61][5]-r[63][3]}, flush {r[63][4]-r[61][5]}")
+    print(f"  batch: residuals + bounds + first table {r[63][1]-r[63][0]}, step loop {r[63][2]-r[63][1]}, sums parked {r[63][3]-r[63][2]}; then (next iteration's top) requests for the next batch "
+          f"{r[61][0]-r[63][4]}, this batch's epilogue staged {r[61][1]-r[61][0]}, flushed {r[61][2]-r[61][1]}  [shader clocks]")
     print("  chains of this wave per item:", [int(x) & 0xFFFF for x in r[62][:4]], "items in the batch:", int(r[62][0]) >> 32)
     print("  step | barrier+cw | build | late barrier | gathers | total")
+    tot = 0
     for k in range(0, 24):
-        s = r[k]
-        if s[0] == 0:
+        s_ = r[k]
+        if s_[0] == 0:
             break
-        print(f"  {k:4d} | {s[1]-s[0]:6d} | {s[2]-s[1]:6d} | {s[3]-s[2]:6d} | {s[4]-s[3]:6d} | {s[4]-s[0]:6d}")
+        tot += s_[4] - s_[0]
+        print(f"  {k:4d} | {s_[1]-s_[0]:6d} | {s_[2]-s_[1]:6d} | {s_[3]-s_[2]:6d} | {s_[4]-s_[3]:6d} | {s_[4]-s_[0]:6d}")
+    ch = sum(int(x) & 0xFFFF for x in r[62][:4])
+    print(f"  LDS-pipe time of the batch's gathers at 7 clocks per wave-gather: ~{ch * 8 * 96 * 7} clocks (if every wave held this wave's {ch} chains) against {tot} in the step loop")
