@@ -18,3 +18,5 @@ done
 timeout 420 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/p9 -- $RUN > $OUT/p9.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/pmc_collect.py $OUT gpurun_out/$1.json ${PMC_ADC_LEG:-ivfpq} ${PMC_ROWS:-1000000}
+# the raw counter CSVs are tens of MB per pass: gpurun copies back at most 64 MiB of gpurun_out/
+mkdir -p /tmp/pmc_raw && mv $OUT /tmp/pmc_raw/ 2>/dev/null || rm -rf $OUT
