@@ -8,11 +8,12 @@ namespace {
 void check_live_indexes(Ctx* c, const char* where) {
     for (void* p : c->live_indexes) { const comet_index* ix = static_cast<const comet_index*>(p); if (!ix->guards_ok()) { ix->guards_dump(where); std::abort(); } }
 }
-// The guard words around the index objects' host-side containers (round 4: a late 8-byte write into a PQ index object) are CHECKED only on request since
-// round 6 — COMET_GUARDS=1 (read once), what tools/soak.py's runs set: fifteen 900 s soaks on three seeds since the private per-index streams went have not
-// tripped them once, and walking every live index on entry and exit of every call is what a debug aid costs. The words themselves stay in the objects.
+// The guard words around the index objects' host-side containers (round 4: a late 8-byte write into a PQ index object) are checked on entry and exit of
+// every call. COMET_GUARDS=0 (read once) switches the checks off — they have not fired in twenty 900 s soaks since the private per-index streams went, and walking
+// every live index per call is what a debug aid costs — but they stay ON by default: round 6's soaks met one unexplained (and unreproduced) wrong result, so the
+// conditions the review set for retiring them ("nine clean runs on three seeds") are not met.
 comet_index* adopt(Ctx* c, comet_index* ix) {
-    static const bool guards_on = [] { const char* e = getenv("COMET_GUARDS"); return e && e[0] == '1'; }();
+    static const bool guards_on = [] { const char* e = getenv("COMET_GUARDS"); return !(e && e[0] == '0'); }();
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (guards_on) c->check_live = check_live_indexes;
     c->live_indexes.push_back(ix); return ix;

@@ -13,8 +13,14 @@
 // Exactness is untouched: LUT[m][k] = sum_i ((q - c)[m*DSUB+i] - cb[m][k][i])^2 with the reference's expression, order and rounding (adc_build_slab's),
 // a candidate's sum = the table entries added in subspace order from 0, float32.
 //
+//   * a batch boundary was a chain of global round trips (ticket -> records -> rows and bounds; cursor atomic -> survivor stores), 6-14 k clocks each on the loaded
+//     chip: batches are software-pipelined (adc_scan2_kernel's comment) and a batch's eight staging areas are flushed by its eight waves at once.
+// Where it is used (launch_adc_scan): single-stage launches of indexes whose average list holds >= 1536 codes — configs[3]'s shape: 0.506 -> 0.455 ms; on short or very
+// uneven lists and on the two-stage search's small launches round 5's kernel is faster (profiles/r06_adc_ab.txt) and stays.
+//
 // LDS (dynamic only — the kernel declares no static __shared__, so that the dynamic region starts at LDS address 0 and every table address is an
-// immediate): [0, 32 KiB) table buffer 0, [32, 64 KiB) table buffer 1, then the survivor staging area of the fused filter and a few words of state.
+// immediate): [0, 32 KiB) table buffer 0, [32, 64 KiB) table buffer 1 — and, once a batch's last gathers are done, [0, 96 KiB) the batch's parked sums —
+// [96, 128 KiB) the batch's residual pairs, [128, 144 KiB) eight survivor staging areas (item x query half), then a few words of state and the records of two batches.
 constexpr int A2_WAVES = 8;
 constexpr int A2_THREADS = A2_WAVES * 64;
 constexpr int A2_CH = 6;                                        // chains (64-code blocks) per wave and item

@@ -926,7 +926,8 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
                                                          int* __restrict__ qcount, int* __restrict__ queues, unsigned* __restrict__ tq, int* __restrict__ cursor, int n_q, int lead,
                                                          const long* __restrict__ list_base, int stage, const unsigned char* __restrict__ dead, int* __restrict__ used,
                                                          int* __restrict__ gstats /*nullable: [2] += 64-code blocks the items cover, [3] += items, [4] += (query, block) pairs, [5] += searches*/, int strict,
-                                                         unsigned long long* __restrict__ cand_init /*nullable*/, long ldD, int seg_codes /*codes per item: ADC_SEG_CODES or A2_SEG_CODES*/) {
+                                                         unsigned long long* __restrict__ cand_init /*nullable*/, long ldD, int seg_codes /*codes per item: ADC_SEG_CODES or A2_SEG_CODES*/,
+                                                         int seg_equal /*adc_scan2: a list longer than an item is cut into EQUAL segments (whole 64-code blocks) instead of full ones + a tail: a batch's steps are alike*/) {
     // workgroups 1.. (launched only where a search begins: stage <= 1 of a fused-filter search) fill the first ADC_REFINE_MAX entries of every query's survivor
     // row with all-ones: the scan's bound refinement reads a row while it is being appended to, and a slot not yet written must read as +inf
     if (blockIdx.x > 0) {
@@ -1047,7 +1048,8 @@ __global__ __launch_bounds__(1024) void adc_order_kernel(const unsigned* __restr
             for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
             const int off = base + inc - ns[b];
             for (int sgi = 0; sgi < ns[b]; sgi++) if (off + sgi < qcap) {
-                r[b].start = sgi * seg_codes; r[b].seg_end = min(len[b], r[b].start + seg_codes);
+                const int segw = seg_equal ? (((len[b] + ns[b] - 1) / ns[b] + 63) & ~63) : seg_codes;     // (<= seg_codes: seg_codes is a multiple of 64 and ns = ceil(len / seg_codes))
+                r[b].start = min(sgi * segw, (len[b] + 63) & ~63); r[b].seg_end = min(len[b], r[b].start + segw);     // (a list of > 48 items' worth of codes: the rounding can leave a last, empty segment)
                 qitems[(long)x * qcap + off + sgi] = r[b];
             }
             base += __shfl(inc, 63);
@@ -1718,7 +1720,7 @@ void launch_adc_scan(Ctx* c, const float* Qp, int ld, int dim, const float* cent
                                                                                                            n_slots, order, slist, qitems, (int)qcap, qcount, queues,
                                                                                                            flt ? flt->tq + b0 : nullptr, flt ? flt->cursor + b0 : nullptr, bn, (lead && stage == 0) ? 1 : 0, (const long*)list_base,
                                                                                                            stage, dead, used, flt ? flt->stats : nullptr, strict,
-                                                                                                           init_rows ? flt->cand + (size_t)b0 * ldD : nullptr, (long)ldD, seg_codes);
+                                                                                                           init_rows ? flt->cand + (size_t)b0 * ldD : nullptr, (long)ldD, seg_codes, scan2 ? 1 : 0);
                 LAUNCH_CHECK();
             }
             if (!build) {

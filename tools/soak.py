@@ -66,11 +66,27 @@ def compare(g, o, Q, k, tag, **kw):
             probe(g, tag + " | oracle searches")
         m = min(n, ids.shape[1])
         if not (cnt[b] == n and np.array_equal(ids[b, :m], oi[:m]) and np.array_equal(bits(sc[b, :m]), bits(os_[:m]))):
-            raise SystemExit(f"MISMATCH {tag} query {b}: gpu cnt {cnt[b]} ids {ids[b, :8]} vs oracle cnt {n} ids {oi[:8]}")
+            # what kind of failure: the same call again (a transient of the search, or a state the index is left in?), the strict kernels (mode 1: no shadow, no deferred
+            # verification), and which queries of the batch are wrong
+            def ok_row(res, bb, nn, oo, ss):
+                mm = min(nn, res[0].shape[1])
+                return bool(res[2][bb] == nn and np.array_equal(res[0][bb, :mm], oo[:mm]) and np.array_equal(bits(res[1][bb, :mm]), bits(ss[:mm])))
+            extra = ""
+            try:
+                again = g.search_batch(Q, k, **opts)
+                strict = g.search_batch(Q, k, mode=1, **opts)
+                extra = f" | the same call again: query {b} {'matches the oracle' if ok_row(again, b, n, oi, os_) else 'is wrong again: ' + str(again[0][b, :8])}; strict kernels (mode 1): " \
+                        f"{'match' if ok_row(strict, b, n, oi, os_) else 'wrong: ' + str(strict[0][b, :8])}; first call's scores {sc[b, :4]} vs oracle {os_[:4]}"
+                if hasattr(g, "stat"):
+                    extra += f"; fast_queries {g.stat('fast_queries')}, strict_queries {g.stat('strict_queries')}, i8_slices {g.stat('i8_slices')}"
+            except Exception as e:      # noqa: BLE001
+                extra = f" | diagnostics failed: {e}"
+            raise SystemExit(f"MISMATCH {tag} query {b}: gpu cnt {cnt[b]} ids {ids[b, :8]} vs oracle cnt {n} ids {oi[:8]}" + extra)
 
 
 import os
 SKIP = int(os.environ.get("SOAK_SKIP", "0"))          # replay: the first SKIP configurations only draw their random numbers (no GPU, no oracle)
+REPEAT = int(os.environ.get("SOAK_REPEAT", "1"))
 FIND = os.environ.get("SOAK_FIND")                    # print the number of the first configuration whose tag starts with this, and stop (no GPU)
 t_end, rounds, kinds = time.time() + budget, 0, {}
 while time.time() < t_end:
@@ -142,6 +158,13 @@ while time.time() < t_end:
     tag = f"#{rounds} " + tag
     if real:
         compare(g, o, Q, k, tag, **kw)
+        # replay aid (SOAK_REPEAT=N with SOAK_SKIP=<configuration>): the Flat index of the configuration is built and searched N more times against the same oracle —
+        # for a mismatch that one run in several shows (round 6: configuration #684 of seed 60016001 under HSA_ENABLE_SDMA=0)
+        if kind == "flat" and REPEAT > 1:
+            for rep in range(REPEAT):
+                g.close()
+                g = ca.FlatIndex(ctx, d, metric); g.add_batch(ids, X)
+                compare(g, o, Q, k, tag + f" repeat {rep}", **kw)
     if rng.random() < 0.5:
         flt = [int(i) for i in rng.choice(ids, size=max(1, n // 3), replace=False)]
         if real:
