@@ -47,6 +47,9 @@ def probe(g, step):
     g.lib.comet_index_get_stat(g.h, b"fast_queries", __import__("ctypes").byref(out))
 
 
+g_X = None      # the configuration's rows (for the mismatch diagnostics)
+
+
 def compare(g, o, Q, k, tag, **kw):
     if TRACE:
         TRACE.seek(0); TRACE.truncate(); TRACE.write(f"{tag} k_call={k} kw={ {a: (b if a != 'filter_ids' else len(b)) for a, b in kw.items()} }\n"); TRACE.flush()
@@ -72,6 +75,10 @@ def compare(g, o, Q, k, tag, **kw):
                 mm = min(nn, res[0].shape[1])
                 return bool(res[2][bb] == nn and np.array_equal(res[0][bb, :mm], oo[:mm]) and np.array_equal(bits(res[1][bb, :mm]), bits(ss[:mm])))
             extra = ""
+            # data() never produces a non-finite value: a NaN / Inf in the host arrays at this point is a late write into host memory (round 4's signature was eight
+            # bytes of 0xFF = two float32 NaNs) — and then the ORACLE may be the side that searched garbage
+            badq, badx = int((~np.isfinite(Q)).sum()), int((~np.isfinite(g_X)).sum()) if g_X is not None else -1
+            extra += f" | non-finite values in the host arrays now: Q {badq}, X {badx}; Q[{b}][:4] bits {bits(Q[b][:4])}"
             try:
                 again = g.search_batch(Q, k, **opts)
                 strict = g.search_batch(Q, k, mode=1, **opts)
@@ -97,6 +104,7 @@ while time.time() < t_end:
     n = int(rng.integers(1500, 9000)) if kind != "flat" else int(rng.integers(6000, 30000))
     if kind == "hnsw": n = int(rng.integers(300, 4000)); d = min(d, 96)
     X = data(n, d, int(rng.integers(5, 60)))
+    g_X = X
     ids = np.arange(1, n + 1, dtype=np.uint32)
     B = int(rng.choice([1, 3, 8, 17, 40, 70, 130, 256], p=[0.2, 0.15, 0.15, 0.15, 0.15, 0.08, 0.07, 0.05]))
     Q = np.vstack([data(B, d, 7)[:max(1, B - 1)], X[:1]])[:B]
