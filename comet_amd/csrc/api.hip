@@ -107,6 +107,7 @@ int comet_ctx_destroy(comet_ctx* c) {
         if (c->lane0_fence) (void)hipEventDestroy(c->lane0_fence);
         if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
         if (c->pinned) (void)hipHostFree(c->pinned);
+        if (c->bounce) (void)hipHostFree(c->bounce);
         (void)hipStreamDestroy(c->stream);
         delete c;
         return COMET_OK;

@@ -76,6 +76,7 @@ struct comet_comm {
     DevBuf idle_tq;                      // +inf bounds a failed search contributes
     uint64_t uid = 0;                    // never reused (a later communicator may be allocated at this one's address): what an index remembers its placement check by
     DevBuf scalar;                       // small device scratch for barrier / all-reduce
+    double* hscalar = nullptr;           // pinned: the all-reduced value comes back here (the GPU does not write stack or heap memory, common.hpp: Ctx::d2h)
     struct Slot {
         bool active = false; uint64_t ticket = 0, search_ticket = 0;
         comet_index* idx = nullptr; int B = 0, k_cap = 0, k = 0;
@@ -134,6 +135,7 @@ int comet_comm_destroy(comet_comm* cm) {
         c->quiesce_all(); (void)hipStreamSynchronize(cm->xstream);
         for (auto& s : cm->slots) { if (s.searched) (void)hipEventDestroy(s.searched); if (s.merged) (void)hipEventDestroy(s.merged); }
         if (cm->bound_a) { (void)hipEventDestroy(cm->bound_a); (void)hipEventDestroy(cm->bound_b); }
+        if (cm->hscalar) (void)hipHostFree(cm->hscalar);
         if (cm->comm && rccl().CommDestroy) (void)rccl().CommDestroy(cm->comm);
         (void)hipStreamDestroy(cm->xstream);
         delete cm;
@@ -146,11 +148,13 @@ int comet_comm_world(const comet_comm* cm) { return cm->world; }
 // host-value all-reduce on the exchange stream (context mutex held): op NCCL_MAX / NCCL_MIN / NCCL_SUM; returns when every rank's value is in
 static double allreduce_host(comet_comm* cm, double v, int op) {
     double* d = cm->scalar.as<double>();
-    HIP_CHECK(hipMemcpyAsync(d, &v, 8, hipMemcpyHostToDevice, cm->xstream));
+    if (!cm->hscalar) HIP_CHECK(hipHostMalloc((void**)&cm->hscalar, 16, hipHostMallocDefault));
+    cm->hscalar[1] = v;
+    HIP_CHECK(hipMemcpyAsync(d, cm->hscalar + 1, 8, hipMemcpyHostToDevice, cm->xstream));
     RCCL_CHECK(rccl().AllReduce(d, d + 1, 1, NCCL_FLOAT64, op, cm->comm, cm->xstream));
-    HIP_CHECK(hipMemcpyAsync(&v, d + 1, 8, hipMemcpyDeviceToHost, cm->xstream));
+    HIP_CHECK(hipMemcpyAsync(cm->hscalar, d + 1, 8, hipMemcpyDeviceToHost, cm->xstream));
     HIP_CHECK(hipStreamSynchronize(cm->xstream));
-    return v;
+    return cm->hscalar[0];
 }
 // all ranks: *inout = max over ranks (op 0) or sum over ranks (op 1) of a host double; blocks until complete (a barrier).
 int comet_comm_allreduce_f64(comet_comm* cm, double* inout, int32_t op) {

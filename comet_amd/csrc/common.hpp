@@ -180,8 +180,38 @@ struct Ctx {
         return pinned;
     }
     void sync() { quiesce_all(); collect_profile(); }
-    void h2d(void* dst, const void* src, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream)); }
-    void d2h(void* dst, const void* src, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream)); }
+    // Host <-> device copies between device memory and memory the library does not own (callers' arrays, std::vector storage, stack words) go through a PINNED bounce
+    // buffer of the context with a stream synchronisation per piece: the HIP runtime's own staging of pageable asynchronous copies is not used, and the GPU never reads
+    // or writes pageable memory. Why: round 6's soaks under HSA_ENABLE_SDMA=0 (copies by shader blits) met wrong results — an index whose rows in one
+    // window were not the rows that were added (the same wrong answer from every kernel, again and again), a result row that was wrong once and right on the next
+    // identical call, a wrong answer of the CPU ORACLE (host memory that changed under it) — one pass in four on some boxes, with nothing but pageable hipMemcpyAsync
+    // between the host arrays and the kernels; and round 4's crash was eight bytes of 0xFF in a heap object (the padding of a result row is 0xFFFFFFFF ids).
+    // COMET_COPY_DIRECT=1 restores the direct pageable hipMemcpyAsync (what every round up to 5 did).
+    void* bounce = nullptr; static constexpr size_t kBounce = (size_t)8 << 20;
+    static bool copy_direct() { static const bool d = getenv("COMET_COPY_DIRECT") != nullptr; return d; }
+    void h2d(void* dst, const void* src, size_t bytes) {
+        if (!bytes) return;
+        if (copy_direct()) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream)); return; }
+        if (!bounce) HIP_CHECK(hipHostMalloc(&bounce, kBounce, hipHostMallocDefault));
+        for (size_t off = 0; off < bytes; off += kBounce) {
+            const size_t m = std::min(kBounce, bytes - off);
+            std::memcpy(bounce, (const char*)src + off, m);
+            HIP_CHECK(hipMemcpyAsync((char*)dst + off, bounce, m, hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));              // the bounce buffer is free again (and the caller's memory was read on the host, now)
+        }
+    }
+    // (device -> host: the same bounce buffer, the host memcpy behind the synchronisation; the copy is SYNCHRONOUS — a caller's own hipStreamSynchronize behind it finds an idle stream)
+    void d2h(void* dst, const void* src, size_t bytes) {
+        if (!bytes) return;
+        if (copy_direct()) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream)); return; }
+        if (!bounce) HIP_CHECK(hipHostMalloc(&bounce, kBounce, hipHostMallocDefault));
+        for (size_t off = 0; off < bytes; off += kBounce) {
+            const size_t m = std::min(kBounce, bytes - off);
+            HIP_CHECK(hipMemcpyAsync(bounce, (const char*)src + off, m, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            std::memcpy((char*)dst + off, bounce, m);
+        }
+    }
     void d2d(void* dst, const void* src, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream)); }
     void zero(void* dst, size_t bytes) { if (bytes) HIP_CHECK(hipMemsetAsync(dst, 0, bytes, stream)); }
 

@@ -48,6 +48,7 @@ def probe(g, step):
 
 
 g_X = None      # the configuration's rows (for the mismatch diagnostics)
+RECENT = []     # tags of the configurations that ran
 
 
 def compare(g, o, Q, k, tag, **kw):
@@ -82,12 +83,23 @@ def compare(g, o, Q, k, tag, **kw):
             try:
                 again = g.search_batch(Q, k, **opts)
                 strict = g.search_batch(Q, k, mode=1, **opts)
-                extra = f" | the same call again: query {b} {'matches the oracle' if ok_row(again, b, n, oi, os_) else 'is wrong again: ' + str(again[0][b, :8])}; strict kernels (mode 1): " \
+                extra += f" | the same call again: query {b} {'matches the oracle' if ok_row(again, b, n, oi, os_) else 'is wrong again: ' + str(again[0][b, :8])}; strict kernels (mode 1): " \
                         f"{'match' if ok_row(strict, b, n, oi, os_) else 'wrong: ' + str(strict[0][b, :8])}; first call's scores {sc[b, :4]} vs oracle {os_[:4]}"
-                if hasattr(g, "stat"):
+                try:
                     extra += f"; fast_queries {g.stat('fast_queries')}, strict_queries {g.stat('strict_queries')}, i8_slices {g.stat('i8_slices')}"
+                except Exception:      # noqa: BLE001
+                    pass
+                # the oracle again: a wrong ORACLE answer that does not repeat is host memory that changed under it
+                if "nprobes" in kw:
+                    n2, oi2, _ = o.search(Q[b], k, kw["nprobes"], threshold=opts["threshold"], filter_ids=opts["document_ids"])
+                elif "ef" in kw:
+                    n2, oi2, _ = o.search(Q[b], k, kw["ef"], threshold=opts["threshold"], filter_ids=opts["document_ids"])
+                else:
+                    n2, oi2, _ = o.search(Q[b], k, threshold=opts["threshold"], filter_ids=opts["document_ids"])
+                extra += f"; the oracle again: cnt {n2} ids {oi2[:8]}"
             except Exception as e:      # noqa: BLE001
-                extra = f" | diagnostics failed: {e}"
+                extra += f" | diagnostics failed: {e}"
+            extra += f" | configurations before it: {RECENT[-6:]}"
             raise SystemExit(f"MISMATCH {tag} query {b}: gpu cnt {cnt[b]} ids {ids[b, :8]} vs oracle cnt {n} ids {oi[:8]}" + extra)
 
 
@@ -165,6 +177,7 @@ while time.time() < t_end:
         print(f"configuration {rounds}: {tag}"); break
     tag = f"#{rounds} " + tag
     if real:
+        RECENT.append(tag)
         compare(g, o, Q, k, tag, **kw)
         # replay aid (SOAK_REPEAT=N with SOAK_SKIP=<configuration>): the Flat index of the configuration is built and searched N more times against the same oracle —
         # for a mismatch that one run in several shows (round 6: configuration #684 of seed 60016001 under HSA_ENABLE_SDMA=0)
