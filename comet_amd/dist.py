@@ -50,10 +50,15 @@ def merge_topk_host(ids: np.ndarray, scores: np.ndarray, counts: np.ndarray, k: 
     return out_ids, out_sc, out_cnt
 
 
-def _rendezvous_id(lib, rank: int, world: int, addr: str, port: int, timeout_s: float = 120.0) -> bytes:
-    """Rank 0 makes the RCCL unique id and hands it to the other ranks over TCP (control plane only)."""
+def _rendezvous_id(lib, rank: int, world: int, addr: str, port: int, timeout_s: float | None = None) -> bytes:
+    """Rank 0 makes the RCCL unique id and hands it to the other ranks over TCP (control plane only).
+    The ranks of a fresh node start minutes apart (the first import of the runtime pages the image in, N processes at once): the wait is
+    COMET_RDZV_TIMEOUT seconds, default 600."""
+    import os
     import socket
     import time
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("COMET_RDZV_TIMEOUT", "600"))
     if rank == 0:
         buf = (C.c_uint8 * 128)()
         from ._lib import check

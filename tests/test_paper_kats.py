@@ -1,8 +1,9 @@
 """Hand-computed known-answer cases (tests/golden/paper_kats.json: every number follows from the reference's source by arithmetic written out in the file) for the
-parts of the path the reference's own tests hold no numbers for — PQ / IVFPQ training, codes, distances and tie order, BM25 scores. Asserted on the CPU oracle here
+parts of the path the reference's own tests hold no numbers for — PQ / IVFPQ training, codes, distances and tie order, BM25 scores, the shape of an HNSW graph
+(nine nodes, every searchLayer / prune step written out; the GPU insert kernel's graphs are compared with the oracle's byte for byte in tests/test_hnsw_gpu.py). Asserted on the CPU oracle here
 (no GPU) and on the GPU through the C ABI (-m gpu): with these the oracle is pinned for PQ / IVFPQ / BM25 by something other than itself.
 Reference: clustering.go:119-243, pq_index.go:189-260,439-471, pq_index_search.go:243-306, ivfpq_index.go:176-260,467-500, ivfpq_index_search.go:231-390,
-bm25_index_search.go:278-397."""
+bm25_index_search.go:278-397, hnsw_index.go:228-288,493-694, hnsw_index_search.go:248-354."""
 import json
 import math
 from pathlib import Path
@@ -104,6 +105,51 @@ def test_bm25_paper_case_on_the_oracle():
         n, ids, _s32, s64 = o.search(q, k)
         return n, ids, s64
     check_bm25(c, search)
+
+
+def hnsw_case(metric):
+    c = K["hnsw_dim2_m2_efc3"]
+    o = orc.HNSW(c["dim"], metric, c["M"], c["efConstruction"], c["efSearch"])
+    for i in c["insert_order"]:
+        assert o.add(i, np.array(c["vectors"][str(i)], np.float32), c["levels"][str(i)]) == 0
+    return c, o
+
+
+@pytest.mark.parametrize("metric", ["l2_squared", "l2"])
+def test_hnsw_paper_case_on_the_oracle(metric):
+    """insertNode / searchLayer / selectNeighbors / pruneConnections and the search, on nine points whose every step is written out in the fixture:
+    edge lists with their order, entry point, maxLevel, the node no search can reach, result ids and distances. Euclidean takes the root of the same
+    (distinct) squared distances: the same graph, scores float32(math.Sqrt(float64(d2))) (distance.go:120)."""
+    c, o = hnsw_case(metric)
+    ids, levels, vecs, eoff, edges = o.export()
+    assert list(ids) == c["insert_order"] and [int(x) for x in levels] == [c["levels"][str(i)] for i in c["insert_order"]]
+    assert o.entry() == c["entry"] and o.max_level() == c["max_level"]
+    slot = 0
+    for i, lv in zip(ids, levels):
+        for layer in range(int(lv) + 1):
+            got = [int(x) for x in edges[eoff[slot]:eoff[slot + 1]]]
+            assert got == c["graph"][str(int(i))][layer], (int(i), layer, got)
+            slot += 1
+    inbound = {int(x) for x in edges}
+    assert 7 not in inbound and inbound == {1, 2, 3, 4, 5, 6, 8, 9}            # the prune quirk (hnsw_index.go:283-284,673-676): node 7 is linked from nowhere
+    for q in c["queries"]:
+        n, gi, gs = o.search(np.array(q["q"], np.float32), q["k"], q["ef"])
+        want = np.array(q["d2"], np.float32) if metric == "l2_squared" else np.array([root32(x) for x in q["d2"]], np.float32)
+        assert n == len(q["ids"]) and [int(x) for x in gi[:n]] == q["ids"], (q, gi[:n])
+        assert np.array_equal(bits(gs[:n]), bits(want)), (q, gs[:n])
+
+
+def test_hnsw_paper_case_trace_printer_agrees():
+    """tools/hnsw_paper_sim.py — the plain-Python restatement the fixture's trace was checked with (no code shared with the oracle) — still gives the fixture's graph and results"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hnsw_paper_sim", Path(__file__).resolve().parent.parent / "tools" / "hnsw_paper_sim.py")
+    sim = importlib.util.module_from_spec(spec); spec.loader.exec_module(sim)
+    c = K["hnsw_dim2_m2_efc3"]
+    g = sim.build_case({k: c[k] for k in ("M", "efConstruction", "efSearch", "insert_order", "vectors", "levels")})
+    assert {str(i): n["e"] for i, n in g.nodes.items()} == c["graph"] and g.entry == c["entry"] and g.maxLevel == c["max_level"]
+    for q in c["queries"]:
+        r = g.search(list(q["q"]), q["k"], q["ef"])
+        assert [b for _a, b in r] == q["ids"] and [a for a, _b in r] == q["d2"], q
 
 
 # ---------------------------------------------------------------------------------------------- the same cases on the GPU, through the C ABI
