@@ -89,6 +89,19 @@ def weighted_sum_fusion(vector: dict[int, float], text: dict[int, float], wv: fl
     return out
 
 
+def max_fusion(vector: dict[int, float], text: dict[int, float]) -> dict[int, float]:
+    """maxFusion.Combine (fusion.go:252-271): the union of the two maps, the larger score where a document is in both."""
+    out = dict(vector)
+    for d, s in text.items():
+        out[d] = max(out[d], s) if d in out else s
+    return out
+
+
+def min_fusion(vector: dict[int, float], text: dict[int, float]) -> dict[int, float]:
+    """minFusion.Combine (fusion.go:291-306): only documents present in BOTH maps, the smaller score."""
+    return {d: min(s, text[d]) for d, s in vector.items() if d in text}
+
+
 class HybridSearch:
     """hybridSearch builder (hybrid_search_index.go:326-365) over a GPU vector index and a GPU BM25 index."""
 
@@ -141,10 +154,10 @@ class HybridSearch:
                 comb = reciprocal_rank_fusion(vres, tres, self.rrf_k)
             elif self.fusion_kind == WEIGHTED_SUM_FUSION:
                 comb = weighted_sum_fusion(vres, tres)
-            elif self.fusion_kind == MAX_FUSION:      # maxFusion.Combine fusion.go:252-271: union, larger score where both
-                comb = {d: max(vres.get(d, float("-inf")), tres.get(d, float("-inf"))) for d in {**vres, **tres}}
-            elif self.fusion_kind == MIN_FUSION:      # minFusion.Combine fusion.go:291-306: only documents present in BOTH maps
-                comb = {d: min(vres[d], tres[d]) for d in vres if d in tres}
+            elif self.fusion_kind == MAX_FUSION:
+                comb = max_fusion(vres, tres)
+            elif self.fusion_kind == MIN_FUSION:
+                comb = min_fusion(vres, tres)
             else:
                 raise ValueError(f"unknown fusion kind: {self.fusion_kind}")
         else:

@@ -21,6 +21,23 @@ def test_rrf_reference_kat():
     assert score_map_to_ranks({1: 20.0, 2: 15.0, 4: 10.0}, False) == {1: 0, 2: 1, 4: 2}
 
 
+def test_weighted_sum_max_min_fusion_reference_kats():
+    """fusion_test.go:8-135 (weighted sum: equal / custom / zero weights :483-508, one side empty, both empty), :203-243 (max), :245-315 (min, no overlap) — the
+    reference's maps and the values its tests compare with `!=`, on the host mirror's Combine restatements."""
+    from comet_amd.hybrid import max_fusion, min_fusion, weighted_sum_fusion
+    v, t = {1: 0.5, 2: 0.3, 3: 0.8}, {1: 10.0, 2: 20.0, 4: 15.0}
+    assert weighted_sum_fusion(v, t, 1.0, 1.0) == {1: 10.5, 2: 20.3, 3: 0.8, 4: 15.0}
+    assert weighted_sum_fusion({1: 0.5}, {1: 10.0}, 2.0, 0.5) == {1: 6.0}
+    assert weighted_sum_fusion({1: 0.5}, {1: 100.0}, 1.0, 0.0) == {1: 0.5}
+    assert weighted_sum_fusion({1: 0.5, 2: 0.3}, {}) == {1: 0.5, 2: 0.3}                   # DefaultFusion: weights 1 / 1 (fusion.go: DefaultFusionConfig)
+    assert weighted_sum_fusion({}, {1: 10.0, 2: 20.0}) == {1: 10.0, 2: 20.0}
+    assert weighted_sum_fusion({}, {}) == {}
+    v, t = {1: 0.5, 2: 0.8, 3: 0.3}, {1: 10.0, 2: 5.0, 4: 15.0}
+    assert max_fusion(v, t) == {1: 10.0, 2: 5.0, 3: 0.3, 4: 15.0}
+    assert min_fusion(v, t) == {1: 0.5, 2: 0.8}
+    assert min_fusion({1: 0.5, 2: 0.8}, {3: 10.0, 4: 15.0}) == {}
+
+
 def test_min_max_fusion_follow_the_reference():
     """minFusion keeps only documents in BOTH result maps (fusion.go:291-306); maxFusion the union (fusion.go:252-271)."""
     from comet_amd.hybrid import MAX_FUSION, MIN_FUSION

@@ -123,3 +123,40 @@ def test_bm25_document_filter_table():
         n, gi, _s32, s64 = o.search(tok(case["query"]), 10, filter_ids=case["filter"])
         check_ids(c, gi[:n], case["ids"], True)
         assert np.all(np.diff(s64[:n]) <= 0) and np.all(s64[:n] > 0)
+
+
+@pytest.mark.parametrize("seed", [1, 12345])
+def test_hnsw_search_behaviours_of_the_reference_tests(seed):
+    """hnsw_index_search_test.go:123-330 (Simple, ExactMatch, KGreaterThanSize, WithThreshold, ThresholdStrictFiltering), :646-852 (zero-vector cosine query, empty index,
+    all rows deleted + Flush, single node, the three metrics, cosine nearest) — rows added without ids (the index assigns them from 0: hnsw_index.go:259-262)."""
+    c = K["hnsw_search"]
+    for case in c["cases"]:
+        o = orc.HNSW(c["dim"], case["metric"], c["M"], c["efConstruction"], c["efSearch"], seed=seed)
+        for v in case["vectors"]:
+            assert o.add(0, np.array(v, np.float32)) == 0, case["name"]
+        ids, _lv, vecs, _eo, _ed = o.export() if case["vectors"] else (np.zeros(0, np.uint32), None, np.zeros((0, 3), np.float32), None, None)
+        assert list(ids) == list(range(len(case["vectors"]))), case["name"]            # auto ids 0, 1, 2, …
+        if case.get("remove_all_and_flush"):
+            for i in ids:
+                assert o.remove(int(i)) == 0
+            o.flush()
+        n, gi, gs = o.search(np.array(case["query"], np.float32), case["k"], 0, threshold=case.get("threshold", 0.0), cap=16)
+        if case.get("error"):
+            assert n < 0, case["name"]                                                  # ErrZeroVector from Preprocess (distance.go: cosine)
+            continue
+        if "count" in case:
+            assert n == case["count"], (case["name"], n)
+        if "min_count" in case:
+            assert n >= case["min_count"], (case["name"], n)
+        byid = {int(i): v for i, v in zip(ids, vecs)}
+        if "first" in case:
+            assert np.allclose(byid[int(gi[0])], _unit(case["first"]) if case["metric"] == "cosine" else case["first"], atol=1e-3), (case["name"], gi[:n])
+        if "max_distance" in case:
+            for i in gi[:n]:
+                assert np.sqrt(((byid[int(i)] - np.array(case["query"], np.float32)) ** 2).sum()) <= case["max_distance"], case["name"]
+        assert np.all(np.diff(gs[:n]) >= 0)
+
+
+def _unit(v):
+    v = np.array(v, np.float32)
+    return v / np.sqrt((v * v).sum())
