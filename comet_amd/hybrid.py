@@ -115,6 +115,7 @@ class HybridSearch:
         self.threshold = 0.0
         self.fusion_kind = WEIGHTED_SUM_FUSION
         self.rrf_k = 60.0
+        self.vector_weight, self.text_weight = 1.0, 1.0          # DefaultFusionConfig (fusion.go)
         self.document_ids: list[int] = []
 
     def with_vector(self, q): self.vector_query = q; return self
@@ -125,6 +126,13 @@ class HybridSearch:
     def with_threshold(self, t): self.threshold = float(t); return self
     def with_fusion_kind(self, kind, rrf_k: float = 60.0): self.fusion_kind = kind; self.rrf_k = rrf_k; return self
     def with_document_ids(self, *ids): self.document_ids = [int(i) for i in ids]; return self
+
+    def with_fusion(self, kind, vector_weight: float = 1.0, text_weight: float = 1.0, rrf_k: float = 60.0):
+        """WithFusion(NewFusion(kind, &FusionConfig{VectorWeight, TextWeight, K})) (hybrid_search_index.go:456-459, fusion.go:86-103)"""
+        if kind not in (RECIPROCAL_RANK_FUSION, WEIGHTED_SUM_FUSION, MAX_FUSION, MIN_FUSION):
+            raise ValueError(f"unknown fusion kind: {kind}")
+        self.fusion_kind, self.vector_weight, self.text_weight, self.rrf_k = kind, float(vector_weight), float(text_weight), float(rrf_k)
+        return self
 
     def execute(self) -> list[HybridSearchResult]:
         vres: dict[int, float] = {}
@@ -153,7 +161,7 @@ class HybridSearch:
             if self.fusion_kind == RECIPROCAL_RANK_FUSION:
                 comb = reciprocal_rank_fusion(vres, tres, self.rrf_k)
             elif self.fusion_kind == WEIGHTED_SUM_FUSION:
-                comb = weighted_sum_fusion(vres, tres)
+                comb = weighted_sum_fusion(vres, tres, self.vector_weight, self.text_weight)
             elif self.fusion_kind == MAX_FUSION:
                 comb = max_fusion(vres, tres)
             elif self.fusion_kind == MIN_FUSION:

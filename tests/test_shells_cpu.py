@@ -1,0 +1,96 @@
+"""The product's host-side Execute() shells (comet_amd.index.VectorSearch / TextSearch, comet_amd.hybrid.HybridSearch) run on the CPU over oracle-backed
+indexes (tests/shell_adapters.py) through the reference's own tests of those shells: ivf_index_search_test.go:8-205 (a query and a node id in one Execute(),
+several of each, with a threshold: results de-duplicated by node id), :208-295 (validation), hybrid_search_index_test.go:10-90 (vector only, text only),
+:316-402 (weights), flat_index_search_test.go (k bounds through the shell). No GPU."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from comet_amd.hybrid import WEIGHTED_SUM_FUSION, HybridSearch
+from shell_adapters import OracleTextIndex, OracleVectorIndex
+
+
+def ivf_index(rows):
+    o = orc.IVF(3, "l2", 2)
+    assert o.train(np.array([[0, 0, 0], [10, 10, 10], [1, 0, 0], [11, 10, 10]], np.float32)) == 0
+    idx = OracleVectorIndex(o, 3, "ivf")
+    return idx, [idx.add(v) for v in rows]
+
+
+def unique_ids(res):
+    ids = [r.id for r in res]
+    assert len(set(ids)) == len(ids), ids
+    return ids
+
+
+def test_ivf_query_and_node_in_one_execute():
+    idx, ids = ivf_index([[1, 0, 0], [0, 1, 0], [0, 0, 1], [2, 0, 0], [10, 10, 10], [11, 10, 10]])
+    res = idx.new_search().with_query([0, 1, 0]).with_node(ids[0]).with_k(2).with_n_probes(2).execute()
+    assert 2 <= len(unique_ids(res)) <= 2                       # two queries x k 2, de-duplicated (sum aggregation), then LimitResults(k)
+    # what the shell must have done: per-query top-2 = {[0,1,0] d 0, [1,0,0] d sqrt 2 (first of the ties in scan order)} and {[1,0,0] d 0, [2,0,0] d 1};
+    # summed per id -> id0: sqrt2 + 0, id1: 0, id3: 1 -> ascending: id1 (0), id3 (1); cut to k = 2
+    assert [r.id for r in res] == [ids[1], ids[3]] and [float(r.score) for r in res] == [0.0, 1.0]
+
+
+def test_ivf_several_queries_and_nodes():
+    idx, ids = ivf_index([[1, 0, 0], [0, 1, 0], [0, 0, 1], [2, 0, 0], [0, 2, 0], [10, 10, 10]])
+    res = idx.new_search().with_query([1.1, 0, 0], [0, 1.1, 0]).with_node(ids[2], ids[3]).with_k(2).with_n_probes(2).execute()
+    assert len(unique_ids(res)) == 2
+    with pytest.raises(KeyError):
+        idx.new_search().with_node(9999).with_k(2).execute()    # lookupNodeVectors: unknown node (ivf_index_search.go: "node %d not found")
+
+
+def test_ivf_query_and_node_with_threshold():
+    idx, ids = ivf_index([[1, 0, 0], [0, 1, 0], [0, 0, 1], [5, 0, 0], [0, 5, 0]])
+    res = idx.new_search().with_query([1, 0, 0]).with_node(ids[1]).with_k(10).with_n_probes(2).with_threshold(2.0).execute()
+    got = unique_ids(res)
+    assert got and set(got) == {ids[0], ids[1], ids[2]}         # the two rows at distance 4+ from both queries never appear
+    # sums over the two queries: [1,0,0]: 0 + sqrt2, [0,1,0]: sqrt2 + 0, [0,0,1]: sqrt2 + sqrt2
+    r2 = np.float32(np.sqrt(np.float64(2.0)))
+    assert [float(r.score) for r in res] == [float(r2), float(r2), float(np.float32(r2 + r2))]
+
+
+def test_search_validation_through_the_shell():
+    idx, ids = ivf_index([[1, 0, 0], [0, 1, 0]])
+    with pytest.raises(ValueError, match="must specify either queries or node IDs"):
+        idx.new_search().with_k(1).execute()
+    with pytest.raises(ValueError, match="query dimension mismatch: expected 3, got 2"):
+        idx.new_search().with_query([1, 0]).with_k(1).execute()
+    with pytest.raises(ValueError, match="unknown aggregation kind"):
+        idx.new_search().with_query([1, 0, 0]).with_score_aggregation("median").execute()
+    # k bounds through LimitResults (flat_index_search_test.go:348-389: 0 / -1 / 100 -> all, 1 -> 1)
+    for k, want in ((0, 2), (-1, 2), (100, 2), (1, 1)):
+        assert len(idx.new_search().with_query([1, 0, 0]).with_k(k).with_n_probes(2).execute()) == want
+
+
+def test_hybrid_vector_only_and_text_only():
+    v = OracleVectorIndex(orc.Flat(3, "cosine"), 3, "flat")
+    for row in ([1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [1.0, 0.1, 0.0]):
+        v.add(row)
+    res = HybridSearch(v, None).with_vector([1.0, 0.0, 0.0]).with_k(2).execute()
+    assert len(res) == 2 and res[0].score > res[1].score        # the test's own check: the hybrid shell sorts DESCENDING, distances included
+    assert [r.id for r in res] == [3, 1] and res[1].score == 0.0
+    t = OracleTextIndex()
+    for i, text in enumerate(("the quick brown fox jumps over the lazy dog", "the quick brown cat climbs a tree", "a lazy dog sleeps all day"), 1):
+        t.add(i, text)
+    res = HybridSearch(None, t).with_text(t.tok("quick brown")).with_k(2).execute()
+    assert sorted(r.id for r in res) == [1, 2] and res[0].score >= res[1].score
+    with pytest.raises(ValueError, match="no vector index configured"):
+        HybridSearch(None, t).with_vector([1, 0, 0]).execute()
+
+
+def test_hybrid_weights():
+    v = OracleVectorIndex(orc.Flat(3, "cosine"), 3, "flat")
+    t = OracleTextIndex()
+    for i, (row, text) in enumerate((([1.0, 0.0, 0.0], "machine learning algorithms"), ([0.0, 1.0, 0.0], "machine learning basics")), 1):
+        v.add(row, i); t.add(i, text)
+    q = t.tok("machine learning")
+    r1 = HybridSearch(v, t).with_vector([1.0, 0.0, 0.0]).with_text(q).with_k(10).execute()
+    r2 = HybridSearch(v, t).with_vector([1.0, 0.0, 0.0]).with_text(q).with_fusion(WEIGHTED_SUM_FUSION, 10.0, 0.1).with_k(10).execute()
+    assert len(r1) == 2 and len(r2) == 2
+    # the two documents have the same length and both hold both query terms: equal BM25 scores s; cosine distances 0 and 1 -> combined s and 1 + s
+    # (10 * 0 + 0.1 s and 10 + 0.1 s with the vector-heavy weights): the shell ranks the document at distance 1 FIRST (descending), as the reference does
+    n, ti, ts32, _ = t.o.search(q, 10)
+    s = float(np.float32(ts32[0])); assert n == 2 and ts32[0] == ts32[1]
+    assert [r.id for r in r1] == [2, 1] and [r.score for r in r1] == [1.0 + s, 0.0 + s]
+    assert [r.id for r in r2] == [2, 1] and [r.score for r in r2] == [10.0 * 1.0 + 0.1 * s, 10.0 * 0.0 + 0.1 * s]
