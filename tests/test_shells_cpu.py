@@ -94,3 +94,48 @@ def test_hybrid_weights():
     s = float(np.float32(ts32[0])); assert n == 2 and ts32[0] == ts32[1]
     assert [r.id for r in r1] == [2, 1] and [r.score for r in r1] == [1.0 + s, 0.0 + s]
     assert [r.id for r in r2] == [2, 1] and [r.score for r in r2] == [10.0 * 1.0 + 0.1 * s, 10.0 * 0.0 + 0.1 * s]
+
+
+def text_index(docs):
+    t = OracleTextIndex()
+    for i, text in docs:
+        t.add(i, text)
+    return t
+
+
+def descending(res):
+    return all(res[i].score <= res[i - 1].score for i in range(1, len(res)))
+
+
+def test_text_search_shell_tables():
+    """bm25_index_search_test.go:55-93 (WithK), :95-139 (aggregation kinds over two queries), :141-182 (cutoff), :184-271 (Execute table: empty and unmatched
+    queries give no results and no error), :273-304 (several queries), :378-415 (ordering) — TextSearch.execute over the oracle's BM25"""
+    from comet_amd.index import MAX_AGGREGATION, MEAN_AGGREGATION, SUM_AGGREGATION
+    t = text_index([(i, "the quick brown fox jumps") for i in range(1, 11)])
+    for k, want in ((3, 3), (5, 5), (10, 10), (0, 10), (-1, 10), (100, 10)):
+        assert len(t.new_search().with_query(t.tok("quick")).with_k(k).execute()) == want, k
+    t = text_index([(1, "fox dog cat"), (2, "fox dog"), (3, "cat mouse"), (4, "dog")])
+    for kind in (SUM_AGGREGATION, MAX_AGGREGATION, MEAN_AGGREGATION):
+        res = t.new_search().with_query(t.tok("fox"), t.tok("dog")).with_score_aggregation(kind).with_k(5).execute()
+        assert res and descending(res) and {r.id for r in res} == {1, 2, 4}, kind
+    t = text_index([(1, "fox fox fox fox"), (2, "fox fox"), (3, "the lazy dog sleeps"), (4, "cat and mouse"), (5, "quick brown fox jumps")])
+    full = t.new_search().with_query(t.tok("fox")).with_k(10).with_cutoff(-1).execute()
+    assert {r.id for r in full} == {1, 2, 5}
+    for cutoff in (1, 2):
+        cut = t.new_search().with_query(t.tok("fox")).with_k(10).with_cutoff(cutoff).execute()
+        assert 1 <= len(cut) <= len(full) and [r.id for r in cut] == [r.id for r in full[:len(cut)]]
+    t = text_index([(1, "the quick brown fox jumps over the lazy dog"), (2, "the lazy cat sleeps under the warm sun"), (3, "quick brown rabbits run through the forest"),
+                    (4, "the forest is dark and mysterious"), (5, "dogs and cats are popular pets")])
+    for query, least in (("fox", 1), ("quick brown", 2), ("elephant", 0), ("", 0)):
+        res = t.new_search().with_query(t.tok(query)).with_k(5).execute()
+        assert len(res) >= least and all(r.id != 0 and r.score >= 0 for r in res) and descending(res), query
+        if query in ("elephant", ""):
+            assert res == []
+    t = text_index([(1, "fox and dog"), (2, "fox and cat"), (3, "dog and cat"), (4, "rabbit and mouse")])
+    res = t.new_search().with_query(t.tok("fox"), t.tok("dog")).with_k(5).execute()
+    assert res[0].id == 1 and {r.id for r in res} == {1, 2, 3}           # document 1 holds both query terms: its summed score leads
+    t = text_index([(1, "fox fox fox fox fox"), (2, "fox fox fox"), (3, "fox"), (4, "the quick brown fox jumps"), (5, "cat and dog")])
+    res = t.new_search().with_query(t.tok("fox")).with_k(10).execute()
+    assert len(res) == 4 and res[0].id == 1 and descending(res)
+    with pytest.raises(ValueError, match="must specify either queries or node IDs"):
+        t.new_search().with_k(3).execute()
