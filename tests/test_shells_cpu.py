@@ -139,3 +139,49 @@ def test_text_search_shell_tables():
     assert len(res) == 4 and res[0].id == 1 and descending(res)
     with pytest.raises(ValueError, match="must specify either queries or node IDs"):
         t.new_search().with_k(3).execute()
+
+
+def pq_fixture():
+    """createTrainedPQIndex(8, 4, 6, Euclidean), pq_index_search_test.go:9-53"""
+    o = orc.PQ(8, "l2", 4, 6)
+    assert o.train(np.array([[(i * 8 + j) % 10 for j in range(8)] for i in range(100)], np.float32)) == 0
+    idx = OracleVectorIndex(o, 8, "pq")
+    rows = [[1, 0, 0, 0, 0, 0, 0, 0], [0, 1, 0, 0, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0, 0, 0], [1, 1, 0, 0, 0, 0, 0, 0], [2, 0, 0, 0, 0, 0, 0, 0], [3, 0, 0, 0, 0, 0, 0, 0]]
+    return idx, [idx.add(v) for v in rows]
+
+
+def test_pq_search_shell_tables():
+    """pq_index_search_test.go:56-276 (simple, threshold, by node, several nodes, unknown node, query + node, batch queries), :356-390 (k bounds 1/3/5/6/100 -> 1/3/5/6/6)"""
+    idx, ids = pq_fixture()
+    e0 = [1, 0, 0, 0, 0, 0, 0, 0]; e1 = [0, 1, 0, 0, 0, 0, 0, 0]; e2 = [0, 0, 1, 0, 0, 0, 0, 0]
+    assert len(idx.new_search().with_query(e0).with_k(2).execute()) == 2
+    res = idx.new_search().with_query(e0).with_k(10).with_threshold(1.5).execute()
+    assert all(float(r.score) <= 1.5 for r in res)
+    assert len(idx.new_search().with_node(ids[0]).with_k(3).execute()) == 3
+    for s in (idx.new_search().with_node(ids[0], ids[1]).with_k(2), idx.new_search().with_query(e1).with_node(ids[0]).with_k(2),
+              idx.new_search().with_query(e0, e1).with_node(ids[0], ids[1]).with_k(2), idx.new_search().with_query(e0, e1, e2).with_k(2)):
+        assert len(unique_ids(s.execute())) == 2
+    with pytest.raises(KeyError):
+        idx.new_search().with_node(99999).with_k(3).execute()
+    for k, want in ((1, 1), (3, 3), (5, 5), (6, 6), (100, 6)):
+        assert len(idx.new_search().with_query(e0).with_k(k).execute()) == want
+    # an index that was trained and holds nothing (:392-423)
+    o = orc.PQ(8, "l2", 4, 6); assert o.train(np.array([[i] * 8 for i in range(100)], np.float32)) == 0
+    assert OracleVectorIndex(o, 8, "pq").new_search().with_query(e0).with_k(5).execute() == []
+
+
+def test_ivfpq_search_shell_tables():
+    """ivfpq_index_search_test.go:9-72 (dim 8, nlist 2, M 4, nbits 4, 100 ramp training rows: 1..3 results for k 3), :596-661 (k bounds 1/3/5/10/100 -> 1/3/5/5/5)"""
+    ramp = np.array([[i * 8 + j for j in range(8)] for i in range(100)], np.float32)
+    o = orc.IVFPQ(8, "l2", 2, 4, 4); assert o.train(ramp) == 0
+    idx = OracleVectorIndex(o, 8, "ivfpq")
+    for v in ([1, 2, 3, 4, 5, 6, 7, 8], [2, 3, 4, 5, 6, 7, 8, 9], [10, 11, 12, 13, 14, 15, 16, 17], [0] * 8, [1] * 8):
+        idx.add(v)
+    res = idx.new_search().with_query([1, 2, 3, 4, 5, 6, 7, 8]).with_k(3).with_n_probes(2).execute()
+    assert 1 <= len(res) <= 3 and len(res) == 3                  # both lists probed: all five rows are candidates
+    o = orc.IVFPQ(8, "l2", 2, 4, 4); assert o.train(ramp) == 0
+    idx = OracleVectorIndex(o, 8, "ivfpq")
+    for i in range(5):
+        idx.add([i * 10 + j for j in range(8)])
+    for k, want in ((1, 1), (3, 3), (5, 5), (10, 5), (100, 5)):
+        assert len(idx.new_search().with_query([0, 1, 2, 3, 4, 5, 6, 7]).with_k(k).with_n_probes(2).execute()) == want
