@@ -185,3 +185,35 @@ def test_ivfpq_search_shell_tables():
         idx.add([i * 10 + j for j in range(8)])
     for k, want in ((1, 1), (3, 3), (5, 5), (10, 5), (100, 5)):
         assert len(idx.new_search().with_query([0, 1, 2, 3, 4, 5, 6, 7]).with_k(k).with_n_probes(2).execute()) == want
+
+
+def hnsw_index(rows, efs=200):
+    o = orc.HNSW(3, "l2", 16, 200, efs, seed=7)
+    idx = OracleVectorIndex(o, 3, "hnsw")
+    return idx, [idx.add(v) for v in rows]
+
+
+def test_hnsw_search_shell_tables():
+    """hnsw_index_search_test.go:333-431 (by node: the query node leads; two nodes far apart -> two de-duplicated results; unknown node), :1047-1290 (efSearch default,
+    override, 0 and -1 fall back to the index's efSearch) — VectorSearch.execute over the oracle's HNSW"""
+    idx, ids = hnsw_index([[1, 0, 0], [0, 1, 0], [0, 0, 1], [2, 0, 0]])
+    res = idx.new_search().with_node(ids[0]).with_k(2).execute()
+    assert [r.id for r in res] == [ids[0], ids[3]] and [float(r.score) for r in res] == [0.0, 1.0]
+    idx, ids = hnsw_index([[i, 0, 0] for i in range(5)])
+    res = idx.new_search().with_node(ids[0], ids[4]).with_k(2).execute()
+    assert [r.id for r in res] == [ids[0], ids[4]] and [float(r.score) for r in res] == [0.0, 0.0]      # per query {0, 1} and {4, 3}: four ids, the two zero sums lead
+    with pytest.raises(KeyError):
+        hnsw_index([[1, 0, 0]])[0].new_search().with_node(9999).with_k(1).execute()
+    rows5 = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [2, 0, 0]]
+    idx, ids = hnsw_index(rows5)
+    res = idx.new_search().with_query([1, 0, 0]).with_k(2).execute()
+    assert len(res) == 2 and res[0].id == ids[0]
+    rows10 = rows5 + [[0, 2, 0], [0, 0, 2], [1, 1, 1], [2, 2, 0], [0, 2, 2]]
+    idx, ids = hnsw_index(rows10, efs=50)
+    r1 = idx.new_search().with_query([1, 0, 0]).with_k(5).with_ef_search(200).execute()
+    r2 = idx.new_search().with_query([1, 0, 0]).with_k(5).execute()
+    assert len(r1) == 5 and [(r.id, float(r.score)) for r in r1] == [(r.id, float(r.score)) for r in r2]   # ten fully linked nodes: any ef >= 10 sees them all
+    for ef in (0, -1):
+        idx, ids = hnsw_index([[1, 0, 0], [0, 1, 0], [0, 0, 1]])
+        res = idx.new_search().with_query([1, 0, 0]).with_k(2).with_ef_search(ef).execute()
+        assert len(res) == 2 and res[0].id == ids[0], ef
