@@ -217,3 +217,39 @@ def test_hnsw_search_shell_tables():
         idx, ids = hnsw_index([[1, 0, 0], [0, 1, 0], [0, 0, 1]])
         res = idx.new_search().with_query([1, 0, 0]).with_k(2).with_ef_search(ef).execute()
         assert len(res) == 2 and res[0].id == ids[0], ef
+
+
+def test_constructor_validation_tables():
+    """TestNewFlatIndex / TestNewIVFIndex / TestNewPQIndex / TestNewIVFPQIndex / TestNewHNSWIndex (flat_index_test.go:11, ivf_index_test.go:11-40, pq_index_test.go:46-70,
+    ivfpq_index_test.go:21-50, hnsw_index_test.go:15): the error rows whose checks come before any device work, with the reference's messages (flat_index.go:127,
+    ivf_index.go:147-160, pq_index.go:135-155, ivfpq_index.go:113-140). No context is needed to fail."""
+    from comet_amd import FlatIndex, HNSWIndex, IVFIndex, IVFPQIndex, PQIndex
+    from comet_amd.index import _metric_code
+    E, dim_msg = "l2", "dimension must be positive"
+    for d in (0, -1):
+        for make in (lambda: FlatIndex(None, d, E), lambda: IVFIndex(None, d, 10, E), lambda: PQIndex(None, d, E, 8, 8), lambda: IVFPQIndex(None, d, E, 10, 8, 8),
+                     lambda: HNSWIndex(None, d, E)):
+            with pytest.raises(ValueError, match=dim_msg):
+                make()
+    for nl in (0, -1):
+        with pytest.raises(ValueError, match="nlist must be positive"):
+            IVFIndex(None, 128, nl, E)
+        with pytest.raises(ValueError, match="nlist must be positive"):
+            IVFPQIndex(None, 128, E, nl, 8, 8)
+    for M in (0, -1):
+        with pytest.raises(ValueError, match="parameter M must be positive"):
+            PQIndex(None, 128, E, M, 8)
+        with pytest.raises(ValueError, match="parameter M must be positive"):
+            IVFPQIndex(None, 128, E, 10, M, 8)
+    with pytest.raises(ValueError, match="dimension 100 must be divisible by M 8"):
+        PQIndex(None, 100, E, 8, 8)
+    with pytest.raises(ValueError, match="dimension 100 must be divisible by M 8"):
+        IVFPQIndex(None, 100, E, 10, 8, 8)
+    for nb in (0, -1, 17):
+        with pytest.raises(ValueError, match=r"parameter Nbits must be in \[1,16\]"):
+            PQIndex(None, 128, E, 8, nb)
+        with pytest.raises(ValueError, match=r"parameter Nbits must be in \[1,16\]"):
+            IVFPQIndex(None, 128, E, 10, 8, nb)
+    with pytest.raises(Exception, match="unknown distance kind"):           # NewDistance: distance.go:9 — the rows "invalid distance kind"
+        _metric_code("invalid")
+    assert [_metric_code(k) for k in ("l2", "l2_squared", "cosine")] == [0, 1, 2]
