@@ -128,7 +128,8 @@ def test_bm25_document_filter_table():
 @pytest.mark.parametrize("seed", [1, 12345])
 def test_hnsw_search_behaviours_of_the_reference_tests(seed):
     """hnsw_index_search_test.go:123-330 (Simple, ExactMatch, KGreaterThanSize, WithThreshold, ThresholdStrictFiltering), :646-852 (zero-vector cosine query, empty index,
-    all rows deleted + Flush, single node, the three metrics, cosine nearest) — rows added without ids (the index assigns them from 0: hnsw_index.go:259-262)."""
+    all rows deleted + Flush, single node, the three metrics, cosine nearest). The tests' NewVectorNode draws ids from a process-wide counter (node.go:55-61); here the rows go in with id 0
+    and take the index's own ids (hnsw_index.go:259-262: nextID, from 0 — the first node's id 0 is also the 'no entry point' value of :268) — none of the expectations depends on the ids."""
     c = K["hnsw_search"]
     for case in c["cases"]:
         o = orc.HNSW(c["dim"], case["metric"], c["M"], c["efConstruction"], c["efSearch"], seed=seed)
