@@ -2,7 +2,9 @@
  *   hnsw     the hand-traced HNSW case of tests/golden/paper_kats.json (hnsw_dim2_m2_efc3): nine nodes inserted by hnsw_insert_kernel with the given levels, the exported
  *            graph (14 edge lists, order included), entry point, maxLevel and six searches against the values written out on paper, L2^2 and Euclidean;
  *   filters  the reference's document-filter test tables (tests/golden/reference_kats_r06.json: flat / ivf / pq / ivfpq / hnsw / bm25 _index_document_filter_test.go);
- *   searches the behaviours of hnsw_index_search_test.go:123-330,646-852 held in the same file.
+ *   searches the behaviours of hnsw_index_search_test.go:123-330,646-852 held in the same file;
+ *   lifecycle training preconditions, Add / search before Train, zero vectors under cosine, soft delete / Flush bookkeeping and searches over deleted rows for the five
+ *            vector kinds, HNSW's Flush of the entry point and of every node (the *_index_test.go files) — status codes and the reference's messages.
  * The expected values are copied from those fixtures. Exit 0 and one "... OK" line per check, 1 and the first difference, 77 when there is no gfx950 device.
  *   gcc -O1 -std=c11 -I include tests/paper_checks.c -o tests/paper_checks -L comet_amd -lcomet_hip -Wl,-rpath,$PWD/comet_amd -lm */
 #include <math.h>
@@ -200,6 +202,80 @@ static int searches(void) {
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------ lifecycle behaviours of the reference's *_index_test.go files
+ * (flat_index_test.go:188-313,343-435; ivf_index_test.go:97-132,204-378; pq_index_test.go:159-227,319-531; ivfpq_index_test.go:150-204,297-506; hnsw_index_test.go:443-672):
+ * status codes AND the reference's messages (ivf_index.go:212,257; pq_index.go:199,269; ivfpq_index.go:186,285; *_index_search.go "must be trained before searching" /
+ * "index not trained"; distance.go ErrZeroVector; flat_index.go:233,236) */
+#define FAILS(call, code, text) do { int rc_ = (call); EXPECT(rc_ == (code) && strstr(comet_last_error(), (text)) != NULL, "%s -> %d \"%s\", expected %d \"%s\"", #call, rc_, comet_last_error(), (int)(code), (text)); } while (0)
+static float R8[100][8], S8[100][8];
+static int make_kind(int kind, int metric, comet_index** h) {
+    const float off = metric == COMET_COSINE ? 1.0f : 0.0f;                          /* (no zero row in a cosine training set) */
+    for (int i = 0; i < 100; i++) for (int j = 0; j < 8; j++) { R8[i][j] = (float)(i * 8 + j) + off; S8[i][j] = (float)((i * 8 + j) % 10) + off; }
+    switch (kind) {
+    case 0: CK(comet_flat_create(ctx, 8, metric, h)); break;
+    case 1: CK(comet_ivf_create(ctx, 8, metric, 2, h)); CK(comet_index_train(*h, &R8[0][0], 100)); break;
+    case 2: CK(comet_pq_create(ctx, 8, metric, 4, 6, h)); CK(comet_index_train(*h, &S8[0][0], 100)); break;
+    case 3: CK(comet_ivfpq_create(ctx, 8, metric, 2, 4, 4, h)); CK(comet_index_train(*h, &R8[0][0], 100)); break;
+    default: CK(comet_hnsw_create(ctx, 8, metric, 16, 200, 200, h)); CK(comet_hnsw_set_level_seed(*h, 99)); break;
+    }
+    return 0;
+}
+static int lifecycle(void) {
+    static const char* NAME[5] = {"flat", "ivf", "pq", "ivfpq", "hnsw"};
+    uint32_t got[32]; comet_index* h = NULL; int64_t added = -1; int n;
+    const float e8[8] = {1, 0, 0, 0, 0, 0, 0, 0}, z8[8] = {0}; const uint32_t one = 1, two = 2;
+    /* training preconditions, Add / search before Train */
+    { float five3[5][3]; for (int i = 0; i < 5; i++) { five3[i][0] = (float)i; five3[i][1] = five3[i][2] = 0; }
+      CK(comet_ivf_create(ctx, 3, COMET_L2, 10, &h)); FAILS(comet_index_train(h, &five3[0][0], 5), COMET_ERR_TRAIN_DATA, "need at least 10 training vectors for 10 clusters (got 5)"); CK(comet_index_destroy(h));
+      float five8[5][8]; memset(five8, 0, sizeof(five8)); for (int i = 0; i < 5; i++) five8[i][0] = (float)i;
+      CK(comet_ivfpq_create(ctx, 8, COMET_L2, 10, 4, 4, &h)); FAILS(comet_index_train(h, &five8[0][0], 5), COMET_ERR_TRAIN_DATA, "need at least 100 vectors for training"); CK(comet_index_destroy(h));
+      float same[100][8]; for (int i = 0; i < 100; i++) for (int j = 0; j < 8; j++) same[i][j] = (float)i;
+      CK(comet_pq_create(ctx, 8, COMET_L2, 4, 8, &h)); FAILS(comet_index_train(h, &same[0][0], 100), COMET_ERR_TRAIN_DATA, "need at least 256 vectors for training"); CK(comet_index_destroy(h));
+      const float q3[3] = {1, 0, 0};
+      CK(comet_ivf_create(ctx, 3, COMET_L2, 2, &h)); FAILS(comet_index_add(h, &one, q3, 1, &added, NULL), COMET_ERR_NOT_TRAINED, "index must be trained before adding vectors");
+      EXPECT(ids_of(h, q3, 5, 0, 1, 0, NULL, 0, got, NULL) == -1000 - COMET_ERR_NOT_TRAINED && strstr(comet_last_error(), "index must be trained before searching"), "ivf search before train: %s", comet_last_error()); CK(comet_index_destroy(h));
+      CK(comet_pq_create(ctx, 8, COMET_L2, 4, 6, &h)); FAILS(comet_index_add(h, &one, e8, 1, &added, NULL), COMET_ERR_NOT_TRAINED, "index must be trained before adding");
+      EXPECT(ids_of(h, e8, 5, 0, 0, 0, NULL, 0, got, NULL) == -1000 - COMET_ERR_NOT_TRAINED && strstr(comet_last_error(), "index not trained"), "pq search before train: %s", comet_last_error()); CK(comet_index_destroy(h));
+      CK(comet_ivfpq_create(ctx, 8, COMET_L2, 2, 4, 4, &h)); FAILS(comet_index_add(h, &one, e8, 1, &added, NULL), COMET_ERR_NOT_TRAINED, "index must be trained before adding");
+      EXPECT(ids_of(h, e8, 5, 0, 1, 0, NULL, 0, got, NULL) == -1000 - COMET_ERR_NOT_TRAINED && strstr(comet_last_error(), "index must be trained before searching"), "ivfpq search before train: %s", comet_last_error()); CK(comet_index_destroy(h)); }
+    for (int kind = 0; kind < 5; kind++) {
+        /* a zero vector under cosine stops the batch at that row (ErrZeroVector); Euclidean takes it */
+        if (make_kind(kind, COMET_COSINE, &h)) return 1;
+        FAILS(comet_index_add(h, &one, z8, 1, &added, NULL), COMET_ERR_ZERO_VECTOR, "zero vector not allowed for this metric"); EXPECT(added == 0, "%s: %ld rows added before the zero vector", NAME[kind], (long)added);
+        CK(comet_index_add(h, &two, e8, 1, &added, NULL)); EXPECT(added == 1 && comet_index_size(h) == 1, "%s: size %ld after one good row", NAME[kind], (long)comet_index_size(h)); CK(comet_index_destroy(h));
+        /* soft delete, Flush, searches over deleted rows */
+        if (make_kind(kind, COMET_L2, &h)) return 1;
+        const uint32_t ids[4] = {11, 12, 13, 14}; float rows[4][8]; memset(rows, 0, sizeof(rows)); for (int i = 0; i < 4; i++) rows[i][0] = (float)(i + 1);
+        if (add_rows(h, ids, &rows[0][0], 4)) return 1;
+        const float q[8] = {1.5f, 0, 0, 0, 0, 0, 0, 0}; const int np = (kind == 1 || kind == 3) ? 2 : 0;
+        n = ids_of(h, q, 10, 0, np, 0, NULL, 0, got, NULL); EXPECT(n == 4 && got[0] == 11 && got[3] == 14, "%s: %d results before any delete", NAME[kind], n);
+        CK(comet_index_remove(h, 12)); CK(comet_index_remove(h, 13)); EXPECT(comet_index_size(h) == 4, "%s: size %ld after two soft deletes", NAME[kind], (long)comet_index_size(h));
+        FAILS(comet_index_remove(h, 12), COMET_ERR_ALREADY_DELETED, "12 already deleted"); FAILS(comet_index_remove(h, 9999), COMET_ERR_NOT_FOUND, "9999 not found");
+        n = ids_of(h, q, 10, 0, np, 0, NULL, 0, got, NULL); EXPECT(n == 2 && got[0] == 11 && got[1] == 14, "%s: %d results after two soft deletes", NAME[kind], n);
+        const uint32_t f[3] = {11, 12, 13}; n = ids_of(h, q, 10, 0, np, 0, f, 3, got, NULL); EXPECT(n == 1 && got[0] == 11, "%s: %d results with a filter naming deleted rows", NAME[kind], n);
+        CK(comet_index_flush(h)); EXPECT(comet_index_size(h) == 2, "%s: size %ld after Flush", NAME[kind], (long)comet_index_size(h));
+        n = ids_of(h, q, 10, 0, np, 0, NULL, 0, got, NULL); EXPECT(n == 2 && got[0] == 11 && got[1] == 14, "%s: %d results after Flush", NAME[kind], n);
+        FAILS(comet_index_remove(h, 12), COMET_ERR_NOT_FOUND, "12 not found"); CK(comet_index_flush(h)); EXPECT(comet_index_size(h) == 2, "%s: size after a second Flush", NAME[kind]);
+        CK(comet_index_remove(h, 11)); CK(comet_index_remove(h, 14)); CK(comet_index_flush(h)); EXPECT(comet_index_size(h) == 0, "%s: size %ld after flushing everything", NAME[kind], (long)comet_index_size(h));
+        n = ids_of(h, q, 10, 0, np, 0, NULL, 0, got, NULL); EXPECT(n == 0, "%s: %d results from the emptied index", NAME[kind], n);
+        CK(comet_index_destroy(h));
+    }
+    /* hnsw_index_test.go:586-629: the entry point removed and flushed -> another node takes over; :631-672: everything flushed -> entry 0, maxLevel -1 */
+    { CK(comet_hnsw_create(ctx, 3, COMET_L2, 16, 200, 200, &h)); CK(comet_hnsw_set_level_seed(h, 3));
+      uint32_t ids[5]; float v[5][3]; memset(v, 0, sizeof(v)); for (int i = 0; i < 5; i++) { ids[i] = (uint32_t)(i + 1); v[i][0] = (float)i; }
+      if (add_rows(h, ids, &v[0][0], 5)) return 1;
+      int64_t nn = 0, slots = 0, ne = 0; uint32_t entry = 99; int32_t maxl = -9;
+      CK(comet_hnsw_export_graph(h, &nn, &slots, &ne, NULL, NULL, NULL, NULL, NULL, &entry, &maxl)); EXPECT(entry == 1 && nn == 5, "entry %u of %ld nodes", entry, (long)nn);
+      CK(comet_index_remove(h, 1)); CK(comet_index_flush(h));
+      CK(comet_hnsw_export_graph(h, &nn, &slots, &ne, NULL, NULL, NULL, NULL, NULL, &entry, &maxl)); EXPECT(entry != 1 && entry != 0 && nn == 4, "after flushing the entry point: entry %u, %ld nodes", entry, (long)nn);
+      const float q0[3] = {0, 0, 0}; n = ids_of(h, q0, 10, 0, 0, 0, NULL, 0, got, NULL); EXPECT(n == 4 && got[0] == 2 && got[3] == 5, "after flushing the entry point: %d results", n);
+      for (uint32_t i = 2; i <= 5; i++) CK(comet_index_remove(h, i));
+      CK(comet_index_flush(h));
+      CK(comet_hnsw_export_graph(h, &nn, &slots, &ne, NULL, NULL, NULL, NULL, NULL, &entry, &maxl)); EXPECT(nn == 0 && entry == 0 && maxl == -1, "after flushing everything: %ld nodes, entry %u, maxLevel %d", (long)nn, entry, maxl);
+      n = ids_of(h, q0, 10, 0, 0, 0, NULL, 0, got, NULL); EXPECT(n == 0, "emptied HNSW: %d results", n); CK(comet_index_destroy(h)); }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const char* what = argc > 1 ? argv[1] : "all";
     if (comet_ctx_create(0, &ctx) != 0) { fprintf(stderr, "paper_checks: %s\n", comet_last_error()); return 77; }
@@ -207,6 +283,7 @@ int main(int argc, char** argv) {
     if (all || !strcmp(what, "hnsw")) { if (hnsw_paper(COMET_L2SQ) || hnsw_paper(COMET_L2)) return 1; printf("paper HNSW case OK (graph, entry point, maxLevel, six searches; L2^2 and Euclidean)\n"); }
     if (all || !strcmp(what, "filters")) { if (filters()) return 1; printf("document-filter tables OK (flat, ivf, pq, ivfpq, hnsw, bm25)\n"); }
     if (all || !strcmp(what, "searches")) { if (searches()) return 1; printf("HNSW search behaviours OK\n"); }
+    if (all || !strcmp(what, "lifecycle")) { if (lifecycle()) return 1; printf("lifecycle behaviours OK (training preconditions, zero vectors, soft delete / Flush for five kinds, HNSW entry-point flush; codes and messages)\n"); }
     comet_ctx_destroy(ctx);
     return 0;
 }

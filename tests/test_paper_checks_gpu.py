@@ -1,6 +1,6 @@
 """tests/paper_checks.c: known-answer checks on the GPU through the C ABI without Python — the hand-traced HNSW case of tests/golden/paper_kats.json (graph built by
 hnsw_insert_kernel, exported, compared edge for edge; six searches), the reference's document-filter test tables and the behaviours of hnsw_index_search_test.go
-(tests/golden/reference_kats_r06.json). On the GPU box it must pass; without a device it must fail LOUDLY (exit 77, "no HIP device"), never fall back to anything.
+(tests/golden/reference_kats_r06.json), and the lifecycle behaviours of the *_index_test.go files with the reference's error messages. On the GPU box it must pass; without a device it must fail LOUDLY (exit 77, "no HIP device"), never fall back to anything.
 The same cases are asserted on the CPU oracle in test_paper_kats.py / test_reference_tables_cpu.py."""
 import subprocess
 from pathlib import Path
@@ -29,7 +29,8 @@ def test_paper_checks_build_and_refuse_to_run_without_a_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("what,line", [("hnsw", "paper HNSW case OK"), ("filters", "document-filter tables OK"), ("searches", "HNSW search behaviours OK")])
+@pytest.mark.parametrize("what,line", [("hnsw", "paper HNSW case OK"), ("filters", "document-filter tables OK"), ("searches", "HNSW search behaviours OK"),
+                                       ("lifecycle", "lifecycle behaviours OK")])
 def test_paper_checks_pass_on_the_gpu(what, line):
     _build()
     r = subprocess.run([str(BIN), what], capture_output=True, text=True, timeout=600)
