@@ -68,7 +68,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--regions", type=int, default=11, help="timed regions of --steps steps each; the median is reported (11: the step time keeps falling over the first ~100 steps "
+                    "behind the warm-up — 6.45 5.82 5.46 5.30 5.26 ms per 20 steps in round 6's record, the same slope from the C harness, profiles/r06_c_bench.txt — and the "
+                    "median of five regions sat in the middle of that slope; every region's time is in `timing.region_ms`)")
     ap.add_argument("--sustain-s", type=float, default=2.0, help="length of the sustained (back-to-back) measurement of every leg")
     ap.add_argument("--rows", type=int, default=N_ROWS)
     ap.add_argument("--dim", type=int, default=DIM)
