@@ -116,6 +116,8 @@ class HybridSearch:
         self.fusion_kind = WEIGHTED_SUM_FUSION
         self.rrf_k = 60.0
         self.vector_weight, self.text_weight = 1.0, 1.0          # DefaultFusionConfig (fusion.go)
+        self.score_aggregation = "sum"   # SumAggregation, cutoff -1: hybrid_search_index.go:230-239
+        self.cutoff = -1
         self.document_ids: list[int] = []
 
     def with_vector(self, q): self.vector_query = q; return self
@@ -126,6 +128,8 @@ class HybridSearch:
     def with_threshold(self, t): self.threshold = float(t); return self
     def with_fusion_kind(self, kind, rrf_k: float = 60.0): self.fusion_kind = kind; self.rrf_k = rrf_k; return self
     def with_document_ids(self, *ids): self.document_ids = [int(i) for i in ids]; return self
+    def with_score_aggregation(self, kind): self.score_aggregation = kind; return self      # handed to both sub-searches (:512, :549)
+    def with_cutoff(self, cutoff): self.cutoff = int(cutoff); return self                   # Autocut inside both sub-searches (:513, :550)
 
     def with_fusion(self, kind, vector_weight: float = 1.0, text_weight: float = 1.0, rrf_k: float = 60.0):
         """WithFusion(NewFusion(kind, &FusionConfig{VectorWeight, TextWeight, K})) (hybrid_search_index.go:456-459, fusion.go:86-103)"""
@@ -140,7 +144,7 @@ class HybridSearch:
         if self.vector_query is not None:
             if self.vector_index is None:
                 raise ValueError("vector query specified but no vector index configured")
-            s = self.vector_index.new_search().with_query(self.vector_query).with_k(self.k)
+            s = self.vector_index.new_search().with_query(self.vector_query).with_k(self.k).with_score_aggregation(self.score_aggregation).with_cutoff(self.cutoff)
             if self.n_probes > 0:
                 s = s.with_n_probes(self.n_probes)
             if self.ef_search > 0:
@@ -153,7 +157,7 @@ class HybridSearch:
         if self.text_queries:
             if self.text_index is None:
                 raise ValueError("text query specified but no text index configured")
-            s = self.text_index.new_search().with_query(*self.text_queries).with_k(self.k)
+            s = self.text_index.new_search().with_query(*self.text_queries).with_k(self.k).with_score_aggregation(self.score_aggregation).with_cutoff(self.cutoff)
             if self.document_ids:
                 s = s.with_document_ids(*self.document_ids)
             tres = {r.id: float(r.score) for r in s.execute()}

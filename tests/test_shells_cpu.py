@@ -253,3 +253,23 @@ def test_constructor_validation_tables():
     with pytest.raises(Exception, match="unknown distance kind"):           # NewDistance: distance.go:9 — the rows "invalid distance kind"
         _metric_code("invalid")
     assert [_metric_code(k) for k in ("l2", "l2_squared", "cosine")] == [0, 1, 2]
+
+
+def test_hybrid_hands_aggregation_and_cutoff_to_both_sub_searches():
+    """hybridSearch.Execute passes WithScoreAggregation / WithCutoff to the vector and the text search (hybrid_search_index.go:508-513,545-550; defaults Sum / -1, :230-239):
+    a cutoff of 1 cuts each leg at its first score jump before the fusion; an unknown aggregation kind fails in the sub-search"""
+    from comet_amd.index import MAX_AGGREGATION
+    v = OracleVectorIndex(orc.Flat(3, "l2"), 3, "flat")
+    for i, row in enumerate(([1, 0, 0], [1.01, 0, 0], [9, 0, 0], [9.5, 0, 0]), 1):
+        v.add(row, i)
+    t = text_index([(1, "fox fox fox"), (2, "fox"), (3, "dog"), (4, "dog cat")])
+    q = t.tok("fox")
+    full = HybridSearch(v, t).with_vector([1, 0, 0]).with_text(q).with_k(4).execute()
+    assert {r.id for r in full} == {1, 2, 3, 4}
+    cut = HybridSearch(v, t).with_vector([1, 0, 0]).with_text(q).with_k(4).with_cutoff(1).with_score_aggregation(MAX_AGGREGATION).execute()
+    vec_cut = [r.id for r in v.new_search().with_query([1, 0, 0]).with_k(4).with_cutoff(1).execute()]
+    txt_cut = [r.id for r in t.new_search().with_query(q).with_k(4).with_cutoff(1).execute()]
+    assert 1 <= len(vec_cut) < 4 and 1 <= len(txt_cut) <= 2
+    assert {r.id for r in cut} == set(vec_cut) | set(txt_cut) and len(cut) < len(full)
+    with pytest.raises(ValueError, match="unknown aggregation kind"):
+        HybridSearch(v, None).with_vector([1, 0, 0]).with_score_aggregation("median").execute()
