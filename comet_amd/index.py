@@ -774,12 +774,45 @@ def aggregate_text(results: list[TextResult], kind: str) -> list[TextResult]:
     return out
 
 
+class DocTokenStore:
+    """docTokens / deletedDocs of the reference's BM25 index (bm25_index.go: Add stores a document's tokens, Remove soft-deletes, Flush drops) — the host-side state
+    WithNode needs (lookupNodeTexts bm25_index_search.go:233-260: a document's own tokens become a query). Mixed into BM25SearchIndex; the device never sees it."""
+
+    def _dt_init(self):
+        self._doc_tokens: dict[int, np.ndarray] = {}
+        self._deleted_docs: set[int] = set()
+
+    def _dt_add(self, doc_id: int, tokens) -> None:
+        self._doc_tokens[int(doc_id)] = np.array(tokens, dtype=np.uint32)              # (a copy: one small array per document, no per-token Python objects)
+        self._deleted_docs.discard(int(doc_id))
+
+    def _dt_remove(self, doc_id: int) -> None:
+        if int(doc_id) in self._doc_tokens:
+            self._deleted_docs.add(int(doc_id))
+
+    def _dt_flush(self) -> None:
+        for d in self._deleted_docs:
+            self._doc_tokens.pop(d, None)
+        self._deleted_docs.clear()
+
+    def _lookup_node_tokens(self, node_ids) -> list[list[int]]:
+        out = []
+        for i in node_ids:
+            if int(i) in self._deleted_docs:
+                raise KeyError(f"node ID {int(i)} not found in index (deleted)")
+            if int(i) not in self._doc_tokens:
+                raise KeyError(f"node ID {int(i)} not found in index")
+            out.append([int(t) for t in self._doc_tokens[int(i)]])
+        return out
+
+
 class TextSearch:
     """Fluent text search builder (TextSearch, index_search.go:358-430) over token-id queries."""
 
     def __init__(self, index: "BM25SearchIndex"):
         self.index = index
         self.queries: list[list[int]] = []
+        self.node_ids: list[int] = []
         self.k = 10
         self.aggregation = ""
         self.cutoff = -1
@@ -787,6 +820,11 @@ class TextSearch:
 
     def with_query(self, *token_lists) -> "TextSearch":
         self.queries = [list(map(int, t)) for t in token_lists]
+        return self
+
+    def with_node(self, *node_ids) -> "TextSearch":
+        """WithNode: the stored tokens of these documents are searched for as queries of their own, behind the direct queries (bm25_index_search.go:63-66,194-210)"""
+        self.node_ids = [int(i) for i in node_ids]
         return self
 
     def with_k(self, k: int) -> "TextSearch":
@@ -806,13 +844,16 @@ class TextSearch:
         return self
 
     def execute(self) -> list[TextResult]:
-        if not self.queries:
+        if not self.queries and not self.node_ids:
             raise ValueError("must specify either queries or node IDs")
         agg = self.aggregation or SUM_AGGREGATION
+        all_q = list(self.queries)
+        if self.node_ids:
+            all_q += self.index._lookup_node_tokens(self.node_ids)
         nd = max(1, self.index.num_docs())
         k_cap = max(1, min(nd, self.k if self.k > 0 else nd))
-        ids, sc, _, cnt = self.index.search_batch(self.queries, self.k, document_ids=self.document_ids, k_cap=k_cap)
-        allr = [TextResult(int(ids[b, i]), np.float32(sc[b, i])) for b in range(len(self.queries)) for i in range(min(cnt[b], k_cap))]
+        ids, sc, _, cnt = self.index.search_batch(all_q, self.k, document_ids=self.document_ids, k_cap=k_cap)
+        allr = [TextResult(int(ids[b, i]), np.float32(sc[b, i])) for b in range(len(all_q)) for i in range(min(cnt[b], k_cap))]
         res = aggregate_text(allr, agg)
         res = res[:sanitize_k(self.k, len(res))]
         if self.cutoff != -1 and res:
@@ -820,12 +861,13 @@ class TextSearch:
         return res
 
 
-class BM25SearchIndex:
+class BM25SearchIndex(DocTokenStore):
     """comet.NewBM25SearchIndex() with documents / queries given as token ids (tokenisation stays in Go)."""
 
     def __init__(self, ctx: Context):
         self.ctx, self.lib = ctx, ctx.lib
         self.h = C.c_void_p()
+        self._dt_init()
         check(self.lib.comet_bm25_create(ctx.h, C.byref(self.h)))
 
     def close(self):
@@ -842,12 +884,15 @@ class BM25SearchIndex:
     def add(self, doc_id: int, tokens) -> None:
         t = np.ascontiguousarray(list(tokens), dtype=np.uint32)
         check(self.lib.comet_bm25_add(self.h, C.c_uint32(int(doc_id)), t.ctypes.data_as(C.c_void_p), int(t.size)))
+        self._dt_add(doc_id, t)
 
     def remove(self, doc_id: int) -> None:
         check(self.lib.comet_bm25_remove(self.h, C.c_uint32(int(doc_id))))
+        self._dt_remove(doc_id)
 
     def flush(self) -> None:
         check(self.lib.comet_bm25_flush(self.h))
+        self._dt_flush()
 
     def num_docs(self) -> int:
         return int(self.lib.comet_bm25_num_docs(self.h))

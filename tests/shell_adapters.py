@@ -5,7 +5,7 @@ oracle's, so these tests check the shells, not the kernels."""
 import numpy as np
 
 import oracle_lib as orc
-from comet_amd.index import TextSearch, VectorSearch
+from comet_amd.index import DocTokenStore, TextSearch, VectorSearch
 
 
 class OracleVectorIndex:
@@ -53,17 +53,28 @@ class OracleVectorIndex:
         return ids, sc, cnt
 
 
-class OracleTextIndex:
-    """token ids per distinct lower-case word (plain ASCII text: the reference's normalize + tokenize reduce to a split on spaces)"""
+class OracleTextIndex(DocTokenStore):
+    """token ids per distinct lower-case word (plain ASCII text: the reference's normalize + tokenize reduce to a split on spaces); the docTokens / deletedDocs
+    bookkeeping is the product's own (comet_amd.index.DocTokenStore, what BM25SearchIndex mixes in)"""
 
     def __init__(self):
         self.o, self.vocab, self.n = orc.BM25(), {}, 0
+        self._dt_init()
 
     def tok(self, text):
         return [self.vocab.setdefault(w, len(self.vocab) + 1) for w in text.split(" ") if w]
 
     def add(self, doc_id, text):
-        self.o.add(int(doc_id), self.tok(text)); self.n += 1
+        toks = self.tok(text)
+        self.o.add(int(doc_id), toks); self.n += 1
+        self._dt_add(doc_id, toks)
+
+    def remove(self, doc_id):
+        assert self.o.remove(int(doc_id)) == 0
+        self._dt_remove(doc_id)
+
+    def flush(self):
+        self.o.flush(); self._dt_flush()
 
     def num_docs(self): return self.n
     def new_search(self): return TextSearch(self)

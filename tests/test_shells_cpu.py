@@ -273,3 +273,49 @@ def test_hybrid_hands_aggregation_and_cutoff_to_both_sub_searches():
     assert {r.id for r in cut} == set(vec_cut) | set(txt_cut) and len(cut) < len(full)
     with pytest.raises(ValueError, match="unknown aggregation kind"):
         HybridSearch(v, None).with_vector([1, 0, 0]).with_score_aggregation("median").execute()
+
+
+def test_text_search_with_node():
+    """bm25_index_search_test.go:32-53 (WithNode), :306-329 (a node and a direct query together), :345-358 (unknown node) + lookupNodeTexts' messages (bm25_index_search.go:233-260):
+    a document's own tokens are searched for as a query; soft-deleted and unknown documents fail by name"""
+    t = text_index([(1, "quick brown fox"), (2, "lazy brown dog"), (3, "quick rabbit"), (4, "slow turtle")])
+    res = t.new_search().with_node(1).with_k(5).execute()
+    assert res and res[0].id == 1 and {r.id for r in res} == {1, 2, 3}                    # "quick brown fox" finds itself first, then the documents sharing a word
+    both = t.new_search().with_node(1).with_query(t.tok("lazy dog")).with_k(5).execute()
+    assert {r.id for r in both} == {1, 2, 3} and descending(both)
+    by_hand = t.new_search().with_query(t.tok("lazy dog"), t.tok("quick brown fox")).with_k(5).execute()       # direct queries first, node queries behind them: the same sums
+    assert [(r.id, float(r.score)) for r in both] == [(r.id, float(r.score)) for r in by_hand]
+    with pytest.raises(KeyError, match="node ID 99 not found in index"):
+        t.new_search().with_node(99).with_k(5).execute()
+    t.remove(3)
+    with pytest.raises(KeyError, match=r"node ID 3 not found in index \(deleted\)"):
+        t.new_search().with_node(3).execute()
+    assert {r.id for r in t.new_search().with_node(1).with_k(5).execute()} == {1, 2}     # the soft-deleted document is no hit either
+    t.flush()
+    with pytest.raises(KeyError, match="node ID 3 not found in index'$"):                 # (str(KeyError) quotes its message)
+        t.new_search().with_node(3).execute()
+
+
+def test_bm25_search_index_keeps_the_token_store_in_step_with_the_library():
+    """BM25SearchIndex.add / remove / flush update the host-side docTokens / deletedDocs behind the library calls (a stub library stands in for libcomet_hip.so here:
+    every entry point returns COMET_OK) — what TextSearch.with_node reads"""
+    from comet_amd.index import BM25SearchIndex
+
+    class StubLib:
+        def __getattr__(self, name):
+            return lambda *a: 0
+
+    class StubCtx:
+        lib, h = StubLib(), None
+
+    ix = BM25SearchIndex(StubCtx())
+    ix.add(7, np.array([3, 1, 2], np.uint32)); ix.add(8, [5, 5])
+    assert ix._lookup_node_tokens([8, 7]) == [[5, 5], [3, 1, 2]]
+    ix.remove(7)
+    with pytest.raises(KeyError, match=r"node ID 7 not found in index \(deleted\)"):
+        ix._lookup_node_tokens([7])
+    ix.flush()
+    with pytest.raises(KeyError, match="node ID 7 not found in index'$"):
+        ix._lookup_node_tokens([7])
+    ix.add(7, [9]); assert ix._lookup_node_tokens([7]) == [[9]]                           # re-added after the flush
+    ix.h = None                                                                          # (nothing to destroy)
